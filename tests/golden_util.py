@@ -1,0 +1,57 @@
+"""Helpers shared by the parity tests: load a golden case (tests/golden/case_*.npz)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = [
+    "pl_test",
+    "plpeak",
+    "plpeak_full",
+    "bspline_test",
+    "bspline_iid",
+    "bspline_full",
+    "gwtc3_pl_test",
+    "gwtc3_bspline_test",
+]
+
+
+class GoldenCase:
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, f"case_{name}.npz"))
+        self.meta = json.loads(str(z["meta"]))
+        self.pe = {k[3:]: z[k] for k in z.files if k.startswith("pe/")}
+        self.inj = {k[4:]: z[k] for k in z.files if k.startswith("inj/")}
+        self.theta = {k[6:]: z[k] for k in z.files if k.startswith("theta/")}
+        self.n_points = self.meta["n_points"]
+        self.sites = {}
+        for k in z.files:
+            if k.startswith("sites/"):
+                _, fs, site = k.split("/", 2)
+                self.sites.setdefault(fs, {})[site] = z[k]
+        self.fdgrad = {}
+        for k in z.files:
+            if k.startswith("fdgrad/"):
+                _, i, name_ = k.split("/", 2)
+                self.fdgrad.setdefault(int(i), {})[name_] = z[k]
+        self.weights_pe = z["weights/pe"]
+        self.weights_inj = z["weights/inj"]
+        self.composition = self.meta["composition"]
+        self.total_inj = self.meta["total_inj"]
+        self.nobs = self.meta["nobs"]
+        self.tobs = self.meta["tobs"]
+        self.flagsets = self.meta["flagsets"]
+
+    def point(self, i):
+        return {k: (v[i] if v.ndim > 1 else float(v[i])) for k, v in self.theta.items()}
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        d = np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+    d = np.where(a == b, 0.0, d)  # covers +-inf == +-inf and exact zeros
+    return float(np.max(d)) if d.size else 0.0
