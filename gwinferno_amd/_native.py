@@ -1,0 +1,186 @@
+"""ctypes binding of include/gwi_engine.h (the C ABI of the HIP engine).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``)
+to ``gwinferno_amd/_lib/libgwi_engine.so``.  There is no CPU fallback anywhere in this package:
+if the library is missing, or no MI355X is visible, the calls below raise ``NativeEngineError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+GWI_ABI_VERSION = 1
+GWI_MAX_TERMS = 12
+GWI_MAX_THETA = 160
+GWI_MAX_NORMS = 8
+GWI_MAX_COLS = 16
+
+# term kinds (include/gwi_engine.h)
+TERM_POWERLAW = 1
+TERM_PLPEAK = 2
+TERM_POWERLAW_RATIO = 3
+TERM_BETA = 4
+TERM_TILT_MIXTURE = 5
+TERM_POWERLAW_REDSHIFT = 6
+TERM_EXP_SPLINE = 7
+TERM_TRUNCNORM = 8
+
+SPLINE_OUTSIDE_ZERO_EXPONENT = 1
+
+STATUS_NAMES = {0: "GWI_OK", -1: "GWI_ERR_INVALID", -2: "GWI_ERR_NO_DEVICE", -3: "GWI_ERR_HIP", -4: "GWI_ERR_UNSUPPORTED", -5: "GWI_ERR_TIMEOUT"}
+
+_DP = C.POINTER(C.c_double)
+
+
+class NativeEngineError(RuntimeError):
+    pass
+
+
+class GwiTerm(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("cols", C.c_int32 * 2),
+        ("theta", C.c_int32 * 4),
+        ("n_basis", C.c_int32),
+        ("coef_off", C.c_int32),
+        ("flags", C.c_int32),
+        ("norm", C.c_int32),
+        ("reserved", C.c_int32),
+        ("p", C.c_double * 4),
+    ]
+
+
+class GwiNorm(C.Structure):
+    _fields_ = [
+        ("n_pts", C.c_int32),
+        ("expo_theta", C.c_int32),
+        ("n_basis", C.c_int32),
+        ("coef_off", C.c_int32),
+        ("spline_flags", C.c_int32),
+        ("reserved", C.c_int32),
+        ("expo_add", C.c_double),
+        ("lo", C.c_double),
+        ("hi", C.c_double),
+        ("tw", _DP),
+        ("lb", _DP),
+        ("l1", _DP),
+        ("us", _DP),
+    ]
+
+
+class GwiSpec(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("kappa_col", C.c_int32),
+        ("n_theta", C.c_int32),
+        ("n_terms", C.c_int32),
+        ("n_norms", C.c_int32),
+        ("vt_norm", C.c_int32),
+        ("reserved", C.c_int32),
+        ("terms", GwiTerm * GWI_MAX_TERMS),
+        ("norms", GwiNorm * GWI_MAX_NORMS),
+    ]
+
+
+class GwiOptions(C.Structure):
+    _fields_ = [
+        ("n_obs", C.c_double),
+        ("total_inj", C.c_double),
+        ("marginalize_selection", C.c_int32),
+        ("min_neff_cut", C.c_int32),
+        ("max_variance_cut", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class GwiSummary(C.Structure):
+    _fields_ = [
+        ("log_likelihood", C.c_double),
+        ("log_l", C.c_double),
+        ("sum_logBFs", C.c_double),
+        ("selection_factor", C.c_double),
+        ("log_det_eff", C.c_double),
+        ("log_nEff_inj", C.c_double),
+        ("variance_log_detection_efficiency", C.c_double),
+        ("variance_log_likelihood", C.c_double),
+        ("min_log_nEff", C.c_double),
+        ("surveyed_hypervolume_norm", C.c_double),
+        ("log_norm_const", C.c_double),
+        ("reserved", C.c_double * 5),
+    ]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgwi_engine.so")
+
+# every symbol include/gwi_engine.h declares
+EXPORTED_SYMBOLS = [
+    "gwi_create",
+    "gwi_eval",
+    "gwi_log_weights",
+    "gwi_partial_len",
+    "gwi_eval_partial",
+    "gwi_combine",
+    "gwi_last_kernel_ms",
+    "gwi_set_timing",
+    "gwi_last_error",
+    "gwi_destroy",
+    "gwi_abi_version",
+    "gwi_kernel_variants",
+    "gwi_kernel_variant_name",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the engine; raises NativeEngineError (never silently degrades) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeEngineError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). gwinferno_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise NativeEngineError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp = C.c_void_p
+    lib.gwi_create.restype = C.c_int32
+    lib.gwi_create.argtypes = [C.POINTER(GwiSpec), C.POINTER(_DP), C.c_int64, C.c_int64, C.POINTER(_DP), C.c_int64, C.c_int32, C.POINTER(vp)]
+    lib.gwi_eval.restype = C.c_int32
+    lib.gwi_eval.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_log_weights.restype = C.c_int32
+    lib.gwi_log_weights.argtypes = [vp, _DP, _DP, _DP]
+    lib.gwi_partial_len.restype = C.c_int64
+    lib.gwi_partial_len.argtypes = [vp]
+    lib.gwi_eval_partial.restype = C.c_int32
+    lib.gwi_eval_partial.argtypes = [vp, _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_combine.restype = C.c_int32
+    lib.gwi_combine.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP]
+    lib.gwi_last_kernel_ms.restype = C.c_int32
+    lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.gwi_set_timing.restype = C.c_int32
+    lib.gwi_set_timing.argtypes = [vp, C.c_int32]
+    lib.gwi_last_error.restype = C.c_char_p
+    lib.gwi_last_error.argtypes = [vp]
+    lib.gwi_destroy.restype = None
+    lib.gwi_destroy.argtypes = [vp]
+    lib.gwi_abi_version.restype = C.c_int32
+    lib.gwi_kernel_variants.restype = C.c_int32
+    lib.gwi_kernel_variant_name.restype = C.c_char_p
+    lib.gwi_kernel_variant_name.argtypes = [C.c_int32]
+    if lib.gwi_abi_version() != GWI_ABI_VERSION:
+        raise NativeEngineError(f"ABI mismatch: library {lib.gwi_abi_version()} vs binding {GWI_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def as_dp(arr):
+    return arr.ctypes.data_as(_DP) if arr is not None else None
+
+
+def f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)

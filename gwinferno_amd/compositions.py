@@ -1,0 +1,223 @@
+"""The model compositions of the BASELINE configurations, written against this package's
+drop-in model API exactly as a user's NumPyro model function would write them against the
+reference.  bench.py, smoke() and the parity tests build engines from these.
+
+Each composition exposes
+  PARAMS                    ordered {name: shape} of its hyper-parameters
+  weights(p, pe_samples)    lazy importance weights  p(theta | Lambda) / prior
+  hypervolume(p)            lazy redshift normaliser passed as ``surveyed_hypervolume``
+  engine(...)               NativePopulationLikelihood bound to the catalog
+  theta(p)                  flat theta vector in the engine's layout
+"""
+import numpy as np
+
+from . import models as M
+from .engine import NativePopulationLikelihood
+from .interpolation import LogXLogYBSpline, LogYBSpline
+from .lazy import where_finite
+
+
+class Composition:
+    PARAMS = {}
+
+    def __init__(self, pedict, injdict, mmin=5.0, mmax=100.0):
+        self.pe = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in pedict.items()}
+        self.inj = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in injdict.items()}
+        self.mmin, self.mmax = float(mmin), float(mmax)
+        self._engine = None
+        self._slices = None
+
+    def data(self, pe_samples):
+        return self.pe if pe_samples else self.inj
+
+    def placeholder(self):
+        """Any parameter point (used only to establish the model structure)."""
+        return {k: (np.zeros(s) if s else 1.0) for k, s in self.PARAMS.items()}
+
+    def engine(self, device=-1, rank=0, world=1):
+        if self._engine is None:
+            p = self.placeholder()
+            self._engine = NativePopulationLikelihood(self.weights(p, True), self.weights(p, False), self.hypervolume(p), device=device, rank=rank, world=world)
+        return self._engine
+
+    def _theta_map(self):
+        """For every theta slot, which (parameter name, flat index) feeds it.  Found once by pushing
+        uniquely coded parameter values through the model function."""
+        if self._slices is None:
+            eng = self.engine()
+            coded, code = {}, 1.0
+            lookup = {}
+            for name, shape in self.PARAMS.items():
+                size = int(np.prod(shape)) if shape else 1
+                vals = np.arange(code, code + size)
+                for i in range(size):
+                    lookup[code + i] = (name, i)
+                coded[name] = vals.reshape(shape) if shape else float(vals[0])
+                code += size
+            th = eng.bound.theta_of(self.weights(coded, True))
+            self._slices = [lookup[v] for v in th]
+        return self._slices
+
+    def theta(self, p):
+        """Flat theta for parameter dict ``p`` (layout = order in which the factors consume parameters)."""
+        return np.array([np.asarray(p[name], dtype=np.float64).flat[i] for name, i in self._theta_map()])
+
+    def named_gradient(self, grad):
+        """Scatter a flat gradient back onto parameter names (a parameter feeding several theta
+        slots receives the sum, as autodiff would give)."""
+        out = {name: np.zeros(int(np.prod(shape)) if shape else 1) for name, shape in self.PARAMS.items()}
+        for g, (name, i) in zip(grad, self._theta_map()):
+            out[name][i] += g
+        return {name: (v.reshape(self.PARAMS[name]) if self.PARAMS[name] else float(v[0])) for name, v in out.items()}
+
+
+class PLTest(Composition):
+    """tests/inference_test.py:162-197."""
+
+    PARAMS = {"alpha": (), "beta": (), "lamb": ()}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_m1q = M.powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=p["alpha"], beta=p["beta"], mmin=self.mmin, mmax=self.mmax)
+        return where_finite(p_m1q * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+class PLPeak(PLTest):
+    """BASELINE config 2."""
+
+    PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "lamb": ()}
+
+    def mass(self, p, d):
+        return M.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        return where_finite(self.mass(p, d) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q.update(mpp=30.0, sigpp=5.0, lam=0.1)
+        return q
+
+
+class PLPeakFull(PLPeak):
+    """BASELINE config 1 (examples/simple_powerlaw_peak_example.py:82-94)."""
+
+    PARAMS = {k: () for k in ("alpha", "beta", "mpp", "sigpp", "lam", "alpha_a1", "beta_a1", "alpha_a2", "beta_a2", "xi1", "xi2", "sig_t1", "sig_t2", "lamb")}
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_a = M.independent_spin_magnitude_beta_dist(d["a_1"], d["a_2"], p["alpha_a1"], p["beta_a1"], p["alpha_a2"], p["beta_a2"])
+        p_ct = M.independent_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi1"], p["xi2"], p["sig_t1"], p["sig_t2"])
+        return where_finite(self.mass(p, d) * p_a * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+
+class BSplineTest(Composition):
+    """tests/inference_test.py:124-143, 244-285."""
+
+    NM, NQ, NZ = 10, 5, 5
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.NM,), "q_coefs": (self.NQ,), "z_coefs": (self.NZ,), "lamb": ()}
+        self.mass_model = M.BSplinePrimaryBSplineRatio(self.NM, self.NQ, self.pe["mass_1"], self.inj["mass_1"], self.pe["mass_ratio"], self.inj["mass_ratio"],
+                                                       m1min=self.mmin, m2min=self.mmin, mmax=self.mmax, kwargs_m={"basis": LogXLogYBSpline}, kwargs_q={"basis": LogYBSpline})
+        self.z_model = M.PowerlawSplineRedshiftModel(self.NZ, self.pe["redshift"], self.inj["redshift"])
+
+    def spins(self, p, pe_samples):
+        return None
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        w = self.mass_model(p["m1_coefs"], p["q_coefs"], pe_samples=pe_samples)
+        s = self.spins(p, pe_samples)
+        if s is not None:
+            w = w * s
+        return where_finite(w * self.z_model(d["redshift"], p["lamb"], p["z_coefs"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"], p["z_coefs"])
+
+
+class BSplineFull(BSplineTest):
+    """BASELINE config 5 (examples/simple_bspline_example.py:47-71; pipeline/utils.py:104-155)."""
+
+    NM, NQ, NA, NT, NZ = 30, 14, 12, 12, 12
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.NM,), "q_coefs": (self.NQ,), "a1_coefs": (self.NA,), "a2_coefs": (self.NA,), "t1_coefs": (self.NT,), "t2_coefs": (self.NT,),
+                       "z_coefs": (self.NZ,), "lamb": ()}
+        self.mag_model = M.BSplineIndependentSpinMagnitudes(self.NA, self.NA, self.pe["a_1"], self.pe["a_2"], self.inj["a_1"], self.inj["a_2"], normalize=True)
+        self.tilt_model = M.BSplineIndependentSpinTilts(self.NT, self.NT, self.pe["cos_tilt_1"], self.pe["cos_tilt_2"], self.inj["cos_tilt_1"], self.inj["cos_tilt_2"],
+                                                        normalize=True)
+
+    def spins(self, p, pe_samples):
+        return self.mag_model(p["a1_coefs"], p["a2_coefs"], pe_samples=pe_samples) * self.tilt_model(p["t1_coefs"], p["t2_coefs"], pe_samples=pe_samples)
+
+
+class BSplineIID(Composition):
+    """BASELINE configs 3/4."""
+
+    NM, NA, NT = 30, 16, 16
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.NM,), "beta": (), "a_coefs": (self.NA,), "t_coefs": (self.NT,), "lamb": ()}
+        self.mass_model = M.BSplinePrimaryPowerlawRatio(self.NM, self.pe["mass_1"], self.inj["mass_1"], mmin=self.mmin, mmax=self.mmax)
+        self.mag_model = M.BSplineIIDSpinMagnitudes(self.NA, self.pe["a_1"], self.pe["a_2"], self.inj["a_1"], self.inj["a_2"], normalize=True)
+        self.tilt_model = M.BSplineIIDSpinTilts(self.NT, self.pe["cos_tilt_1"], self.pe["cos_tilt_2"], self.inj["cos_tilt_1"], self.inj["cos_tilt_2"], normalize=True)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_m1q = self.mass_model(d["mass_1"], d["mass_ratio"], p["beta"], self.mmin, p["m1_coefs"], pe_samples=pe_samples)
+        p_a = self.mag_model(p["a_coefs"], pe_samples=pe_samples)
+        p_t = self.tilt_model(p["t_coefs"], pe_samples=pe_samples)
+        return where_finite(p_m1q * p_a * p_t * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+COMPOSITIONS = {
+    "pl_test": PLTest,
+    "plpeak": PLPeak,
+    "plpeak_full": PLPeakFull,
+    "bspline_test": BSplineTest,
+    "bspline_iid": BSplineIID,
+    "bspline_full": BSplineFull,
+}
+
+
+def draw_params(name, rng):
+    """Hyper-parameter draws of SURVEY.md section 8(d)."""
+    cls = COMPOSITIONS[name]
+    if name == "pl_test":
+        return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
+    if name in ("plpeak", "plpeak_full"):
+        p = {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "mpp": rng.uniform(20.0, 50.0), "sigpp": rng.uniform(1.0, 10.0), "lam": rng.uniform(0.0, 0.2),
+             "lamb": rng.normal(2.7, 1.0)}
+        if name == "plpeak_full":
+            p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
+                     xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
+        return {k: p[k] for k in cls.PARAMS}
+    shapes = {
+        "bspline_test": {"m1_coefs": 10, "q_coefs": 5, "z_coefs": 5},
+        "bspline_iid": {"m1_coefs": 30, "a_coefs": 16, "t_coefs": 16},
+        "bspline_full": {"m1_coefs": 30, "q_coefs": 14, "a1_coefs": 12, "a2_coefs": 12, "t1_coefs": 12, "t2_coefs": 12, "z_coefs": 12},
+    }[name]
+    p = {k: rng.normal(size=n) for k, n in shapes.items()}
+    if "z_coefs" in p:
+        p["z_coefs"][0] = 0.0  # pipeline/utils.py:213-214
+    if name == "bspline_iid":
+        p["beta"] = rng.normal(1.0, 1.0)
+    p["lamb"] = rng.normal(2.7, 1.0)
+    return p

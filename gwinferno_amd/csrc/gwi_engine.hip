@@ -1,0 +1,702 @@
+// gwi_engine.hip -- host side + C ABI of the population-likelihood engine (see include/gwi_engine.h).
+// gfx950 only; no CPU fallback: every entry point that computes needs a live HIP device.
+#include "gwi_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace gwi;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// compiled term sequences: each entry below is one explicit instantiation of scan_kernel.
+// ------------------------------------------------------------------------------------------------
+using ScanFn = void (*)(const KArgs);
+
+struct Variant {
+  const char* name;
+  int n;
+  int kinds[GWI_MAX_TERMS];
+  ScanFn scan;
+  ScanFn logw;
+};
+
+#define K_PL GWI_TERM_POWERLAW
+#define K_PP GWI_TERM_PLPEAK
+#define K_PQ GWI_TERM_POWERLAW_RATIO
+#define K_BE GWI_TERM_BETA
+#define K_TI GWI_TERM_TILT_MIXTURE
+#define K_PZ GWI_TERM_POWERLAW_REDSHIFT
+#define K_SP GWI_TERM_EXP_SPLINE
+#define K_TN GWI_TERM_TRUNCNORM
+
+#define GWI_VARIANT(NAME, ...) \
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, &scan_kernel<false, __VA_ARGS__>, &scan_kernel<true, __VA_ARGS__> }
+
+// Term sequences are canonical: the host sorts a model's terms by kind id (stable).
+const Variant kVariants[] = {
+    // tests/inference_test.py:162-197 -- powerlaw_primary_ratio_pdf x PowerlawRedshiftModel
+    GWI_VARIANT("pl+plq+plz", K_PL, K_PQ, K_PZ),
+    // BASELINE config 2 -- PL+Peak m1 x PL q [x PL z]
+    GWI_VARIANT("plpeak+plq", K_PP, K_PQ),
+    GWI_VARIANT("plpeak+plq+plz", K_PP, K_PQ, K_PZ),
+    // BASELINE config 1 -- + independent Beta magnitudes + independent tilt mixtures
+    GWI_VARIANT("plpeak+plq+beta2+tilt2+plz", K_PP, K_PQ, K_BE, K_BE, K_TI, K_TI, K_PZ),
+    // tests/inference_test.py:244-285 -- PL z x {BSpline m1, BSpline q, spline(log z)}
+    GWI_VARIANT("plz+spline3", K_PZ, K_SP, K_SP, K_SP),
+    // BASELINE config 3/4 -- PL q x PL z x {BSpline m1, IID spin magnitudes [, IID tilts]}
+    GWI_VARIANT("plq+plz+spline3", K_PQ, K_PZ, K_SP, K_SP, K_SP),
+    GWI_VARIANT("plq+plz+spline5", K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
+    // BASELINE config 5 -- PL z x {BSpline m1, q, a1, a2, ct1, ct2, spline(log z)}
+    GWI_VARIANT("plz+spline7", K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
+    // PLPeakPrimaryBSplineRatio (separable.py:368-443) x PL z
+    GWI_VARIANT("plpeak+plz+spline", K_PP, K_PZ, K_SP),
+    // mass-only B-spline models: BSplinePrimaryBSplineRatio / BSplinePrimaryPowerlawRatio x PL z
+    GWI_VARIANT("plz+spline2", K_PZ, K_SP, K_SP),
+    GWI_VARIANT("plq+plz+spline", K_PQ, K_PZ, K_SP),
+    // single-term sequences (term-level parity tests)
+    GWI_VARIANT("pl", K_PL),
+    GWI_VARIANT("plpeak", K_PP),
+    GWI_VARIANT("plq", K_PQ),
+    GWI_VARIANT("beta", K_BE),
+    GWI_VARIANT("tilt", K_TI),
+    GWI_VARIANT("plz", K_PZ),
+    GWI_VARIANT("spline", K_SP),
+    GWI_VARIANT("truncnorm", K_TN),
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+const Variant* find_variant(const gwi_spec& s) {
+  for (int v = 0; v < kNumVariants; ++v) {
+    if (kVariants[v].n != s.n_terms) continue;
+    bool same = true;
+    for (int t = 0; t < s.n_terms; ++t) same = same && kVariants[v].kinds[t] == s.terms[t].kind;
+    if (same) return &kVariants[v];
+  }
+  return nullptr;
+}
+
+// record published by final_kernel (doubles):
+//   [0] completion stamp  [1] sum_i logsumexp_i  [2] sum_i variance_i  [3] min_i nan_to_num(log n_eff_i)
+//   [4] inj M  [5] inj S1  [6] inj S2  [7] n_ev (local)  [8..) norms, grad_pe[n_theta], grad_inj[n_theta]
+constexpr int kRecNormOff = 8;
+
+// ------------------------------------------------------------------------------------------------
+// hyper-parameter-only scalars ("prelude"), computed on the host in double precision
+// ------------------------------------------------------------------------------------------------
+// log of the power-law normaliser (1+a)/(hi^(1+a) - lo^(1+a)) and its alpha-derivative
+// (distributions.py:112-116), evaluated in the log domain so large |alpha| cannot overflow.
+void powerlaw_lognorm(double alpha, double lo, double hi, double* logA, double* dlogA) {
+  const double a1 = 1.0 + alpha, llo = std::log(lo), lhi = std::log(hi);
+  if (a1 == 0.0) {
+    *logA = -std::log(lhi - llo);
+    *dlogA = -0.5 * (lhi + llo);
+    return;
+  }
+  if (a1 > 0) {
+    const double rho = std::exp(a1 * (llo - lhi));  // (lo/hi)^a1
+    *logA = std::log(a1) - (a1 * lhi + std::log1p(-rho));
+    *dlogA = 1.0 / a1 - (lhi - rho * llo) / (1.0 - rho);
+  } else {
+    const double rho = std::exp(a1 * (lhi - llo));  // (hi/lo)^a1
+    *logA = std::log(-a1) - (a1 * llo + std::log1p(-rho));
+    *dlogA = 1.0 / a1 - (llo - rho * lhi) / (1.0 - rho);
+  }
+}
+
+// log of the truncated-normal normaliser 1/(sig sqrt(2pi) (Phi(b)-Phi(a))) and its derivatives
+// (distributions.py:136-142)
+void truncnorm_lognorm(double mu, double sg, double lo, double hi, double* logC, double* dmu, double* dsg) {
+  const double r2 = std::sqrt(2.0);
+  const double a = (lo - mu) / sg, b = (hi - mu) / sg;
+  const double dphi = 0.5 * (1.0 + std::erf(b / r2)) - 0.5 * (1.0 + std::erf(a / r2));
+  const double inv_s2pi = 1.0 / std::sqrt(2.0 * M_PI);
+  const double pa = std::exp(-0.5 * a * a) * inv_s2pi, pb = std::exp(-0.5 * b * b) * inv_s2pi;
+  *logC = -std::log(sg) - 0.5 * std::log(2.0 * M_PI) - std::log(dphi);
+  *dmu = (pb - pa) / (sg * dphi);
+  *dsg = -1.0 / sg + (b * pb - a * pa) / (sg * dphi);
+}
+
+}  // namespace
+
+struct gwi_engine {
+  gwi_spec spec;
+  const Variant* variant = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  long long n_ev = 0, n_pe = 0, n_inj = 0;
+  // device memory
+  std::vector<double*> d_cols_pe, d_cols_inj;
+  const double** d_pe_table = nullptr;
+  const double** d_inj_table = nullptr;
+  NormD* d_norms = nullptr;
+  std::vector<double*> d_norm_arrays;
+  double *d_partials = nullptr, *d_norm_out = nullptr, *d_ev_out = nullptr, *d_ev_grad = nullptr, *d_inj_out = nullptr, *d_inj_grad = nullptr;
+  double *d_logw_pe = nullptr, *d_logw_inj = nullptr;
+  // pinned, device-visible host memory
+  double *h_record = nullptr, *h_record_dev = nullptr;
+  double *h_ev = nullptr, *h_ev_dev = nullptr;
+  // launch geometry
+  int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
+  unsigned long long seq = 0;
+  // results of the last prelude
+  double host_const = 0.0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_ms[3] = {0, 0, 0};
+  std::string err;
+  KArgs kargs;
+};
+
+namespace {
+
+#define GWI_HIP(call)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+      return GWI_ERR_HIP;                                                                           \
+    }                                                                                               \
+  } while (0)
+
+gwi_status fail(gwi_handle h, gwi_status s, const std::string& msg) {
+  if (h) h->err = msg;
+  return s;
+}
+
+int record_len(const gwi_engine* h) { return kRecNormOff + h->spec.n_norms + 2 * h->spec.n_theta; }
+
+gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
+  if (s->abi_version != GWI_ABI_VERSION) return fail(h, GWI_ERR_INVALID, "abi_version mismatch");
+  if (s->n_cols < 1 || s->n_cols > GWI_MAX_COLS) return fail(h, GWI_ERR_INVALID, "n_cols out of range");
+  if (s->n_terms < 1 || s->n_terms > GWI_MAX_TERMS) return fail(h, GWI_ERR_INVALID, "n_terms out of range");
+  if (s->n_theta < 1 || s->n_theta > GWI_MAX_THETA) return fail(h, GWI_ERR_INVALID, "n_theta out of range");
+  if (s->n_norms < 0 || s->n_norms > GWI_MAX_NORMS) return fail(h, GWI_ERR_INVALID, "n_norms out of range");
+  if (s->kappa_col < 0 || s->kappa_col >= s->n_cols) return fail(h, GWI_ERR_INVALID, "kappa_col out of range");
+  if (s->vt_norm >= s->n_norms) return fail(h, GWI_ERR_INVALID, "vt_norm out of range");
+  auto theta_ok = [&](int i) { return i >= 0 && i < s->n_theta; };
+  auto col_ok = [&](int i) { return i >= 0 && i < s->n_cols; };
+  for (int t = 0; t < s->n_terms; ++t) {
+    const gwi_term& tm = s->terms[t];
+    int n_cols = 1, n_th = 1;
+    switch (tm.kind) {
+      case GWI_TERM_POWERLAW: break;
+      case GWI_TERM_PLPEAK: n_cols = 2; n_th = 4; break;
+      case GWI_TERM_POWERLAW_RATIO: n_cols = 2; break;
+      case GWI_TERM_BETA: n_cols = 2; n_th = 2; break;
+      case GWI_TERM_TILT_MIXTURE: n_th = 2; break;
+      case GWI_TERM_POWERLAW_REDSHIFT: break;
+      case GWI_TERM_TRUNCNORM: n_th = 2; break;
+      case GWI_TERM_EXP_SPLINE:
+        n_th = 0;
+        if (tm.n_basis < 4 || !theta_ok(tm.coef_off) || !theta_ok(tm.coef_off + tm.n_basis - 1)) return fail(h, GWI_ERR_INVALID, "spline coefficient range invalid");
+        if (!(tm.p[1] > tm.p[0])) return fail(h, GWI_ERR_INVALID, "spline domain invalid");
+        break;
+      default: return fail(h, GWI_ERR_INVALID, "unknown term kind");
+    }
+    for (int c = 0; c < n_cols; ++c)
+      if (!col_ok(tm.cols[c])) return fail(h, GWI_ERR_INVALID, "term column index out of range");
+    for (int k = 0; k < n_th; ++k)
+      if (!theta_ok(tm.theta[k])) return fail(h, GWI_ERR_INVALID, "term theta index out of range");
+    if (tm.norm >= s->n_norms) return fail(h, GWI_ERR_INVALID, "term norm index out of range");
+  }
+  for (int j = 0; j < s->n_norms; ++j) {
+    const gwi_norm& nm = s->norms[j];
+    if (nm.n_pts < 2 || !nm.tw) return fail(h, GWI_ERR_INVALID, "normaliser grid invalid");
+    if (nm.expo_theta >= 0 && (!theta_ok(nm.expo_theta) || !nm.l1)) return fail(h, GWI_ERR_INVALID, "normaliser exponent invalid");
+    if (nm.n_basis > 0 && (nm.n_basis < 4 || !nm.us || !theta_ok(nm.coef_off) || !theta_ok(nm.coef_off + nm.n_basis - 1) || !(nm.hi > nm.lo)))
+      return fail(h, GWI_ERR_INVALID, "normaliser spline invalid");
+  }
+  return GWI_OK;
+}
+
+// theta -> derived scalars of every term + the sample-independent log-normaliser total
+void prelude(gwi_engine* h, const double* theta) {
+  KArgs& k = h->kargs;
+  double c = 0.0;
+  for (int t = 0; t < h->spec.n_terms; ++t) {
+    const gwi_term& tm = h->spec.terms[t];
+    double* d = k.derived[t];
+    for (int i = 0; i < kMaxDerived; ++i) d[i] = 0.0;
+    switch (tm.kind) {
+      case GWI_TERM_POWERLAW: {
+        double la, dla;
+        powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &la, &dla);
+        c += la;
+        break;
+      }
+      case GWI_TERM_PLPEAK: {
+        powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &d[0], &d[1]);
+        truncnorm_lognorm(theta[tm.theta[1]], theta[tm.theta[2]], tm.p[0], tm.p[1], &d[2], &d[3], &d[4]);
+        break;
+      }
+      case GWI_TERM_BETA: {
+        const double a = theta[tm.theta[0]], b = theta[tm.theta[1]];
+        c -= std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b);  // betaln (distributions.py:161)
+        break;
+      }
+      case GWI_TERM_TILT_MIXTURE: {
+        double dmu;
+        truncnorm_lognorm(1.0, theta[tm.theta[1]], -1.0, 1.0, &d[0], &dmu, &d[1]);
+        break;
+      }
+      case GWI_TERM_TRUNCNORM: {
+        double lc, dmu, dsg;
+        truncnorm_lognorm(theta[tm.theta[0]], theta[tm.theta[1]], tm.p[0], tm.p[1], &lc, &dmu, &dsg);
+        c += lc;
+        break;
+      }
+      default: break;
+    }
+  }
+  h->host_const = c;
+  std::memcpy(k.theta, theta, sizeof(double) * h->spec.n_theta);
+}
+
+gwi_status launch_scan(gwi_handle h, bool logw) {
+  const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);
+  ScanFn fn = logw ? h->variant->logw : h->variant->scan;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, h->stream, h->kargs);
+  GWI_HIP(hipGetLastError());
+  return GWI_OK;
+}
+
+gwi_status run_pipeline(gwi_handle h, const double* theta) {
+  prelude(h, theta);
+  if (h->timing) GWI_HIP(hipEventRecord(h->ev[0], h->stream));
+  gwi_status st = launch_scan(h, false);
+  if (st != GWI_OK) return st;
+  if (h->timing) GWI_HIP(hipEventRecord(h->ev[1], h->stream));
+  CombineArgs ca;
+  ca.partials = h->d_partials;
+  ca.ev_out = h->d_ev_out;
+  ca.ev_grad = h->d_ev_grad;
+  ca.inj_out = h->d_inj_out;
+  ca.inj_grad = h->d_inj_grad;
+  ca.n_ev = (int)h->n_ev;
+  ca.tiles_per_event = h->tiles_per_event;
+  ca.n_inj_tiles = h->n_inj_tiles;
+  ca.n_theta = h->spec.n_theta;
+  ca.rec_stride = h->rec_stride;
+  ca.n_pe = (double)h->n_pe;
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)h->n_ev + 1), dim3(kBlock), 0, h->stream, ca);
+  GWI_HIP(hipGetLastError());
+  if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
+  FinalArgs fa;
+  fa.ev_out = h->d_ev_out;
+  fa.ev_grad = h->d_ev_grad;
+  fa.inj_out = h->d_inj_out;
+  fa.inj_grad = h->d_inj_grad;
+  fa.norm_out = h->d_norm_out;
+  fa.record = h->h_record_dev;
+  fa.ev_host = h->h_ev_dev;
+  fa.n_ev = (int)h->n_ev;
+  fa.n_theta = h->spec.n_theta;
+  fa.n_norms = h->spec.n_norms;
+  fa.seq = ++h->seq;
+  hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
+  GWI_HIP(hipGetLastError());
+  if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+  GWI_HIP(hipStreamSynchronize(h->stream));
+  if (h->timing) {
+    for (int i = 0; i < 3; ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
+  }
+  unsigned long long stamp;
+  std::memcpy(&stamp, h->h_record, sizeof(stamp));
+  if (stamp != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
+  return GWI_OK;
+}
+
+// Assemble the sites of analysis.py:259-319 from gathered per-rank records.
+void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi_options* opt, gwi_summary* out, double* grad, double* norms) {
+  const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
+  const int len = record_len(h);
+  const double NEG_BIG = -1.7976931348623157e308;  // jnp.nan_to_num(-inf)
+  double sum_lse = 0.0, sum_var = 0.0, min_lneff = INFINITY, n_ev_total = 0.0, M = -INFINITY;
+  for (int r = 0; r < n_ranks; ++r) {
+    const double* rec = records + (size_t)r * len;
+    sum_lse += rec[1];
+    sum_var += rec[2];
+    min_lneff = std::fmin(min_lneff, rec[3]);
+    M = std::fmax(M, rec[4]);
+    n_ev_total += rec[7];
+  }
+  double S1 = 0.0, S2 = 0.0;
+  std::vector<double> g_pe(n_theta, 0.0), g_inj(n_theta, 0.0);
+  for (int r = 0; r < n_ranks; ++r) {
+    const double* rec = records + (size_t)r * len;
+    const double f = (rec[4] == -INFINITY) ? 0.0 : std::exp(rec[4] - M);
+    S1 += f * rec[5];
+    S2 += f * f * rec[6];
+    const double* gp = rec + kRecNormOff + n_norms;
+    const double* gi = gp + n_theta;
+    for (int p = 0; p < n_theta; ++p) {
+      g_pe[p] += gp[p];
+      g_inj[p] += f * gi[p];
+    }
+  }
+  const double* nrm = records + kRecNormOff;  // every rank integrates the same grids
+  double log_const = h->host_const;
+  for (int t = 0; t < h->spec.n_terms; ++t)
+    if (h->spec.terms[t].norm >= 0) log_const -= std::log(nrm[h->spec.terms[t].norm]);
+  if (norms)
+    for (int j = 0; j < n_norms; ++j) norms[j] = nrm[j];
+
+  const double n_obs = opt->n_obs, n_tot = opt->total_inj, n_pe = (double)h->n_pe;
+  gwi_summary s;
+  std::memset(&s, 0, sizeof(s));
+  s.log_norm_const = log_const;
+  s.sum_logBFs = sum_lse + n_ev_total * (log_const - std::log(n_pe));
+  // detection_efficiency (analysis.py:124-136), scale-free forms of var and n_eff
+  const double log_mu = std::log(S1) + M - std::log(n_tot) + log_const;
+  const double log_neff_inj = 2.0 * std::log(S1) - std::log(S2 - S1 * S1 / n_tot);
+  const double var_mu = 1.0 / std::exp(log_neff_inj) - 1.0 / n_tot;
+  s.log_det_eff = log_mu;
+  s.log_nEff_inj = log_neff_inj;
+  s.variance_log_detection_efficiency = var_mu;
+  s.min_log_nEff = min_lneff;
+  s.surveyed_hypervolume_norm = h->spec.vt_norm >= 0 ? nrm[h->spec.vt_norm] : NAN;
+  double lde = log_mu;
+  if (opt->marginalize_selection) lde = lde - (3.0 + n_obs) / (2.0 * std::exp(log_neff_inj));  // :271
+  bool cut = false;
+  if (opt->min_neff_cut && !(log_neff_inj >= std::log(4.0 * n_obs))) lde = INFINITY;  // :273-277
+  s.selection_factor = std::isinf(lde) ? NEG_BIG : -n_obs * lde;                       // :278-281
+  if (std::isinf(lde)) cut = true;
+  double log_l = s.selection_factor + s.sum_logBFs;
+  if (std::isnan(log_l)) {
+    log_l = NEG_BIG;  // :287-288
+    cut = true;
+  } else if (std::isinf(log_l)) {
+    log_l = log_l > 0 ? 1.7976931348623157e308 : NEG_BIG;  // nan_to_num :289
+    cut = true;
+  }
+  s.log_l = log_l;
+  if (opt->min_neff_cut) {
+    const double min_neff = std::exp(min_lneff);  // :295
+    if (min_neff <= n_obs) {                      // :296-303
+      log_l = NEG_BIG;
+      cut = true;
+    }
+  }
+  s.variance_log_likelihood = n_obs * n_obs * var_mu + sum_var;  // :305-308
+  if (opt->max_variance_cut && !(s.variance_log_likelihood <= 1.0)) {  // :309-317
+    log_l = NEG_BIG;
+    cut = true;
+  }
+  s.log_likelihood = log_l;
+  if (out) *out = s;
+  if (grad) {
+    // d log_l / d theta = sum_i sum_j s_ij dl_ij - N_obs sum_j s_j dl_j  (SURVEY.md appendix A);
+    // a cut replaces log_l by a constant, whose gradient is zero.
+    for (int p = 0; p < n_theta; ++p) grad[p] = cut ? 0.0 : g_pe[p] - n_obs * (S1 > 0 ? g_inj[p] / S1 : 0.0);
+  }
+}
+
+void destroy_impl(gwi_engine* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (double* p : h->d_cols_pe) (void)hipFree(p);
+  for (double* p : h->d_cols_inj) (void)hipFree(p);
+  for (double* p : h->d_norm_arrays) (void)hipFree(p);
+  (void)hipFree((void*)h->d_pe_table);
+  (void)hipFree((void*)h->d_inj_table);
+  (void)hipFree(h->d_norms);
+  (void)hipFree(h->d_partials);
+  (void)hipFree(h->d_norm_out);
+  (void)hipFree(h->d_ev_out);
+  (void)hipFree(h->d_ev_grad);
+  (void)hipFree(h->d_inj_out);
+  (void)hipFree(h->d_inj_grad);
+  (void)hipFree(h->d_logw_pe);
+  (void)hipFree(h->d_logw_inj);
+  if (h->h_record) (void)hipHostFree(h->h_record);
+  if (h->h_ev) (void)hipHostFree(h->h_ev);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+gwi_status upload(gwi_handle h, const double* src, size_t n, double** dst, std::vector<double*>* keep) {
+  double* d = nullptr;
+  GWI_HIP(hipMalloc(&d, sizeof(double) * (n ? n : 1)));
+  keep->push_back(d);
+  if (n) GWI_HIP(hipMemcpy(d, src, sizeof(double) * n, hipMemcpyHostToDevice));
+  *dst = d;
+  return GWI_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int32_t gwi_abi_version(void) { return GWI_ABI_VERSION; }
+int32_t gwi_kernel_variants(void) { return kNumVariants; }
+const char* gwi_kernel_variant_name(int32_t i) { return (i >= 0 && i < kNumVariants) ? kVariants[i].name : nullptr; }
+
+const char* gwi_last_error(gwi_handle h) {
+  static const char* none = "";
+  static const char* null_handle = "null handle (gwi_create failed before an engine existed: no HIP device?)";
+  if (!h) return null_handle;
+  return h->err.empty() ? none : h->err.c_str();
+}
+
+void gwi_destroy(gwi_handle h) { destroy_impl(h); }
+
+gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
+                      int32_t device, gwi_handle* out) {
+  if (!out) return GWI_ERR_INVALID;
+  *out = nullptr;
+  if (!spec || !pe_cols || !inj_cols || n_ev < 0 || n_pe < 1 || n_inj < 0) return GWI_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return GWI_ERR_NO_DEVICE;
+  gwi_engine* h = new (std::nothrow) gwi_engine();
+  if (!h) return GWI_ERR_INVALID;
+  *out = h;  // returned even on failure so gwi_last_error() can explain; caller must gwi_destroy()
+  gwi_status st = validate_spec(h, spec);
+  if (st != GWI_OK) return st;
+  h->spec = *spec;
+  h->variant = find_variant(*spec);
+  if (!h->variant) {
+    std::string seq;
+    for (int t = 0; t < spec->n_terms; ++t) seq += (t ? "," : "") + std::to_string(spec->terms[t].kind);
+    return fail(h, GWI_ERR_UNSUPPORTED, "no compiled kernel for term-kind sequence [" + seq + "]; add it to kVariants in gwi_engine.hip");
+  }
+  if (device < 0) {
+    GWI_HIP(hipGetDevice(&h->device));
+  } else {
+    if (device >= n_dev) return fail(h, GWI_ERR_NO_DEVICE, "device index out of range");
+    h->device = device;
+  }
+  GWI_HIP(hipSetDevice(h->device));
+  hipDeviceProp_t prop;
+  GWI_HIP(hipGetDeviceProperties(&prop, h->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
+  GWI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
+  h->n_ev = n_ev;
+  h->n_pe = n_pe;
+  h->n_inj = n_inj;
+
+  // ---- columns -> HBM (struct-of-arrays: one contiguous fp64 array per column and sample set)
+  std::vector<const double*> tab_pe(spec->n_cols), tab_inj(spec->n_cols);
+  for (int c = 0; c < spec->n_cols; ++c) {
+    double* d;
+    if ((st = upload(h, pe_cols[c], (size_t)(n_ev * n_pe), &d, &h->d_cols_pe)) != GWI_OK) return st;
+    tab_pe[c] = d;
+    if ((st = upload(h, inj_cols[c], (size_t)n_inj, &d, &h->d_cols_inj)) != GWI_OK) return st;
+    tab_inj[c] = d;
+  }
+  GWI_HIP(hipMalloc((void**)&h->d_pe_table, sizeof(double*) * spec->n_cols));
+  GWI_HIP(hipMalloc((void**)&h->d_inj_table, sizeof(double*) * spec->n_cols));
+  GWI_HIP(hipMemcpy((void*)h->d_pe_table, tab_pe.data(), sizeof(double*) * spec->n_cols, hipMemcpyHostToDevice));
+  GWI_HIP(hipMemcpy((void*)h->d_inj_table, tab_inj.data(), sizeof(double*) * spec->n_cols, hipMemcpyHostToDevice));
+
+  // ---- normaliser grids
+  std::vector<NormD> nd(spec->n_norms ? spec->n_norms : 1);
+  for (int j = 0; j < spec->n_norms; ++j) {
+    const gwi_norm& nm = spec->norms[j];
+    NormD& d = nd[j];
+    std::memset(&d, 0, sizeof(d));
+    d.n_pts = nm.n_pts;
+    d.expo_theta = nm.expo_theta;
+    d.n_basis = nm.n_basis;
+    d.coef_off = nm.coef_off;
+    d.flags = nm.spline_flags;
+    d.expo_add = nm.expo_add;
+    d.lo = nm.lo;
+    d.hi = nm.hi;
+    double* p;
+    if ((st = upload(h, nm.tw, nm.n_pts, &p, &h->d_norm_arrays)) != GWI_OK) return st;
+    d.tw = p;
+    if (nm.lb) {
+      if ((st = upload(h, nm.lb, nm.n_pts, &p, &h->d_norm_arrays)) != GWI_OK) return st;
+      d.lb = p;
+    }
+    if (nm.expo_theta >= 0) {
+      if ((st = upload(h, nm.l1, nm.n_pts, &p, &h->d_norm_arrays)) != GWI_OK) return st;
+      d.l1 = p;
+    }
+    if (nm.n_basis > 0) {
+      if ((st = upload(h, nm.us, nm.n_pts, &p, &h->d_norm_arrays)) != GWI_OK) return st;
+      d.us = p;
+    }
+    // the spec's host pointers are not retained
+    h->spec.norms[j].tw = h->spec.norms[j].lb = h->spec.norms[j].l1 = h->spec.norms[j].us = nullptr;
+  }
+  GWI_HIP(hipMalloc(&h->d_norms, sizeof(NormD) * nd.size()));
+  GWI_HIP(hipMemcpy(h->d_norms, nd.data(), sizeof(NormD) * nd.size(), hipMemcpyHostToDevice));
+
+  // ---- launch geometry: ~2048 scan workgroups (8 per CU) unless that would make them tiny
+  long long spb = 0;
+  if (const char* env = std::getenv("GWI_SAMPLES_PER_BLOCK")) spb = std::atoll(env);
+  if (spb <= 0) {
+    const long long total = n_ev * n_pe + n_inj;
+    spb = (total + 2047) / 2048;
+  }
+  spb = ((spb + kBlock - 1) / kBlock) * kBlock;
+  if (spb < kBlock) spb = kBlock;
+  const long long n_pe_pad = ((n_pe + kBlock - 1) / kBlock) * kBlock;
+  h->chunk_pe = (int)(spb < n_pe_pad ? spb : n_pe_pad);
+  h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
+  h->chunk_inj = (int)spb;
+  h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
+  h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
+  h->rec_stride = kRecHeader + spec->n_theta;
+
+  GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
+  GWI_HIP(hipMalloc(&h->d_norm_out, sizeof(double) * (spec->n_norms ? spec->n_norms : 1)));
+  GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * 4 * (size_t)(n_ev ? n_ev : 1)));
+  GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
+  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * 4));
+  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * spec->n_theta));
+  GWI_HIP(hipHostMalloc((void**)&h->h_record, sizeof(double) * record_len(h), hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_record_dev, h->h_record, 0));
+  GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_ev_dev, h->h_ev, 0));
+  std::memset(h->h_record, 0, sizeof(double) * record_len(h));
+
+  // ---- constant part of the kernel-argument block
+  KArgs& k = h->kargs;
+  std::memset(&k, 0, sizeof(k));
+  k.pe_cols = h->d_pe_table;
+  k.inj_cols = h->d_inj_table;
+  k.norms = h->d_norms;
+  k.partials = h->d_partials;
+  k.norm_out = h->d_norm_out;
+  k.n_pe = n_pe;
+  k.n_inj = n_inj;
+  k.n_ev = (int)n_ev;
+  k.tiles_per_event = h->tiles_per_event;
+  k.chunk_pe = h->chunk_pe;
+  k.n_inj_tiles = h->n_inj_tiles;
+  k.chunk_inj = h->chunk_inj;
+  k.n_norms = spec->n_norms;
+  k.n_terms = spec->n_terms;
+  k.n_theta = spec->n_theta;
+  k.kappa_col = spec->kappa_col;
+  k.rec_stride = h->rec_stride;
+  for (int t = 0; t < spec->n_terms; ++t) {
+    const gwi_term& tm = spec->terms[t];
+    TermD& d = k.terms[t];
+    d.kind = tm.kind;
+    d.col0 = tm.cols[0];
+    d.col1 = tm.cols[1];
+    d.n_basis = tm.n_basis;
+    d.th0 = tm.theta[0];
+    d.th1 = tm.theta[1];
+    d.th2 = tm.theta[2];
+    d.th3 = tm.theta[3];
+    d.flags = tm.flags;
+    d.p0 = tm.p[0];
+    d.p1 = tm.p[1];
+    d.p2 = tm.p[2];
+    if (tm.kind == GWI_TERM_EXP_SPLINE) {
+      d.th0 = tm.coef_off;
+      d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
+    }
+  }
+  return GWI_OK;
+}
+
+gwi_status gwi_set_timing(gwi_handle h, int32_t enabled) {
+  if (!h) return GWI_ERR_INVALID;
+  h->timing = enabled != 0;
+  return GWI_OK;
+}
+
+gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]) {
+  if (!h || !ms) return GWI_ERR_INVALID;
+  for (int i = 0; i < 3; ++i) ms[i] = h->last_ms[i];
+  return GWI_OK;
+}
+
+int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
+
+gwi_status gwi_eval_partial(gwi_handle h, const double* theta, double* record_host, double* log_bfs, double* log_neffs, double* variances) {
+  if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
+  GWI_HIP(hipSetDevice(h->device));
+  gwi_status st = run_pipeline(h, theta);
+  if (st != GWI_OK) return st;
+  if (record_host) std::memcpy(record_host, h->h_record, sizeof(double) * record_len(h));
+  const size_t n = (size_t)h->n_ev;
+  // per-event sites without the global constant (added by the caller after gwi_combine)
+  if (log_bfs) std::memcpy(log_bfs, h->h_ev, sizeof(double) * n);
+  if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
+  if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
+  return GWI_OK;
+}
+
+gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, const gwi_options* opt, gwi_summary* summary, double* grad, double* norms) {
+  if (!h || !records || n_ranks < 1 || !opt) return GWI_ERR_INVALID;
+  if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
+    return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
+  if (opt->marginalize_selection && grad)
+    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+  assemble(h, records, n_ranks, opt, summary, grad, norms);
+  return GWI_OK;
+}
+
+gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs,
+                    double* variances, double* norms) {
+  if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
+  if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
+    return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
+  if (opt->marginalize_selection && grad)
+    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+  GWI_HIP(hipSetDevice(h->device));
+  gwi_status st = run_pipeline(h, theta);
+  if (st != GWI_OK) return st;
+  gwi_summary s;
+  assemble(h, h->h_record, 1, opt, &s, grad, norms);
+  if (summary) *summary = s;
+  const size_t n = (size_t)h->n_ev;
+  const double shift = s.log_norm_const - std::log((double)h->n_pe);
+  if (log_bfs)
+    for (size_t i = 0; i < n; ++i) log_bfs[i] = h->h_ev[i] + shift;  // logBF_i = logsumexp_i - log N_pe (analysis.py:80)
+  if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
+  if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
+  return GWI_OK;
+}
+
+gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, double* inj_logw) {
+  if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
+  GWI_HIP(hipSetDevice(h->device));
+  const size_t n_pe_tot = (size_t)(h->n_ev * h->n_pe), n_inj = (size_t)h->n_inj;
+  if (!h->d_logw_pe) GWI_HIP(hipMalloc(&h->d_logw_pe, sizeof(double) * (n_pe_tot ? n_pe_tot : 1)));
+  if (!h->d_logw_inj) GWI_HIP(hipMalloc(&h->d_logw_inj, sizeof(double) * (n_inj ? n_inj : 1)));
+  // normaliser values come from a regular evaluation
+  gwi_status st = run_pipeline(h, theta);
+  if (st != GWI_OK) return st;
+  double log_const = h->host_const;
+  const double* nrm = h->h_record + kRecNormOff;
+  for (int t = 0; t < h->spec.n_terms; ++t)
+    if (h->spec.terms[t].norm >= 0) log_const -= std::log(nrm[h->spec.terms[t].norm]);
+  h->kargs.logw_pe = h->d_logw_pe;
+  h->kargs.logw_inj = h->d_logw_inj;
+  st = launch_scan(h, true);
+  if (st != GWI_OK) return st;
+  GWI_HIP(hipStreamSynchronize(h->stream));
+  if (pe_logw) {
+    GWI_HIP(hipMemcpy(pe_logw, h->d_logw_pe, sizeof(double) * n_pe_tot, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_pe_tot; ++i) pe_logw[i] += log_const;
+  }
+  if (inj_logw) {
+    GWI_HIP(hipMemcpy(inj_logw, h->d_logw_inj, sizeof(double) * n_inj, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_inj; ++i) inj_logw[i] += log_const;
+  }
+  return GWI_OK;
+}
+
+}  // extern "C"

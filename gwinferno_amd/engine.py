@@ -1,0 +1,342 @@
+"""Binding of a lazy PE/injection density pair to the HIP engine.
+
+``bind()`` turns the two products built by a user's model function into the flat description of
+include/gwi_engine.h (columns, terms, normaliser grids, theta layout); ``NativePopulationLikelihood``
+owns the resulting engine handle and exposes value-and-gradient evaluations.  This is host-side
+bookkeeping only -- every per-sample operation runs in gwinferno_amd/csrc (HIP, gfx950).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .lazy import INJ, PE, Density, LazyNorm
+
+NEG_BIG = float(np.nan_to_num(-np.inf))
+
+
+class BoundModel:
+    """Flat model description + data columns, ready for gwi_create."""
+
+    def __init__(self):
+        self.col_keys = []      # dedup keys
+        self.pe_cols = []       # list of (N_ev, N_pe) arrays
+        self.inj_cols = []      # list of (N_inj,) arrays
+        self.terms = []         # dicts mirroring gwi_term
+        self.norms = []         # (GridNorm, expo_theta, coef_off)
+        self.norm_keys = []
+        self.layout = []        # [(factor_index, "scalar", k, offset) | (factor_index, "coefs", n, offset)]
+        self.n_theta = 0
+        self.kappa_col = -1
+        self.vt_norm = -1
+        self.n_ev = self.n_pe = self.n_inj = 0
+        self.log_const = 0.0    # log of scalar multipliers common to both sides
+
+    def theta_of(self, density):
+        """Current hyper-parameter values of ``density`` in this model's theta layout."""
+        theta = np.zeros(self.n_theta)
+        for fi, what, k, off in self.layout:
+            f = density.factors[fi]
+            if what == "scalar":
+                theta[off] = float(np.asarray(f.scalars[k]))
+            else:
+                theta[off : off + k] = np.asarray(f.coefs, dtype=np.float64).ravel()
+        return theta
+
+    def theta_slices(self, names):
+        """Map a list of per-layout-entry names to slices (helper for named compositions)."""
+        out = {}
+        for name, (fi, what, k, off) in zip(names, self.layout):
+            out[name] = slice(off, off + (1 if what == "scalar" else k))
+        return out
+
+
+def structure_key(pe, inj):
+    """Hashable description of everything except hyper-parameter VALUES: engines are cached on it."""
+    parts = []
+    for d in (pe, inj):
+        parts.append(tuple(f.structure() + tuple(c.key() for c in f.columns) for f in d.factors))
+        parts.append(tuple(id(a) for a in d.log_static))
+    return tuple(parts)
+
+
+def bind(pe, inj, hypervolume=None):
+    if not isinstance(pe, Density) or not isinstance(inj, Density):
+        raise TypeError("weights must be lazy densities produced by gwinferno_amd.models (dense arrays are what the engine replaces)")
+    if pe.side not in (PE, None) or inj.side not in (INJ, None):
+        raise ValueError("first argument must be the PE-sample product, second the injection product")
+    if len(pe.factors) != len(inj.factors):
+        raise ValueError("PE and injection products have different numbers of factors")
+    if len(pe.factors) > N.GWI_MAX_TERMS:
+        raise ValueError(f"at most {N.GWI_MAX_TERMS} factors are supported")
+    if abs(pe.log_const - inj.log_const) > 0:
+        raise ValueError("PE and injection products carry different constant multipliers")
+    bm = BoundModel()
+    bm.log_const = pe.log_const
+
+    # ---- shapes from the first column
+    first_pe = pe.factors[0].columns[0].values()
+    first_inj = inj.factors[0].columns[0].values()
+    bm.n_ev, bm.n_pe = first_pe.shape
+    bm.n_inj = first_inj.shape[0]
+
+    def add_column(cpe, cinj):
+        key = (cpe.key(), cinj.key())
+        if key in bm.col_keys:
+            return bm.col_keys.index(key)
+        vpe, vinj = cpe.values(), cinj.values()
+        if vpe.shape != (bm.n_ev, bm.n_pe) or vinj.shape != (bm.n_inj,):
+            raise ValueError("all PE arrays must share one (N_ev, N_pe) shape and all injection arrays one (N_inj,) shape")
+        bm.col_keys.append(key)
+        bm.pe_cols.append(vpe)
+        bm.inj_cols.append(vinj)
+        return len(bm.col_keys) - 1
+
+    # ---- theta layout (shared coefficient vectors -- the IID models -- get one block)
+    # canonical term order (sorted by kind, stable): the engine compiles one kernel per kind sequence
+    order = sorted(range(len(pe.factors)), key=lambda i: pe.factors[i].kind)
+    coef_blocks = {}
+    factor_theta = {}
+    for fi in order:
+        fp, fj = pe.factors[fi], inj.factors[fi]
+        if fp.structure() != fj.structure():
+            raise ValueError(f"factor {fi}: PE side {fp.structure()} does not match injection side {fj.structure()}")
+        slots = []
+        for k in range(len(fp.scalars)):
+            slots.append(bm.n_theta)
+            bm.layout.append((fi, "scalar", k, bm.n_theta))
+            bm.n_theta += 1
+        coef_off = -1
+        if fp.coefs is not None:
+            n = int(np.size(fp.coefs))
+            if n != fp.n_basis:
+                raise ValueError(f"factor {fi}: expected {fp.n_basis} spline coefficients, got {n}")
+            key = id(fp.coefs)
+            if key in coef_blocks:
+                coef_off = coef_blocks[key]
+            else:
+                coef_off = bm.n_theta
+                coef_blocks[key] = coef_off
+                bm.layout.append((fi, "coefs", n, coef_off))
+                bm.n_theta += n
+        factor_theta[fi] = (slots, coef_off)
+    if bm.n_theta > N.GWI_MAX_THETA:
+        raise ValueError(f"{bm.n_theta} hyper-parameters exceed GWI_MAX_THETA={N.GWI_MAX_THETA}")
+    factor_index = {id(f): i for i, f in enumerate(pe.factors)}
+    factor_index.update({id(f): i for i, f in enumerate(inj.factors)})
+
+    # ---- kappa = sum of theta-independent log factors, -inf where any static truncation excludes
+    kap_pe = np.zeros((bm.n_ev, bm.n_pe))
+    kap_inj = np.zeros(bm.n_inj)
+    with np.errstate(all="ignore"):
+        for d, kap in ((pe, kap_pe), (inj, kap_inj)):
+            kap += d.log_const  # plain scalar multipliers (e.g. the 0.5 of a symmetrised density)
+            for arr in d.log_static:
+                kap += arr
+            for f in d.factors:
+                if f.static_log is not None:
+                    kap += f.static_log
+            for f in d.factors:
+                if f.mask is not None:
+                    kap[~f.mask] = -np.inf
+            # NaN or +inf weights count as zero (tests/inference_test.py:172); a NaN / +inf kappa can
+            # only ever produce those
+            kap[~(kap < np.inf)] = -np.inf
+
+    # ---- terms
+    for fi in order:
+        fp, fj = pe.factors[fi], inj.factors[fi]
+        cols = [add_column(cp, cj) for cp, cj in zip(fp.columns, fj.columns)]
+        slots, coef_off = factor_theta[fi]
+        norm_idx = -1
+        if fp.norm is not None:
+            nkey = (id(fp.norm_owner), fp.tag) if fp.norm_owner is not None else (id(fp), fp.tag)
+            if nkey in bm.norm_keys:
+                norm_idx = bm.norm_keys.index(nkey)
+            else:
+                g = fp.norm
+                expo_theta = -1
+                if g.expo_param is not None:
+                    ref_factor, k = g.expo_param
+                    expo_theta = factor_theta[factor_index[id(ref_factor)]][0][k]
+                bm.norm_keys.append(nkey)
+                bm.norms.append((g, expo_theta, coef_off if g.n_basis > 0 else 0))
+                norm_idx = len(bm.norms) - 1
+        bm.terms.append(dict(kind=fp.kind, cols=cols, theta=slots, n_basis=fp.n_basis, coef_off=max(coef_off, 0), flags=fp.flags, norm=norm_idx, p=fp.consts,
+                             owner=fp.norm_owner))
+    if len(bm.norms) > N.GWI_MAX_NORMS:
+        raise ValueError(f"{len(bm.norms)} normalisers exceed GWI_MAX_NORMS={N.GWI_MAX_NORMS}")
+    bm.kappa_col = len(bm.pe_cols)
+    bm.pe_cols.append(kap_pe)
+    bm.inj_cols.append(kap_inj)
+    if len(bm.pe_cols) > N.GWI_MAX_COLS:
+        raise ValueError(f"{len(bm.pe_cols)} columns exceed GWI_MAX_COLS={N.GWI_MAX_COLS}")
+
+    # ---- which normaliser is the surveyed hypervolume (analysis.py:267)
+    if hypervolume is not None:
+        if not isinstance(hypervolume, LazyNorm):
+            raise TypeError("surveyed_hypervolume must come from z_model.normalization(...)")
+        for t in bm.terms:
+            if t["norm"] >= 0 and t["owner"] is hypervolume.owner:
+                bm.vt_norm = t["norm"]
+        if bm.vt_norm < 0:
+            raise ValueError("surveyed_hypervolume refers to a model that is not part of the weights")
+    return bm
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced blocks: the first ``n % world`` ranks get one extra item."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class EvalResult:
+    __slots__ = ("log_likelihood", "grad", "summary", "log_bfs", "log_neffs", "variances", "norms")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class NativePopulationLikelihood:
+    """One catalog + one model structure on one MI355X.
+
+    ``rank`` / ``world`` select this process's shard (contiguous events + injection slice,
+    SURVEY.md section 8e); the model objects must have been built from the GLOBAL arrays.
+    """
+
+    def __init__(self, pe_density, inj_density, hypervolume=None, device=-1, rank=0, world=1):
+        self.lib = N.load_library()
+        self.bound = bm = bind(pe_density, inj_density, hypervolume)
+        self.n_theta = bm.n_theta
+        self.n_ev_global = bm.n_ev
+        self.rank, self.world = rank, world
+        e0, e1 = shard_bounds(bm.n_ev, rank, world)
+        j0, j1 = shard_bounds(bm.n_inj, rank, world)
+        self.event_range, self.inj_range = (e0, e1), (j0, j1)
+        self.n_ev, self.n_pe, self.n_inj = e1 - e0, bm.n_pe, j1 - j0
+        pe_cols = [N.f64(c[e0:e1]) for c in bm.pe_cols]
+        inj_cols = [N.f64(c[j0:j1]) for c in bm.inj_cols]
+
+        spec = N.GwiSpec()
+        spec.abi_version = N.GWI_ABI_VERSION
+        spec.n_cols = len(pe_cols)
+        spec.kappa_col = bm.kappa_col
+        spec.n_theta = bm.n_theta
+        spec.n_terms = len(bm.terms)
+        spec.n_norms = len(bm.norms)
+        spec.vt_norm = bm.vt_norm
+        for i, t in enumerate(bm.terms):
+            g = spec.terms[i]
+            g.kind = t["kind"]
+            for k in range(2):
+                g.cols[k] = t["cols"][k] if k < len(t["cols"]) else -1
+            for k in range(4):
+                g.theta[k] = t["theta"][k] if k < len(t["theta"]) else -1
+            g.n_basis = t["n_basis"]
+            g.coef_off = t["coef_off"]
+            g.flags = t["flags"]
+            g.norm = t["norm"]
+            for k in range(4):
+                g.p[k] = t["p"][k] if k < len(t["p"]) else 0.0
+        self._keep = [pe_cols, inj_cols]
+        for j, (g, expo_theta, coef_off) in enumerate(bm.norms):
+            nm = spec.norms[j]
+            nm.n_pts = len(g.tw)
+            nm.expo_theta = expo_theta
+            nm.n_basis = g.n_basis
+            nm.coef_off = coef_off
+            nm.spline_flags = g.spline_flags
+            nm.expo_add = g.expo_add
+            nm.lo, nm.hi = g.lo, g.hi
+            nm.tw = N.as_dp(g.tw)
+            nm.lb = N.as_dp(g.lb)
+            nm.l1 = N.as_dp(g.l1)
+            nm.us = N.as_dp(g.us)
+        pe_ptrs = (N._DP * len(pe_cols))(*[N.as_dp(c) for c in pe_cols])
+        inj_ptrs = (N._DP * len(inj_cols))(*[N.as_dp(c) for c in inj_cols])
+        handle = C.c_void_p()
+        st = self.lib.gwi_create(C.byref(spec), pe_ptrs, self.n_ev, self.n_pe, inj_ptrs, self.n_inj, device, C.byref(handle))
+        self.handle = handle
+        if st != 0:
+            msg = self.lib.gwi_last_error(handle).decode() if handle else "no HIP device visible (gwi_create returned before allocating an engine)"
+            if handle:
+                self.lib.gwi_destroy(handle)
+                self.handle = None
+            raise N.NativeEngineError(f"gwi_create failed: {N.STATUS_NAMES.get(st, st)}: {msg}")
+        self._keep = None  # the engine copied everything it needs
+        self.bytes_per_sample = 8 * len(pe_cols)
+        self.partial_len = int(self.lib.gwi_partial_len(self.handle))
+
+    # ---------------------------------------------------------------------------------------------
+    def _check(self, st):
+        if st != 0:
+            raise N.NativeEngineError(f"{N.STATUS_NAMES.get(st, st)}: {self.lib.gwi_last_error(self.handle).decode()}")
+
+    def _options(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        o = N.GwiOptions()
+        o.n_obs = float(self.n_ev_global if nobs is None else nobs)
+        o.total_inj = float(total_inj)
+        o.marginalize_selection = int(bool(marginalize_selection))
+        o.min_neff_cut = int(bool(min_neff_cut))
+        o.max_variance_cut = int(bool(max_variance_cut))
+        return o
+
+    def evaluate(self, theta, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True):
+        """Value, gradient and diagnostics of ``hierarchical_likelihood`` at ``theta`` (single device)."""
+        theta = N.f64(theta)
+        if theta.shape != (self.n_theta,):
+            raise ValueError(f"theta must have shape ({self.n_theta},)")
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        summ = N.GwiSummary()
+        grad = np.zeros(self.n_theta) if want_grad else None
+        lb, ln, lv = np.zeros(self.n_ev), np.zeros(self.n_ev), np.zeros(self.n_ev)
+        norms = np.zeros(max(len(self.bound.norms), 1))
+        self._check(self.lib.gwi_eval(self.handle, N.as_dp(theta), C.byref(opt), C.byref(summ), N.as_dp(grad), N.as_dp(lb), N.as_dp(ln), N.as_dp(lv), N.as_dp(norms)))
+        return EvalResult(log_likelihood=summ.log_likelihood, grad=grad, summary=summ, log_bfs=lb, log_neffs=ln, variances=lv, norms=norms[: len(self.bound.norms)])
+
+    def eval_partial(self, theta):
+        """This rank's partial record (+ local per-event arrays without the global constant)."""
+        theta = N.f64(theta)
+        rec = np.zeros(self.partial_len)
+        lb, ln, lv = np.zeros(self.n_ev), np.zeros(self.n_ev), np.zeros(self.n_ev)
+        self._check(self.lib.gwi_eval_partial(self.handle, N.as_dp(theta), N.as_dp(rec), N.as_dp(lb), N.as_dp(ln), N.as_dp(lv)))
+        return rec, lb, ln, lv
+
+    def combine(self, records, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True):
+        records = N.f64(records).reshape(-1, self.partial_len)
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        summ = N.GwiSummary()
+        grad = np.zeros(self.n_theta) if want_grad else None
+        norms = np.zeros(max(len(self.bound.norms), 1))
+        self._check(self.lib.gwi_combine(self.handle, N.as_dp(records), records.shape[0], C.byref(opt), C.byref(summ), N.as_dp(grad), N.as_dp(norms)))
+        return EvalResult(log_likelihood=summ.log_likelihood, grad=grad, summary=summ, log_bfs=None, log_neffs=None, variances=None, norms=norms[: len(self.bound.norms)])
+
+    def log_weights(self, theta):
+        """Per-sample log importance weights (diagnostic; parity with the arrays the reference's
+        model function builds, tests/inference_test.py:174-175)."""
+        theta = N.f64(theta)
+        pe = np.zeros((self.n_ev, self.n_pe))
+        inj = np.zeros(self.n_inj)
+        self._check(self.lib.gwi_log_weights(self.handle, N.as_dp(theta), N.as_dp(pe), N.as_dp(inj)))
+        return pe, inj
+
+    def set_timing(self, on=True):
+        self._check(self.lib.gwi_set_timing(self.handle, int(on)))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 3)()
+        self._check(self.lib.gwi_last_kernel_ms(self.handle, ms))
+        return [float(x) for x in ms]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gwi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

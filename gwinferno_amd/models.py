@@ -1,0 +1,351 @@
+"""Population models with the reference's names, signatures and calling conventions, returning
+lazy :class:`~gwinferno_amd.lazy.Density` objects instead of dense arrays.
+
+Mirrors (paths relative to the reference root):
+  gwinferno/distributions.py                      powerlaw_pdf, truncnorm_pdf, betadist
+  gwinferno/models/parametric/parametric.py       mass / spin functions, PowerlawRedshiftModel
+  gwinferno/models/bsplines/single.py             Base1DBSplineModel and its subclasses
+  gwinferno/models/bsplines/separable.py          products of 1-D models
+  gwinferno/models/spline_perturbation.py         PowerlawSplineRedshiftModel
+
+Construction does the reference's one-time work (masks, zmin/zmax, dVc/dz per sample, grids) in
+NumPy; the per-step arithmetic happens in the HIP engine.
+"""
+import numpy as np
+
+from . import _native as N
+from .cosmology import planck15_lvk
+from .interpolation import BSpline, LogXBSpline, LogXLogYBSpline, LogYBSpline, trapezoid_weights
+from .lazy import INJ, PE, Column, Density, Factor, GridNorm, LazyNorm, side_of
+
+__all__ = [
+    "powerlaw_pdf", "truncnorm_pdf", "betadist",
+    "powerlaw_primary_ratio_pdf", "plpeak_primary_pdf", "plpeak_primary_ratio_pdf",
+    "beta_spin_magnitude", "iid_spin_magnitude", "independent_spin_magnitude_beta_dist",
+    "mixture_isoalign_spin_tilt", "iid_spin_tilt", "independent_spin_tilt",
+    "PowerlawRedshiftModel", "PowerlawSplineRedshiftModel",
+    "Base1DBSplineModel", "BSplineMass", "BSplineRatio", "BSplineSpinMagnitude", "BSplineSpinTilt",
+    "BSplineIIDSpinMagnitudes", "BSplineIndependentSpinMagnitudes", "BSplineIIDSpinTilts", "BSplineIndependentSpinTilts",
+    "BSplinePrimaryPowerlawRatio", "PLPeakPrimaryBSplineRatio", "BSplinePrimaryBSplineRatio",
+]
+
+
+def _f(x):
+    return np.asarray(x, dtype=np.float64)
+
+
+# ================================================================================================
+# closed-form densities (gwinferno/distributions.py)
+# ================================================================================================
+def powerlaw_pdf(xx, alpha, low, high, floor=0.0):
+    """distributions.py:100-119.  ``low`` may be a scalar (fixed truncation) or a per-sample array
+    (``mmin / m1``, parametric.py:28); the array form requires ``high == 1``."""
+    if floor != 0.0:
+        raise NotImplementedError("floor != 0 is not used by any reference model")
+    xx = _f(xx)
+    side = side_of(xx)
+    with np.errstate(all="ignore"):
+        if np.ndim(low) == 0:
+            mask = ~((xx < low) | (xx > high))
+            return Density([Factor(N.TERM_POWERLAW, side, [Column("log", xx)], [alpha], consts=(low, high), mask=mask)], side)
+        if float(high) != 1.0:
+            raise NotImplementedError("per-sample lower bound is implemented for high == 1 (the reference's only use)")
+        low = _f(low)
+        mask = ~((xx < low) | (xx > high))
+        # log r = 0 - (-log low)
+        return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", xx), Column("neglog", low)], [alpha], consts=(0.0,), mask=mask)], side)
+
+
+def _powerlaw_ratio(q, m1, beta, mmin):
+    """powerlaw_pdf(q, beta, mmin/m1, 1) sharing the log m1 column (parametric.py:28, :40; separable.py:364)."""
+    q, m1 = _f(q), _f(m1)
+    side = side_of(q)
+    with np.errstate(all="ignore"):
+        low = mmin / m1
+        mask = ~((q < low) | (q > 1))
+    return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", q), Column("log", m1)], [beta], consts=(np.log(mmin),), mask=mask)], side)
+
+
+def truncnorm_pdf(xx, mu, sig, low, high, log=False):
+    """distributions.py:122-143 (log=False branch)."""
+    if log:
+        raise NotImplementedError("log-normal branch is not used by any reference model")
+    xx = _f(xx)
+    side = side_of(xx)
+    with np.errstate(all="ignore"):
+        mask = ~((xx > high) | (xx < low))
+    return Density([Factor(N.TERM_TRUNCNORM, side, [Column("id", xx)], [mu, sig], consts=(low, high), mask=mask)], side)
+
+
+def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
+    """distributions.py:146-162 (scale == 1)."""
+    if float(scale) != 1.0 or floor != 0.0:
+        raise NotImplementedError("scale != 1 / floor != 0 are not used by any reference model")
+    xx = _f(xx)
+    side = side_of(xx)
+    with np.errstate(all="ignore"):
+        mask = (xx <= scale) & (xx >= 0)
+    return Density([Factor(N.TERM_BETA, side, [Column("log", xx), Column("log1m", xx)], [alpha, beta], mask=mask)], side)
+
+
+# ================================================================================================
+# parametric models (gwinferno/models/parametric/parametric.py)
+# ================================================================================================
+def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
+    """parametric.py:49-53 (delta=None)."""
+    if delta is not None:
+        raise NotImplementedError("low-mass smoothing (delta) is not used by the BASELINE configurations")
+    m1 = _f(m1)
+    side = side_of(m1)
+    with np.errstate(all="ignore"):
+        mask = ~((m1 < mmin) | (m1 > mmax))
+    return Density([Factor(N.TERM_PLPEAK, side, [Column("id", m1), Column("log", m1)], [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
+
+
+def powerlaw_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax):
+    """parametric.py:27-30."""
+    return _powerlaw_ratio(q, m1, beta, mmin) * powerlaw_pdf(m1, alpha, mmin, mmax)
+
+
+def plpeak_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax, mpp, sigpp, lam, delta=None):
+    """parametric.py:39-46 (delta=None)."""
+    return _powerlaw_ratio(q, m1, beta, mmin) * plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=delta)
+
+
+def beta_spin_magnitude(a, alpha, beta, amax=1):
+    return betadist(a, alpha, beta, scale=amax)  # parametric.py:63-64
+
+
+def iid_spin_magnitude(a1, a2, alpha_mag, beta_mag, amax=1):
+    return betadist(a1, alpha_mag, beta_mag, scale=amax) * betadist(a2, alpha_mag, beta_mag, scale=amax)  # :67-68
+
+
+def independent_spin_magnitude_beta_dist(a1, a2, alpha_mag1, beta_mag1, alpha_mag2, beta_mag2, amax1=1, amax2=1):
+    return betadist(a1, alpha_mag1, beta_mag1, scale=amax1) * betadist(a2, alpha_mag2, beta_mag2, scale=amax2)  # :71-81
+
+
+def mixture_isoalign_spin_tilt(ct, xi_tilt, sigma_tilt):
+    """parametric.py:84-86."""
+    ct = _f(ct)
+    side = side_of(ct)
+    with np.errstate(all="ignore"):
+        mask = ~((ct > 1) | (ct < -1))
+    return Density([Factor(N.TERM_TILT_MIXTURE, side, [Column("id", ct)], [xi_tilt, sigma_tilt], mask=mask)], side)
+
+
+def iid_spin_tilt(ct1, ct2, xi_tilt, sigma_tilt):
+    return mixture_isoalign_spin_tilt(ct1, xi_tilt, sigma_tilt) * mixture_isoalign_spin_tilt(ct2, xi_tilt, sigma_tilt)  # :89-90
+
+
+def independent_spin_tilt(ct1, ct2, xi_tilt_1, xi_tilt_2, sigma_tilt1, sigma_tilt2):
+    return mixture_isoalign_spin_tilt(ct1, xi_tilt_1, sigma_tilt1) * mixture_isoalign_spin_tilt(ct2, xi_tilt_2, sigma_tilt2)  # :93-94
+
+
+class PowerlawRedshiftModel(object):
+    """parametric.py:112-145.  ``zmin``/``zmax`` come from the GLOBAL PE and injection arrays
+    (:114-115) -- construct the model before sharding a catalog across GPUs."""
+
+    def __init__(self, z_pe, z_inj):
+        cosmo = planck15_lvk()
+        z_pe, z_inj = _f(z_pe), _f(z_inj)
+        self.zmin = max(np.min(z_pe), np.min(z_inj))
+        self.zmax = min(np.max(z_pe), np.max(z_inj))
+        self.zs = np.linspace(self.zmin, self.zmax, 1000)
+        self.dVdz_ = cosmo.dVc_dz(self.zs)
+        self._z = {PE: z_pe, INJ: z_inj}
+        self.dVdzs = [cosmo.dVc_dz(z_inj), cosmo.dVc_dz(z_pe)]
+        with np.errstate(all="ignore"):
+            self._log_dVdz = {PE: np.log(self.dVdzs[1]), INJ: np.log(self.dVdzs[0])}
+            self._grid_lb = np.log(self.dVdz_)
+            self._grid_l1 = np.log(1.0 + self.zs)
+        self._grid_tw = trapezoid_weights(self.zs)
+
+    def _side_data(self, z):
+        side = side_of(z)
+        z = _f(z)
+        if z.shape != self._z[side].shape:
+            raise ValueError("z must be the array the model was constructed with (the reference looks its dVc/dz table up by rank, parametric.py:139-140)")
+        return side, self._z[side]
+
+    def _powerlaw_factor(self, z, lamb):
+        side, zz = self._side_data(z)
+        with np.errstate(all="ignore"):
+            mask = zz <= self.zmax
+        return Factor(N.TERM_POWERLAW_REDSHIFT, side, [Column("log1p", zz)], [lamb], mask=mask, static_log=self._log_dVdz[side], owner=self, tag="plz")
+
+    def normalization(self, lamb):
+        return LazyNorm(self, [lamb])
+
+    def __call__(self, z, lamb):
+        f = self._powerlaw_factor(z, lamb)
+        f.norm = GridNorm(self._grid_tw, lb=self._grid_lb, l1=self._grid_l1, expo_param=(f, 0), expo_add=-1.0)
+        return Density([f], f.side)
+
+
+class PowerlawSplineRedshiftModel(PowerlawRedshiftModel):
+    """models/spline_perturbation.py:304-372: power law x exp(B-spline in log z) with an
+    un-normalised LogXBSpline on (zmin, zmax) (:317) whose bases are 0 outside the domain."""
+
+    def __init__(self, n_splines, z_pe, z_inj, basis=LogXBSpline):
+        super().__init__(z_pe, z_inj)
+        if basis is not LogXBSpline:
+            raise NotImplementedError("only the default LogXBSpline basis is implemented")
+        self.n_splines = int(n_splines)
+        self.interpolator = LogXBSpline(self.n_splines, xrange=(self.zmin, self.zmax), k=4, normalize=False)
+        self._grid_us = self.interpolator.coordinate(self.zs)
+
+    def normalization(self, lamb, cs):
+        return LazyNorm(self, [lamb], cs)
+
+    def __call__(self, z, lamb, cs):
+        pl = self._powerlaw_factor(z, lamb)
+        it = self.interpolator
+        sp = Factor(N.TERM_EXP_SPLINE, pl.side, [Column("log", self._z[pl.side])], coefs=cs, consts=(it.lo, it.hi), n_basis=it.N,
+                    flags=N.SPLINE_OUTSIDE_ZERO_EXPONENT, owner=self, tag="zspline")
+        sp.norm = GridNorm(self._grid_tw, lb=self._grid_lb, l1=self._grid_l1, expo_param=(pl, 0), expo_add=-1.0, us=self._grid_us, n_basis=it.N, lo=it.lo,
+                           hi=it.hi, spline_flags=N.SPLINE_OUTSIDE_ZERO_EXPONENT)
+        return Density([pl, sp], pl.side)
+
+
+# ================================================================================================
+# 1-D B-spline models (gwinferno/models/bsplines/single.py)
+# ================================================================================================
+class Base1DBSplineModel(object):
+    """single.py:16-128.  Only exponentiated bases (LogYBSpline, LogXLogYBSpline) are implemented:
+    they are the defaults of every mass / ratio / spin model (:151, :185, :344, :384)."""
+
+    def __init__(self, n_splines, xx, xx_inj, xrange=(0.0, 1.0), degree=3, basis=BSpline, **kwargs):
+        if degree != 3:
+            raise NotImplementedError("only cubic splines are implemented")
+        if basis not in (LogYBSpline, LogXLogYBSpline):
+            raise NotImplementedError(f"basis {getattr(basis, '__name__', basis)} is not implemented for 1-D density models (LogYBSpline / LogXLogYBSpline are)")
+        self.n_splines = int(n_splines)
+        self.xmin, self.xmax = xrange
+        self.degree = degree
+        self.interpolator = basis(n_splines, xrange=xrange, k=degree + 1, **kwargs)
+        it = self.interpolator
+        self._x = {PE: _f(xx), INJ: _f(xx_inj)}
+        self._mask = {}
+        self._coord = {}
+        for side, x in self._x.items():
+            with np.errstate(all="ignore"):
+                valid = (x >= self.xmin) & (x <= self.xmax)  # single.py:54-55
+                coord = it.coordinate(x)
+                valid = valid & ~it.outside(coord)           # -inf columns of the log-Y bases (:407, :449)
+            self._mask[side] = valid
+            # excluded samples never reach the spline (kappa = -inf); park them inside the domain
+            self._coord[side] = np.ascontiguousarray(np.where(valid, coord, it.lo))
+        self._norm = None
+        if it.normalize:
+            tw, us = it.grid_tables()
+            self._norm = GridNorm(tw, us=us, n_basis=it.N, lo=it.lo, hi=it.hi)
+        self.scale = 1.0
+
+    def _factor(self, coefs, pe_samples):
+        side = PE if pe_samples else INJ
+        it = self.interpolator
+        return Factor(N.TERM_EXP_SPLINE, side, [Column("id", self._coord[side])], coefs=coefs, consts=(it.lo, it.hi), n_basis=it.N, mask=self._mask[side],
+                      norm=self._norm, owner=self)
+
+    def __call__(self, coefs, pe_samples=True):
+        side = PE if pe_samples else INJ
+        d = Density([self._factor(coefs, pe_samples)], side)
+        return d if self.scale == 1.0 else d * self.scale
+
+
+class BSplineSpinMagnitude(Base1DBSplineModel):
+    def __init__(self, n_splines, a, a_inj, basis=LogYBSpline, **kwargs):  # single.py:131-162
+        xrange = kwargs.pop("xrange", (0.0, 1.0))
+        super().__init__(n_splines, a, a_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+class BSplineSpinTilt(Base1DBSplineModel):
+    def __init__(self, n_splines, ct, ct_inj, basis=LogYBSpline, **kwargs):  # single.py:165-196
+        xrange = kwargs.pop("xrange", (-1.0, 1.0))
+        super().__init__(n_splines, ct, ct_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+class BSplineRatio(Base1DBSplineModel):
+    def __init__(self, n_splines, q, q_inj, qmin=0, basis=LogYBSpline, **kwargs):  # single.py:321-355
+        xrange = kwargs.pop("xrange", (qmin, 1))
+        super().__init__(n_splines, q, q_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+class BSplineMass(Base1DBSplineModel):
+    def __init__(self, n_splines, m, m_inj, mmin=2, mmax=100, basis=LogXLogYBSpline, **kwargs):  # single.py:358-395
+        xrange = kwargs.pop("xrange", (mmin, mmax))
+        super().__init__(n_splines, m, m_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+# ================================================================================================
+# separable products (gwinferno/models/bsplines/separable.py)
+# ================================================================================================
+class _PairModel(object):
+    primary_cls = secondary_cls = None
+
+    def _pair(self, c1, c2, pe_samples):
+        return self.primary_model(c1, pe_samples=pe_samples) * self.secondary_model(c2, pe_samples=pe_samples)
+
+
+class BSplineIIDSpinMagnitudes(_PairModel):
+    def __init__(self, n_splines, a1, a2, a1_inj, a2_inj, **kwargs):  # separable.py:17-79
+        self.primary_model = BSplineSpinMagnitude(n_splines=n_splines, a=a1, a_inj=a1_inj, **kwargs)
+        self.secondary_model = BSplineSpinMagnitude(n_splines=n_splines, a=a2, a_inj=a2_inj, **kwargs)
+
+    def __call__(self, coefs, pe_samples=True):
+        return self._pair(coefs, coefs, pe_samples)
+
+
+class BSplineIndependentSpinMagnitudes(_PairModel):
+    def __init__(self, n_splines1, n_splines2, a1, a2, a1_inj, a2_inj, kwargs1={}, kwargs2={}, **kwargs):  # separable.py:82-153
+        self.primary_model = BSplineSpinMagnitude(n_splines=n_splines1, a=a1, a_inj=a1_inj, **kwargs1, **kwargs)
+        self.secondary_model = BSplineSpinMagnitude(n_splines=n_splines2, a=a2, a_inj=a2_inj, **kwargs2, **kwargs)
+
+    def __call__(self, pcoefs, scoefs, pe_samples=True):
+        return self._pair(pcoefs, scoefs, pe_samples)
+
+
+class BSplineIIDSpinTilts(_PairModel):
+    def __init__(self, n_splines, ct1, ct2, ct1_inj, ct2_inj, **kwargs):  # separable.py:156-218
+        self.primary_model = BSplineSpinTilt(n_splines=n_splines, ct=ct1, ct_inj=ct1_inj, **kwargs)
+        self.secondary_model = BSplineSpinTilt(n_splines=n_splines, ct=ct2, ct_inj=ct2_inj, **kwargs)
+
+    def __call__(self, coefs, pe_samples=True):
+        return self._pair(coefs, coefs, pe_samples)
+
+
+class BSplineIndependentSpinTilts(_PairModel):
+    def __init__(self, n_splines1, n_splines2, ct1, ct2, ct1_inj, ct2_inj, kwargs1={}, kwargs2={}, **kwargs):  # separable.py:221-292
+        self.primary_model = BSplineSpinTilt(n_splines=n_splines1, ct=ct1, ct_inj=ct1_inj, **kwargs1, **kwargs)
+        self.secondary_model = BSplineSpinTilt(n_splines=n_splines2, ct=ct2, ct_inj=ct2_inj, **kwargs2, **kwargs)
+
+    def __call__(self, pcoefs, scoefs, pe_samples=True):
+        return self._pair(pcoefs, scoefs, pe_samples)
+
+
+class BSplinePrimaryPowerlawRatio(object):
+    def __init__(self, n_splines, m1, m1_inj, mmin=2, mmax=100, **kwargs):  # separable.py:295-365
+        self.primary_model = BSplineMass(n_splines, m1, m1_inj, mmin=mmin, mmax=mmax, **kwargs)
+
+    def __call__(self, m1, q, beta, mmin, coefs, pe_samples=True):
+        p_m1 = self.primary_model(coefs, pe_samples=pe_samples)
+        return p_m1 * _powerlaw_ratio(q, m1, beta, mmin)  # separable.py:363-365
+
+
+class PLPeakPrimaryBSplineRatio(object):
+    def __init__(self, n_splines, q, q_inj, **kwargs):  # separable.py:368-443
+        self.ratio_model = BSplineRatio(n_splines, q, q_inj, **kwargs)
+
+    def __call__(self, m1, alpha, mmin, mmax, peak_mean, peak_sd, peak_frac, coefs, pe_samples=True):
+        p_q = self.ratio_model(coefs, pe_samples=pe_samples)
+        return plpeak_primary_pdf(m1, alpha, mmin, mmax, peak_mean, peak_sd, peak_frac) * p_q  # separable.py:441-443
+
+
+class BSplinePrimaryBSplineRatio(object):
+    def __init__(self, n_splines_m, n_splines_q, m1, m1_inj, q, q_inj, mmax=100.0, m1min=3.0, m2min=3.0, kwargs_m={}, kwargs_q={}, **kwargs):
+        # separable.py:446-530; q domain (m2min/mmax, 1) :508
+        self.primary_model = BSplineMass(n_splines_m, m1, m1_inj, mmin=m1min, mmax=mmax, **kwargs_m, **kwargs)
+        self.ratio_model = BSplineRatio(n_splines_q, q, q_inj, qmin=m2min / mmax, **kwargs_q, **kwargs)
+
+    def __call__(self, mcoefs, qcoefs, pe_samples=True):
+        return self.primary_model(mcoefs, pe_samples=pe_samples) * self.ratio_model(qcoefs, pe_samples=pe_samples)

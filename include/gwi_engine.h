@@ -1,0 +1,209 @@
+/* gwi_engine.h -- C ABI of the MI355X-native hierarchical population-likelihood engine.
+ *
+ * GWInferno (the reference) has no FFI layer: its hot path is a set of Python calling
+ * conventions.  This header is the C-ABI seam a binding would target; every
+ * entry point names the reference interface it stands in for (paths relative to the reference
+ * root).  The library behind it is gwinferno_amd/_lib/libgwi_engine.so (hand-written HIP for
+ * gfx950); there is NO CPU fallback -- without a usable GPU gwi_create() fails with
+ * GWI_ERR_NO_DEVICE.
+ *
+ * Data model
+ *   A *catalog* is two sample sets that share one column schema:
+ *     PE set         n_ev x n_pe samples, event-major (pedict[param] : (N_ev, N_pe),
+ *                    gwinferno/pipeline/utils.py:82-84)
+ *     injection set  n_inj samples        (injdict[param] : (N_inj,), pipeline/utils.py:86)
+ *   Columns are float64 and hold per-sample quantities that do not depend on the
+ *   hyper-parameters (log m1, log q, log(1+z), spline coordinates, ...).  One column, `kappa`,
+ *   holds log(dVc/dz) - log(prior) with -inf for samples any static truncation excludes
+ *   (models/bsplines/single.py:54-55, distributions.py:119,143,162, parametric.py:141-145,
+ *   tests/inference_test.py:172).
+ *   A *model* is a product of terms (gwi_term); each term reads <= 2 columns and a few entries of
+ *   the flat hyper-parameter vector theta.  Grid normalisers (interpolation.py:280-291,
+ *   parametric.py:123-124, spline_perturbation.py:323-336) are described by gwi_norm.
+ *
+ * Threading: one handle = one device + one HIP stream; gwi_eval* are not re-entrant per handle;
+ * distinct handles are independent.  Ownership: the caller owns every host buffer passed in or
+ * out; the engine copies inputs during gwi_create and owns all device memory.  Errors: integer
+ * status, never C++ exceptions; non-finite likelihood values are VALUES (reference semantics,
+ * jnp.nan_to_num at pipeline/analysis.py:280-315), not errors.
+ */
+#ifndef GWI_ENGINE_H
+#define GWI_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWI_ABI_VERSION 1
+#define GWI_MAX_TERMS 12
+#define GWI_MAX_THETA 160
+#define GWI_MAX_NORMS 8
+#define GWI_MAX_COLS 16
+
+typedef int32_t gwi_status;
+enum {
+  GWI_OK = 0,
+  GWI_ERR_INVALID = -1,     /* malformed spec / argument */
+  GWI_ERR_NO_DEVICE = -2,   /* no usable gfx950 device: the engine never falls back to the CPU */
+  GWI_ERR_HIP = -3,         /* a HIP runtime call failed; see gwi_last_error() */
+  GWI_ERR_UNSUPPORTED = -4, /* term sequence has no compiled kernel */
+  GWI_ERR_TIMEOUT = -5
+};
+
+/* Term kinds.  `cols[]` index the catalog's column table, `theta[]` index the flat
+ * hyper-parameter vector, `p[]` are fixed constants. */
+enum {
+  /* x^alpha on the fixed interval [lo,hi]           distributions.py:100-119 (scalar bounds)
+   * cols[0]=log x; theta[0]=alpha; p[0]=lo, p[1]=hi */
+  GWI_TERM_POWERLAW = 1,
+  /* (1-lam) PL(x;alpha,lo,hi) + lam TN(x;mpp,sigpp,lo,hi)   parametric.py:49-53 (delta=None)
+   * cols[0]=x, cols[1]=log x; theta = alpha, mpp, sigpp, lam; p[0]=lo, p[1]=hi */
+  GWI_TERM_PLPEAK = 2,
+  /* q^beta on [mmin/m1, 1]: powerlaw_pdf(q, beta, mmin/m1, 1)   parametric.py:28,40; separable.py:364
+   * cols[0]=log q, cols[1]=log m1; theta[0]=beta; p[0]=log(mmin) */
+  GWI_TERM_POWERLAW_RATIO = 3,
+  /* Beta(a; alpha, beta) on [0, 1]                  distributions.py:146-162, parametric.py:63-81
+   * cols[0]=log a, cols[1]=log(1-a); theta = alpha, beta */
+  GWI_TERM_BETA = 4,
+  /* (1-xi)/2 + xi TN(ct; 1, sigma, -1, 1)           parametric.py:84-86
+   * cols[0]=cos tilt; theta = xi, sigma */
+  GWI_TERM_TILT_MIXTURE = 5,
+  /* dVc/dz (1+z)^(lamb-1) / Z(lamb)                 parametric.py:112-145
+   * cols[0]=log(1+z) (log dVc/dz lives in kappa); theta[0]=lamb; norm = grid normaliser id */
+  GWI_TERM_POWERLAW_REDSHIFT = 6,
+  /* exp(sum_k c_k B_k(x)) [/ Z(c)] on uniform cubic B-splines   interpolation.py:360-449,
+   * models/bsplines/single.py:77-109, spline_perturbation.py:352
+   * cols[0]=spline coordinate (x or log x); coef_off/n_basis; p[0]=lo, p[1]=hi of the coordinate;
+   * flags: GWI_SPLINE_OUTSIDE_ZERO_EXPONENT; norm = grid normaliser id or -1 */
+  GWI_TERM_EXP_SPLINE = 7,
+  /* truncated normal TN(x; mu, sigma, lo, hi)       distributions.py:122-143 (log=False)
+   * cols[0]=x; theta = mu, sigma; p[0]=lo, p[1]=hi */
+  GWI_TERM_TRUNCNORM = 8
+};
+
+/* EXP_SPLINE flag: outside [lo,hi] the basis is 0 (BSpline/LogXBSpline.bases,
+ * interpolation.py:175) so the factor is exp(0)=1, instead of the sample being excluded
+ * (LogY bases, :407,:449 -- those are folded into kappa by the caller). */
+#define GWI_SPLINE_OUTSIDE_ZERO_EXPONENT 1
+
+typedef struct {
+  int32_t kind;
+  int32_t cols[2];
+  int32_t theta[4];
+  int32_t n_basis;  /* EXP_SPLINE */
+  int32_t coef_off; /* EXP_SPLINE: theta offset of c_0 */
+  int32_t flags;
+  int32_t norm;     /* index into gwi_spec.norms of the normaliser dividing this term, or -1 */
+  int32_t reserved;
+  double p[4];
+} gwi_term;
+
+/* Grid normaliser  Z = sum_g tw[g] * exp( lb[g] + (theta[expo_theta]+expo_add) * l1[g]
+ *                                        + sum_k theta[coef_off+k] B_k(us[g]) )
+ * tw = trapezoid weights of the reference's grid (0 where the reference's integrand is masked). */
+typedef struct {
+  int32_t n_pts;
+  int32_t expo_theta; /* -1: no power-law factor */
+  int32_t n_basis;    /* 0: no spline factor */
+  int32_t coef_off;
+  int32_t spline_flags;
+  int32_t reserved;
+  double expo_add;
+  double lo, hi;      /* spline coordinate domain */
+  const double* tw;
+  const double* lb;   /* may be NULL (zeros) */
+  const double* l1;   /* may be NULL iff expo_theta < 0 */
+  const double* us;   /* may be NULL iff n_basis == 0 */
+} gwi_norm;
+
+typedef struct {
+  int32_t abi_version; /* GWI_ABI_VERSION */
+  int32_t n_cols;
+  int32_t kappa_col;
+  int32_t n_theta;
+  int32_t n_terms;
+  int32_t n_norms;
+  int32_t vt_norm;     /* normaliser reported as `surveyed_hypervolume` (analysis.py:267), or -1 */
+  int32_t reserved;
+  gwi_term terms[GWI_MAX_TERMS];
+  gwi_norm norms[GWI_MAX_NORMS];
+} gwi_spec;
+
+/* Likelihood options == keyword arguments of hierarchical_likelihood (analysis.py:139-163). */
+typedef struct {
+  double n_obs;        /* Nobs (global number of events) */
+  double total_inj;    /* total_inj */
+  int32_t marginalize_selection;
+  int32_t min_neff_cut;
+  int32_t max_variance_cut;
+  int32_t reserved;
+} gwi_options;
+
+/* Scalar results of one evaluation; names follow the numpyro sites of analysis.py:260-319. */
+typedef struct {
+  double log_likelihood;      /* numpyro.factor("log_likelihood") :319 (after every cut) */
+  double log_l;               /* site "log_l" :284-291 */
+  double sum_logBFs;          /* :282 */
+  double selection_factor;    /* :278-281 */
+  double log_det_eff;         /* log mu before marginalisation / cuts :259 */
+  double log_nEff_inj;        /* :260 */
+  double variance_log_detection_efficiency; /* :265 */
+  double variance_log_likelihood;           /* :305-308 */
+  double min_log_nEff;        /* min_i log n_eff_i (:295) */
+  double surveyed_hypervolume_norm; /* Z of spec.vt_norm (raw; the site divides by 1e9, x Tobs) */
+  double log_norm_const;      /* sum of sample-independent log-normalisers folded out of the scan */
+  double reserved[5];
+} gwi_summary;
+
+typedef struct gwi_engine* gwi_handle;
+
+/* Build an engine for one catalog + model.  Stands in for the reference's model construction
+ * (Base1DBSplineModel.__init__, single.py:35-58; PowerlawRedshiftModel.__init__,
+ * parametric.py:113-121): copies the columns to HBM once.  `pe_cols[c]` has n_ev*n_pe entries
+ * (event-major), `inj_cols[c]` n_inj.  device < 0 selects the current HIP device. */
+gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe,
+                      const double* const* inj_cols, int64_t n_inj, int32_t device, gwi_handle* out);
+
+/* One value-and-gradient evaluation == one execution of the user's NumPyro model body ending in
+ * hierarchical_likelihood(...) (analysis.py:139-319) under jit(value_and_grad)
+ * (tests/inference_test.py:320-326).  theta has spec.n_theta entries.  Nullable outputs:
+ * grad[n_theta] = d log_likelihood / d theta; log_bfs / log_neffs / variances [n_ev] = sites
+ * "logBFs", "log_nEffs", "variance_log_BFs"; norms[n_norms] = normaliser values Z. */
+gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
+                    double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
+
+/* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the
+ * reference passes to hierarchical_likelihood as pe_weights / inj_weights (tests/inference_test.py:
+ * 174-175).  Diagnostic / parity entry point; not used on the sampling path. */
+gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, double* inj_logw);
+
+/* Multi-GPU (one process per GPU): each rank's engine holds a contiguous block of events and a
+ * slice of the injections.  gwi_eval_partial() runs the scan and leaves this rank's partial
+ * record (gwi_partial_len() doubles) in `record`; the caller exchanges records (RCCL all-gather
+ * over xGMI) and every rank calls gwi_combine() on the gathered buffer. */
+int64_t gwi_partial_len(gwi_handle h);
+gwi_status gwi_eval_partial(gwi_handle h, const double* theta, double* record_host, double* log_bfs,
+                            double* log_neffs, double* variances);
+gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, const gwi_options* opt,
+                       gwi_summary* summary, double* grad, double* norms);
+
+/* Timing of the most recent gwi_eval*: HIP-event milliseconds of each launch on the engine's
+ * stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce). */
+gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]);
+/* Enable/disable per-launch HIP-event timing (off by default: events add host overhead). */
+gwi_status gwi_set_timing(gwi_handle h, int32_t enabled);
+
+const char* gwi_last_error(gwi_handle h);
+void gwi_destroy(gwi_handle h);
+
+/* Library-level queries usable without a GPU. */
+int32_t gwi_abi_version(void);
+int32_t gwi_kernel_variants(void);         /* number of compiled term sequences */
+const char* gwi_kernel_variant_name(int32_t i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWI_ENGINE_H */

@@ -1,0 +1,175 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against
+  (1) the golden vectors produced by the unmodified reference (tests/golden/case_*.npz):
+      every hierarchical_likelihood site for every hyper-point and flag set, per-sample weights,
+      and the 4th-order finite-difference gradients;
+  (2) the NumPy oracle on seeded mid-size catalogs;
+  (3) size-independent properties at the BASELINE sizes.
+Tolerances (fp64): 1e-9 relative on values (BASELINE.json north_star), 1e-6 on gradients vs the
+finite-difference oracle (whose own truncation error is ~1e-8)."""
+import numpy as np
+import pytest
+from golden_util import CASES, GoldenCase, rel_err
+
+pytestmark = pytest.mark.gpu
+
+VALUE_RTOL = 1e-9
+
+
+def _engine(case):
+    from gwinferno_amd.compositions import COMPOSITIONS
+
+    comp = COMPOSITIONS[case.composition](case.pe, case.inj, mmin=case.meta["mmin"], mmax=case.meta["mmax"])
+    return comp, comp.engine()
+
+
+def _sites_from(res, case, opt_unscaled_rate=30.0):
+    s = res.summary
+    out = {
+        "log_likelihood": s.log_likelihood,
+        "log_l": s.log_l,
+        "sum_logBFs": s.sum_logBFs,
+        "selection_factor": s.selection_factor,
+        "log_nEff_inj": s.log_nEff_inj,
+        "detection_efficiency": np.exp(s.log_det_eff),
+        "variance_log_detection_efficiency": s.variance_log_detection_efficiency,
+        "variance_log_likelihood": s.variance_log_likelihood,
+        "logBFs": res.log_bfs,
+        "log_nEffs": res.log_neffs,
+        "variance_log_BFs": res.variances,
+        "surveyed_hypervolume": s.surveyed_hypervolume_norm / 1e9 * case.tobs,
+    }
+    out["rate"] = opt_unscaled_rate / out["detection_efficiency"] / out["surveyed_hypervolume"]
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sites_match_reference_golden(name):
+    case = GoldenCase(name)
+    comp, eng = _engine(case)
+    for fs, flags in case.flagsets.items():
+        flags = {k: v for k, v in flags.items() if k != "log"}  # log/linear are the same arithmetic here
+        for i in range(case.n_points):
+            res = eng.evaluate(comp.theta(case.point(i)), case.total_inj, want_grad=not flags.get("marginalize_selection", False), **flags)
+            got = _sites_from(res, case)
+            for site, val in got.items():
+                ref = case.sites[fs][site][i]
+                # variances are differences of O(1) quantities: compare absolutely at 1e-9 of 1/n_eff scale
+                if site.startswith("variance"):
+                    assert np.allclose(val, ref, rtol=1e-8, atol=1e-12), (name, fs, i, site, val, ref)
+                else:
+                    assert rel_err(val, ref) < VALUE_RTOL, (name, fs, i, site, val, ref)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_per_sample_weights_match_reference(name):
+    case = GoldenCase(name)
+    comp, eng = _engine(case)
+    lpe, linj = eng.log_weights(comp.theta(case.point(0)))
+    with np.errstate(all="ignore"):
+        rpe, rinj = np.log(case.weights_pe), np.log(case.weights_inj)
+    for got, ref in ((lpe, rpe), (linj, rinj)):
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+        ok = np.isfinite(ref)
+        assert np.max(np.abs(got[ok] - ref[ok])) < 1e-10
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gradient_matches_finite_differences_of_reference(name):
+    case = GoldenCase(name)
+    comp, eng = _engine(case)
+    for i, fd in case.fdgrad.items():
+        res = eng.evaluate(comp.theta(case.point(i)), case.total_inj, min_neff_cut=False)
+        g = comp.named_gradient(res.grad)
+        for pname, ref in fd.items():
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname, g[pname], ref)
+    eng.close()
+
+
+@pytest.mark.parametrize("comp_name,n_ev,n_pe,n_inj", [("plpeak", 69, 1000, 20000), ("bspline_iid", 20, 700, 9000), ("bspline_full", 12, 1500, 15001), ("plpeak_full", 10, 1000, 5000)])
+def test_against_oracle_midsize(comp_name, n_ev, n_pe, n_inj):
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle import numpy_oracle as O
+
+    pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=99)
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    eng = comp.engine()
+    orc = O.COMPOSITIONS[comp_name](pe, inj)
+    rng = np.random.default_rng(17)
+    for _ in range(3):
+        p = draw_params(comp_name, rng)
+        res = eng.evaluate(comp.theta(p), total, min_neff_cut=False)
+        ref = orc.evaluate(p, total, min_neff_cut=False)
+        assert rel_err(res.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        assert rel_err(res.log_bfs, ref["logBFs"]) < VALUE_RTOL
+        assert rel_err(res.log_neffs, ref["log_nEffs"]) < VALUE_RTOL
+        assert rel_err(res.summary.log_nEff_inj, ref["log_nEff_inj"]) < VALUE_RTOL
+        assert rel_err(np.exp(res.summary.log_det_eff), ref["detection_efficiency"]) < VALUE_RTOL
+    eng.close()
+
+
+def test_empty_and_ragged_inputs():
+    """Events whose samples are all excluded, a ragged last tile, and an injection set smaller than
+    one workgroup."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle import numpy_oracle as O
+
+    pe, inj, total = make_catalog(5, 257, 100, seed=5)
+    pe["mass_1"][2, :] = 1.0  # below mmin: every sample of event 2 excluded
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = comp.engine()
+    p = draw_params("plpeak", np.random.default_rng(1))
+    res = eng.evaluate(comp.theta(p), total, min_neff_cut=False)
+    ref = O.COMPOSITIONS["plpeak"](pe, inj).evaluate(p, total, min_neff_cut=False)
+    assert res.log_bfs[2] == -np.inf and ref["logBFs"][2] == -np.inf
+    ok = np.isfinite(ref["logBFs"])
+    assert rel_err(res.log_bfs[ok], ref["logBFs"][ok]) < VALUE_RTOL
+    assert res.log_likelihood == float(ref["log_likelihood"])  # -1.797e308 sentinel (analysis.py:284-291)
+    assert np.all(res.grad == 0.0)
+    eng.close()
+
+
+def test_run_to_run_bit_stability():
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(16, 900, 7000, seed=8)
+    comp = COMPOSITIONS["bspline_test"](pe, inj)
+    eng = comp.engine()
+    th = comp.theta(draw_params("bspline_test", np.random.default_rng(2)))
+    a = eng.evaluate(th, total, min_neff_cut=False)
+    b = eng.evaluate(th, total, min_neff_cut=False)
+    assert a.log_likelihood == b.log_likelihood
+    assert np.array_equal(a.log_bfs, b.log_bfs)
+    # scalar-parameter gradients are reduced in a fixed order; spline-coefficient numerators go through
+    # LDS atomics whose order may vary: allow last-bits differences there
+    assert np.allclose(a.grad, b.grad, rtol=1e-12, atol=1e-13)
+    eng.close()
+
+
+def test_partial_records_combine_like_single_device():
+    """Two shards evaluated on the same GPU and combined == the unsharded evaluation (the
+    multi-GPU path minus the RCCL exchange)."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import NativePopulationLikelihood
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 500, 3001, seed=21)
+    comp = COMPOSITIONS["bspline_test"](pe, inj)
+    p = draw_params("bspline_test", np.random.default_rng(4))
+    full = comp.engine()
+    th = comp.theta(p)
+    ref = full.evaluate(th, total, min_neff_cut=False)
+    recs = []
+    for r in range(2):
+        e = NativePopulationLikelihood(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p), rank=r, world=2)
+        recs.append(e.eval_partial(th)[0])
+        last = e
+    out = last.combine(np.stack(recs), total, nobs=9, min_neff_cut=False)
+    assert rel_err(out.log_likelihood, ref.log_likelihood) < 1e-12
+    assert np.allclose(out.grad, ref.grad, rtol=1e-10, atol=1e-11)
+    full.close()

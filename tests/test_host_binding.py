@@ -1,0 +1,104 @@
+"""CPU: the host-side model mirrors (gwinferno_amd.models / compositions / engine.bind) produce
+columns, masks, normaliser grids and a theta layout that reproduce the reference's per-sample
+weights and hierarchical_likelihood sites (golden vectors), when evaluated by the NumPy
+BoundModel evaluator in tests/bound_eval.py.  The HIP kernels are checked against the same
+vectors in test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+from bound_eval import log_weights
+from golden_util import CASES, GoldenCase, rel_err
+
+from gwinferno_amd import _native as N
+from gwinferno_amd.compositions import COMPOSITIONS
+from gwinferno_amd.engine import bind, shard_bounds
+from oracle import numpy_oracle as O
+
+
+def _bound(case):
+    comp = COMPOSITIONS[case.composition](case.pe, case.inj, mmin=case.meta["mmin"], mmax=case.meta["mmax"])
+    p = case.point(0)
+    return comp, bind(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bound_model_reproduces_reference_weights(name):
+    case = GoldenCase(name)
+    comp, bm = _bound(case)
+    theta = bm.theta_of(comp.weights(case.point(0), True))
+    lpe, linj, norms = log_weights(bm, theta)
+    with np.errstate(all="ignore"):
+        ref_pe, ref_inj = np.log(case.weights_pe), np.log(case.weights_inj)
+    assert np.array_equal(np.isneginf(lpe), np.isneginf(ref_pe))
+    assert np.array_equal(np.isneginf(linj), np.isneginf(ref_inj))
+    ok = np.isfinite(ref_pe)
+    assert np.max(np.abs(lpe[ok] - ref_pe[ok])) < 2e-12
+    ok = np.isfinite(ref_inj)
+    assert np.max(np.abs(linj[ok] - ref_inj[ok])) < 2e-12
+    # surveyed hypervolume = Z of the designated normaliser / 1e9 * Tobs (analysis.py:267)
+    assert rel_err(norms[bm.vt_norm] / 1e9 * case.tobs, case.sites["lin"]["surveyed_hypervolume"][0]) < 1e-12
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bound_model_sites_via_oracle_reductions(name):
+    """weights from the bound model + the oracle's reductions == golden sites, all hyper-points."""
+    case = GoldenCase(name)
+    comp, bm = _bound(case)
+    for i in range(case.n_points):
+        theta = bm.theta_of(comp.weights(case.point(i), True))
+        lpe, linj, norms = log_weights(bm, theta)
+        got = O.hierarchical_likelihood(lpe, linj, case.total_inj, case.nobs, case.tobs, norms[bm.vt_norm], log=True, min_neff_cut=False)
+        for site in ("log_likelihood", "logBFs", "log_nEffs", "log_nEff_inj", "detection_efficiency", "rate", "variance_log_likelihood"):
+            assert rel_err(got[site], case.sites["log"][site][i]) < 1e-10, (name, i, site)
+
+
+def test_theta_layout_and_shared_coefficients():
+    case = GoldenCase("bspline_iid")
+    comp, bm = _bound(case)
+    # IID spin models: two spline terms share ONE coefficient block (separable.py:77-79)
+    spl = [t for t in bm.terms if t["kind"] == N.TERM_EXP_SPLINE]
+    offs = [t["coef_off"] for t in spl]
+    assert len(spl) == 5 and len(set(offs)) == 3
+    assert bm.n_theta == 30 + 1 + 16 + 16 + 1
+    # terms are in canonical (sorted-by-kind) order
+    kinds = [t["kind"] for t in bm.terms]
+    assert kinds == sorted(kinds)
+
+
+def test_column_sharing_and_count():
+    case = GoldenCase("plpeak")
+    _, bm = _bound(case)
+    # m1, log m1 (shared by PL+Peak and the q power law), log q, log(1+z), kappa
+    assert len(bm.pe_cols) == 5
+    case = GoldenCase("bspline_full")
+    _, bm = _bound(case)
+    assert len(bm.pe_cols) == 9  # C = 9 for config 5
+
+
+def test_structure_mismatch_is_rejected():
+    case = GoldenCase("pl_test")
+    comp = COMPOSITIONS["pl_test"](case.pe, case.inj)
+    p = case.point(0)
+    with pytest.raises(ValueError):
+        bind(comp.weights(p, False), comp.weights(p, True))  # sides swapped
+    with pytest.raises(TypeError):
+        bind(np.ones((2, 2)), comp.weights(p, False))
+
+
+def test_shard_bounds_partition():
+    for n, w in ((69, 8), (200, 8), (5, 8), (100000, 3)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_named_theta_roundtrip():
+    case = GoldenCase("bspline_full")
+    comp = COMPOSITIONS["bspline_full"](case.pe, case.inj)
+    bm = bind(comp.weights(case.point(1), True), comp.weights(case.point(1), False), comp.hypervolume(case.point(1)))
+    comp._engine = type("E", (), {"bound": bm})()  # layout only; no GPU needed
+    th = comp.theta(case.point(1))
+    assert np.array_equal(th, bm.theta_of(comp.weights(case.point(1), True)))
+    g = comp.named_gradient(np.arange(len(th), dtype=float))
+    assert set(g) == set(comp.PARAMS) and g["m1_coefs"].shape == (30,)

@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/gwi_engine.h declares.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gwinferno_amd import _native
+
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return _native.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    from gwinferno_amd import _native
+
+    hdr = open(os.path.join(ROOT, "include", "gwi_engine.h")).read()
+    declared = set(re.findall(r"\b(gwi_[a-z_]+)\s*\(", hdr))
+    declared -= {"gwi_engine"}
+    assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    for sym in declared:
+        assert hasattr(raw, sym), sym
+
+
+def test_struct_sizes_match_header(lib):
+    """ctypes mirrors vs the C layout (sizes computed by hand from include/gwi_engine.h)."""
+    from gwinferno_amd import _native as N
+
+    assert ctypes.sizeof(N.GwiTerm) == 4 * 12 + 8 * 4
+    assert ctypes.sizeof(N.GwiNorm) == 4 * 6 + 8 * 3 + 8 * 4
+    assert ctypes.sizeof(N.GwiSpec) == 4 * 8 + ctypes.sizeof(N.GwiTerm) * N.GWI_MAX_TERMS + ctypes.sizeof(N.GwiNorm) * N.GWI_MAX_NORMS
+    assert ctypes.sizeof(N.GwiOptions) == 32
+    assert ctypes.sizeof(N.GwiSummary) == 16 * 8
+
+
+def test_version_and_variants(lib):
+    assert lib.gwi_abi_version() == 1
+    names = [lib.gwi_kernel_variant_name(i).decode() for i in range(lib.gwi_kernel_variants())]
+    for needed in ("plpeak+plq+plz", "plpeak+plq+beta2+tilt2+plz", "plq+plz+spline5", "plz+spline7", "plz+spline3", "pl+plq+plz"):
+        assert needed in names
+    assert lib.gwi_kernel_variant_name(10_000) is None
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU gwi_create must fail with GWI_ERR_NO_DEVICE; the Python layer must raise."""
+    import numpy as np
+
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    from gwinferno_amd import _native as N
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, _ = make_catalog(2, 8, 16)
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    with pytest.raises(N.NativeEngineError):
+        comp.engine()
