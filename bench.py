@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- log-likelihood evaluations per second of the hierarchical population likelihood.
+
+One *step* = one value-and-gradient evaluation of ``hierarchical_likelihood`` (log_l, d log_l/d theta
+and every diagnostic site) for one hyper-parameter point, end to end from a host ``theta`` to host
+results, with the catalog already resident in HBM -- what one NUTS leapfrog costs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5]
+
+N = 1: a single engine.  N > 1 (launched by torch.distributed.run, one rank per GPU): events and
+injections are sharded across ranks, each rank scans its shard, ONE RCCL all-gather of the small
+partial records is the only exchange, and every rank assembles the same result ("strong" scaling:
+the BASELINE catalog size is fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# name -> (composition, catalog, SURVEY 8(d) algorithmic fp64 scalars per sample, description)
+CONFIGS = {
+    "c1": ("plpeak_full", "c1", 10, "C1: PL+Peak m1 x PL q x Beta spins x iso+aligned tilts x PL z, 10 ev x 1000 PE x 5k inj"),
+    "c2": ("plpeak", "c2", 4, "C2: PL+Peak m1 x PL q x PL z, 69 ev x 5000 PE x 50k inj"),
+    "c3": ("bspline_iid", "c3", 8, "C3: B-spline m1(30) x PL q x IID spin mag(16) x IID tilt(16) x PL z, 69 ev x 5000 PE x 100k inj"),
+    "c5": ("bspline_full", "c5", 9, "C5: B-spline m1(30) q(14) a1,a2(12) ct1,ct2(12) x PL z x spline z(12), 200 ev x 10000 PE x 500k inj"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(comp_name, pe, inj, total, params, budget_s=10.0):
+    """NumPy oracle (value only, reference formulation: dense design matrices) on the host cores."""
+    from oracle import numpy_oracle as O
+
+    t0 = time.perf_counter()
+    orc = O.COMPOSITIONS[comp_name](pe, inj)
+    setup = time.perf_counter() - t0
+    n, t_used = 0, 0.0
+    while t_used < budget_s and n < len(params):
+        t0 = time.perf_counter()
+        orc.evaluate(params[n], total, min_neff_cut=False)
+        t_used += time.perf_counter() - t0
+        n += 1
+    return {
+        "value": n / t_used,
+        "unit": "evals/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} value-only evals of the full catalog by the NumPy oracle (reference formulation, no gradient); setup {setup:.1f}s excluded",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-every", type=int, default=4, help="HIP-event kernel timing on every n-th timed step")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_config_catalog
+
+    comp_name, cat_name, c_alg, desc = CONFIGS[args.config]
+    pe, inj, total = make_config_catalog(cat_name)
+    n_ev, n_pe = pe["mass_1"].shape
+    n_inj = inj["mass_1"].shape[0]
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    eng = comp.engine(device=local_rank, rank=rank, world=world)
+    rng = np.random.default_rng(1234)
+    pool = [draw_params(comp_name, rng) for _ in range(64)]
+    thetas = [comp.theta(p) for p in pool]
+
+    gather_buf = None
+    if world > 1:
+        from gwinferno_amd.distributed import ShardedLikelihood
+
+        sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank))
+
+        def step(i):
+            return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
+    else:
+
+        def step(i):
+            return eng.evaluate(thetas[i % len(thetas)], total, min_neff_cut=False, copy=False)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps -----------------------------------------------------------
+    scan_ms, comb_ms, fin_ms = [], [], []
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timed = args.timing_every > 0 and (i % args.timing_every == 0)
+        if timed:
+            eng.set_timing(True)
+        res = step(i)
+        if timed:
+            ms = eng.last_kernel_ms()
+            scan_ms.append(ms[0])
+            comb_ms.append(ms[1])
+            fin_ms.append(ms[2])
+            eng.set_timing(False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        evals_per_s = args.steps / elapsed
+        scan_us = 1e3 * float(np.mean(scan_ms)) if scan_ms else float("nan")
+        alg_bytes = 8.0 * c_alg * (n_ev * n_pe + n_inj) / world  # per launch on one GPU
+        achieved = alg_bytes / (scan_us * 1e-6) / 1e9 if scan_ms else float("nan")
+        out = {
+            "metric": "log-likelihood evals/sec (value + gradient + diagnostic sites, host theta -> host results)",
+            "value": evals_per_s,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": desc,
+                "composition": comp_name,
+                "n_events": int(n_ev),
+                "n_pe": int(n_pe),
+                "n_inj": int(n_inj),
+                "n_theta": int(eng.n_theta),
+                "flags": "min_neff_cut=False (tests/inference_test.py:185)",
+                "parallelism": f"events+injections sharded over {world} GPU(s), one all-gather of partial records" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "scan_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
+                "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
+                "timed_launches": len(scan_ms),
+            },
+            "last_log_likelihood": float(res.log_likelihood),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(comp_name, pe, inj, total, pool)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ namespace gwi {
 
 constexpr int kBlock = 256;            // 4 wavefronts of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxDerived = 6;
+constexpr int kMaxDerived = 8;
 constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerators in a record
 
 struct TermD {
@@ -60,16 +60,51 @@ static_assert(sizeof(KArgs) <= 4096, "kernel argument block must fit the 4 KiB k
 #define GWI_NEG_INF (-__builtin_huge_val())
 #define GWI_POS_INF (__builtin_huge_val())
 
-// ---- wave-level reductions (64 lanes) -----------------------------------------------------
+// ---- wave-level reductions (64 lanes) on the DPP path ----------------------------------------------
+// Row-shift scan inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 fold the four rows;
+// the total lands in lane 63 and is broadcast through an SGPR pair (v_readlane), so the result is
+// wave-uniform.  Only lane 63 is ever read: lanes whose DPP source is out of range receive 0
+// (bound_ctrl) and rows masked off by row_mask keep stale register contents, but the scan
+// structure never routes those lanes into lane 63, so no identity preload is needed.
+// No LDS traffic and no ds_bpermute latency chain (12 DPP moves + 6 VALU per fp64 value).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_take<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_take<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_take<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_take<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_take<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v += dpp_take<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
+  return lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_take<0x111, 0xf>(v));
+  v = fmax(v, dpp_take<0x112, 0xf>(v));
+  v = fmax(v, dpp_take<0x114, 0xf>(v));
+  v = fmax(v, dpp_take<0x118, 0xf>(v));
+  v = fmax(v, dpp_take<0x142, 0xa>(v));
+  v = fmax(v, dpp_take<0x143, 0xc>(v));
+  return lane63(v);
+}
+
+// 1/x to ~1 ulp for normal x: hardware seed + two Newton steps (no IEEE special-case handling:
+// callers only need it where the weight is non-zero)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
 }
 
 // ---- uniform cubic B-spline: 4 taps from the fractional knot coordinate --------------------
@@ -99,70 +134,86 @@ __device__ __forceinline__ void spline_locate(double x, double lo, double inv_dx
   t = u - (double)kk;
 }
 
+// Column loads: the column pointers come out of a pointer table, so the compiler cannot infer their
+// address space and would emit flat_load; they are HBM (global) pointers.
+typedef const double __attribute__((address_space(1))) * gptr_t;
+__device__ __forceinline__ double gload(const double* p, long long idx) { return ((gptr_t)p)[idx]; }
+
 // ---- evaluation context --------------------------------------------------------------------
 struct Ctx {
-  const KArgs* a;
-  const double* theta;          // LDS copy of theta
+  const KArgs* a;               // kernel arguments: scalar hyper-parameters are read from here
+                                // (uniform index -> scalar loads), never from LDS
+  const double* coefs;          // LDS copy of theta for the lane-varying spline coefficient reads
   double* gacc;                 // this wave's LDS gradient-numerator row [n_theta]
   const double* const* cols;    // column table of the sample set this workgroup scans
 };
 
 // ---- term library --------------------------------------------------------------------------
-// Each term contributes l_t = log f_t(x; theta) without its sample-independent normaliser (those
-// are added on the host: they cancel in log_l and its gradient), caches what the gradient needs in
-// State, and after the weight w = e^{l-m} is known adds w * dl/dtheta into register accumulators
-// (scalar hyper-parameters) or the wave's LDS row (spline coefficients).
+// A sample's weight is  w = L * exp(l - m):  each term either adds to the log part l (power laws,
+// splines: already exponents) or multiplies the linear part L (mixtures, the ratio normaliser:
+// sums of exponentials whose log would cost a transcendental for nothing) -- the reference
+// multiplies densities in the linear domain throughout.  Sample-independent normalisers are left
+// out (added on the host: they cancel in log_l and in its gradient).  State caches dl/dtheta; once
+// w is known accumulate() adds w * dl/dtheta into registers (scalars) or the wave's LDS row
+// (spline coefficients).
 template <int K>
 struct Term;
 
-// x^alpha on fixed [lo,hi] (distributions.py:100-119); log-normaliser is sample independent.
+#define GWI_ACC1(member)                                                                    \
+  __device__ static void init(Acc& a) { a.member = 0; }                                     \
+  __device__ static void rescale(Acc& a, double sc) { a.member *= sc; }
+
+// x^alpha on fixed [lo,hi] (distributions.py:100-119)
 template <>
 struct Term<GWI_TERM_POWERLAW> {
+  static constexpr bool kSpline = false;
   struct State {
     double lx;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    s.lx = c.cols[t.col0][idx];
-    return c.theta[t.th0] * s.lx;
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
+    s.lx = gload(c.cols[t.col0], idx);
+    return c.a->theta[t.th0] * s.lx;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.lx; }
-  __device__ static void init(Acc& a) { a.g0 = 0; }
-  __device__ static void rescale(Acc& a, double sc) { a.g0 *= sc; }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r = wave_sum(a.g0);
-    if (lane == 0) c.gacc[t.th0] += r;
+  GWI_ACC1(g0)
+  static constexpr int kNumAcc = 1;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g0;
+    th[0] = t.th0;
   }
 };
 
 // (1-lam) A x^alpha + lam Cn exp(-(x-mu)^2/(2 sig^2))  (parametric.py:49-53)
-// derived: d0=log A, d1=dlogA/dalpha, d2=log Cn, d3=dlogCn/dmu, d4=dlogCn/dsig
+// derived: d0=log A, d1=dlogA/dalpha, d2=log Cn, d3=dlogCn/dmu, d4=dlogCn/dsig, d5=1/sig^2, d6=1/sig^3
 template <>
 struct Term<GWI_TERM_PLPEAK> {
+  static constexpr bool kSpline = false;
   struct State {
     double da, dmu, dsg, dlam;
   };
   struct Acc {
     double g[4];
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s) {
-    const double x = c.cols[t.col0][idx];
-    const double lx = c.cols[t.col1][idx];
-    const double alpha = c.theta[t.th0], mu = c.theta[t.th1], sg = c.theta[t.th2], lam = c.theta[t.th3];
-    const double inv_s2 = 1.0 / (sg * sg);
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
+    const double x = gload(c.cols[t.col0], idx);
+    const double lx = gload(c.cols[t.col1], idx);
+    const double alpha = c.a->theta[t.th0], mu = c.a->theta[t.th1], lam = c.a->theta[t.th3];
     const double dx = x - mu;
+    const double dx2 = dx * dx;
     const double e_pl = exp(alpha * lx + d[0]);
-    const double e_tn = exp(-0.5 * dx * dx * inv_s2 + d[2]);
+    const double e_tn = exp(-0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
-    const double ip = 1.0 / p;
+    const double ip = fast_rcp(p);
     s.da = P * (lx + d[1]) * ip;
-    s.dmu = T * (dx * inv_s2 + d[3]) * ip;
-    s.dsg = T * (dx * dx * inv_s2 / sg + d[4]) * ip;
+    s.dmu = T * (dx * d[5] + d[3]) * ip;
+    s.dsg = T * (dx2 * d[6] + d[4]) * ip;
     s.dlam = (e_tn - e_pl) * ip;
-    return log(p);
+    lin *= p;
+    return 0.0;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
     a.g[0] += w * s.da;
@@ -175,61 +226,67 @@ struct Term<GWI_TERM_PLPEAK> {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a.g[j] *= sc;
   }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const int th[4] = {t.th0, t.th1, t.th2, t.th3};
+  static constexpr int kNumAcc = 4;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double r = wave_sum(a.g[j]);
-      if (lane == 0) c.gacc[th[j]] += r;
-    }
+    for (int j = 0; j < 4; ++j) vals[j] = a.g[j];
+    th[0] = t.th0;
+    th[1] = t.th1;
+    th[2] = t.th2;
+    th[3] = t.th3;
   }
 };
 
 // q^beta (1+beta)/(1 - r^(1+beta)), r = mmin/m1  (distributions.py:111-116 with low = mmin/m1)
+// derived: d0 = 1/(1+beta)
 template <>
 struct Term<GWI_TERM_POWERLAW_RATIO> {
+  static constexpr bool kSpline = false;
   struct State {
     double db;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    const double lq = c.cols[t.col0][idx];
-    const double lr = t.p0 - c.cols[t.col1][idx];  // log(mmin/m1) <= 0 for every non-excluded sample
-    const double beta = c.theta[t.th0];
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
+    const double lq = gload(c.cols[t.col0], idx);
+    const double lr = t.p0 - gload(c.cols[t.col1], idx);  // log(mmin/m1) <= 0 for every non-excluded sample
+    const double beta = c.a->theta[t.th0];
     const double b1 = 1.0 + beta;
     if (b1 == 0.0) {  // alpha == -1 branch of the reference: 1/log(high/low)
       s.db = lq - 0.5 * lr;
-      return -lq - log(-lr);
+      lin *= -fast_rcp(lr);
+      return -lq;
     }
-    const double em1 = expm1(b1 * lr);  // r^(1+beta) - 1
-    const double denom = -em1;          // 1 - r^(1+beta)
-    s.db = lq + 1.0 / b1 + (em1 + 1.0) * lr / denom;
-    return beta * lq + log(b1 / denom);
+    const double em1 = expm1(b1 * lr);   // r^(1+beta) - 1
+    const double inv_den = -fast_rcp(em1);  // 1/(1 - r^(1+beta))
+    s.db = lq + d[0] + (em1 + 1.0) * lr * inv_den;
+    lin *= b1 * inv_den;
+    return beta * lq;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.db; }
-  __device__ static void init(Acc& a) { a.g0 = 0; }
-  __device__ static void rescale(Acc& a, double sc) { a.g0 *= sc; }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r = wave_sum(a.g0);
-    if (lane == 0) c.gacc[t.th0] += r;
+  GWI_ACC1(g0)
+  static constexpr int kNumAcc = 1;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g0;
+    th[0] = t.th0;
   }
 };
 
 // Beta(a; alpha, beta): (alpha-1) log a + (beta-1) log(1-a) - betaln  (distributions.py:160-161)
 template <>
 struct Term<GWI_TERM_BETA> {
+  static constexpr bool kSpline = false;
   struct State {
     double la, l1;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    s.la = c.cols[t.col0][idx];
-    s.l1 = c.cols[t.col1][idx];
-    return (c.theta[t.th0] - 1.0) * s.la + (c.theta[t.th1] - 1.0) * s.l1;
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
+    s.la = gload(c.cols[t.col0], idx);
+    s.l1 = gload(c.cols[t.col1], idx);
+    return (c.a->theta[t.th0] - 1.0) * s.la + (c.a->theta[t.th1] - 1.0) * s.l1;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
     a.g[0] += w * s.la;
@@ -240,35 +297,38 @@ struct Term<GWI_TERM_BETA> {
     a.g[0] *= sc;
     a.g[1] *= sc;
   }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r0 = wave_sum(a.g[0]), r1 = wave_sum(a.g[1]);
-    if (lane == 0) {
-      c.gacc[t.th0] += r0;
-      c.gacc[t.th1] += r1;
-    }
+  static constexpr int kNumAcc = 2;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g[0];
+    vals[1] = a.g[1];
+    th[0] = t.th0;
+    th[1] = t.th1;
   }
 };
 
-// (1-xi)/2 + xi Cn exp(-(ct-1)^2/(2 sig^2))  (parametric.py:84-86); derived: d0=log Cn, d1=dlogCn/dsig
+// (1-xi)/2 + xi Cn exp(-(ct-1)^2/(2 sig^2))  (parametric.py:84-86)
+// derived: d0=log Cn, d1=dlogCn/dsig, d2=1/sig^2, d3=1/sig^3
 template <>
 struct Term<GWI_TERM_TILT_MIXTURE> {
+  static constexpr bool kSpline = false;
   struct State {
     double dxi, dsg;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s) {
-    const double ct = c.cols[t.col0][idx];
-    const double xi = c.theta[t.th0], sg = c.theta[t.th1];
-    const double inv_s2 = 1.0 / (sg * sg);
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
+    const double ct = gload(c.cols[t.col0], idx);
+    const double xi = c.a->theta[t.th0];
     const double dx = ct - 1.0;
-    const double e_tn = exp(-0.5 * dx * dx * inv_s2 + d[0]);
+    const double dx2 = dx * dx;
+    const double e_tn = exp(-0.5 * dx2 * d[2] + d[0]);
     const double p = 0.5 * (1.0 - xi) + xi * e_tn;
-    const double ip = 1.0 / p;
+    const double ip = fast_rcp(p);
     s.dxi = (e_tn - 0.5) * ip;
-    s.dsg = xi * e_tn * (dx * dx * inv_s2 / sg + d[1]) * ip;
-    return log(p);
+    s.dsg = xi * e_tn * (dx2 * d[3] + d[1]) * ip;
+    lin *= p;
+    return 0.0;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
     a.g[0] += w * s.dxi;
@@ -279,32 +339,32 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
     a.g[0] *= sc;
     a.g[1] *= sc;
   }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r0 = wave_sum(a.g[0]), r1 = wave_sum(a.g[1]);
-    if (lane == 0) {
-      c.gacc[t.th0] += r0;
-      c.gacc[t.th1] += r1;
-    }
+  static constexpr int kNumAcc = 2;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g[0];
+    vals[1] = a.g[1];
+    th[0] = t.th0;
+    th[1] = t.th1;
   }
 };
 
-// TN(x; mu, sig, lo, hi) alone (distributions.py:136-143); normaliser is sample independent.
+// TN(x; mu, sig, lo, hi) alone (distributions.py:136-143); derived: d0=1/sig^2, d1=1/sig^3
 template <>
 struct Term<GWI_TERM_TRUNCNORM> {
+  static constexpr bool kSpline = false;
   struct State {
     double dmu, dsg;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    const double x = c.cols[t.col0][idx];
-    const double mu = c.theta[t.th0], sg = c.theta[t.th1];
-    const double inv_s2 = 1.0 / (sg * sg);
-    const double dx = x - mu;
-    s.dmu = dx * inv_s2;
-    s.dsg = dx * dx * inv_s2 / sg;
-    return -0.5 * dx * dx * inv_s2;
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double&) {
+    const double x = gload(c.cols[t.col0], idx);
+    const double dx = x - c.a->theta[t.th0];
+    const double dx2 = dx * dx;
+    s.dmu = dx * d[0];
+    s.dsg = dx2 * d[1];
+    return -0.5 * dx2 * d[0];
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
     a.g[0] += w * s.dmu;
@@ -315,34 +375,35 @@ struct Term<GWI_TERM_TRUNCNORM> {
     a.g[0] *= sc;
     a.g[1] *= sc;
   }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r0 = wave_sum(a.g[0]), r1 = wave_sum(a.g[1]);
-    if (lane == 0) {
-      c.gacc[t.th0] += r0;
-      c.gacc[t.th1] += r1;
-    }
+  static constexpr int kNumAcc = 2;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g[0];
+    vals[1] = a.g[1];
+    th[0] = t.th0;
+    th[1] = t.th1;
   }
 };
 
 // (1+z)^(lamb-1) (parametric.py:126-127); dVc/dz is in kappa, the grid normaliser on the host side.
 template <>
 struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
+  static constexpr bool kSpline = false;
   struct State {
     double l1pz;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    s.l1pz = c.cols[t.col0][idx];
-    return (c.theta[t.th0] - 1.0) * s.l1pz;
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
+    s.l1pz = gload(c.cols[t.col0], idx);
+    return (c.a->theta[t.th0] - 1.0) * s.l1pz;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.l1pz; }
-  __device__ static void init(Acc& a) { a.g0 = 0; }
-  __device__ static void rescale(Acc& a, double sc) { a.g0 *= sc; }
-  __device__ static void flush(const TermD& t, const Ctx& c, Acc& a, int lane) {
-    const double r = wave_sum(a.g0);
-    if (lane == 0) c.gacc[t.th0] += r;
+  GWI_ACC1(g0)
+  static constexpr int kNumAcc = 1;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g0;
+    th[0] = t.th0;
   }
 };
 
@@ -350,17 +411,18 @@ struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
 // p0 = lo, p1 = hi, p2 = 1/dx of the spline coordinate; th0 = theta offset of c_0.
 template <>
 struct Term<GWI_TERM_EXP_SPLINE> {
+  static constexpr bool kSpline = true;
   struct State {
     double t;
     int k;  // -1: outside the domain of a zero-outside basis (factor 1, no gradient)
   };
   struct Acc {};
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s) {
-    const double x = c.cols[t.col0][idx];
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
+    const double x = gload(c.cols[t.col0], idx);
     int k;
     double tt;
     spline_locate(x, t.p0, t.p2, t.n_basis, k, tt);
-    const double* cf = c.theta + t.th0 + k;
+    const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
     if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {
@@ -386,43 +448,51 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
-  __device__ static void flush(const TermD&, const Ctx&, Acc&, int) {}
+  static constexpr int kNumAcc = 0;
+  __device__ static void collect(const TermD&, const Acc&, double*, int*) {}
 };
 
-// ---- compile-time chain of terms --------------------------------------------------------------
+// ---- compile-time chain of terms; every lane carries kU samples per loop trip -----------------------
+constexpr int kU = 2;
+
 template <int... Ks>
 struct Chain;
 template <>
 struct Chain<> {
+  static constexpr bool kSpline = false;
+  static constexpr int kNumAcc = 0;
   __device__ void init() {}
-  __device__ double eval(int, const Ctx&, long long) { return 0.0; }
-  __device__ void accumulate(int, const Ctx&, double) {}
+  __device__ double eval(int, int, const Ctx&, long long, double&) { return 0.0; }
+  __device__ void accumulate(int, int, const Ctx&, double) {}
   __device__ void rescale(double) {}
-  __device__ void flush(int, const Ctx&, int) {}
+  __device__ void collect(int, const Ctx&, double*, int*) {}
 };
 template <int K, int... Rest>
 struct Chain<K, Rest...> {
-  typename Term<K>::State st;
+  static constexpr bool kSpline = Term<K>::kSpline || Chain<Rest...>::kSpline;
+  static constexpr int kNumAcc = Term<K>::kNumAcc + Chain<Rest...>::kNumAcc;
+  typename Term<K>::State st[kU];
   typename Term<K>::Acc acc;
   Chain<Rest...> rest;
   __device__ void init() {
     Term<K>::init(acc);
     rest.init();
   }
-  __device__ double eval(int ti, const Ctx& c, long long idx) {
-    return Term<K>::eval(c.a->terms[ti], c.a->derived[ti], c, idx, st) + rest.eval(ti + 1, c, idx);
+  __device__ double eval(int u, int ti, const Ctx& c, long long idx, double& lin) {
+    const double l = Term<K>::eval(c.a->terms[ti], c.a->derived[ti], c, idx, st[u], lin);
+    return l + rest.eval(u, ti + 1, c, idx, lin);
   }
-  __device__ void accumulate(int ti, const Ctx& c, double w) {
-    Term<K>::accumulate(c.a->terms[ti], c, w, st, acc);
-    rest.accumulate(ti + 1, c, w);
+  __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
+    Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
+    rest.accumulate(u, ti + 1, c, w);
   }
   __device__ void rescale(double sc) {
     Term<K>::rescale(acc, sc);
     rest.rescale(sc);
   }
-  __device__ void flush(int ti, const Ctx& c, int lane) {
-    Term<K>::flush(c.a->terms[ti], c, acc, lane);
-    rest.flush(ti + 1, c, lane);
+  __device__ void collect(int ti, const Ctx& c, double* vals, int* th) {
+    Term<K>::collect(c.a->terms[ti], acc, vals, th);
+    rest.collect(ti + 1, c, vals + Term<K>::kNumAcc, th + Term<K>::kNumAcc);
   }
 };
 
@@ -461,22 +531,34 @@ __device__ inline void norm_block(const KArgs& a, int j, const double* s_theta, 
 // grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups + n_norms normaliser
 // workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
 // belongs to that event's logsumexp; an injection workgroup owns `chunk_inj` consecutive
-// injections.  Loads are coalesced: lane i of a wave reads element base+i of each column.
+// injections.  Loads are coalesced: lane i of a wave reads element base+i of each column; each lane
+// carries kU samples (256 apart) per trip so polynomial constants, the wave maximum and the loop
+// overhead are shared between them.
+constexpr int kRedChunk = 8;  // values per pass of the block-level transposed reduction (16 KiB LDS)
+
 template <bool WRITE_LOGW, int... Ks>
 __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
+  using ChainT = Chain<Ks...>;
   __shared__ double s_theta[GWI_MAX_THETA];
   __shared__ double s_gacc[kWaves][GWI_MAX_THETA];
+  __shared__ double s_out[GWI_MAX_THETA];
+  __shared__ double s_red[kRedChunk][kBlock];
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int n_pe_blocks = a.n_ev * a.tiles_per_event;
   const int n_scan_blocks = n_pe_blocks + a.n_inj_tiles;
+  const bool is_norm = b >= n_scan_blocks;
 
-  for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
-  for (int p = tid; p < kWaves * GWI_MAX_THETA; p += kBlock) (&s_gacc[0][0])[p] = 0.0;
-  __syncthreads();
+  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
+  if (ChainT::kSpline || is_norm)
+    for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
+  if (ChainT::kSpline)
+    for (int p = lane; p < a.n_theta; p += 64) s_gacc[wave][p] = 0.0;
+  for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
+  if (ChainT::kSpline || is_norm) __syncthreads();
 
-  if (b >= n_scan_blocks) {
+  if (is_norm) {
     norm_block(a, b - n_scan_blocks, s_theta, &s_wrec[0][0]);
     return;
   }
@@ -484,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   long long start, end, base;
   Ctx ctx;
   ctx.a = &a;
-  ctx.theta = s_theta;
+  ctx.coefs = s_theta;
   ctx.gacc = s_gacc[wave];
   double* logw;
   if (b < n_pe_blocks) {
@@ -506,84 +588,149 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   const double* kappa_col = ctx.cols[a.kappa_col];
 
   double m = GWI_NEG_INF, s1 = 0.0, s2 = 0.0;
-  Chain<Ks...> chain;
+  ChainT chain;
   chain.init();
 
   // the loop condition is wave-uniform: i - lane is the same for every lane of a wave
-  for (long long i = start + tid; i - lane < end; i += kBlock) {
-    const bool valid = i < end;
-    const long long idx = base + (valid ? i : end - 1);
-    double ell = kappa_col[idx] + chain.eval(0, ctx, idx);
-    // NaN or +inf weights count as zero (tests/inference_test.py:172, 260)
-    if (!valid || !(ell < GWI_POS_INF)) ell = GWI_NEG_INF;
-    if (WRITE_LOGW) {
-      if (valid) logw[idx] = ell;
-      continue;
+  for (long long i = start + tid; i - lane < end; i += kU * kBlock) {
+    double ell[kU], lin[kU];
+    bool live[kU];
+    double mx_lane = GWI_NEG_INF;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long iu = i + (long long)u * kBlock;
+      if (u > 0 && iu - lane >= end) {  // wave-uniform: this wave has no u-th sample
+        live[u] = false;
+        ell[u] = GWI_NEG_INF;
+        lin[u] = 0.0;
+        continue;
+      }
+      const bool valid = iu < end;
+      const long long idx = base + (valid ? iu : end - 1);
+      lin[u] = 1.0;
+      ell[u] = gload(kappa_col, idx) + chain.eval(u, 0, ctx, idx, lin[u]);
+      // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
+      live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
+      if (!live[u]) ell[u] = GWI_NEG_INF;
+      if (WRITE_LOGW) {
+        if (valid) logw[idx] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
+      }
+      mx_lane = fmax(mx_lane, ell[u]);
     }
-    const double mx = wave_max(ell);
+    if (WRITE_LOGW) continue;
+    const double mx = wave_max(mx_lane);
     if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
       const double sc = exp(m - mx);
       s1 *= sc;
       s2 *= sc * sc;
       chain.rescale(sc);
-      for (int p = lane; p < a.n_theta; p += 64) ctx.gacc[p] *= sc;
+      if (ChainT::kSpline)
+        for (int p = lane; p < a.n_theta; p += 64) ctx.gacc[p] *= sc;
       m = mx;
     }
-    const double w = (ell == GWI_NEG_INF) ? 0.0 : exp(ell - m);
-    s1 += w;
-    s2 += w * w;
-    chain.accumulate(0, ctx, w);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+      const double w = live[u] ? lin[u] * exp(ell[u] - m) : 0.0;
+      s1 += w;
+      s2 += w * w;
+      chain.accumulate(u, 0, ctx, w);
+    }
   }
   if (WRITE_LOGW) return;
 
-  chain.flush(0, ctx, lane);
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if (lane == 0) {
-    s_wrec[wave][0] = m;
-    s_wrec[wave][1] = s1;
-    s_wrec[wave][2] = s2;
-  }
+  // ---- workgroup record: common exponent M, then a transposed LDS reduction of every scalar sum
+  if (lane == 0) s_wrec[wave][0] = m;
   __syncthreads();
   double M = s_wrec[0][0];
 #pragma unroll
   for (int w_ = 1; w_ < kWaves; ++w_) M = fmax(M, s_wrec[w_][0]);
-  double f[kWaves];
+  const double f = (m == GWI_NEG_INF) ? 0.0 : exp(m - M);  // this wave's rescale factor
+
+  constexpr int kNV = 2 + ChainT::kNumAcc;
+  double vals[kNV];
+  int th[kNV];
+  vals[0] = s1 * f;
+  vals[1] = s2 * f * f;
+  th[0] = th[1] = -1;
+  chain.collect(0, ctx, vals + 2, th + 2);
 #pragma unroll
-  for (int w_ = 0; w_ < kWaves; ++w_) f[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : exp(s_wrec[w_][0] - M);
+  for (int v = 2; v < kNV; ++v) vals[v] *= f;
   double* out = a.partials + (long long)b * a.rec_stride;
-  if (tid == 0) {
-    double S1 = 0.0, S2 = 0.0;
 #pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) {
-      S1 += f[w_] * s_wrec[w_][1];
-      S2 += f[w_] * f[w_] * s_wrec[w_][2];
+  for (int v0 = 0; v0 < kNV; v0 += kRedChunk) {
+    if (v0 > 0) __syncthreads();
+#pragma unroll
+    for (int v = v0; v < kNV && v < v0 + kRedChunk; ++v) s_red[v - v0][tid] = vals[v];
+    __syncthreads();
+    // wave w reduces values v0 + w, v0 + w + 4, ...: 4 strided reads (fixed order) + one DPP sum
+#pragma unroll
+    for (int v = v0; v < kNV && v < v0 + kRedChunk; ++v) {
+      if (((v - v0) & (kWaves - 1)) != wave) continue;  // wave-uniform
+      const double* row = s_red[v - v0];
+      const double r = wave_sum((row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]));
+      if (lane == 0) {
+        if (v == 0)
+          out[1] = r;
+        else if (v == 1)
+          out[2] = r;
+        else
+          unsafeAtomicAdd(&s_out[th[v]], r);  // several accumulators may feed one theta slot
+      }
     }
-    out[0] = M;
-    out[1] = S1;
-    out[2] = S2;
+  }
+  if (tid == 0) out[0] = M;
+  __syncthreads();
+  // gradient numerators: scalar sums from s_out, spline-coefficient sums from the per-wave rows
+  double fw[kWaves];
+  if (ChainT::kSpline) {
+#pragma unroll
+    for (int w_ = 0; w_ < kWaves; ++w_) fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : exp(s_wrec[w_][0] - M);
   }
   for (int p = tid; p < a.n_theta; p += kBlock) {
-    double g = 0.0;
+    double g = s_out[p];
+    if (ChainT::kSpline) {
 #pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) g += f[w_] * s_gacc[w_][p];
+      for (int w_ = 0; w_ < kWaves; ++w_) g += fw[w_] * s_gacc[w_][p];
+    }
     out[kRecHeader + p] = g;
   }
 }
 
+// ---- block-wide deterministic reductions over a [rows][vp] LDS tile --------------------------------
+// Thread (row = tid / vp, col = tid % vp) holds one partial for value `col`; rows are folded in a
+// fixed binary tree, so results are bit-reproducible run to run.
+__device__ __forceinline__ void fold_rows(double* tile, int vp, int rows, int tid) {
+  for (int half = rows >> 1; half > 0; half >>= 1) {
+    __syncthreads();
+    const int row = tid / vp, col = tid - row * vp;
+    if (row < half) tile[row * vp + col] += tile[(row + half) * vp + col];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
 // ---- stage 2: combine the tile records of one event (blocks 0..n_ev-1) or of the injection set
-//      (block n_ev) with a common reference exponent ----------------------------------------------
+//      (block n_ev) with a common reference exponent.  All 256 threads work: the record values
+//      (S1, S2, G[0..n_theta)) are the fast index, tiles the slow one. -------------------------------
 struct CombineArgs {
   const double* partials;
   double* ev_out;     // [n_ev][4]: logsumexp (= log sum_j w_ij, no -log N_pe), log n_eff, variance, S1
   double* ev_grad;    // [n_ev][n_theta]: G_p / S1
   double* inj_out;    // [4]: M, S1, S2
   double* inj_grad;   // [n_theta]: G_p relative to M
+  double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
   int n_ev, tiles_per_event, n_inj_tiles, n_theta, rec_stride;
   double n_pe;
 };
 
 __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
+  __shared__ double s_tile[kBlock];
   __shared__ double s_red[kWaves];
   __shared__ double s_M;
   const int tid = threadIdx.x;
@@ -602,52 +749,65 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
   __syncthreads();
   const double M = s_M;
 
-  // S1, S2 by thread 0 in tile order (deterministic); gradient numerators by thread p
-  double S1 = 0.0, S2 = 0.0;
-  if (tid == 0) {
-    for (int t = 0; t < n_tiles; ++t) {
-      const double* r = rec + (long long)t * a.rec_stride;
-      const double f = (r[0] == GWI_NEG_INF) ? 0.0 : exp(r[0] - M);
-      S1 += f * r[1];
-      S2 += f * f * r[2];
+  const int n_val = 2 + a.n_theta;  // S1, S2, G[...]
+  double S1 = 0.0;
+  for (int v0 = 0; v0 < n_val; v0 += kBlock) {  // one pass unless n_theta > 254
+    const int nv = n_val - v0 < kBlock ? n_val - v0 : kBlock;
+    const int vp = pow2_at_least(nv);
+    const int rows = kBlock / vp;
+    const int row = tid / vp, col = tid - row * vp;
+    double acc = 0.0;
+    if (col < nv) {
+      const int v = v0 + col;
+      for (int t = row; t < n_tiles; t += rows) {
+        const double* r = rec + (long long)t * a.rec_stride;
+        const double m_t = r[0];
+        double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
+        if (v == 1) f *= f;  // S2 carries e^{2(m_t - M)}
+        acc += f * r[1 + v];
+      }
     }
-    s_red[0] = S1;
-  }
-  __syncthreads();
-  S1 = s_red[0];
-  for (int p = tid; p < a.n_theta; p += kBlock) {
-    double g = 0.0;
-    for (int t = 0; t < n_tiles; ++t) {
-      const double* r = rec + (long long)t * a.rec_stride;
-      const double f = (r[0] == GWI_NEG_INF) ? 0.0 : exp(r[0] - M);
-      g += f * r[kRecHeader + p];
+    s_tile[tid] = acc;
+    fold_rows(s_tile, vp, rows, tid);
+    if (v0 == 0) S1 = s_tile[0];
+    if (row == 0 && col < nv) {
+      const int v = v0 + col;
+      const double g = s_tile[col];
+      if (v >= 2) {
+        if (is_inj)
+          a.inj_grad[v - 2] = g;
+        else
+          a.ev_grad[(long long)e * a.n_theta + (v - 2)] = S1 > 0.0 ? g / S1 : 0.0;
+      }
     }
-    if (is_inj)
-      a.inj_grad[p] = g;
-    else
-      a.ev_grad[(long long)e * a.n_theta + p] = S1 > 0.0 ? g / S1 : 0.0;
-  }
-  if (tid == 0) {
-    if (is_inj) {
-      a.inj_out[0] = M;
-      a.inj_out[1] = S1;
-      a.inj_out[2] = S2;
-    } else {
-      // analysis.py:78-87: logBF = logsumexp - log N_pe (constant added on the host),
-      // log n_eff = 2 logsumexp(l) - logsumexp(2 l), variance = 1/n_eff - 1/N_pe
-      const double log_s1 = log(S1);
-      const double log_neff = 2.0 * log_s1 - log(S2);
-      double* o = a.ev_out + (long long)e * 4;
-      o[0] = log_s1 + M;
-      o[1] = log_neff;
-      o[2] = 1.0 / exp(log_neff) - 1.0 / a.n_pe;
-      o[3] = S1;
+    if (v0 == 0 && tid == 0) {
+      const double S2 = s_tile[1];
+      if (is_inj) {
+        a.inj_out[0] = M;
+        a.inj_out[1] = S1;
+        a.inj_out[2] = S2;
+      } else {
+        // analysis.py:78-87: logBF = logsumexp - log N_pe (constant added on the host),
+        // log n_eff = 2 logsumexp(l) - logsumexp(2 l), variance = 1/n_eff - 1/N_pe
+        const double log_s1 = log(S1);
+        const double log_neff = 2.0 * log_s1 - log(S2);
+        const double var = 1.0 / exp(log_neff) - 1.0 / a.n_pe;
+        double* o = a.ev_out + (long long)e * 4;
+        o[0] = log_s1 + M;
+        o[1] = log_neff;
+        o[2] = var;
+        o[3] = S1;
+        a.ev_host[e] = log_s1 + M;
+        a.ev_host[a.n_ev + e] = log_neff;
+        a.ev_host[2 * a.n_ev + e] = var;
+      }
     }
+    __syncthreads();
   }
 }
 
 // ---- stage 3: reduce over events and publish this device's record to pinned host memory -----------
-// record layout (doubles): see RecordLayout in gwi_engine.hip
+// record layout (doubles): see kRecNormOff in gwi_engine.hip
 struct FinalArgs {
   const double* ev_out;
   const double* ev_grad;
@@ -655,12 +815,12 @@ struct FinalArgs {
   const double* inj_grad;
   const double* norm_out;
   double* record;       // device-visible pinned host buffer
-  double* ev_host;      // [3][n_ev] pinned host: logsumexp, log n_eff, variance
   int n_ev, n_theta, n_norms;
   unsigned long long seq;  // written last to record[0] as a completion stamp
 };
 
 __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
+  __shared__ double s_tile[kBlock];
   __shared__ double s_sum[kWaves], s_var[kWaves], s_min[kWaves];
   const int tid = threadIdx.x;
   double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
@@ -673,9 +833,6 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
     if (le != le) le = 0.0;
     le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
     mn = fmin(mn, le);
-    a.ev_host[e] = o[0];
-    a.ev_host[a.n_ev + e] = o[1];
-    a.ev_host[2 * a.n_ev + e] = o[2];
   }
   sum = wave_sum(sum);
   var = wave_sum(var);
@@ -687,11 +844,22 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
   }
   double* r = a.record;
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
-  for (int p = tid; p < a.n_theta; p += kBlock) {
-    double g = 0.0;
-    for (int e = 0; e < a.n_ev; ++e) g += a.ev_grad[(long long)e * a.n_theta + p];
-    r[off_gpe + p] = g;
-    r[off_ginj + p] = a.inj_grad[p];
+  // sum_e ev_grad[e][p]: p is the fast index, events the slow one, fixed-tree fold over rows
+  for (int p0 = 0; p0 < a.n_theta; p0 += kBlock) {
+    const int nv = a.n_theta - p0 < kBlock ? a.n_theta - p0 : kBlock;
+    const int vp = pow2_at_least(nv);
+    const int rows = kBlock / vp;
+    const int row = tid / vp, col = tid - row * vp;
+    double acc = 0.0;
+    if (col < nv)
+      for (int e = row; e < a.n_ev; e += rows) acc += a.ev_grad[(long long)e * a.n_theta + p0 + col];
+    s_tile[tid] = acc;
+    fold_rows(s_tile, vp, rows, tid);
+    if (row == 0 && col < nv) {
+      r[off_gpe + p0 + col] = s_tile[col];
+      r[off_ginj + p0 + col] = a.inj_grad[p0 + col];
+    }
+    __syncthreads();
   }
   for (int j = tid; j < a.n_norms; j += kBlock) r[off_norm + j] = a.norm_out[j];
   __syncthreads();

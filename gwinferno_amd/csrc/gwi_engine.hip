@@ -2,6 +2,7 @@
 // gfx950 only; no CPU fallback: every entry point that computes needs a live HIP device.
 #include "gwi_device.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -149,6 +150,7 @@ struct gwi_engine {
   double host_const = 0.0;
   // timing
   bool timing = false;
+  bool spin_wait = true;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   std::string err;
@@ -235,6 +237,14 @@ void prelude(gwi_engine* h, const double* theta) {
       case GWI_TERM_PLPEAK: {
         powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &d[0], &d[1]);
         truncnorm_lognorm(theta[tm.theta[1]], theta[tm.theta[2]], tm.p[0], tm.p[1], &d[2], &d[3], &d[4]);
+        const double sg = theta[tm.theta[2]];
+        d[5] = 1.0 / (sg * sg);
+        d[6] = d[5] / sg;
+        break;
+      }
+      case GWI_TERM_POWERLAW_RATIO: {
+        const double b1 = 1.0 + theta[tm.theta[0]];
+        d[0] = b1 != 0.0 ? 1.0 / b1 : 0.0;
         break;
       }
       case GWI_TERM_BETA: {
@@ -245,12 +255,18 @@ void prelude(gwi_engine* h, const double* theta) {
       case GWI_TERM_TILT_MIXTURE: {
         double dmu;
         truncnorm_lognorm(1.0, theta[tm.theta[1]], -1.0, 1.0, &d[0], &dmu, &d[1]);
+        const double sg = theta[tm.theta[1]];
+        d[2] = 1.0 / (sg * sg);
+        d[3] = d[2] / sg;
         break;
       }
       case GWI_TERM_TRUNCNORM: {
         double lc, dmu, dsg;
         truncnorm_lognorm(theta[tm.theta[0]], theta[tm.theta[1]], tm.p[0], tm.p[1], &lc, &dmu, &dsg);
         c += lc;
+        const double sg = theta[tm.theta[1]];
+        d[0] = 1.0 / (sg * sg);
+        d[1] = d[0] / sg;
         break;
       }
       default: break;
@@ -286,6 +302,7 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   ca.n_theta = h->spec.n_theta;
   ca.rec_stride = h->rec_stride;
   ca.n_pe = (double)h->n_pe;
+  ca.ev_host = h->h_ev_dev;
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)h->n_ev + 1), dim3(kBlock), 0, h->stream, ca);
   GWI_HIP(hipGetLastError());
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
@@ -296,7 +313,6 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   fa.inj_grad = h->d_inj_grad;
   fa.norm_out = h->d_norm_out;
   fa.record = h->h_record_dev;
-  fa.ev_host = h->h_ev_dev;
   fa.n_ev = (int)h->n_ev;
   fa.n_theta = h->spec.n_theta;
   fa.n_norms = h->spec.n_norms;
@@ -304,13 +320,28 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
   GWI_HIP(hipGetLastError());
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
-  GWI_HIP(hipStreamSynchronize(h->stream));
+  // Completion: final_kernel stores the sequence stamp into pinned host memory LAST (system-scope
+  // release after __threadfence_system), so the host can poll it instead of paying a stream
+  // synchronise; after ~2 ms of polling fall back to the blocking call (and surface any error).
+  volatile unsigned long long* stamp = reinterpret_cast<volatile unsigned long long*>(h->h_record);
+  bool done = false;
+  if (!h->timing && h->spin_wait) {
+    for (long spin = 0; spin < 400000; ++spin) {
+      if (*stamp == h->seq) {
+        done = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) {
+    GWI_HIP(hipStreamSynchronize(h->stream));
+    if (*stamp != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
+  }
   if (h->timing) {
     for (int i = 0; i < 3; ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
   }
-  unsigned long long stamp;
-  std::memcpy(&stamp, h->h_record, sizeof(stamp));
-  if (stamp != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
   return GWI_OK;
 }
 
@@ -484,6 +515,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
   GWI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  if (const char* env = std::getenv("GWI_SPIN_WAIT")) h->spin_wait = std::atoi(env) != 0;
   for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
   h->n_ev = n_ev;
   h->n_pe = n_pe;
@@ -545,9 +577,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     const long long total = n_ev * n_pe + n_inj;
     spb = (total + 2047) / 2048;
   }
-  spb = ((spb + kBlock - 1) / kBlock) * kBlock;
-  if (spb < kBlock) spb = kBlock;
-  const long long n_pe_pad = ((n_pe + kBlock - 1) / kBlock) * kBlock;
+  const long long gran = (long long)kU * kBlock;  // every lane carries kU samples per trip
+  spb = ((spb + gran - 1) / gran) * gran;
+  if (spb < gran) spb = gran;
+  const long long n_pe_pad = ((n_pe + gran - 1) / gran) * gran;
   h->chunk_pe = (int)(spb < n_pe_pad ? spb : n_pe_pad);
   h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
   h->chunk_inj = (int)spb;
