@@ -51,6 +51,7 @@ struct KArgs {
   long long n_inj;
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
+  int gacc_rep, gacc_pad;  // spline-gradient LDS rows: replicas per wave (power of two), row stride (odd)
   TermD terms[GWI_MAX_TERMS];
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
@@ -539,8 +540,12 @@ constexpr int kRedChunk = 8;  // values per pass of the block-level transposed r
 template <bool WRITE_LOGW, int... Ks>
 __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   using ChainT = Chain<Ks...>;
+  // Spline-coefficient gradient numerators: per wave, gacc_rep replicas of a row of gacc_pad
+  // doubles.  Lane l adds into replica l % gacc_rep, so the 64 ds_add_f64 of one wave instruction
+  // that target ONE coefficient (posterior samples of an event cluster in a few knot intervals)
+  // are spread over gacc_rep addresses in different banks (gacc_pad is odd).
+  extern __shared__ double s_gacc[];
   __shared__ double s_theta[GWI_MAX_THETA];
-  __shared__ double s_gacc[kWaves][GWI_MAX_THETA];
   __shared__ double s_out[GWI_MAX_THETA];
   __shared__ double s_red[kRedChunk][kBlock];
   __shared__ double s_wrec[kWaves][4];
@@ -553,8 +558,10 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
   if (ChainT::kSpline || is_norm)
     for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
+  const int wave_span = a.gacc_rep * a.gacc_pad;
+  double* const wave_rows = s_gacc + wave * wave_span;
   if (ChainT::kSpline)
-    for (int p = lane; p < a.n_theta; p += 64) s_gacc[wave][p] = 0.0;
+    for (int p = lane; p < wave_span; p += 64) wave_rows[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
   if (ChainT::kSpline || is_norm) __syncthreads();
 
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   Ctx ctx;
   ctx.a = &a;
   ctx.coefs = s_theta;
-  ctx.gacc = s_gacc[wave];
+  ctx.gacc = wave_rows + (lane & (a.gacc_rep - 1)) * a.gacc_pad;
   double* logw;
   if (b < n_pe_blocks) {
     const int e = b / a.tiles_per_event;
@@ -620,12 +627,14 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
     if (WRITE_LOGW) continue;
     const double mx = wave_max(mx_lane);
     if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
-      const double sc = exp(m - mx);
-      s1 *= sc;
-      s2 *= sc * sc;
-      chain.rescale(sc);
-      if (ChainT::kSpline)
-        for (int p = lane; p < a.n_theta; p += 64) ctx.gacc[p] *= sc;
+      if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
+        const double sc = exp(m - mx);
+        s1 *= sc;
+        s2 *= sc * sc;
+        chain.rescale(sc);
+        if (ChainT::kSpline)
+          for (int p = lane; p < wave_span; p += 64) wave_rows[p] *= sc;
+      }
       m = mx;
     }
 #pragma unroll
@@ -691,7 +700,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
     double g = s_out[p];
     if (ChainT::kSpline) {
 #pragma unroll
-      for (int w_ = 0; w_ < kWaves; ++w_) g += fw[w_] * s_gacc[w_][p];
+      for (int w_ = 0; w_ < kWaves; ++w_) {
+        const double* rows = s_gacc + w_ * wave_span + p;
+        double gw = 0.0;
+        for (int r = 0; r < a.gacc_rep; ++r) gw += rows[r * a.gacc_pad];
+        g += fw[w_] * gw;
+      }
     }
     out[kRecHeader + p] = g;
   }
@@ -715,17 +729,19 @@ __device__ __forceinline__ int pow2_at_least(int v) {
   return p;
 }
 
-// ---- stage 2: combine the tile records of one event (blocks 0..n_ev-1) or of the injection set
-//      (block n_ev) with a common reference exponent.  All 256 threads work: the record values
-//      (S1, S2, G[0..n_theta)) are the fast index, tiles the slow one. -------------------------------
+// ---- stage 2: combine the tile records of one GROUP with a common reference exponent.  Groups
+//      0..n_ev-1 are the events (all tiles of one event); groups n_ev.. split the injection tiles
+//      into n_inj_groups contiguous runs so that no single workgroup has to walk thousands of
+//      records.  All 256 threads work: the record values (S1, S2, G[0..n_theta)) are the fast index,
+//      tiles the slow one; rows are folded in a fixed tree (bit-reproducible). --------------------------
 struct CombineArgs {
   const double* partials;
   double* ev_out;     // [n_ev][4]: logsumexp (= log sum_j w_ij, no -log N_pe), log n_eff, variance, S1
   double* ev_grad;    // [n_ev][n_theta]: G_p / S1
-  double* inj_out;    // [4]: M, S1, S2
-  double* inj_grad;   // [n_theta]: G_p relative to M
+  double* inj_out;    // [n_inj_groups][4]: M, S1, S2
+  double* inj_grad;   // [n_inj_groups][n_theta]: G_p relative to that group's M
   double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
-  int n_ev, tiles_per_event, n_inj_tiles, n_theta, rec_stride;
+  int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   double n_pe;
 };
 
@@ -735,9 +751,18 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
   __shared__ double s_M;
   const int tid = threadIdx.x;
   const int e = blockIdx.x;
-  const bool is_inj = e == a.n_ev;
-  const int n_tiles = is_inj ? a.n_inj_tiles : a.tiles_per_event;
-  const long long first = is_inj ? (long long)a.n_ev * a.tiles_per_event : (long long)e * a.tiles_per_event;
+  const bool is_inj = e >= a.n_ev;
+  int n_tiles;
+  long long first;
+  if (is_inj) {
+    const int j = e - a.n_ev;
+    const int t0 = j * a.tiles_per_inj_group;
+    n_tiles = a.n_inj_tiles - t0 < a.tiles_per_inj_group ? a.n_inj_tiles - t0 : a.tiles_per_inj_group;
+    first = (long long)a.n_ev * a.tiles_per_event + t0;
+  } else {
+    n_tiles = a.tiles_per_event;
+    first = (long long)e * a.tiles_per_event;
+  }
   const double* rec = a.partials + first * a.rec_stride;
 
   double mx = GWI_NEG_INF;
@@ -759,6 +784,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
     double acc = 0.0;
     if (col < nv) {
       const int v = v0 + col;
+#pragma unroll 4
       for (int t = row; t < n_tiles; t += rows) {
         const double* r = rec + (long long)t * a.rec_stride;
         const double m_t = r[0];
@@ -775,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
       const double g = s_tile[col];
       if (v >= 2) {
         if (is_inj)
-          a.inj_grad[v - 2] = g;
+          a.inj_grad[(long long)(e - a.n_ev) * a.n_theta + (v - 2)] = g;
         else
           a.ev_grad[(long long)e * a.n_theta + (v - 2)] = S1 > 0.0 ? g / S1 : 0.0;
       }
@@ -783,9 +809,10 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
     if (v0 == 0 && tid == 0) {
       const double S2 = s_tile[1];
       if (is_inj) {
-        a.inj_out[0] = M;
-        a.inj_out[1] = S1;
-        a.inj_out[2] = S2;
+        double* o = a.inj_out + (long long)(e - a.n_ev) * 4;
+        o[0] = M;
+        o[1] = S1;
+        o[2] = S2;
       } else {
         // analysis.py:78-87: logBF = logsumexp - log N_pe (constant added on the host),
         // log n_eff = 2 logsumexp(l) - logsumexp(2 l), variance = 1/n_eff - 1/N_pe
@@ -806,8 +833,8 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
   }
 }
 
-// ---- stage 3: reduce over events and publish this device's record to pinned host memory -----------
-// record layout (doubles): see kRecNormOff in gwi_engine.hip
+// ---- stage 3: reduce over events, merge the injection groups, and publish this device's record to
+//      pinned host memory.  record layout (doubles): see kRecNormOff in gwi_engine.hip -------------------
 struct FinalArgs {
   const double* ev_out;
   const double* ev_grad;
@@ -815,13 +842,14 @@ struct FinalArgs {
   const double* inj_grad;
   const double* norm_out;
   double* record;       // device-visible pinned host buffer
-  int n_ev, n_theta, n_norms;
+  int n_ev, n_theta, n_norms, n_inj_groups;
   unsigned long long seq;  // written last to record[0] as a completion stamp
 };
 
 __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
   __shared__ double s_tile[kBlock];
   __shared__ double s_sum[kWaves], s_var[kWaves], s_min[kWaves];
+  __shared__ double s_inj[4];
   const int tid = threadIdx.x;
   double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
   for (int e = tid; e < a.n_ev; e += kBlock) {
@@ -842,23 +870,51 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
     s_var[tid >> 6] = var;
     s_min[tid >> 6] = mn;
   }
+  // injection groups: common exponent, then S1/S2 in group order
+  if (tid == 0) {
+    double M = GWI_NEG_INF;
+    for (int j = 0; j < a.n_inj_groups; ++j) M = fmax(M, a.inj_out[j * 4]);
+    double S1 = 0.0, S2 = 0.0;
+    for (int j = 0; j < a.n_inj_groups; ++j) {
+      const double m_j = a.inj_out[j * 4];
+      const double f = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - M);
+      S1 += f * a.inj_out[j * 4 + 1];
+      S2 += f * f * a.inj_out[j * 4 + 2];
+    }
+    s_inj[0] = M;
+    s_inj[1] = S1;
+    s_inj[2] = S2;
+  }
+  __syncthreads();
+  const double Minj = s_inj[0];
   double* r = a.record;
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
-  // sum_e ev_grad[e][p]: p is the fast index, events the slow one, fixed-tree fold over rows
+  // sum_e ev_grad[e][p] and sum_j f_j inj_grad[j][p]: p is the fast index, fixed-tree fold over rows
   for (int p0 = 0; p0 < a.n_theta; p0 += kBlock) {
     const int nv = a.n_theta - p0 < kBlock ? a.n_theta - p0 : kBlock;
     const int vp = pow2_at_least(nv);
     const int rows = kBlock / vp;
     const int row = tid / vp, col = tid - row * vp;
     double acc = 0.0;
-    if (col < nv)
+    if (col < nv) {
+#pragma unroll 8
       for (int e = row; e < a.n_ev; e += rows) acc += a.ev_grad[(long long)e * a.n_theta + p0 + col];
+    }
     s_tile[tid] = acc;
     fold_rows(s_tile, vp, rows, tid);
-    if (row == 0 && col < nv) {
-      r[off_gpe + p0 + col] = s_tile[col];
-      r[off_ginj + p0 + col] = a.inj_grad[p0 + col];
+    if (row == 0 && col < nv) r[off_gpe + p0 + col] = s_tile[col];
+    __syncthreads();
+    acc = 0.0;
+    if (col < nv) {
+      for (int j = row; j < a.n_inj_groups; j += rows) {
+        const double m_j = a.inj_out[j * 4];
+        const double f = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
+        acc += f * a.inj_grad[(long long)j * a.n_theta + p0 + col];
+      }
     }
+    s_tile[tid] = acc;
+    fold_rows(s_tile, vp, rows, tid);
+    if (row == 0 && col < nv) r[off_ginj + p0 + col] = s_tile[col];
     __syncthreads();
   }
   for (int j = tid; j < a.n_norms; j += kBlock) r[off_norm + j] = a.norm_out[j];
@@ -867,9 +923,9 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
     r[1] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
     r[2] = (s_var[0] + s_var[1]) + (s_var[2] + s_var[3]);
     r[3] = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
-    r[4] = a.inj_out[0];
-    r[5] = a.inj_out[1];
-    r[6] = a.inj_out[2];
+    r[4] = s_inj[0];
+    r[5] = s_inj[1];
+    r[6] = s_inj[2];
     r[7] = (double)a.n_ev;
   }
   __syncthreads();

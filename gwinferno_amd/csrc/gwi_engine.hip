@@ -145,6 +145,8 @@ struct gwi_engine {
   double *h_ev = nullptr, *h_ev_dev = nullptr;
   // launch geometry
   int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
+  int n_inj_groups = 1, tiles_per_inj_group = 1;
+  size_t scan_lds_bytes = 0;
   unsigned long long seq = 0;
   // results of the last prelude
   double host_const = 0.0;
@@ -279,7 +281,7 @@ void prelude(gwi_engine* h, const double* theta) {
 gwi_status launch_scan(gwi_handle h, bool logw) {
   const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);
   ScanFn fn = logw ? h->variant->logw : h->variant->scan;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, h->stream, h->kargs);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), h->scan_lds_bytes, h->stream, h->kargs);
   GWI_HIP(hipGetLastError());
   return GWI_OK;
 }
@@ -299,11 +301,13 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   ca.n_ev = (int)h->n_ev;
   ca.tiles_per_event = h->tiles_per_event;
   ca.n_inj_tiles = h->n_inj_tiles;
+  ca.n_inj_groups = h->n_inj_groups;
+  ca.tiles_per_inj_group = h->tiles_per_inj_group;
   ca.n_theta = h->spec.n_theta;
   ca.rec_stride = h->rec_stride;
   ca.n_pe = (double)h->n_pe;
   ca.ev_host = h->h_ev_dev;
-  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)h->n_ev + 1), dim3(kBlock), 0, h->stream, ca);
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups)), dim3(kBlock), 0, h->stream, ca);
   GWI_HIP(hipGetLastError());
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
   FinalArgs fa;
@@ -316,6 +320,7 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   fa.n_ev = (int)h->n_ev;
   fa.n_theta = h->spec.n_theta;
   fa.n_norms = h->spec.n_norms;
+  fa.n_inj_groups = h->n_inj_groups;
   fa.seq = ++h->seq;
   hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
   GWI_HIP(hipGetLastError());
@@ -587,13 +592,28 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
   h->rec_stride = kRecHeader + spec->n_theta;
+  // injection tiles are combined in groups of <= 32 records (one workgroup each)
+  h->tiles_per_inj_group = 32;
+  h->n_inj_groups = (h->n_inj_tiles + h->tiles_per_inj_group - 1) / h->tiles_per_inj_group;
+  if (h->n_inj_groups < 1) h->n_inj_groups = 1;
+  // spline-gradient LDS rows: replicas per wave (see scan_kernel); 8 by default, <= 16
+  int rep = 8;
+  if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
+  if (rep < 1) rep = 1;
+  if (rep > 16) rep = 16;
+  while (rep & (rep - 1)) rep &= rep - 1;  // power of two
+  const int pad = spec->n_theta | 1;        // odd row stride: replicas land in different banks
+  bool has_spline = false;
+  for (int t = 0; t < spec->n_terms; ++t) has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE;
+  if (!has_spline) rep = 1;
+  h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
 
   GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
   GWI_HIP(hipMalloc(&h->d_norm_out, sizeof(double) * (spec->n_norms ? spec->n_norms : 1)));
   GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * 4 * (size_t)(n_ev ? n_ev : 1)));
   GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
-  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * 4));
-  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * spec->n_theta));
+  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * 4 * (size_t)h->n_inj_groups));
+  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * (size_t)h->n_inj_groups * spec->n_theta));
   GWI_HIP(hipHostMalloc((void**)&h->h_record, sizeof(double) * record_len(h), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_record_dev, h->h_record, 0));
   GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
@@ -620,6 +640,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   k.n_theta = spec->n_theta;
   k.kappa_col = spec->kappa_col;
   k.rec_stride = h->rec_stride;
+  k.gacc_rep = rep;
+  k.gacc_pad = pad;
   for (int t = 0; t < spec->n_terms; ++t) {
     const gwi_term& tm = spec->terms[t];
     TermD& d = k.terms[t];
