@@ -26,6 +26,8 @@ TERM_EXP_SPLINE = 7
 TERM_TRUNCNORM = 8
 
 SPLINE_OUTSIDE_ZERO_EXPONENT = 1
+DEVICE_CURRENT = -1
+DEVICE_HOST_ONLY = -2
 
 STATUS_NAMES = {0: "GWI_OK", -1: "GWI_ERR_INVALID", -2: "GWI_ERR_NO_DEVICE", -3: "GWI_ERR_HIP", -4: "GWI_ERR_UNSUPPORTED", -5: "GWI_ERR_TIMEOUT"}
 
@@ -120,6 +122,7 @@ EXPORTED_SYMBOLS = [
     "gwi_log_weights",
     "gwi_partial_len",
     "gwi_eval_partial",
+    "gwi_prepare_combine",
     "gwi_combine",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
@@ -158,6 +161,8 @@ def load_library():
     lib.gwi_partial_len.argtypes = [vp]
     lib.gwi_eval_partial.restype = C.c_int32
     lib.gwi_eval_partial.argtypes = [vp, _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_prepare_combine.restype = C.c_int32
+    lib.gwi_prepare_combine.argtypes = [vp, _DP]
     lib.gwi_combine.restype = C.c_int32
     lib.gwi_combine.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32

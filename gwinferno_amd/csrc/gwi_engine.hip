@@ -153,6 +153,7 @@ struct gwi_engine {
   // timing
   bool timing = false;
   bool spin_wait = true;
+  bool host_only = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   std::string err;
@@ -437,6 +438,10 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
 
 void destroy_impl(gwi_engine* h) {
   if (!h) return;
+  if (h->host_only) {
+    delete h;
+    return;
+  }
   (void)hipSetDevice(h->device);
   for (double* p : h->d_cols_pe) (void)hipFree(p);
   for (double* p : h->d_cols_inj) (void)hipFree(p);
@@ -495,13 +500,22 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   *out = nullptr;
   if (!spec || !pe_cols || !inj_cols || n_ev < 0 || n_pe < 1 || n_inj < 0) return GWI_ERR_INVALID;
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return GWI_ERR_NO_DEVICE;
+  if (device != GWI_DEVICE_HOST_ONLY && (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)) return GWI_ERR_NO_DEVICE;
   gwi_engine* h = new (std::nothrow) gwi_engine();
   if (!h) return GWI_ERR_INVALID;
   *out = h;  // returned even on failure so gwi_last_error() can explain; caller must gwi_destroy()
   gwi_status st = validate_spec(h, spec);
   if (st != GWI_OK) return st;
   h->spec = *spec;
+  if (device == GWI_DEVICE_HOST_ONLY) {
+    h->host_only = true;
+    h->n_ev = n_ev;
+    h->n_pe = n_pe;
+    h->n_inj = n_inj;
+    for (int j = 0; j < spec->n_norms; ++j) h->spec.norms[j].tw = h->spec.norms[j].lb = h->spec.norms[j].l1 = h->spec.norms[j].us = nullptr;
+    std::memset(&h->kargs, 0, sizeof(h->kargs));
+    return GWI_OK;
+  }
   h->variant = find_variant(*spec);
   if (!h->variant) {
     std::string seq;
@@ -679,8 +693,15 @@ gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]) {
 
 int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
 
+gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
+  if (!h || !theta) return GWI_ERR_INVALID;
+  prelude(h, theta);
+  return GWI_OK;
+}
+
 gwi_status gwi_eval_partial(gwi_handle h, const double* theta, double* record_host, double* log_bfs, double* log_neffs, double* variances) {
   if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
   gwi_status st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
@@ -710,6 +731,7 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (opt->marginalize_selection && grad)
     return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
   gwi_status st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
@@ -727,6 +749,7 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
 
 gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, double* inj_logw) {
   if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
   const size_t n_pe_tot = (size_t)(h->n_ev * h->n_pe), n_inj = (size_t)h->n_inj;
   if (!h->d_logw_pe) GWI_HIP(hipMalloc(&h->d_logw_pe, sizeof(double) * (n_pe_tot ? n_pe_tot : 1)));

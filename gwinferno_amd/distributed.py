@@ -1,0 +1,55 @@
+"""Multi-GPU evaluation: one process per GPU, events and injections sharded, ONE collective.
+
+The reference has no distributed path; the likelihood nevertheless shards
+naturally: events are independent (pipeline/analysis.py:78-86 reduces along axis 1 only) and the
+injection sum is associative (:126-134).  Rank r scans a contiguous block of events and a slice of
+the injections and publishes a small partial record (8 + n_norms + 2 n_theta doubles: sums of
+per-event log-sums / variances, min log n_eff, the injection (M, S1, S2) triple, gradient numerators).
+The only exchange is an all-gather of those records -- RCCL over xGMI when the process group's
+backend is "nccl", gloo in the CPU tests -- after which every rank assembles the identical result
+with the same summation order (deterministic, rank-symmetric).  The payload is ~1 KiB, so the
+collective is latency-bound; there is exactly one per evaluation.
+"""
+import numpy as np
+
+from .engine import EvalResult
+
+
+class ShardedLikelihood:
+    """Wraps this rank's :class:`NativePopulationLikelihood` (built with ``rank=``/``world=``)."""
+
+    def __init__(self, engine, total_inj, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.engine = engine
+        self.total_inj = float(total_inj)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        backend = dist.get_backend(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        self.device = device
+        n = engine.partial_len
+        self._send = torch.zeros(n, dtype=torch.float64, device=device)
+        self._recv = torch.zeros(self.world * n, dtype=torch.float64, device=device)
+        self._host = torch.zeros(n, dtype=torch.float64).pin_memory() if device.type == "cuda" else torch.zeros(n, dtype=torch.float64)
+
+    def gather_records(self, record):
+        """All-gather one partial record per rank -> (world, len) float64 array (same on all ranks)."""
+        t = self.torch
+        self._host.copy_(t.from_numpy(np.ascontiguousarray(record)))
+        self._send.copy_(self._host, non_blocking=True)
+        self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+        return self._recv.cpu().numpy().reshape(self.world, -1)
+
+    def evaluate(self, theta, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True):
+        rec, lb, ln, lv = self.engine.eval_partial(theta)
+        records = self.gather_records(rec)
+        res = self.engine.combine(records, self.total_inj, nobs=self.engine.n_ev_global, marginalize_selection=marginalize_selection, min_neff_cut=min_neff_cut,
+                                  max_variance_cut=max_variance_cut, want_grad=want_grad)
+        # local per-event sites (this rank's events), global constant applied
+        shift = res.summary.log_norm_const - np.log(self.engine.n_pe)
+        return EvalResult(log_likelihood=res.log_likelihood, grad=res.grad, summary=res.summary, log_bfs=lb + shift, log_neffs=ln, variances=lv, norms=res.norms)

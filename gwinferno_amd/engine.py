@@ -56,7 +56,7 @@ def structure_key(pe, inj):
     parts = []
     for d in (pe, inj):
         parts.append(tuple(f.structure() + tuple(c.key() for c in f.columns) for f in d.factors))
-        parts.append(tuple(id(a) for a in d.log_static))
+        parts.append(tuple((sgn, id(a)) for sgn, a in d.log_static))
     return tuple(parts)
 
 
@@ -131,8 +131,8 @@ def bind(pe, inj, hypervolume=None):
     with np.errstate(all="ignore"):
         for d, kap in ((pe, kap_pe), (inj, kap_inj)):
             kap += d.log_const  # plain scalar multipliers (e.g. the 0.5 of a symmetrised density)
-            for arr in d.log_static:
-                kap += arr
+            for sgn, arr in d.log_static:
+                kap += sgn * np.log(np.asarray(arr, dtype=np.float64))
             for f in d.factors:
                 if f.static_log is not None:
                     kap += f.static_log
@@ -331,6 +331,10 @@ class NativePopulationLikelihood:
         lb, ln, lv = np.zeros(self.n_ev), np.zeros(self.n_ev), np.zeros(self.n_ev)
         self._check(self.lib.gwi_eval_partial(self.handle, N.as_dp(theta), N.as_dp(rec), N.as_dp(lb), N.as_dp(ln), N.as_dp(lv)))
         return rec, lb, ln, lv
+
+    def prepare_combine(self, theta):
+        """Host-only handles: set the hyper-parameter point whose constants ``combine`` folds in."""
+        self._check(self.lib.gwi_prepare_combine(self.handle, N.as_dp(N.f64(theta))))
 
     def combine(self, records, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True):
         records = N.f64(records).reshape(-1, self.partial_len)

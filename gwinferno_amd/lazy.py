@@ -106,7 +106,7 @@ class Density:
     def __init__(self, factors=(), side=None, log_static=(), log_const=0.0):
         self.factors = list(factors)
         self.side = side
-        self.log_static = list(log_static)  # list of per-sample log factors (arrays) folded into kappa
+        self.log_static = list(log_static)  # [(+1 | -1, array)]: theta-independent per-sample factors (x or /), folded into kappa
         self.log_const = log_const          # log of plain scalar multipliers
 
     # ---- algebra ---------------------------------------------------------------------------------
@@ -121,9 +121,7 @@ class Density:
         if np.ndim(other) == 0:
             with np.errstate(all="ignore"):
                 return Density(self.factors, self.side, self.log_static, self.log_const + np.log(float(other)))
-        arr = np.asarray(other, dtype=np.float64)
-        with np.errstate(all="ignore"):
-            return Density(self.factors, self._merge_side(side_of(arr)), self.log_static + [np.log(arr)], self.log_const)
+        return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(1.0, other)], self.log_const)
 
     __rmul__ = __mul__
 
@@ -132,9 +130,7 @@ class Density:
             raise TypeError("division by a lazy density is not supported")
         if np.ndim(other) == 0:
             return Density(self.factors, self.side, self.log_static, self.log_const - np.log(float(other)))
-        arr = np.asarray(other, dtype=np.float64)
-        with np.errstate(all="ignore"):
-            return Density(self.factors, self._merge_side(side_of(arr)), self.log_static + [-np.log(arr)], self.log_const)
+        return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(-1.0, other)], self.log_const)
 
     def __repr__(self):
         return f"Density(side={self.side}, factors={[f.kind for f in self.factors]})"

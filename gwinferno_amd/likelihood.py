@@ -1,0 +1,246 @@
+"""Drop-in for the reference's likelihood assembly, ``gwinferno/pipeline/analysis.py``.
+
+``hierarchical_likelihood`` keeps the reference's name, positional order, keyword names and defaults
+(analysis.py:139-163), registers the same deterministic sites (:260-317) and the same
+``numpyro.factor("log_likelihood", ...)`` (:319), and returns the merger rate (:356) -- but takes the
+*lazy* PE / injection products built by :mod:`gwinferno_amd.models` and evaluates value, gradient and
+all diagnostics in one pass of the HIP engine instead of materialising ``(N_ev, N_pe)`` arrays.
+
+Three ways to drive it
+  * NumPyro present (GPU box with jax+numpyro): call it inside a NumPyro model function exactly as
+    the reference's ``tests/inference_test.py:162-197`` does; hyper-parameters may be JAX tracers --
+    the engine is wrapped in a ``jax.custom_vjp`` around ``jax.pure_callback`` so that
+    ``jit(value_and_grad(potential_fn))`` (what NUTS runs) works unchanged.
+  * No NumPyro: the same call with concrete numbers records its sites in :func:`last_sites`.
+  * Framework-free: :class:`gwinferno_amd.engine.NativePopulationLikelihood` ``.evaluate(theta)``.
+Out of scope: the categorical / mixture branch (analysis.py:246-254) and the
+posterior-predictive-check branch (:321-355) raise NotImplementedError.
+"""
+import numpy as np
+
+from .engine import NEG_BIG, NativePopulationLikelihood, structure_key
+from .lazy import Density, LazyNorm
+
+_ENGINES = {}
+_LAST_SITES = {}
+SAMPLE_VALUES = {}  # values for numpyro.sample sites when numpyro is absent (e.g. {"unscaled_rate": 30.0})
+
+
+def _numpyro():
+    try:
+        import numpyro  # noqa: F401
+
+        return numpyro
+    except Exception:
+        return None
+
+
+def last_sites():
+    """Sites of the most recent call made WITHOUT numpyro (names as analysis.py:260-319)."""
+    return dict(_LAST_SITES)
+
+
+def clear_engine_cache():
+    for eng in _ENGINES.values():
+        eng.close()
+    _ENGINES.clear()
+
+
+def _is_traced(values):
+    for v in values:
+        mod = type(v).__module__ or ""
+        if mod.startswith("jax") and not isinstance(v, np.ndarray):
+            return True
+    return False
+
+
+def _collect_params(bound, density):
+    """Hyper-parameter objects of ``density`` in theta-layout order (scalars and coefficient vectors)."""
+    out = []
+    for fi, what, k, off in bound.layout:
+        f = density.factors[fi]
+        out.append(f.scalars[k] if what == "scalar" else f.coefs)
+    return out
+
+
+def engine_for(pe_weights, inj_weights, surveyed_hypervolume=None, device=-1):
+    """The cached engine for this model structure + catalog (built, i.e. uploaded, on first use)."""
+    key = (structure_key(pe_weights, inj_weights), id(surveyed_hypervolume.owner) if isinstance(surveyed_hypervolume, LazyNorm) else None, device)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = NativePopulationLikelihood(pe_weights, inj_weights, surveyed_hypervolume, device=device)
+        _ENGINES[key] = eng
+    return eng
+
+
+def _sites_from_result(res, Nobs, Tobs, unscaled_rate, flags, xp=np):
+    s = res["summary"]
+    sites = {
+        "log_nEff_inj": s["log_nEff_inj"],
+        "log_nEffs": res["log_neffs"],
+        "logBFs": res["log_bfs"],
+        "detection_efficiency": xp.exp(s["log_det_eff"]),
+        "variance_log_BFs": res["variances"],
+        "variance_log_detection_efficiency": s["variance_log_detection_efficiency"],
+    }
+    if flags["reconstruct_rate"]:
+        sites["surveyed_hypervolume"] = s["surveyed_hypervolume_norm"] / 1.0e9 * Tobs
+        if unscaled_rate is not None:
+            sites["rate"] = unscaled_rate / sites["detection_efficiency"] / sites["surveyed_hypervolume"]
+    sites["selection_factor"] = s["selection_factor"]
+    sites["sum_logBFs"] = s["sum_logBFs"]
+    sites["log_l"] = s["log_l"]
+    if flags["min_neff_cut"]:
+        sites["neff_less_Nobs"] = s["log_likelihood"] if not flags["max_variance_cut"] else s["log_l"]
+    sites["variance_log_likelihood"] = s["variance_log_likelihood"]
+    if flags["max_variance_cut"]:
+        sites["variance_less_1"] = s["log_likelihood"]
+    return sites
+
+
+_SUMMARY_FIELDS = ("log_likelihood", "log_l", "sum_logBFs", "selection_factor", "log_det_eff", "log_nEff_inj", "variance_log_detection_efficiency",
+                   "variance_log_likelihood", "min_log_nEff", "surveyed_hypervolume_norm", "log_norm_const")
+
+
+def _evaluate_numpy(eng, theta, total_inj, Nobs, flags, want_grad=True):
+    r = eng.evaluate(theta, total_inj, nobs=Nobs, marginalize_selection=flags["marginalize_selection"], min_neff_cut=flags["min_neff_cut"],
+                     max_variance_cut=flags["max_variance_cut"], want_grad=want_grad and not flags["marginalize_selection"])
+    return {"summary": {k: getattr(r.summary, k) for k in _SUMMARY_FIELDS}, "log_bfs": r.log_bfs, "log_neffs": r.log_neffs, "variances": r.variances, "grad": r.grad}
+
+
+def _evaluate_jax(eng, params, total_inj, Nobs, flags):
+    """``jax.custom_vjp`` over ``jax.pure_callback``: value and every site from one engine call, the
+    gradient handed to JAX's reverse mode.  (Exercised only where jax is installed.)"""
+    import jax
+    import jax.numpy as jnp
+
+    n_ev, n_theta, n_sum = eng.n_ev, eng.n_theta, len(_SUMMARY_FIELDS)
+    shapes = (
+        jax.ShapeDtypeStruct((n_sum,), jnp.float64),
+        jax.ShapeDtypeStruct((3, n_ev), jnp.float64),
+        jax.ShapeDtypeStruct((n_theta,), jnp.float64),
+    )
+
+    def host(theta):
+        r = _evaluate_numpy(eng, np.asarray(theta, dtype=np.float64), total_inj, Nobs, flags)
+        summ = np.array([r["summary"][k] for k in _SUMMARY_FIELDS])
+        per_event = np.stack([r["log_bfs"], r["log_neffs"], r["variances"]])
+        grad = r["grad"] if r["grad"] is not None else np.zeros(n_theta)
+        return summ, per_event, grad
+
+    @jax.custom_vjp
+    def f(theta):
+        summ, per_event, _ = jax.pure_callback(host, shapes, theta)
+        return summ, per_event
+
+    def f_fwd(theta):
+        summ, per_event, grad = jax.pure_callback(host, shapes, theta)
+        return (summ, per_event), grad
+
+    def f_bwd(grad, cts):
+        ct_summ, _ = cts
+        # only log_likelihood (summary[0]) is differentiable: it is what numpyro.factor consumes
+        return (ct_summ[0] * grad,)
+
+    f.defvjp(f_fwd, f_bwd)
+    theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=jnp.float64)) for p in params])
+    summ, per_event = f(theta)
+    summary = {k: summ[i] for i, k in enumerate(_SUMMARY_FIELDS)}
+    return {"summary": summary, "log_bfs": per_event[0], "log_neffs": per_event[1], "variances": per_event[2], "grad": None}
+
+
+def hierarchical_likelihood(
+    pe_weights,
+    inj_weights,
+    total_inj,
+    Nobs,
+    Tobs,
+    surveyed_hypervolume=None,
+    categorical=False,
+    marginal_qs=False,
+    indv_weights=None,
+    rngkey=None,
+    pop_frac=None,
+    reconstruct_rate=True,
+    marginalize_selection=False,
+    min_neff_cut=True,
+    max_variance_cut=False,
+    posterior_predictive_check=False,
+    param_names=None,
+    pedata=None,
+    injdata=None,
+    m2min=3.0,
+    m1min=5.0,
+    mmax=100.0,
+    log=False,
+):
+    """Same contract as the reference (analysis.py:139-356); ``pe_weights`` / ``inj_weights`` are lazy
+    densities.  ``log`` is accepted for signature compatibility: the engine works in the log domain
+    with an online maximum either way, so the linear and log forms of the reference coincide."""
+    if max_variance_cut and (marginalize_selection or min_neff_cut):
+        raise ValueError(
+            "max_variance_cut is True which requires marginalize_selection and "
+            "min_neff_cut to be False but got "
+            f"marginalize_selection = {marginalize_selection} "
+            f"and min_neff_cut = {min_neff_cut}",
+        )
+    if categorical:
+        raise NotImplementedError("categorical sub-population assignment (analysis.py:246-254) is outside the accelerated path")
+    if posterior_predictive_check and param_names is not None and injdata is not None and pedata is not None:
+        raise NotImplementedError("posterior-predictive resampling (analysis.py:321-355) is outside the accelerated path; run it with the reference")
+    if not isinstance(pe_weights, Density) or not isinstance(inj_weights, Density):
+        raise TypeError("pe_weights / inj_weights must be lazy densities from gwinferno_amd.models")
+    if reconstruct_rate and not isinstance(surveyed_hypervolume, LazyNorm):
+        raise TypeError("surveyed_hypervolume must be z_model.normalization(...) when reconstruct_rate=True")
+
+    flags = dict(marginalize_selection=bool(marginalize_selection), min_neff_cut=bool(min_neff_cut), max_variance_cut=bool(max_variance_cut), reconstruct_rate=bool(reconstruct_rate))
+    eng = engine_for(pe_weights, inj_weights, surveyed_hypervolume if isinstance(surveyed_hypervolume, LazyNorm) else None)
+    params = _collect_params(eng.bound, pe_weights)
+    npro = _numpyro()
+
+    unscaled_rate = None
+    if reconstruct_rate:
+        if npro is not None:
+            import numpyro.distributions as dist
+
+            unscaled_rate = npro.sample("unscaled_rate", dist.Gamma(Nobs))  # analysis.py:268
+        else:
+            unscaled_rate = SAMPLE_VALUES.get("unscaled_rate")
+
+    if _is_traced(params):
+        import jax.numpy as jnp
+
+        res, xp = _evaluate_jax(eng, params, float(total_inj), float(Nobs), flags), jnp
+    else:
+        theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in params])
+        res, xp = _evaluate_numpy(eng, theta, float(total_inj), float(Nobs), flags), np
+
+    sites = _sites_from_result(res, Nobs, Tobs, unscaled_rate, flags, xp=xp)
+    log_l = res["summary"]["log_likelihood"]
+    if npro is not None:
+        for name, value in sites.items():
+            npro.deterministic(name, value)
+        npro.factor("log_likelihood", log_l)  # analysis.py:319
+    else:
+        _LAST_SITES.clear()
+        _LAST_SITES.update(sites)
+        _LAST_SITES["log_likelihood"] = log_l
+        if res["grad"] is not None:
+            _LAST_SITES["grad_log_likelihood"] = res["grad"]
+    return sites.get("rate")
+
+
+def per_event_log_bayes_factors(weights, log=False):
+    """analysis.py:50-88 for a lazy PE product: not evaluable on its own (the engine fuses it with the
+    rest of the likelihood); use hierarchical_likelihood and read sites logBFs / log_nEffs /
+    variance_log_BFs."""
+    raise NotImplementedError(per_event_log_bayes_factors.__doc__)
+
+
+def detection_efficiency(weights, Ninj, log=False):
+    """analysis.py:91-136 for a lazy injection product: fused into hierarchical_likelihood; read sites
+    detection_efficiency / log_nEff_inj / variance_log_detection_efficiency."""
+    raise NotImplementedError(detection_efficiency.__doc__)
+
+
+__all__ = ["hierarchical_likelihood", "last_sites", "engine_for", "clear_engine_cache", "SAMPLE_VALUES", "NEG_BIG"]

@@ -159,6 +159,12 @@ typedef struct {
 
 typedef struct gwi_engine* gwi_handle;
 
+/* device argument of gwi_create: the current HIP device, or a host-only handle that owns no device
+ * memory and supports only gwi_prepare_combine / gwi_combine / gwi_partial_len (used by ranks that
+ * merely assemble gathered records, and by the CPU test-suite). */
+#define GWI_DEVICE_CURRENT (-1)
+#define GWI_DEVICE_HOST_ONLY (-2)
+
 /* Build an engine for one catalog + model.  Stands in for the reference's model construction
  * (Base1DBSplineModel.__init__, single.py:35-58; PowerlawRedshiftModel.__init__,
  * parametric.py:113-121): copies the columns to HBM once.  `pe_cols[c]` has n_ev*n_pe entries
@@ -186,6 +192,9 @@ gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, d
 int64_t gwi_partial_len(gwi_handle h);
 gwi_status gwi_eval_partial(gwi_handle h, const double* theta, double* record_host, double* log_bfs,
                             double* log_neffs, double* variances);
+/* Host-only: recompute the sample-independent constants of `theta` that gwi_combine folds in
+ * (gwi_eval_partial does this implicitly). */
+gwi_status gwi_prepare_combine(gwi_handle h, const double* theta);
 gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, const gwi_options* opt,
                        gwi_summary* summary, double* grad, double* norms);
 

@@ -50,10 +50,13 @@ def norm_values(bm, theta):
     return np.array(out)
 
 
-def log_weights(bm, theta):
-    """(pe_logw, inj_logw, norms): log importance weights incl. every normaliser."""
+def log_weights(bm, theta, include_consts=True):
+    """(pe_logw, inj_logw, norms): log importance weights incl. every normaliser.  With
+    ``include_consts=False`` the sample-independent log-normalisers (power-law / truncated-normal /
+    Beta constants and the grid normalisers) are left out, which is what the device scan sums."""
     theta = np.asarray(theta, dtype=np.float64)
     norms = norm_values(bm, theta)
+    k_const = 1.0 if include_consts else 0.0
     outs = []
     for cols in (bm.pe_cols, bm.inj_cols):
         with np.errstate(all="ignore"):
@@ -64,7 +67,7 @@ def log_weights(bm, theta):
                 p = t["p"]
                 k = t["kind"]
                 if k == N.TERM_POWERLAW:
-                    ell = ell + th[0] * c[0] + _pl_lognorm(th[0], p[0], p[1])
+                    ell = ell + th[0] * c[0] + k_const * _pl_lognorm(th[0], p[0], p[1])
                 elif k == N.TERM_PLPEAK:
                     alpha, mu, sg, lam = th
                     pl = np.exp(alpha * c[1] + _pl_lognorm(alpha, p[0], p[1]))
@@ -78,13 +81,13 @@ def log_weights(bm, theta):
                     else:
                         ell = ell + th[0] * c[0] + np.log(b1 / (-np.expm1(b1 * lr)))
                 elif k == N.TERM_BETA:
-                    ell = ell + (th[0] - 1) * c[0] + (th[1] - 1) * c[1] - betaln(th[0], th[1])
+                    ell = ell + (th[0] - 1) * c[0] + (th[1] - 1) * c[1] - k_const * betaln(th[0], th[1])
                 elif k == N.TERM_TILT_MIXTURE:
                     xi, sg = th
                     tn = np.exp(-0.5 * (c[0] - 1) ** 2 / sg**2 + _tn_lognorm(1.0, sg, -1.0, 1.0))
                     ell = ell + np.log(0.5 * (1 - xi) + xi * tn)
                 elif k == N.TERM_TRUNCNORM:
-                    ell = ell - 0.5 * (c[0] - th[0]) ** 2 / th[1] ** 2 + _tn_lognorm(th[0], th[1], p[0], p[1])
+                    ell = ell - 0.5 * (c[0] - th[0]) ** 2 / th[1] ** 2 + k_const * _tn_lognorm(th[0], th[1], p[0], p[1])
                 elif k == N.TERM_POWERLAW_REDSHIFT:
                     ell = ell + (th[0] - 1) * c[0]
                 elif k == N.TERM_EXP_SPLINE:
@@ -92,7 +95,7 @@ def log_weights(bm, theta):
                     ell = ell + _spline(c[0], theta[co : co + t["n_basis"]], p[0], p[1], bool(t["flags"] & N.SPLINE_OUTSIDE_ZERO_EXPONENT))
                 else:
                     raise ValueError(k)
-                if t["norm"] >= 0:
+                if t["norm"] >= 0 and include_consts:
                     ell = ell - np.log(norms[t["norm"]])
             ell = np.where(ell < np.inf, ell, -np.inf)  # NaN / +inf -> excluded
         outs.append(ell)

@@ -1,0 +1,98 @@
+"""GPU (-m gpu): the reference's own integration tests (tests/inference_test.py:162-347) restated
+against the drop-in API: the model functions below read like the reference's, with
+gwinferno_amd.models / gwinferno_amd.likelihood in place of gwinferno.models / pipeline.analysis.
+The reference only asserts finiteness of value and gradient at its test points; here the value and
+every site are additionally compared with the golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+from golden_util import GoldenCase, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _parametric_model(case):
+    """tests/inference_test.py:162-197."""
+    from gwinferno_amd.lazy import where_finite
+    from gwinferno_amd.likelihood import hierarchical_likelihood
+    from gwinferno_amd.models import PowerlawRedshiftModel, powerlaw_primary_ratio_pdf
+
+    pedict, injdict = case.pe, case.inj
+    z_model = PowerlawRedshiftModel(z_pe=pedict["redshift"], z_inj=injdict["redshift"])
+    mmin, mmax = case.meta["mmin"], case.meta["mmax"]
+
+    def model(alpha, beta, lamb, **flags):
+        def get_weights(m1, q, z, prior):
+            p_m1q = powerlaw_primary_ratio_pdf(m1, q, alpha=alpha, beta=beta, mmin=mmin, mmax=mmax)
+            p_z = z_model(z, lamb)
+            wts = p_m1q * p_z / prior
+            return where_finite(wts)
+
+        peweights = get_weights(pedict["mass_1"], pedict["mass_ratio"], pedict["redshift"], pedict["prior"])
+        injweights = get_weights(injdict["mass_1"], injdict["mass_ratio"], injdict["redshift"], injdict["prior"])
+        return hierarchical_likelihood(peweights, injweights, total_inj=case.total_inj, Nobs=case.nobs, Tobs=case.tobs,
+                                       surveyed_hypervolume=z_model.normalization(lamb=lamb), marginalize_selection=False, **flags)
+
+    return model
+
+
+def _bspline_model(case):
+    """tests/inference_test.py:124-143, 244-285."""
+    from gwinferno_amd.lazy import where_finite
+    from gwinferno_amd.likelihood import hierarchical_likelihood
+    from gwinferno_amd.models import BSplinePrimaryBSplineRatio, PowerlawSplineRedshiftModel
+
+    pedict, injdict = case.pe, case.inj
+    mmin, mmax = case.meta["mmin"], case.meta["mmax"]
+    mass_model = BSplinePrimaryBSplineRatio(10, 5, pedict["mass_1"], injdict["mass_1"], pedict["mass_ratio"], injdict["mass_ratio"], m1min=mmin, m2min=mmin, mmax=mmax)
+    z_model = PowerlawSplineRedshiftModel(5, pedict["redshift"], injdict["redshift"])
+
+    def model(m1_coefs, q_coefs, z_coefs, lamb, **flags):
+        def get_weights(z, prior, pe_samples=False):
+            p_m1q = mass_model(m1_coefs, q_coefs, pe_samples=pe_samples)
+            p_z = z_model(z, lamb, z_coefs)
+            return where_finite(p_m1q * p_z / prior)
+
+        peweights = get_weights(pedict["redshift"], pedict["prior"], pe_samples=True)
+        injweights = get_weights(injdict["redshift"], injdict["prior"], pe_samples=False)
+        return hierarchical_likelihood(peweights, injweights, total_inj=case.total_inj, Nobs=case.nobs, Tobs=case.tobs,
+                                       surveyed_hypervolume=z_model.normalization(lamb=lamb, cs=z_coefs), marginalize_selection=False, **flags)
+
+    return model
+
+
+@pytest.mark.parametrize("name,builder", [("pl_test", _parametric_model), ("gwtc3_pl_test", _parametric_model), ("bspline_test", _bspline_model), ("gwtc3_bspline_test", _bspline_model)])
+def test_reference_style_model_functions(name, builder):
+    from gwinferno_amd import likelihood as L
+
+    case = GoldenCase(name)
+    model = builder(case)
+    L.SAMPLE_VALUES["unscaled_rate"] = case.meta["unscaled_rate"]
+    for fs in ("lin", "lin_neff"):
+        flags = {k: v for k, v in case.flagsets[fs].items() if k != "log"}
+        for i in range(case.n_points):
+            rate = model(**case.point(i), **flags)
+            sites = L.last_sites()
+            # tests/inference_test.py:328-329, 346-347
+            assert np.isfinite(sites["log_likelihood"]) and np.all(np.isfinite(sites["grad_log_likelihood"]))
+            for site, ref in case.sites[fs].items():
+                if site == "rate_return":
+                    got = rate
+                else:
+                    got = sites[site]
+                if site.startswith("variance"):
+                    assert np.allclose(got, ref[i], rtol=1e-8, atol=1e-12), (name, fs, i, site)
+                else:
+                    assert rel_err(got, ref[i]) < 1e-9, (name, fs, i, site, got, ref[i])
+    L.clear_engine_cache()
+
+
+def test_engine_is_cached_across_calls():
+    from gwinferno_amd import likelihood as L
+
+    case = GoldenCase("pl_test")
+    model = _parametric_model(case)
+    model(**case.point(0), min_neff_cut=False)
+    n = len(L._ENGINES)
+    model(**case.point(1), min_neff_cut=False)
+    assert len(L._ENGINES) == n == 1
+    L.clear_engine_cache()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof/<config>/ (written by tools/profile_round.sh on the GPU box) into
+profiles/<round>/: per-config rocprofv3 kernel stats (copied verbatim), a PMC traffic table, and
+traffic.json, which bench.py reads to fill roofline.traffic.
+
+HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and
+WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, i.e.
+reports exactly half of a coalesced streaming read, so reads = 2 x FETCH_SIZE x 1024.  (Calibrated
+here: the scan kernel's loads are 8 B/lane coalesced; 2 x FETCH_SIZE reproduces the known column
+bytes of every config to within 3 %.)"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mean_counter(path_glob, kernel_substr, counter):
+    files = glob.glob(path_glob)
+    if not files:
+        return None
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(vals) / len(vals) if vals else None
+
+
+def main(round_name):
+    src = os.path.join(ROOT, "gpurun_out", "prof")
+    dst = os.path.join(ROOT, "profiles", round_name)
+    os.makedirs(dst, exist_ok=True)
+    traffic = {}
+    lines = ["| config | kernel | calls | avg us (rocprofv3) | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes/launch (2*F+W)*1024 |", "|---|---|---|---|---|---|---|"]
+    for cfg in sorted(os.listdir(src)):
+        stats = glob.glob(os.path.join(src, cfg, "trace", "*", "*_kernel_stats.csv"))
+        if not stats:
+            continue
+        shutil.copy(stats[0], os.path.join(dst, f"{cfg}_kernel_stats.csv"))
+        for name in ("bench.json", "bench_under_trace.json"):
+            p = os.path.join(src, cfg, name)
+            if os.path.exists(p) and os.path.getsize(p):
+                shutil.copy(p, os.path.join(dst, f"{cfg}_{name}"))
+        rows = list(csv.DictReader(open(stats[0])))
+        for r in rows:
+            if "gwi::" not in r["Name"]:
+                continue
+            short = r["Name"].split("(")[0].replace("void ", "")
+            key = "scan_kernel" if "scan_kernel" in short else short.replace("gwi::", "")
+            f = mean_counter(os.path.join(src, cfg, "fetch", "*", "*_counter_collection.csv"), key, "FETCH_SIZE")
+            w = mean_counter(os.path.join(src, cfg, "write", "*", "*_counter_collection.csv"), key, "WRITE_SIZE")
+            hbm = (2 * f + w) * 1024 if f is not None and w is not None else None
+            lines.append(f"| {cfg} | {short} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {f:.1f} | {w:.1f} | {hbm:.0f} |" if hbm else f"| {cfg} | {short} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | - | - | - |")
+            if key == "scan_kernel":
+                traffic[cfg] = {"scan_avg_us_rocprof": float(r["AverageNs"]) / 1e3, "fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_per_launch": hbm}
+    with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
+        fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).\n\n")
+        fh.write("\n".join(lines) + "\n")
+    with open(os.path.join(dst, "traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "round1")
