@@ -40,8 +40,8 @@ struct NormD {
 };
 
 struct KArgs {
-  const double* const* pe_cols;
-  const double* const* inj_cols;
+  const double* pe_cols[GWI_MAX_COLS];   // column base pointers live in the kernel-argument block:
+  const double* inj_cols[GWI_MAX_COLS];  // one scalar load away, no pointer-table round trip
   const NormD* norms;
   double* partials;   // [n_scan_blocks][rec_stride]
   double* norm_out;   // [n_norms]

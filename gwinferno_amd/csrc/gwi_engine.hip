@@ -134,8 +134,6 @@ struct gwi_engine {
   long long n_ev = 0, n_pe = 0, n_inj = 0;
   // device memory
   std::vector<double*> d_cols_pe, d_cols_inj;
-  const double** d_pe_table = nullptr;
-  const double** d_inj_table = nullptr;
   NormD* d_norms = nullptr;
   std::vector<double*> d_norm_arrays;
   double *d_partials = nullptr, *d_norm_out = nullptr, *d_ev_out = nullptr, *d_ev_grad = nullptr, *d_inj_out = nullptr, *d_inj_grad = nullptr;
@@ -146,6 +144,7 @@ struct gwi_engine {
   // launch geometry
   int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
   int n_inj_groups = 1, tiles_per_inj_group = 1;
+
   size_t scan_lds_bytes = 0;
   unsigned long long seq = 0;
   // results of the last prelude
@@ -293,38 +292,40 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
   gwi_status st = launch_scan(h, false);
   if (st != GWI_OK) return st;
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[1], h->stream));
-  CombineArgs ca;
-  ca.partials = h->d_partials;
-  ca.ev_out = h->d_ev_out;
-  ca.ev_grad = h->d_ev_grad;
-  ca.inj_out = h->d_inj_out;
-  ca.inj_grad = h->d_inj_grad;
-  ca.n_ev = (int)h->n_ev;
-  ca.tiles_per_event = h->tiles_per_event;
-  ca.n_inj_tiles = h->n_inj_tiles;
-  ca.n_inj_groups = h->n_inj_groups;
-  ca.tiles_per_inj_group = h->tiles_per_inj_group;
-  ca.n_theta = h->spec.n_theta;
-  ca.rec_stride = h->rec_stride;
-  ca.n_pe = (double)h->n_pe;
-  ca.ev_host = h->h_ev_dev;
-  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups)), dim3(kBlock), 0, h->stream, ca);
-  GWI_HIP(hipGetLastError());
-  if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
-  FinalArgs fa;
-  fa.ev_out = h->d_ev_out;
-  fa.ev_grad = h->d_ev_grad;
-  fa.inj_out = h->d_inj_out;
-  fa.inj_grad = h->d_inj_grad;
-  fa.norm_out = h->d_norm_out;
-  fa.record = h->h_record_dev;
-  fa.n_ev = (int)h->n_ev;
-  fa.n_theta = h->spec.n_theta;
-  fa.n_norms = h->spec.n_norms;
-  fa.n_inj_groups = h->n_inj_groups;
-  fa.seq = ++h->seq;
-  hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
-  GWI_HIP(hipGetLastError());
+  {
+    CombineArgs ca;
+    ca.partials = h->d_partials;
+    ca.ev_out = h->d_ev_out;
+    ca.ev_grad = h->d_ev_grad;
+    ca.inj_out = h->d_inj_out;
+    ca.inj_grad = h->d_inj_grad;
+    ca.n_ev = (int)h->n_ev;
+    ca.tiles_per_event = h->tiles_per_event;
+    ca.n_inj_tiles = h->n_inj_tiles;
+    ca.n_inj_groups = h->n_inj_groups;
+    ca.tiles_per_inj_group = h->tiles_per_inj_group;
+    ca.n_theta = h->spec.n_theta;
+    ca.rec_stride = h->rec_stride;
+    ca.n_pe = (double)h->n_pe;
+    ca.ev_host = h->h_ev_dev;
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups)), dim3(kBlock), 0, h->stream, ca);
+    GWI_HIP(hipGetLastError());
+    if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
+    FinalArgs fa;
+    fa.ev_out = h->d_ev_out;
+    fa.ev_grad = h->d_ev_grad;
+    fa.inj_out = h->d_inj_out;
+    fa.inj_grad = h->d_inj_grad;
+    fa.norm_out = h->d_norm_out;
+    fa.record = h->h_record_dev;
+    fa.n_ev = (int)h->n_ev;
+    fa.n_theta = h->spec.n_theta;
+    fa.n_norms = h->spec.n_norms;
+    fa.n_inj_groups = h->n_inj_groups;
+    fa.seq = ++h->seq;
+    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
+    GWI_HIP(hipGetLastError());
+  }
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
   // Completion: final_kernel stores the sequence stamp into pinned host memory LAST (system-scope
   // release after __threadfence_system), so the host can poll it instead of paying a stream
@@ -446,8 +447,6 @@ void destroy_impl(gwi_engine* h) {
   for (double* p : h->d_cols_pe) (void)hipFree(p);
   for (double* p : h->d_cols_inj) (void)hipFree(p);
   for (double* p : h->d_norm_arrays) (void)hipFree(p);
-  (void)hipFree((void*)h->d_pe_table);
-  (void)hipFree((void*)h->d_inj_table);
   (void)hipFree(h->d_norms);
   (void)hipFree(h->d_partials);
   (void)hipFree(h->d_norm_out);
@@ -549,10 +548,6 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     if ((st = upload(h, inj_cols[c], (size_t)n_inj, &d, &h->d_cols_inj)) != GWI_OK) return st;
     tab_inj[c] = d;
   }
-  GWI_HIP(hipMalloc((void**)&h->d_pe_table, sizeof(double*) * spec->n_cols));
-  GWI_HIP(hipMalloc((void**)&h->d_inj_table, sizeof(double*) * spec->n_cols));
-  GWI_HIP(hipMemcpy((void*)h->d_pe_table, tab_pe.data(), sizeof(double*) * spec->n_cols, hipMemcpyHostToDevice));
-  GWI_HIP(hipMemcpy((void*)h->d_inj_table, tab_inj.data(), sizeof(double*) * spec->n_cols, hipMemcpyHostToDevice));
 
   // ---- normaliser grids
   std::vector<NormD> nd(spec->n_norms ? spec->n_norms : 1);
@@ -637,8 +632,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   // ---- constant part of the kernel-argument block
   KArgs& k = h->kargs;
   std::memset(&k, 0, sizeof(k));
-  k.pe_cols = h->d_pe_table;
-  k.inj_cols = h->d_inj_table;
+  for (int c = 0; c < spec->n_cols; ++c) {
+    k.pe_cols[c] = tab_pe[c];
+    k.inj_cols[c] = tab_inj[c];
+  }
   k.norms = h->d_norms;
   k.partials = h->d_partials;
   k.norm_out = h->d_norm_out;
