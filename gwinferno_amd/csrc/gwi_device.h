@@ -168,14 +168,18 @@ struct Term;
 template <>
 struct Term<GWI_TERM_POWERLAW> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
   struct State {
     double lx;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
-    s.lx = gload(c.cols[t.col0], idx);
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
+    s.lx = in.x0;
     return c.a->theta[t.th0] * s.lx;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.lx; }
@@ -192,15 +196,22 @@ struct Term<GWI_TERM_POWERLAW> {
 template <>
 struct Term<GWI_TERM_PLPEAK> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
+    in.x0 = gload(c.cols[t.col0], idx);
+    in.x1 = gload(c.cols[t.col1], idx);
+  }
   struct State {
     double da, dmu, dsg, dlam;
   };
   struct Acc {
     double g[4];
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
-    const double x = gload(c.cols[t.col0], idx);
-    const double lx = gload(c.cols[t.col1], idx);
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    const double x = in.x0;
+    const double lx = in.x1;
     const double alpha = c.a->theta[t.th0], mu = c.a->theta[t.th1], lam = c.a->theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;
@@ -243,15 +254,22 @@ struct Term<GWI_TERM_PLPEAK> {
 template <>
 struct Term<GWI_TERM_POWERLAW_RATIO> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
+    in.x0 = gload(c.cols[t.col0], idx);
+    in.x1 = gload(c.cols[t.col1], idx);
+  }
   struct State {
     double db;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
-    const double lq = gload(c.cols[t.col0], idx);
-    const double lr = t.p0 - gload(c.cols[t.col1], idx);  // log(mmin/m1) <= 0 for every non-excluded sample
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    const double lq = in.x0;
+    const double lr = t.p0 - in.x1;  // log(mmin/m1) <= 0 for every non-excluded sample
     const double beta = c.a->theta[t.th0];
     const double b1 = 1.0 + beta;
     if (b1 == 0.0) {  // alpha == -1 branch of the reference: 1/log(high/low)
@@ -278,15 +296,22 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
 template <>
 struct Term<GWI_TERM_BETA> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
+    in.x0 = gload(c.cols[t.col0], idx);
+    in.x1 = gload(c.cols[t.col1], idx);
+  }
   struct State {
     double la, l1;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
-    s.la = gload(c.cols[t.col0], idx);
-    s.l1 = gload(c.cols[t.col1], idx);
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
+    s.la = in.x0;
+    s.l1 = in.x1;
     return (c.a->theta[t.th0] - 1.0) * s.la + (c.a->theta[t.th1] - 1.0) * s.l1;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
@@ -312,14 +337,18 @@ struct Term<GWI_TERM_BETA> {
 template <>
 struct Term<GWI_TERM_TILT_MIXTURE> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
   struct State {
     double dxi, dsg;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double& lin) {
-    const double ct = gload(c.cols[t.col0], idx);
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    const double ct = in.x0;
     const double xi = c.a->theta[t.th0];
     const double dx = ct - 1.0;
     const double dx2 = dx * dx;
@@ -353,14 +382,18 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
 template <>
 struct Term<GWI_TERM_TRUNCNORM> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
   struct State {
     double dmu, dsg;
   };
   struct Acc {
     double g[2];
   };
-  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, long long idx, State& s, double&) {
-    const double x = gload(c.cols[t.col0], idx);
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double&) {
+    const double x = in.x0;
     const double dx = x - c.a->theta[t.th0];
     const double dx2 = dx * dx;
     s.dmu = dx * d[0];
@@ -389,14 +422,18 @@ struct Term<GWI_TERM_TRUNCNORM> {
 template <>
 struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
   static constexpr bool kSpline = false;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
   struct State {
     double l1pz;
   };
   struct Acc {
     double g0;
   };
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
-    s.l1pz = gload(c.cols[t.col0], idx);
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
+    s.l1pz = in.x0;
     return (c.a->theta[t.th0] - 1.0) * s.l1pz;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.l1pz; }
@@ -413,13 +450,17 @@ struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
 template <>
 struct Term<GWI_TERM_EXP_SPLINE> {
   static constexpr bool kSpline = true;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
   struct State {
     double t;
     int k;  // -1: outside the domain of a zero-outside basis (factor 1, no gradient)
   };
   struct Acc {};
-  __device__ static double eval(const TermD& t, const double*, const Ctx& c, long long idx, State& s, double&) {
-    const double x = gload(c.cols[t.col0], idx);
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
+    const double x = in.x0;
     int k;
     double tt;
     spline_locate(x, t.p0, t.p2, t.n_basis, k, tt);
@@ -453,35 +494,47 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   __device__ static void collect(const TermD&, const Acc&, double*, int*) {}
 };
 
-// ---- compile-time chain of terms; every lane carries kU samples per loop trip -----------------------
-constexpr int kU = 2;
-
-template <int... Ks>
+// ---- compile-time chain of terms.  U = samples per lane per trip; inputs are double-buffered in
+//      registers (in[0] = current trip, in[1] = next trip) so the column loads of trip k+1 are in
+//      flight while trip k is being evaluated. ----------------------------------------------------------
+template <int U, int... Ks>
 struct Chain;
-template <>
-struct Chain<> {
+template <int U>
+struct Chain<U> {
   static constexpr bool kSpline = false;
   static constexpr int kNumAcc = 0;
   __device__ void init() {}
-  __device__ double eval(int, int, const Ctx&, long long, double&) { return 0.0; }
+  __device__ void load(int, int, int, const Ctx&, long long) {}
+  __device__ void advance() {}
+  __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
   __device__ void accumulate(int, int, const Ctx&, double) {}
   __device__ void rescale(double) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
 };
-template <int K, int... Rest>
-struct Chain<K, Rest...> {
-  static constexpr bool kSpline = Term<K>::kSpline || Chain<Rest...>::kSpline;
-  static constexpr int kNumAcc = Term<K>::kNumAcc + Chain<Rest...>::kNumAcc;
-  typename Term<K>::State st[kU];
+template <int U, int K, int... Rest>
+struct Chain<U, K, Rest...> {
+  static constexpr bool kSpline = Term<K>::kSpline || Chain<U, Rest...>::kSpline;
+  static constexpr int kNumAcc = Term<K>::kNumAcc + Chain<U, Rest...>::kNumAcc;
+  typename Term<K>::In in[2][U];
+  typename Term<K>::State st[U];
   typename Term<K>::Acc acc;
-  Chain<Rest...> rest;
+  Chain<U, Rest...> rest;
   __device__ void init() {
     Term<K>::init(acc);
     rest.init();
   }
-  __device__ double eval(int u, int ti, const Ctx& c, long long idx, double& lin) {
-    const double l = Term<K>::eval(c.a->terms[ti], c.a->derived[ti], c, idx, st[u], lin);
-    return l + rest.eval(u, ti + 1, c, idx, lin);
+  __device__ void load(int buf, int u, int ti, const Ctx& c, long long idx) {
+    Term<K>::load(c.a->terms[ti], c, idx, in[buf][u]);
+    rest.load(buf, u, ti + 1, c, idx);
+  }
+  __device__ void advance() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) in[0][u] = in[1][u];
+    rest.advance();
+  }
+  __device__ double eval(int u, int ti, const Ctx& c, double& lin) {
+    const double l = Term<K>::eval(c.a->terms[ti], c.a->derived[ti], c, in[0][u], st[u], lin);
+    return l + rest.eval(u, ti + 1, c, lin);
   }
   __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
     Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
@@ -537,9 +590,10 @@ __device__ inline void norm_block(const KArgs& a, int j, const double* s_theta, 
 // overhead are shared between them.
 constexpr int kRedChunk = 8;  // values per pass of the block-level transposed reduction (16 KiB LDS)
 
-template <bool WRITE_LOGW, int... Ks>
+template <bool WRITE_LOGW, int U, int... Ks>
 __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
-  using ChainT = Chain<Ks...>;
+  using ChainT = Chain<U, Ks...>;
+  constexpr int kU = U;
   // Spline-coefficient gradient numerators: per wave, gacc_rep replicas of a row of gacc_pad
   // doubles.  Lane l adds into replica l % gacc_rep, so the 64 ds_add_f64 of one wave instruction
   // that target ONE coefficient (posterior samples of an event cluster in a few knot intervals)
@@ -598,8 +652,26 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   ChainT chain;
   chain.init();
 
-  // the loop condition is wave-uniform: i - lane is the same for every lane of a wave
-  for (long long i = start + tid; i - lane < end; i += kU * kBlock) {
+  // Trip structure: lane `lane` of the workgroup handles samples i, i + 256, ... (U of them) per trip;
+  // every condition on (i - lane) is wave-uniform.  Loads for the NEXT trip are issued before the
+  // current trip is evaluated (register double buffer).
+  double kap[2][kU];
+  auto issue_loads = [&](int buf, long long i) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long iu = i + (long long)u * kBlock;
+      if (iu - lane >= end) continue;  // wave-uniform: no u-th sample for this wave
+      const long long idx = base + (iu < end ? iu : end - 1);
+      kap[buf][u] = gload(kappa_col, idx);
+      chain.load(buf, u, 0, ctx, idx);
+    }
+  };
+  const long long i0 = start + tid;
+  if (i0 - lane < end) issue_loads(0, i0);
+  for (long long i = i0; i - lane < end; i += kU * kBlock) {
+    const long long i_next = i + kU * kBlock;
+    const bool has_next = i_next - lane < end;  // wave-uniform
+    if (has_next) issue_loads(1, i_next);
     double ell[kU], lin[kU];
     bool live[kU];
     double mx_lane = GWI_NEG_INF;
@@ -613,37 +685,42 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
         continue;
       }
       const bool valid = iu < end;
-      const long long idx = base + (valid ? iu : end - 1);
       lin[u] = 1.0;
-      ell[u] = gload(kappa_col, idx) + chain.eval(u, 0, ctx, idx, lin[u]);
+      ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
       // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
       live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
       if (!live[u]) ell[u] = GWI_NEG_INF;
       if (WRITE_LOGW) {
-        if (valid) logw[idx] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
+        if (valid) logw[base + iu] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
       }
       mx_lane = fmax(mx_lane, ell[u]);
     }
-    if (WRITE_LOGW) continue;
-    const double mx = wave_max(mx_lane);
-    if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
-      if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
-        const double sc = exp(m - mx);
-        s1 *= sc;
-        s2 *= sc * sc;
-        chain.rescale(sc);
-        if (ChainT::kSpline)
-          for (int p = lane; p < wave_span; p += 64) wave_rows[p] *= sc;
+    if (!WRITE_LOGW) {
+      const double mx = wave_max(mx_lane);
+      if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
+        if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
+          const double sc = exp(m - mx);
+          s1 *= sc;
+          s2 *= sc * sc;
+          chain.rescale(sc);
+          if (ChainT::kSpline)
+            for (int p = lane; p < wave_span; p += 64) wave_rows[p] *= sc;
+        }
+        m = mx;
       }
-      m = mx;
-    }
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
-      const double w = live[u] ? lin[u] * exp(ell[u] - m) : 0.0;
-      s1 += w;
-      s2 += w * w;
-      chain.accumulate(u, 0, ctx, w);
+      for (int u = 0; u < kU; ++u) {
+        if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+        const double w = live[u] ? lin[u] * exp(ell[u] - m) : 0.0;
+        s1 += w;
+        s2 += w * w;
+        chain.accumulate(u, 0, ctx, w);
+      }
+    }
+    if (has_next) {
+      chain.advance();
+#pragma unroll
+      for (int u = 0; u < kU; ++u) kap[0][u] = kap[1][u];
     }
   }
   if (WRITE_LOGW) return;

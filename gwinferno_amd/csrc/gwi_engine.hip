@@ -24,6 +24,7 @@ struct Variant {
   const char* name;
   int n;
   int kinds[GWI_MAX_TERMS];
+  int samples_per_lane;
   ScanFn scan;
   ScanFn logw;
 };
@@ -37,8 +38,10 @@ struct Variant {
 #define K_SP GWI_TERM_EXP_SPLINE
 #define K_TN GWI_TERM_TRUNCNORM
 
-#define GWI_VARIANT(NAME, ...) \
-  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, &scan_kernel<false, __VA_ARGS__>, &scan_kernel<true, __VA_ARGS__> }
+// U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
+#define GWI_VARIANT_U(NAME, U, ...) \
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, U, __VA_ARGS__>, &scan_kernel<true, U, __VA_ARGS__> }
+#define GWI_VARIANT(NAME, ...) GWI_VARIANT_U(NAME, 2, __VA_ARGS__)
 
 // Term sequences are canonical: the host sorts a model's terms by kind id (stable).
 const Variant kVariants[] = {
@@ -51,11 +54,15 @@ const Variant kVariants[] = {
     GWI_VARIANT("plpeak+plq+beta2+tilt2+plz", K_PP, K_PQ, K_BE, K_BE, K_TI, K_TI, K_PZ),
     // tests/inference_test.py:244-285 -- PL z x {BSpline m1, BSpline q, spline(log z)}
     GWI_VARIANT("plz+spline3", K_PZ, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plz+spline3/u1", 1, K_PZ, K_SP, K_SP, K_SP),
     // BASELINE config 3/4 -- PL q x PL z x {BSpline m1, IID spin magnitudes [, IID tilts]}
     GWI_VARIANT("plq+plz+spline3", K_PQ, K_PZ, K_SP, K_SP, K_SP),
     GWI_VARIANT("plq+plz+spline5", K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plq+plz+spline5/u1", 1, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
     // BASELINE config 5 -- PL z x {BSpline m1, q, a1, a2, ct1, ct2, spline(log z)}
-    GWI_VARIANT("plz+spline7", K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
+    // (one sample per lane: 160 VGPRs -> 3 waves/SIMD; measured 83 vs 93 us per scan on config 5)
+    GWI_VARIANT_U("plz+spline7", 1, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plz+spline7/u2", 2, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
     // PLPeakPrimaryBSplineRatio (separable.py:368-443) x PL z
     GWI_VARIANT("plpeak+plz+spline", K_PP, K_PZ, K_SP),
     // mass-only B-spline models: BSplinePrimaryBSplineRatio / BSplinePrimaryPowerlawRatio x PL z
@@ -73,14 +80,20 @@ const Variant kVariants[] = {
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+// First entry whose kind sequence matches; GWI_SAMPLES_PER_LANE=1|2 prefers that unroll where compiled.
 const Variant* find_variant(const gwi_spec& s) {
+  int prefer = 0;
+  if (const char* env = std::getenv("GWI_SAMPLES_PER_LANE")) prefer = std::atoi(env);
+  const Variant* first = nullptr;
   for (int v = 0; v < kNumVariants; ++v) {
     if (kVariants[v].n != s.n_terms) continue;
     bool same = true;
     for (int t = 0; t < s.n_terms; ++t) same = same && kVariants[v].kinds[t] == s.terms[t].kind;
-    if (same) return &kVariants[v];
+    if (!same) continue;
+    if (!first) first = &kVariants[v];
+    if (prefer && kVariants[v].samples_per_lane == prefer) return &kVariants[v];
   }
-  return nullptr;
+  return first;
 }
 
 // record published by final_kernel (doubles):
@@ -591,7 +604,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     const long long total = n_ev * n_pe + n_inj;
     spb = (total + 2047) / 2048;
   }
-  const long long gran = (long long)kU * kBlock;  // every lane carries kU samples per trip
+  const long long gran = (long long)h->variant->samples_per_lane * kBlock;  // every lane carries U samples per trip
   spb = ((spb + gran - 1) / gran) * gran;
   if (spb < gran) spb = gran;
   const long long n_pe_pad = ((n_pe + gran - 1) / gran) * gran;

@@ -1,0 +1,136 @@
+"""GPU (-m gpu): term-level parity.  Each closed-form density of the reference
+(gwinferno/distributions.py, models/parametric/parametric.py) evaluated ALONE by the engine (the
+single-term kernel variants) against the golden per-term vectors (tests/golden/terms.npz), including
+exact boundary values, nextafter neighbours, out-of-range points and the alpha = -1 branches; plus
+B-spline projections against the golden design-matrix products (tests/golden/bases.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from golden_util import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def _logw(pe_density, inj_density, theta_from):
+    from gwinferno_amd.engine import NativePopulationLikelihood
+
+    eng = NativePopulationLikelihood(pe_density, inj_density)
+    th = eng.bound.theta_of(theta_from)
+    lpe, linj = eng.log_weights(th)
+    eng.close()
+    return lpe, linj
+
+
+def _check(got_log, ref_pdf, tol=1e-11):
+    with np.errstate(all="ignore"):
+        ref_log = np.log(ref_pdf)
+    zero = ~(ref_pdf > 0) | ~np.isfinite(ref_pdf)  # zero, NaN or inf densities all mean "excluded"
+    assert np.array_equal(np.isneginf(got_log), zero), (np.flatnonzero(np.isneginf(got_log) != zero)[:5])
+    ok = ~zero
+    assert np.max(np.abs(got_log[ok] - ref_log[ok])) < tol
+
+
+def _pair(x):
+    """(PE-shaped, injection-shaped) views of one test vector."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return x.reshape(4, -1), x
+
+
+@pytest.fixture(scope="module")
+def terms():
+    return np.load(os.path.join(GOLDEN_DIR, "terms.npz"))
+
+
+def test_powerlaw_fixed_bounds(terms):
+    from gwinferno_amd import models as M
+
+    m1 = terms["m1"]
+    pe, inj = _pair(m1)
+    for tag, a in zip(("a", "b", "neg1", "zero"), terms["powerlaw_alphas"]):
+        d_pe, d_inj = M.powerlaw_pdf(pe, a, 5.0, 100.0), M.powerlaw_pdf(inj, a, 5.0, 100.0)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        _check(linj, terms[f"powerlaw_pdf/{tag}"])
+        _check(lpe.ravel(), terms[f"powerlaw_pdf/{tag}"])
+
+
+def test_powerlaw_per_sample_lower_bound(terms):
+    from gwinferno_amd import models as M
+
+    m1, q = terms["m1"], terms["q"]
+    for tag, b in zip(("a", "b", "neg1", "zero"), terms["powerlaw_alphas"]):
+        qp, qi = _pair(q)
+        with np.errstate(all="ignore"):
+            lowp, lowi = _pair(5.0 / m1)
+        d_pe, d_inj = M.powerlaw_pdf(qp, b, lowp, 1), M.powerlaw_pdf(qi, b, lowi, 1)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        _check(linj, terms[f"powerlaw_q/{tag}"])
+
+
+def test_truncnorm_plpeak_and_ratio(terms):
+    from gwinferno_amd import models as M
+
+    m1, q = terms["m1"], terms["q"]
+    mp, mi = _pair(m1)
+    qp, qi = _pair(q)
+    mu, sig, lo, hi = terms["truncnorm_params"]
+    d_pe, d_inj = M.truncnorm_pdf(mp, mu, sig, lo, hi), M.truncnorm_pdf(mi, mu, sig, lo, hi)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["truncnorm_pdf"])
+    al, lo, hi, mpp, sigpp, lam = terms["plpeak_params"]
+    d_pe, d_inj = M.plpeak_primary_pdf(mp, al, lo, hi, mpp, sigpp, lam), M.plpeak_primary_pdf(mi, al, lo, hi, mpp, sigpp, lam)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["plpeak_primary_pdf"])
+    beta = float(terms["plpeak_ratio_beta"])
+    d_pe = M.plpeak_primary_ratio_pdf(mp, qp, al, beta, lo, hi, mpp, sigpp, lam)
+    d_inj = M.plpeak_primary_ratio_pdf(mi, qi, al, beta, lo, hi, mpp, sigpp, lam)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["plpeak_primary_ratio_pdf"])
+
+
+def test_beta_and_tilt(terms):
+    from gwinferno_amd import models as M
+
+    ap, ai = _pair(terms["a"])
+    a, b = terms["beta_params"]
+    d_pe, d_inj = M.betadist(ap, a, b), M.betadist(ai, a, b)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["betadist"])
+    cp, ci = _pair(terms["ct"])
+    xi, sg = terms["tilt_params"]
+    d_pe, d_inj = M.mixture_isoalign_spin_tilt(cp, xi, sg), M.mixture_isoalign_spin_tilt(ci, xi, sg)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["mixture_isoalign_spin_tilt"])
+
+
+def test_redshift_model(terms):
+    from gwinferno_amd import models as M
+
+    zpe, zinj = terms["z_pe"], terms["z_inj"]
+    zm = M.PowerlawRedshiftModel(zpe, zinj)
+    assert np.array_equal([zm.zmin, zm.zmax], terms["z_model/zmin_zmax"])
+    for i, lamb in enumerate(terms["z_lamb"]):
+        d_pe, d_inj = zm(zpe, lamb), zm(zinj, lamb)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        _check(lpe, terms["z_model/pe"][i])
+        _check(linj, terms["z_model/inj"][i])
+
+
+def test_spline_projection_against_design_matrix():
+    """exp-spline density at the golden sample points == the reference's dense projection
+    (interpolation.py:306-317) for the LogY / LogXLogY bases, incl. domain ends and nextafter points."""
+    from gwinferno_amd import models as M
+    from gwinferno_amd.interpolation import LogXLogYBSpline, LogYBSpline
+
+    z = np.load(os.path.join(GOLDEN_DIR, "bases.npz"))
+    meta = json.loads(str(z["meta"]))
+    cls = {"LogYBSpline": LogYBSpline, "LogXLogYBSpline": LogXLogYBSpline}
+    n_checked = 0
+    for i, m in enumerate(meta):
+        if m["cls"] not in cls:
+            continue
+        xs = z[f"{i}/xs"]
+        xp, xi = _pair(xs)
+        model = M.Base1DBSplineModel(m["n"], xp, xi, xrange=tuple(m["xrange"]), basis=cls[m["cls"]], normalize=True)
+        cs = z[f"{i}/coefs"]
+        d_pe, d_inj = model(cs, pe_samples=True), model(cs, pe_samples=False)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        _check(linj, z[f"{i}/project"], tol=1e-10)
+        n_checked += 1
+    assert n_checked == 6
