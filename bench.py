@@ -74,10 +74,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("GWI_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -94,14 +98,23 @@ def main():
     pool = [draw_params(comp_name, rng) for _ in range(64)]
     thetas = [comp.theta(p) for p in pool]
 
-    gather_buf = None
-    if world > 1:
-        from gwinferno_amd.distributed import ShardedLikelihood
+    if dist is not None:
+        # hot loop: scan + ncclAllGather + assembly inside the engine (no Python/torch in the data path);
+        # GWI_TORCH_COLLECTIVE=1 selects the torch.distributed all_gather_into_tensor variant instead
+        if os.environ.get("GWI_TORCH_COLLECTIVE") == "1":
+            from gwinferno_amd.distributed import ShardedLikelihood
 
-        sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank))
+            sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank))
 
-        def step(i):
-            return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
+            def step(i):
+                return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
+        else:
+            from gwinferno_amd.distributed import init_engine_communicator
+
+            init_engine_communicator(eng)
+
+            def step(i):
+                return eng.evaluate_sharded(thetas[i % len(thetas)], total, min_neff_cut=False, copy=False)
     else:
 
         def step(i):
@@ -137,6 +150,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    out = None
     if rank == 0:
         evals_per_s = args.steps / elapsed
         scan_us = 1e3 * float(np.mean(scan_ms)) if scan_ms else float("nan")
@@ -182,11 +196,20 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(comp_name, pe, inj, total, pool)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

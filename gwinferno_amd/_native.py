@@ -124,6 +124,9 @@ EXPORTED_SYMBOLS = [
     "gwi_eval_partial",
     "gwi_prepare_combine",
     "gwi_combine",
+    "gwi_comm_unique_id",
+    "gwi_comm_init",
+    "gwi_eval_sharded",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
     "gwi_last_error",
@@ -141,6 +144,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (same soname as the
+    # system one).  If torch is importable, load it FIRST so that the engine binds to the runtime
+    # torch.distributed / RCCL will use; otherwise a later `import torch` would bring in a second,
+    # disjoint runtime and the in-engine RCCL exchange (gwi_comm_init) could not see our buffers.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for single-GPU use
+        pass
     if not os.path.exists(LIB_PATH):
         raise NativeEngineError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -165,6 +176,12 @@ def load_library():
     lib.gwi_prepare_combine.argtypes = [vp, _DP]
     lib.gwi_combine.restype = C.c_int32
     lib.gwi_combine.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP]
+    lib.gwi_comm_unique_id.restype = C.c_int32
+    lib.gwi_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+    lib.gwi_comm_init.restype = C.c_int32
+    lib.gwi_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.gwi_eval_sharded.restype = C.c_int32
+    lib.gwi_eval_sharded.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32
     lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.gwi_set_timing.restype = C.c_int32

@@ -1012,4 +1012,12 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
   }
 }
 
+// ---- after the all-gather: copy the gathered records to pinned host memory and stamp completion -----
+__global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered, double* host, int n, unsigned long long seq) {
+  for (int i = threadIdx.x + 1; i < n; i += kBlock) host[i] = gathered[i];
+  __syncthreads();
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace gwi

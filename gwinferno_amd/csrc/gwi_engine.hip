@@ -2,6 +2,8 @@
 // gfx950 only; no CPU fallback: every entry point that computes needs a live HIP device.
 #include "gwi_device.h"
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -139,6 +141,44 @@ void truncnorm_lognorm(double mu, double sg, double lo, double hi, double* logC,
 
 }  // namespace
 
+// ---- RCCL, bound at run time (no link-time dependency; the same librccl the host framework uses) ----
+namespace {
+struct NcclId {  // ncclUniqueId (rccl.h:43), passed by value
+  char b[128];
+};
+struct NcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+NcclApi g_nccl;
+constexpr int kNcclDouble = 8;  // ncclFloat64 (rccl.h:467)
+
+bool load_nccl(const char* path, std::string* err) {
+  if (g_nccl.lib) return true;
+  const char* p = (path && *path) ? path : "librccl.so.1";
+  void* lib = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    *err = std::string("dlopen(") + p + ") failed: " + dlerror();
+    return false;
+  }
+  g_nccl.GetUniqueId = reinterpret_cast<decltype(g_nccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_nccl.CommInitRank = reinterpret_cast<decltype(g_nccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_nccl.AllGather = reinterpret_cast<decltype(g_nccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+  g_nccl.CommDestroy = reinterpret_cast<decltype(g_nccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_nccl.GetErrorString = reinterpret_cast<decltype(g_nccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllGather || !g_nccl.CommDestroy) {
+    *err = std::string("librccl at ") + p + " lacks the expected symbols";
+    return false;
+  }
+  g_nccl.lib = lib;
+  return true;
+}
+}  // namespace
+
 struct gwi_engine {
   gwi_spec spec;
   const Variant* variant = nullptr;
@@ -166,6 +206,11 @@ struct gwi_engine {
   bool timing = false;
   bool spin_wait = true;
   bool host_only = false;
+  // in-engine RCCL communicator (optional)
+  void* nccl_comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  double *d_send = nullptr, *d_recv = nullptr;
+  double *h_gather = nullptr, *h_gather_dev = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   std::string err;
@@ -299,7 +344,11 @@ gwi_status launch_scan(gwi_handle h, bool logw) {
   return GWI_OK;
 }
 
-gwi_status run_pipeline(gwi_handle h, const double* theta) {
+gwi_status wait_for_stamp(gwi_handle h, double* host_buf);
+
+// launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
+// or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
+gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true) {
   prelude(h, theta);
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[0], h->stream));
   gwi_status st = launch_scan(h, false);
@@ -330,7 +379,7 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
     fa.inj_out = h->d_inj_out;
     fa.inj_grad = h->d_inj_grad;
     fa.norm_out = h->d_norm_out;
-    fa.record = h->h_record_dev;
+    fa.record = record_dev ? record_dev : h->h_record_dev;
     fa.n_ev = (int)h->n_ev;
     fa.n_theta = h->spec.n_theta;
     fa.n_norms = h->spec.n_norms;
@@ -340,10 +389,15 @@ gwi_status run_pipeline(gwi_handle h, const double* theta) {
     GWI_HIP(hipGetLastError());
   }
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+  if (!wait) return GWI_OK;
+  return wait_for_stamp(h, h->h_record);
+}
+
+gwi_status wait_for_stamp(gwi_handle h, double* host_buf) {
   // Completion: final_kernel stores the sequence stamp into pinned host memory LAST (system-scope
   // release after __threadfence_system), so the host can poll it instead of paying a stream
   // synchronise; after ~2 ms of polling fall back to the blocking call (and surface any error).
-  volatile unsigned long long* stamp = reinterpret_cast<volatile unsigned long long*>(h->h_record);
+  volatile unsigned long long* stamp = reinterpret_cast<volatile unsigned long long*>(host_buf);
   bool done = false;
   if (!h->timing && h->spin_wait) {
     for (long spin = 0; spin < 400000; ++spin) {
@@ -469,6 +523,10 @@ void destroy_impl(gwi_engine* h) {
   (void)hipFree(h->d_inj_grad);
   (void)hipFree(h->d_logw_pe);
   (void)hipFree(h->d_logw_inj);
+  if (h->nccl_comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(h->nccl_comm);
+  (void)hipFree(h->d_send);
+  (void)hipFree(h->d_recv);
+  if (h->h_gather) (void)hipHostFree(h->h_gather);
   if (h->h_record) (void)hipHostFree(h->h_record);
   if (h->h_ev) (void)hipHostFree(h->h_ev);
   for (auto& e : h->ev)
@@ -752,6 +810,66 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
   if (log_bfs)
     for (size_t i = 0; i < n; ++i) log_bfs[i] = h->h_ev[i] + shift;  // logBF_i = logsumexp_i - log N_pe (analysis.py:80)
+  if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
+  if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
+  return GWI_OK;
+}
+
+gwi_status gwi_comm_unique_id(const char* rccl_path, void* id128) {
+  if (!id128) return GWI_ERR_INVALID;
+  std::string err;
+  if (!load_nccl(rccl_path, &err)) return GWI_ERR_HIP;
+  return g_nccl.GetUniqueId(id128) == 0 ? GWI_OK : GWI_ERR_HIP;
+}
+
+gwi_status gwi_comm_init(gwi_handle h, const char* rccl_path, const void* id128, int32_t rank, int32_t world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return GWI_ERR_INVALID;
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to communicate from");
+  if (!load_nccl(rccl_path, &h->err)) return GWI_ERR_HIP;
+  GWI_HIP(hipSetDevice(h->device));
+  NcclId id;
+  std::memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int rc = g_nccl.CommInitRank(&comm, world, id, rank);
+  if (rc != 0) return fail(h, GWI_ERR_HIP, std::string("ncclCommInitRank: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "error"));
+  h->nccl_comm = comm;
+  h->comm_rank = rank;
+  h->comm_world = world;
+  const size_t len = (size_t)record_len(h);
+  GWI_HIP(hipMalloc(&h->d_send, sizeof(double) * len));
+  GWI_HIP(hipMalloc(&h->d_recv, sizeof(double) * len * world));
+  GWI_HIP(hipHostMalloc((void**)&h->h_gather, sizeof(double) * len * world, hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_gather_dev, h->h_gather, 0));
+  std::memset(h->h_gather, 0, sizeof(double) * len * world);
+  return GWI_OK;
+}
+
+gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary, double* grad, double* log_bfs,
+                            double* log_neffs, double* variances, double* norms) {
+  if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
+  if (!h->nccl_comm) return fail(h, GWI_ERR_INVALID, "gwi_comm_init has not been called");
+  if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
+    return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
+  if (opt->marginalize_selection && grad)
+    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+  GWI_HIP(hipSetDevice(h->device));
+  // scan -> combine -> final (record stays on the device) -> all-gather -> publish, all on one stream
+  gwi_status st = run_pipeline(h, theta, h->d_send, /*wait=*/false);
+  if (st != GWI_OK) return st;
+  const size_t len = (size_t)record_len(h);
+  const int rc = g_nccl.AllGather(h->d_send, h->d_recv, len, kNcclDouble, h->nccl_comm, h->stream);
+  if (rc != 0) return fail(h, GWI_ERR_HIP, std::string("ncclAllGather: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "error"));
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_recv, h->h_gather_dev, (int)(len * h->comm_world), h->seq);
+  GWI_HIP(hipGetLastError());
+  st = wait_for_stamp(h, h->h_gather);
+  if (st != GWI_OK) return st;
+  gwi_summary s;
+  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms);
+  if (summary) *summary = s;
+  const size_t n = (size_t)h->n_ev;
+  const double shift = s.log_norm_const - std::log((double)h->n_pe);
+  if (log_bfs)
+    for (size_t i = 0; i < n; ++i) log_bfs[i] = h->h_ev[i] + shift;
   if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
   if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
   return GWI_OK;

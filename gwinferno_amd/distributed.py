@@ -15,6 +15,38 @@ import numpy as np
 from .engine import EvalResult
 
 
+def rccl_library_path():
+    """The librccl the running PyTorch uses (so the engine and torch.distributed share one copy)."""
+    import os
+
+    import torch
+
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+def init_engine_communicator(engine, group=None):
+    """Create the engine's own RCCL communicator: rank 0 draws the ncclUniqueId, torch.distributed
+    (any backend) broadcasts its 128 bytes, every rank calls ncclCommInitRank inside the engine."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from . import _native as N
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    path = rccl_library_path()
+    box = [None]
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        st = N.load_library().gwi_comm_unique_id(path.encode() if path else None, buf)
+        if st != 0:
+            raise N.NativeEngineError(f"gwi_comm_unique_id failed ({N.STATUS_NAMES.get(st, st)})")
+        box[0] = bytes(buf.raw)
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world, rccl_path=path)
+
+
 class ShardedLikelihood:
     """Wraps this rank's :class:`NativePopulationLikelihood` (built with ``rank=``/``world=``)."""
 

@@ -324,6 +324,36 @@ class NativePopulationLikelihood:
         return EvalResult(log_likelihood=b.summ.log_likelihood, grad=b.grad if want_grad else None, summary=b.summ, log_bfs=b.lb, log_neffs=b.ln, variances=b.lv,
                           norms=b.norms[:n_norms])
 
+    # ---- in-engine RCCL exchange (multi-GPU hot loop without Python/torch in the data path) ----------
+    def comm_init(self, unique_id, rank, world, rccl_path=None):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        path = rccl_path.encode() if rccl_path else None
+        self._check(self.lib.gwi_comm_init(self.handle, path, buf, int(rank), int(world)))
+        self._comm = True
+
+    def evaluate_sharded(self, theta, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True, copy=True):
+        """Like :meth:`evaluate`, for an engine built with ``rank=/world=`` after :meth:`comm_init`:
+        scan of this rank's shard, ncclAllGather of the partial records on the engine's stream,
+        identical assembly on every rank.  Per-event arrays are this rank's events."""
+        b = self._buffers()
+        b.theta[:] = theta
+        o = b.opt
+        o.n_obs = float(self.n_ev_global if nobs is None else nobs)
+        o.total_inj = float(total_inj)
+        o.marginalize_selection = int(bool(marginalize_selection))
+        o.min_neff_cut = int(bool(min_neff_cut))
+        o.max_variance_cut = int(bool(max_variance_cut))
+        st = self.lib.gwi_eval_sharded(self.handle, b.p_theta, b.r_opt, b.r_summ, b.p_grad if want_grad else None, b.p_lb, b.p_ln, b.p_lv, b.p_norms)
+        if st != 0:
+            self._check(st)
+        n_norms = len(self.bound.norms)
+        if copy:
+            summ = N.GwiSummary.from_buffer_copy(b.summ)
+            return EvalResult(log_likelihood=summ.log_likelihood, grad=b.grad.copy() if want_grad else None, summary=summ, log_bfs=b.lb.copy(), log_neffs=b.ln.copy(),
+                              variances=b.lv.copy(), norms=b.norms[:n_norms].copy())
+        return EvalResult(log_likelihood=b.summ.log_likelihood, grad=b.grad if want_grad else None, summary=b.summ, log_bfs=b.lb, log_neffs=b.ln, variances=b.lv,
+                          norms=b.norms[:n_norms])
+
     def eval_partial(self, theta):
         """This rank's partial record (+ local per-event arrays without the global constant)."""
         theta = N.f64(theta)

@@ -198,6 +198,17 @@ gwi_status gwi_prepare_combine(gwi_handle h, const double* theta);
 gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, const gwi_options* opt,
                        gwi_summary* summary, double* grad, double* norms);
 
+/* In-engine collective (one process per GPU, RCCL over xGMI).  gwi_comm_unique_id() fills 128 bytes
+ * on ONE rank (ncclGetUniqueId); the caller distributes them (any out-of-band channel) and every rank
+ * calls gwi_comm_init().  `rccl_path` names the librccl to dlopen (NULL: "librccl.so.1").  Afterwards
+ * gwi_eval_sharded() == gwi_eval_partial + ncclAllGather of the records on the engine's own stream +
+ * gwi_combine, with no host round trip between the scan and the exchange; log_bfs / log_neffs /
+ * variances are this rank's events. */
+gwi_status gwi_comm_unique_id(const char* rccl_path, void* id128);
+gwi_status gwi_comm_init(gwi_handle h, const char* rccl_path, const void* id128, int32_t rank, int32_t world);
+gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
+                            double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
+
 /* Timing of the most recent gwi_eval*: HIP-event milliseconds of each launch on the engine's
  * stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce). */
 gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]);

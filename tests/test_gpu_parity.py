@@ -173,3 +173,32 @@ def test_partial_records_combine_like_single_device():
     assert rel_err(out.log_likelihood, ref.log_likelihood) < 1e-12
     assert np.allclose(out.grad, ref.grad, rtol=1e-10, atol=1e-11)
     full.close()
+
+
+def test_in_engine_rccl_exchange_world1():
+    """gwi_comm_init + gwi_eval_sharded (scan -> ncclAllGather -> publish -> assemble on one stream)
+    with a one-rank communicator reproduces gwi_eval bit for bit."""
+    import ctypes as C
+
+    from gwinferno_amd import _native as N
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.distributed import rccl_library_path
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 500, 3001, seed=21)
+    comp = COMPOSITIONS["bspline_test"](pe, inj)
+    eng = comp.engine()
+    path = rccl_library_path()
+    buf = C.create_string_buffer(128)
+    assert N.load_library().gwi_comm_unique_id(path.encode() if path else None, buf) == 0
+    eng.comm_init(buf.raw, 0, 1, rccl_path=path)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        th = comp.theta(draw_params("bspline_test", rng))
+        a = eng.evaluate(th, total, min_neff_cut=False)
+        b = eng.evaluate_sharded(th, total, min_neff_cut=False)
+        assert a.log_likelihood == b.log_likelihood
+        assert np.array_equal(a.log_bfs, b.log_bfs)
+        assert np.allclose(a.grad, b.grad, rtol=1e-12, atol=1e-13)
+        assert a.summary.log_nEff_inj == b.summary.log_nEff_inj
+    eng.close()
