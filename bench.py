@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timing-every", type=int, default=4, help="HIP-event kernel timing on every n-th timed step")
+    ap.add_argument("--timing-every", type=int, default=16, help="HIP-event kernel timing on every n-th timed step")
     args = ap.parse_args()
 
     import torch
@@ -74,6 +74,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     dist = None
+    collective = None
     force_sharded = os.environ.get("GWI_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
     if world > 1 or force_sharded:
         import torch.distributed as dist
@@ -101,24 +102,35 @@ def main():
     if dist is not None:
         # hot loop: scan + ncclAllGather + assembly inside the engine (no Python/torch in the data path);
         # GWI_TORCH_COLLECTIVE=1 selects the torch.distributed all_gather_into_tensor variant instead
-        if os.environ.get("GWI_TORCH_COLLECTIVE") == "1":
-            from gwinferno_amd.distributed import ShardedLikelihood
+        from gwinferno_amd.distributed import ShardedLikelihood, init_engine_communicator
 
+        use_torch = os.environ.get("GWI_TORCH_COLLECTIVE") == "1"
+        if not use_torch:
+            try:
+                init_engine_communicator(eng)
+                ok = 1
+            except Exception as exc:  # keep the run alive on the torch path; say so
+                print(f"[rank {rank}] in-engine RCCL communicator unavailable ({exc}); using torch.distributed all_gather", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must agree on the path
+            use_torch = int(flag.item()) == 0
+        collective = "torch.distributed all_gather_into_tensor" if use_torch else "ncclAllGather inside the engine"
+        if use_torch:
             sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank))
 
             def step(i):
                 return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
         else:
-            from gwinferno_amd.distributed import init_engine_communicator
-
-            init_engine_communicator(eng)
+            vg = eng.configure(total, min_neff_cut=False)
 
             def step(i):
-                return eng.evaluate_sharded(thetas[i % len(thetas)], total, min_neff_cut=False, copy=False)
+                return vg(thetas[i % len(thetas)])
     else:
+        vg = eng.configure(total, min_neff_cut=False)  # value_and_grad(theta) -> (log_likelihood, grad buffer)
 
         def step(i):
-            return eng.evaluate(thetas[i % len(thetas)], total, min_neff_cut=False, copy=False)
+            return vg(thetas[i % len(thetas)])
 
     for i in range(args.warmup):
         step(i)
@@ -177,7 +189,7 @@ def main():
                 "n_inj": int(n_inj),
                 "n_theta": int(eng.n_theta),
                 "flags": "min_neff_cut=False (tests/inference_test.py:185)",
-                "parallelism": f"events+injections sharded over {world} GPU(s), one all-gather of partial records" if world > 1 else "single GPU",
+                "parallelism": f"events+injections sharded over {world} GPU(s), one all-gather of partial records per eval ({collective})" if dist is not None else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -192,7 +204,8 @@ def main():
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
                 "timed_launches": len(scan_ms),
             },
-            "last_log_likelihood": float(res.log_likelihood),
+            "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
+            "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(comp_name, pe, inj, total, pool)

@@ -127,6 +127,7 @@ EXPORTED_SYMBOLS = [
     "gwi_comm_unique_id",
     "gwi_comm_init",
     "gwi_eval_sharded",
+    "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
     "gwi_last_error",
@@ -182,6 +183,8 @@ def load_library():
     lib.gwi_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.gwi_eval_sharded.restype = C.c_int32
     lib.gwi_eval_sharded.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_selftime.restype = C.c_int32
+    lib.gwi_selftime.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.c_int32, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32
     lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.gwi_set_timing.restype = C.c_int32

@@ -788,29 +788,11 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   }
 }
 
-// ---- block-wide deterministic reductions over a [rows][vp] LDS tile --------------------------------
-// Thread (row = tid / vp, col = tid % vp) holds one partial for value `col`; rows are folded in a
-// fixed binary tree, so results are bit-reproducible run to run.
-__device__ __forceinline__ void fold_rows(double* tile, int vp, int rows, int tid) {
-  for (int half = rows >> 1; half > 0; half >>= 1) {
-    __syncthreads();
-    const int row = tid / vp, col = tid - row * vp;
-    if (row < half) tile[row * vp + col] += tile[(row + half) * vp + col];
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ int pow2_at_least(int v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
 // ---- stage 2: combine the tile records of one GROUP with a common reference exponent.  Groups
 //      0..n_ev-1 are the events (all tiles of one event); groups n_ev.. split the injection tiles
-//      into n_inj_groups contiguous runs so that no single workgroup has to walk thousands of
-//      records.  All 256 threads work: the record values (S1, S2, G[0..n_theta)) are the fast index,
-//      tiles the slow one; rows are folded in a fixed tree (bit-reproducible). --------------------------
+//      into runs of <= tiles_per_inj_group.  Latency is everything here (a few KB per group), so the
+//      kernel has NO workgroup barrier: tiles run across the lanes of a wave, record values across the
+//      waves; every wave derives the group's exponent and S1 itself (DPP reductions, fixed order).
 struct CombineArgs {
   const double* partials;
   double* ev_out;     // [n_ev][4]: logsumexp (= log sum_j w_ij, no -log N_pe), log n_eff, variance, S1
@@ -818,15 +800,36 @@ struct CombineArgs {
   double* inj_out;    // [n_inj_groups][4]: M, S1, S2
   double* inj_grad;   // [n_inj_groups][n_theta]: G_p relative to that group's M
   double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
+  // host-final mode (small problems): every group publishes its whole result row
+  // [stamp, a, b, c, grad[n_theta]] to pinned host memory and the HOST sums over groups, which
+  // removes the third launch; a = logsumexp | M, b = log n_eff | S1, c = variance | S2
+  double* host_rows;  // nullptr: device-final mode
+  unsigned long long seq;
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   double n_pe;
 };
 
+__device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- publishing to pinned host memory without a system-scope fence ---------------------------------
+// __threadfence_system() = write back the whole L2 + invalidate (several us).  Results bound for the
+// host are instead stored write-through at system scope (global_store ... sc0 sc1: they bypass the
+// caches), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
+// barrier, and only then one lane stores the completion stamp, also write-through
+// (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag" hand-off form).
+__device__ __forceinline__ void store_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void publish_stamp(double* slot, unsigned long long seq, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
-  __shared__ double s_tile[kBlock];
-  __shared__ double s_red[kWaves];
-  __shared__ double s_M;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int e = blockIdx.x;
   const bool is_inj = e >= a.n_ev;
   int n_tiles;
@@ -842,49 +845,46 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
   }
   const double* rec = a.partials + first * a.rec_stride;
 
-  double mx = GWI_NEG_INF;
-  for (int t = tid; t < n_tiles; t += kBlock) mx = fmax(mx, rec[(long long)t * a.rec_stride]);
-  mx = wave_max(mx);
-  if ((tid & 63) == 0) s_red[tid >> 6] = mx;
-  __syncthreads();
-  if (tid == 0) s_M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-  __syncthreads();
-  const double M = s_M;
-
-  const int n_val = 2 + a.n_theta;  // S1, S2, G[...]
-  double S1 = 0.0;
-  for (int v0 = 0; v0 < n_val; v0 += kBlock) {  // one pass unless n_theta > 254
-    const int nv = n_val - v0 < kBlock ? n_val - v0 : kBlock;
-    const int vp = pow2_at_least(nv);
-    const int rows = kBlock / vp;
-    const int row = tid / vp, col = tid - row * vp;
+  // phase 1, every wave redundantly: lanes <- tiles.  Common exponent M, per-tile factor f_t, S1, S2.
+  // (host guarantees n_tiles <= 64 per group)
+  const bool has = lane < n_tiles;
+  const double* mine = rec + (long long)(has ? lane : 0) * a.rec_stride;
+  const double m_t = has ? mine[0] : GWI_NEG_INF;
+  const double r1 = has ? mine[1] : 0.0, r2 = has ? mine[2] : 0.0;
+  const double M = wave_max(m_t);
+  const double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
+  const double S1 = wave_sum(f * r1);
+  const double inv_s1 = S1 > 0.0 ? 1.0 / S1 : 0.0;
+  // phase 2: threads <- gradient slots (coalesced across p), tiles in order with f_t broadcast from
+  // its lane: no cross-lane reduction, no barrier, fixed summation order
+  for (int p = tid; p < a.n_theta; p += kBlock) {
     double acc = 0.0;
-    if (col < nv) {
-      const int v = v0 + col;
+    const double* col = rec + kRecHeader + p;
 #pragma unroll 4
-      for (int t = row; t < n_tiles; t += rows) {
-        const double* r = rec + (long long)t * a.rec_stride;
-        const double m_t = r[0];
-        double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
-        if (v == 1) f *= f;  // S2 carries e^{2(m_t - M)}
-        acc += f * r[1 + v];
+    for (int t = 0; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
+    if (a.host_rows)
+      store_sys(a.host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
+    else if (is_inj)
+      a.inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
+    else
+      a.ev_grad[(long long)e * a.n_theta + p] = acc * inv_s1;
+  }
+  if (tid < 64) {
+    const double S2 = wave_sum(f * f * r2);
+    if (lane == 0 && a.host_rows) {
+      double* o = a.host_rows + (long long)e * (4 + a.n_theta);
+      if (is_inj) {
+        store_sys(o + 1, M);
+        store_sys(o + 2, S1);
+        store_sys(o + 3, S2);
+      } else {
+        const double log_s1 = log(S1);
+        const double log_neff = 2.0 * log_s1 - log(S2);  // analysis.py:79
+        store_sys(o + 1, log_s1 + M);
+        store_sys(o + 2, log_neff);
+        store_sys(o + 3, 1.0 / exp(log_neff) - 1.0 / a.n_pe);  // :87
       }
-    }
-    s_tile[tid] = acc;
-    fold_rows(s_tile, vp, rows, tid);
-    if (v0 == 0) S1 = s_tile[0];
-    if (row == 0 && col < nv) {
-      const int v = v0 + col;
-      const double g = s_tile[col];
-      if (v >= 2) {
-        if (is_inj)
-          a.inj_grad[(long long)(e - a.n_ev) * a.n_theta + (v - 2)] = g;
-        else
-          a.ev_grad[(long long)e * a.n_theta + (v - 2)] = S1 > 0.0 ? g / S1 : 0.0;
-      }
-    }
-    if (v0 == 0 && tid == 0) {
-      const double S2 = s_tile[1];
+    } else if (lane == 0) {
       if (is_inj) {
         double* o = a.inj_out + (long long)(e - a.n_ev) * 4;
         o[0] = M;
@@ -901,123 +901,112 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
         o[1] = log_neff;
         o[2] = var;
         o[3] = S1;
-        a.ev_host[e] = log_s1 + M;
-        a.ev_host[a.n_ev + e] = log_neff;
-        a.ev_host[2 * a.n_ev + e] = var;
+        store_sys(a.ev_host + e, log_s1 + M);
+        store_sys(a.ev_host + a.n_ev + e, log_neff);
+        store_sys(a.ev_host + 2 * a.n_ev + e, var);
       }
     }
-    __syncthreads();
   }
+  if (a.host_rows) publish_stamp(a.host_rows + (long long)e * (4 + a.n_theta), a.seq, tid);
 }
 
 // ---- stage 3: reduce over events, merge the injection groups, and publish this device's record to
-//      pinned host memory.  record layout (doubles): see kRecNormOff in gwi_engine.hip -------------------
+//      pinned host memory.  One workgroup of 16 waves; events (or injection groups) run across the
+//      lanes, output values across the waves; one barrier, before the completion stamp.
+//      record layout (doubles): see kRecNormOff in gwi_engine.hip -------------------------------------
+constexpr int kFinalThreads = 1024;
+constexpr int kFinalWaves = kFinalThreads / 64;
+
 struct FinalArgs {
   const double* ev_out;
   const double* ev_grad;
   const double* inj_out;
   const double* inj_grad;
   const double* norm_out;
-  double* record;       // device-visible pinned host buffer
+  double* record;       // device-visible pinned host buffer (or the device send buffer when sharded)
   int n_ev, n_theta, n_norms, n_inj_groups;
   unsigned long long seq;  // written last to record[0] as a completion stamp
 };
 
-__global__ __launch_bounds__(kBlock) void final_kernel(const FinalArgs a) {
-  __shared__ double s_tile[kBlock];
-  __shared__ double s_sum[kWaves], s_var[kWaves], s_min[kWaves];
-  __shared__ double s_inj[4];
-  const int tid = threadIdx.x;
-  double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
-  for (int e = tid; e < a.n_ev; e += kBlock) {
-    const double* o = a.ev_out + (long long)e * 4;
-    sum += o[0];
-    var += o[2];
-    // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295): NaN -> 0, +-inf -> +-max double
-    double le = o[1];
-    if (le != le) le = 0.0;
-    le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
-    mn = fmin(mn, le);
-  }
-  sum = wave_sum(sum);
-  var = wave_sum(var);
-  mn = -wave_max(-mn);
-  if ((tid & 63) == 0) {
-    s_sum[tid >> 6] = sum;
-    s_var[tid >> 6] = var;
-    s_min[tid >> 6] = mn;
-  }
-  // injection groups: common exponent, then S1/S2 in group order
-  if (tid == 0) {
-    double M = GWI_NEG_INF;
-    for (int j = 0; j < a.n_inj_groups; ++j) M = fmax(M, a.inj_out[j * 4]);
-    double S1 = 0.0, S2 = 0.0;
-    for (int j = 0; j < a.n_inj_groups; ++j) {
-      const double m_j = a.inj_out[j * 4];
-      const double f = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - M);
-      S1 += f * a.inj_out[j * 4 + 1];
-      S2 += f * f * a.inj_out[j * 4 + 2];
-    }
-    s_inj[0] = M;
-    s_inj[1] = S1;
-    s_inj[2] = S2;
-  }
-  __syncthreads();
-  const double Minj = s_inj[0];
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+__global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a) {
+  __shared__ double s_tile[kFinalThreads];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* r = a.record;
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
-  // sum_e ev_grad[e][p] and sum_j f_j inj_grad[j][p]: p is the fast index, fixed-tree fold over rows
-  for (int p0 = 0; p0 < a.n_theta; p0 += kBlock) {
-    const int nv = a.n_theta - p0 < kBlock ? a.n_theta - p0 : kBlock;
-    const int vp = pow2_at_least(nv);
-    const int rows = kBlock / vp;
-    const int row = tid / vp, col = tid - row * vp;
-    double acc = 0.0;
-    if (col < nv) {
+
+  // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
+  const int vp = pow2_at_least(a.n_theta < 8 ? 8 : a.n_theta);  // <= 256 (GWI_MAX_THETA = 160)
+  const int rows = kFinalThreads / vp;
+  const int row = tid / vp, col = tid - row * vp;
+  double acc = 0.0;
+  if (col < a.n_theta) {
 #pragma unroll 8
-      for (int e = row; e < a.n_ev; e += rows) acc += a.ev_grad[(long long)e * a.n_theta + p0 + col];
+    for (int e = row; e < a.n_ev; e += rows) acc += a.ev_grad[(long long)e * a.n_theta + col];
+  }
+  s_tile[tid] = acc;
+
+  // ---- meanwhile wave 0: scalar sums over events; wave 1: injection groups
+  if (wave == 0) {
+    double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
+    for (int e = lane; e < a.n_ev; e += 64) {
+      const double* o = a.ev_out + (long long)e * 4;
+      sum += o[0];
+      var += o[2];
+      double le = o[1];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+      if (le != le) le = 0.0;
+      le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
+      mn = fmin(mn, le);
     }
-    s_tile[tid] = acc;
-    fold_rows(s_tile, vp, rows, tid);
-    if (row == 0 && col < nv) r[off_gpe + p0 + col] = s_tile[col];
-    __syncthreads();
-    acc = 0.0;
-    if (col < nv) {
-      for (int j = row; j < a.n_inj_groups; j += rows) {
-        const double m_j = a.inj_out[j * 4];
-        const double f = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
-        acc += f * a.inj_grad[(long long)j * a.n_theta + p0 + col];
-      }
+    sum = wave_sum(sum);
+    var = wave_sum(var);
+    mn = -wave_max(-mn);
+    if (lane == 0) {
+      store_sys(r + 1, sum);
+      store_sys(r + 2, var);
+      store_sys(r + 3, mn);
+      store_sys(r + 7, (double)a.n_ev);
     }
-    s_tile[tid] = acc;
-    fold_rows(s_tile, vp, rows, tid);
-    if (row == 0 && col < nv) r[off_ginj + p0 + col] = s_tile[col];
-    __syncthreads();
   }
-  for (int j = tid; j < a.n_norms; j += kBlock) r[off_norm + j] = a.norm_out[j];
+  // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups
+  const bool hasg = lane < a.n_inj_groups;
+  const double m_j = hasg ? a.inj_out[lane * 4] : GWI_NEG_INF;
+  const double Minj = wave_max(m_j);
+  const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
+  if (wave == 1) {
+    const double S1 = wave_sum(fj * (hasg ? a.inj_out[lane * 4 + 1] : 0.0));
+    const double S2 = wave_sum(fj * fj * (hasg ? a.inj_out[lane * 4 + 2] : 0.0));
+    if (lane == 0) {
+      store_sys(r + 4, Minj);
+      store_sys(r + 5, S1);
+      store_sys(r + 6, S2);
+    }
+  }
+  // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
+  for (int p = tid; p < a.n_theta; p += kFinalThreads) {
+    double g = 0.0;
+    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * a.inj_grad[(long long)j * a.n_theta + p];
+    store_sys(r + off_ginj + p, g);
+  }
+  if (tid < a.n_norms) store_sys(r + off_norm + tid, a.norm_out[tid]);
   __syncthreads();
-  if (tid == 0) {
-    r[1] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-    r[2] = (s_var[0] + s_var[1]) + (s_var[2] + s_var[3]);
-    r[3] = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
-    r[4] = s_inj[0];
-    r[5] = s_inj[1];
-    r[6] = s_inj[2];
-    r[7] = (double)a.n_ev;
+  if (row == 0 && col < a.n_theta) {
+    double g = 0.0;
+    for (int q = 0; q < rows; ++q) g += s_tile[q * vp + col];  // fixed order
+    store_sys(r + off_gpe + col, g);
   }
-  __syncthreads();
-  __threadfence_system();
-  if (tid == 0) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(r), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  publish_stamp(r, a.seq, tid);
 }
 
 // ---- after the all-gather: copy the gathered records to pinned host memory and stamp completion -----
 __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered, double* host, int n, unsigned long long seq) {
-  for (int i = threadIdx.x + 1; i < n; i += kBlock) host[i] = gathered[i];
-  __syncthreads();
-  __threadfence_system();
-  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int i = threadIdx.x + 1; i < n; i += kBlock) store_sys(host + i, gathered[i]);
+  publish_stamp(host, seq, threadIdx.x);
 }
 
 }  // namespace gwi

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -194,6 +195,10 @@ struct gwi_engine {
   // pinned, device-visible host memory
   double *h_record = nullptr, *h_record_dev = nullptr;
   double *h_ev = nullptr, *h_ev_dev = nullptr;
+  // host-final mode: per-group result rows + normaliser values in pinned host memory
+  bool host_final = false;
+  double *h_rows = nullptr, *h_rows_dev = nullptr;
+  double *h_norm = nullptr, *h_norm_dev = nullptr;
   // launch geometry
   int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
   int n_inj_groups = 1, tiles_per_inj_group = 1;
@@ -345,6 +350,7 @@ gwi_status launch_scan(gwi_handle h, bool logw) {
 }
 
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf);
+gwi_status wait_for_rows(gwi_handle h);
 
 // launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
 // or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
@@ -370,22 +376,29 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     ca.rec_stride = h->rec_stride;
     ca.n_pe = (double)h->n_pe;
     ca.ev_host = h->h_ev_dev;
+    ca.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
+    ca.seq = h->seq + 1;
     hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups)), dim3(kBlock), 0, h->stream, ca);
     GWI_HIP(hipGetLastError());
     if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
+    if (ca.host_rows) {
+      ++h->seq;
+      if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+      return wait ? wait_for_rows(h) : GWI_OK;
+    }
     FinalArgs fa;
     fa.ev_out = h->d_ev_out;
     fa.ev_grad = h->d_ev_grad;
     fa.inj_out = h->d_inj_out;
     fa.inj_grad = h->d_inj_grad;
-    fa.norm_out = h->d_norm_out;
+    fa.norm_out = h->host_final ? h->h_norm_dev : h->d_norm_out;
     fa.record = record_dev ? record_dev : h->h_record_dev;
     fa.n_ev = (int)h->n_ev;
     fa.n_theta = h->spec.n_theta;
     fa.n_norms = h->spec.n_norms;
     fa.n_inj_groups = h->n_inj_groups;
     fa.seq = ++h->seq;
-    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kBlock), 0, h->stream, fa);
+    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kFinalThreads), 0, h->stream, fa);
     GWI_HIP(hipGetLastError());
   }
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
@@ -504,6 +517,70 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
   }
 }
 
+// Host-final mode: poll every group's stamp, then do what final_kernel does (fixed summation order)
+// into h_record so that assemble() is shared with the device-final and sharded paths.
+gwi_status wait_for_rows(gwi_handle h) {
+  const int n_groups = (int)h->n_ev + h->n_inj_groups;
+  const int stride = 4 + h->spec.n_theta, n_theta = h->spec.n_theta;
+  bool done = false;
+  if (!h->timing && h->spin_wait) {
+    int g = 0;
+    for (long spin = 0; spin < 400000 && !done; ++spin) {
+      while (g < n_groups && *reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) == h->seq) ++g;
+      done = g == n_groups;
+      if (!done) __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) {
+    GWI_HIP(hipStreamSynchronize(h->stream));
+    for (int g = 0; g < n_groups; ++g)
+      if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq)
+        return fail(h, GWI_ERR_HIP, "group stamp mismatch after stream synchronise");
+  }
+  if (h->timing) {
+    for (int i = 0; i < 3; ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
+  }
+  double* r = h->h_record;
+  const int n_ev = (int)h->n_ev, n_norms = h->spec.n_norms;
+  double sum = 0.0, var = 0.0, mn = INFINITY;
+  double* gpe = r + kRecNormOff + n_norms;
+  double* ginj = gpe + n_theta;
+  for (int p = 0; p < n_theta; ++p) gpe[p] = ginj[p] = 0.0;
+  for (int e = 0; e < n_ev; ++e) {
+    const double* row = h->h_rows + (size_t)e * stride;
+    sum += row[1];
+    var += row[3];
+    double le = row[2];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+    if (le != le) le = 0.0;
+    le = std::fmin(std::fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
+    mn = std::fmin(mn, le);
+    h->h_ev[e] = row[1];
+    h->h_ev[n_ev + e] = row[2];
+    h->h_ev[2 * n_ev + e] = row[3];
+    for (int p = 0; p < n_theta; ++p) gpe[p] += row[4 + p];
+  }
+  double M = -INFINITY;
+  for (int j = 0; j < h->n_inj_groups; ++j) M = std::fmax(M, h->h_rows[(size_t)(n_ev + j) * stride + 1]);
+  double S1 = 0.0, S2 = 0.0;
+  for (int j = 0; j < h->n_inj_groups; ++j) {
+    const double* row = h->h_rows + (size_t)(n_ev + j) * stride;
+    const double f = (row[1] == -INFINITY) ? 0.0 : std::exp(row[1] - M);
+    S1 += f * row[2];
+    S2 += f * f * row[3];
+    for (int p = 0; p < n_theta; ++p) ginj[p] += f * row[4 + p];
+  }
+  r[1] = sum;
+  r[2] = var;
+  r[3] = mn;
+  r[4] = M;
+  r[5] = S1;
+  r[6] = S2;
+  r[7] = (double)n_ev;
+  for (int j = 0; j < n_norms; ++j) r[kRecNormOff + j] = h->h_norm[j];
+  return GWI_OK;
+}
+
 void destroy_impl(gwi_engine* h) {
   if (!h) return;
   if (h->host_only) {
@@ -529,6 +606,8 @@ void destroy_impl(gwi_engine* h) {
   if (h->h_gather) (void)hipHostFree(h->h_gather);
   if (h->h_record) (void)hipHostFree(h->h_record);
   if (h->h_ev) (void)hipHostFree(h->h_ev);
+  if (h->h_rows) (void)hipHostFree(h->h_rows);
+  if (h->h_norm) (void)hipHostFree(h->h_norm);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -673,9 +752,15 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
   h->rec_stride = kRecHeader + spec->n_theta;
   // injection tiles are combined in groups of <= 32 records (one workgroup each)
-  h->tiles_per_inj_group = 32;
+  h->tiles_per_inj_group = 32;  // <= 64: one tile per lane in combine_kernel
   h->n_inj_groups = (h->n_inj_tiles + h->tiles_per_inj_group - 1) / h->tiles_per_inj_group;
   if (h->n_inj_groups < 1) h->n_inj_groups = 1;
+  if (h->n_inj_groups > 64) {  // final_kernel maps groups to the lanes of one wave
+    h->tiles_per_inj_group = (h->n_inj_tiles + 63) / 64;
+    h->n_inj_groups = (h->n_inj_tiles + h->tiles_per_inj_group - 1) / h->tiles_per_inj_group;
+  }
+  if (h->tiles_per_event > 64 || h->tiles_per_inj_group > 64)
+    return fail(h, GWI_ERR_INVALID, "launch geometry: more than 64 tile records per group (raise GWI_SAMPLES_PER_BLOCK)");
   // spline-gradient LDS rows: replicas per wave (see scan_kernel); 8 by default, <= 16
   int rep = 8;
   if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
@@ -699,6 +784,19 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_ev_dev, h->h_ev, 0));
   std::memset(h->h_record, 0, sizeof(double) * record_len(h));
+  // host-final mode for small problems: the per-group rows fit a few KiB, so the host sums them and
+  // the third launch (final_kernel: ~1.5 us boundary + ~6-9 us of latency chain) disappears
+  {
+    const size_t n_groups = (size_t)n_ev + h->n_inj_groups;
+    const size_t row_bytes = sizeof(double) * n_groups * (4 + spec->n_theta);
+    h->host_final = row_bytes <= 32 * 1024;
+    if (const char* env = std::getenv("GWI_HOST_FINAL")) h->host_final = h->host_final && std::atoi(env) != 0;
+    GWI_HIP(hipHostMalloc((void**)&h->h_rows, row_bytes, hipHostMallocMapped));
+    GWI_HIP(hipHostGetDevicePointer((void**)&h->h_rows_dev, h->h_rows, 0));
+    std::memset(h->h_rows, 0, row_bytes);
+    GWI_HIP(hipHostMalloc((void**)&h->h_norm, sizeof(double) * (spec->n_norms ? spec->n_norms : 1), hipHostMallocMapped));
+    GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_dev, h->h_norm, 0));
+  }
 
   // ---- constant part of the kernel-argument block
   KArgs& k = h->kargs;
@@ -709,7 +807,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   }
   k.norms = h->d_norms;
   k.partials = h->d_partials;
-  k.norm_out = h->d_norm_out;
+  k.norm_out = h->host_final ? h->h_norm_dev : h->d_norm_out;
   k.n_pe = n_pe;
   k.n_inj = n_inj;
   k.n_ev = (int)n_ev;
@@ -872,6 +970,19 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
     for (size_t i = 0; i < n; ++i) log_bfs[i] = h->h_ev[i] + shift;
   if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
   if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
+  return GWI_OK;
+}
+
+gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* opt, int32_t n_iter, double* seconds_per_eval) {
+  if (!h || !theta || !opt || n_iter < 1 || !seconds_per_eval) return GWI_ERR_INVALID;
+  std::vector<double> grad(h->spec.n_theta);
+  gwi_summary s;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_iter; ++i) {
+    gwi_status st = gwi_eval(h, theta, opt, &s, grad.data(), nullptr, nullptr, nullptr, nullptr);
+    if (st != GWI_OK) return st;
+  }
+  *seconds_per_eval = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n_iter;
   return GWI_OK;
 }
 

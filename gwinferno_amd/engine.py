@@ -324,6 +324,33 @@ class NativePopulationLikelihood:
         return EvalResult(log_likelihood=b.summ.log_likelihood, grad=b.grad if want_grad else None, summary=b.summ, log_bfs=b.lb, log_neffs=b.ln, variances=b.lv,
                           norms=b.norms[:n_norms])
 
+    def configure(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """Fix the likelihood options once; :meth:`value_and_grad` then has the smallest possible
+        per-call overhead (what a sampler's inner loop wants)."""
+        b = self._buffers()
+        o = b.opt
+        o.n_obs = float(self.n_ev_global if nobs is None else nobs)
+        o.total_inj = float(total_inj)
+        o.marginalize_selection = int(bool(marginalize_selection))
+        o.min_neff_cut = int(bool(min_neff_cut))
+        o.max_variance_cut = int(bool(max_variance_cut))
+        fn = self.lib.gwi_eval_sharded if getattr(self, "_comm", False) else self.lib.gwi_eval
+        args = (self.handle, b.p_theta, b.r_opt, b.r_summ, b.p_grad, b.p_lb, b.p_ln, b.p_lv, b.p_norms)
+        theta_buf, summ, grad = b.theta, b.summ, b.grad
+
+        def value_and_grad(theta):
+            theta_buf[:] = theta
+            st = fn(*args)
+            if st != 0:
+                self._check(st)
+            return summ.log_likelihood, grad
+
+        self.value_and_grad = value_and_grad
+        return value_and_grad
+
+    def value_and_grad(self, theta):  # replaced by configure()
+        raise RuntimeError("call configure(total_inj, ...) first")
+
     # ---- in-engine RCCL exchange (multi-GPU hot loop without Python/torch in the data path) ----------
     def comm_init(self, unique_id, rank, world, rccl_path=None):
         buf = C.create_string_buffer(bytes(unique_id), 128)
@@ -383,6 +410,13 @@ class NativePopulationLikelihood:
         inj = np.zeros(self.n_inj)
         self._check(self.lib.gwi_log_weights(self.handle, N.as_dp(theta), N.as_dp(pe), N.as_dp(inj)))
         return pe, inj
+
+    def selftime(self, theta, total_inj, n_iter=1000, min_neff_cut=True):
+        """Mean seconds per evaluation of a C-side loop of sequential gwi_eval calls (diagnostic)."""
+        opt = self._options(total_inj, None, False, min_neff_cut, False)
+        out = np.zeros(1)
+        self._check(self.lib.gwi_selftime(self.handle, N.as_dp(N.f64(theta)), C.byref(opt), int(n_iter), N.as_dp(out)))
+        return float(out[0])
 
     def set_timing(self, on=True):
         self._check(self.lib.gwi_set_timing(self.handle, int(on)))

@@ -215,6 +215,10 @@ gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]);
 /* Enable/disable per-launch HIP-event timing (off by default: events add host overhead). */
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled);
 
+/* Diagnostic: run `n_iter` sequential gwi_eval calls from C (no binding overhead) and return the
+ * mean seconds per evaluation; separates host-language overhead from launch + device time. */
+gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* opt, int32_t n_iter, double* seconds_per_eval);
+
 const char* gwi_last_error(gwi_handle h);
 void gwi_destroy(gwi_handle h);
 
