@@ -33,6 +33,22 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_traffic(config):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of the latest round
+    (profiles/<round>/traffic.json, produced by tools/profile_round.sh + tools/summarize_profiles.py:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")))
+    if not files:
+        return None, None
+    try:
+        table = json.load(open(files[-1]))
+        return table[config]["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(comp_name, pe, inj, total, params, budget_s=10.0):
     """NumPy oracle (value only, reference formulation: dense design matrices) on the host cores."""
     from oracle import numpy_oracle as O
@@ -198,7 +214,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.config)[0] if world == 1 else None,
+                "traffic_source": pmc_traffic(args.config)[1] if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
