@@ -24,8 +24,12 @@ TERM_TILT_MIXTURE = 5
 TERM_POWERLAW_REDSHIFT = 6
 TERM_EXP_SPLINE = 7
 TERM_TRUNCNORM = 8
+TERM_LINEAR_SPLINE = 9
+TERM_TILT_JOINT = 10
 
 SPLINE_OUTSIDE_ZERO_EXPONENT = 1
+POWERLAW_UNNORMALISED = 2
+NORM_LINEAR_SPLINE = 4
 DEVICE_CURRENT = -1
 DEVICE_HOST_ONLY = -2
 

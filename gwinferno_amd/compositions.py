@@ -187,6 +187,70 @@ class BSplineIID(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class PLPeakDefaultTilt(PLPeak):
+    """PL+Peak x PL q x default_spin_tilt (parametric.py:97-102) x PL z."""
+
+    PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "xi": (), "sig_t": (), "lamb": ()}
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_ct = M.default_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+        return where_finite(self.mass(p, d) * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q.update(xi=0.5, sig_t=1.0)
+        return q
+
+
+class BSplineChiEff(Composition):
+    """BSplinePrimaryBSplineRatio x BSplineEffectiveSpinDims (linear BSpline bases, normalised;
+    separable.py:706-778) x PL z."""
+
+    NM, NQ, NE, NP = 12, 8, 10, 8
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.NM,), "q_coefs": (self.NQ,), "e_coefs": (self.NE,), "p_coefs": (self.NP,), "lamb": ()}
+        self.mass_model = M.BSplinePrimaryBSplineRatio(self.NM, self.NQ, self.pe["mass_1"], self.inj["mass_1"], self.pe["mass_ratio"], self.inj["mass_ratio"],
+                                                       m1min=self.mmin, m2min=self.mmin, mmax=self.mmax)
+        self.chi_model = M.BSplineEffectiveSpinDims(self.NE, self.NP, self.pe["chi_eff"], self.pe["chi_p"], self.inj["chi_eff"], self.inj["chi_p"], normalize=True)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q["e_coefs"] = np.ones(self.NE)
+        q["p_coefs"] = np.ones(self.NP)
+        return q
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        w = self.mass_model(p["m1_coefs"], p["q_coefs"], pe_samples=pe_samples) * self.chi_model(p["e_coefs"], p["p_coefs"], pe_samples=pe_samples)
+        return where_finite(w * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+class BSplineComponentMasses(Composition):
+    """BSplineIIDComponentMasses (separable.py:533-613) x PL z."""
+
+    NM = 16
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m_coefs": (self.NM,), "beta": (), "lamb": ()}
+        self.mass_model = M.BSplineIIDComponentMasses(self.NM, self.pe["mass_1"], self.pe["mass_2"], self.inj["mass_1"], self.inj["mass_2"], mmin=3.0, mmax=self.mmax)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        return where_finite(self.mass_model(p["m_coefs"], beta=p["beta"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
 COMPOSITIONS = {
     "pl_test": PLTest,
     "plpeak": PLPeak,
@@ -194,6 +258,9 @@ COMPOSITIONS = {
     "bspline_test": BSplineTest,
     "bspline_iid": BSplineIID,
     "bspline_full": BSplineFull,
+    "plpeak_default_tilt": PLPeakDefaultTilt,
+    "bspline_chieff": BSplineChiEff,
+    "bspline_component_masses": BSplineComponentMasses,
 }
 
 
@@ -209,6 +276,15 @@ def draw_params(name, rng):
             p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
                      xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
         return {k: p[k] for k in cls.PARAMS}
+    if name == "plpeak_default_tilt":
+        p = draw_params("plpeak", rng)
+        p.update(xi=rng.uniform(0.0, 1.0), sig_t=rng.uniform(0.3, 4.0))
+        return {k: p[k] for k in cls.PARAMS}
+    if name == "bspline_chieff":
+        return {"m1_coefs": rng.normal(size=12), "q_coefs": rng.normal(size=8), "e_coefs": rng.uniform(0.1, 1.0, size=10), "p_coefs": rng.uniform(0.1, 1.0, size=8),
+                "lamb": rng.normal(2.7, 1.0)}
+    if name == "bspline_component_masses":
+        return {"m_coefs": rng.normal(size=16), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
     shapes = {
         "bspline_test": {"m1_coefs": 10, "q_coefs": 5, "z_coefs": 5},
         "bspline_iid": {"m1_coefs": 30, "a_coefs": 16, "t_coefs": 16},

@@ -494,6 +494,100 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   __device__ static void collect(const TermD&, const Acc&, double*, int*) {}
 };
 
+// sum_k c_k B_k(x): linear-Y B-spline density (interpolation.py:293-304; chi_eff / chi_p models,
+// single.py:199-318).  Linear factor; dl/dc_k = B_k / f.  p0 = lo, p1 = hi, p2 = 1/dx.
+template <>
+struct Term<GWI_TERM_LINEAR_SPLINE> {
+  static constexpr bool kSpline = true;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  struct State {
+    double t, inv_f;
+    int k;
+  };
+  struct Acc {};
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double& lin) {
+    const double x = in.x0;
+    int k;
+    double tt;
+    spline_locate(x, t.p0, t.p2, t.n_basis, k, tt);
+    const double* cf = c.coefs + t.th0 + k;
+    const Taps b = cubic_taps(tt);
+    double f = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+    if (!((x >= t.p0) && (x <= t.p1))) f = 0.0;  // bases are 0 outside the closed domain (:175)
+    s.t = tt;
+    s.k = k;
+    s.inv_f = f > 0.0 ? fast_rcp(f) : 0.0;
+    lin *= f;  // f <= 0 makes the sample dead (lin > 0 test in the scan loop)
+    return 0.0;
+  }
+  __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
+    if (w != 0.0) {
+      const Taps b = cubic_taps(s.t);
+      const double wf = w * s.inv_f;
+      double* g = c.gacc + t.th0 + s.k;
+      unsafeAtomicAdd(g + 0, wf * b.b0);
+      unsafeAtomicAdd(g + 1, wf * b.b1);
+      unsafeAtomicAdd(g + 2, wf * b.b2);
+      unsafeAtomicAdd(g + 3, wf * b.b3);
+    }
+  }
+  __device__ static void init(Acc&) {}
+  __device__ static void rescale(Acc&, double) {}
+  static constexpr int kNumAcc = 0;
+  __device__ static void collect(const TermD&, const Acc&, double*, int*) {}
+};
+
+// (1-xi)/4 + xi Cn^2 exp(-((ct1-1)^2 + (ct2-1)^2)/(2 sig^2))  (parametric.py:97-102)
+// derived: d0 = log Cn, d1 = dlogCn/dsig, d2 = 1/sig^2, d3 = 1/sig^3
+template <>
+struct Term<GWI_TERM_TILT_JOINT> {
+  static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
+    in.x0 = gload(c.cols[t.col0], idx);
+    in.x1 = gload(c.cols[t.col1], idx);
+  }
+  struct State {
+    double dxi, dsg;
+  };
+  struct Acc {
+    double g[2];
+  };
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    const double xi = c.a->theta[t.th0];
+    const double d1 = in.x0 - 1.0, d2 = in.x1 - 1.0;
+    const double r2 = d1 * d1 + d2 * d2;
+    const double A = exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
+    const double p = 0.25 * (1.0 - xi) + xi * A;
+    const double ip = fast_rcp(p);
+    s.dxi = (A - 0.25) * ip;
+    s.dsg = xi * A * (r2 * d[3] + 2.0 * d[1]) * ip;
+    lin *= p;
+    return 0.0;
+  }
+  __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
+    a.g[0] += w * s.dxi;
+    a.g[1] += w * s.dsg;
+  }
+  __device__ static void init(Acc& a) { a.g[0] = a.g[1] = 0; }
+  __device__ static void rescale(Acc& a, double sc) {
+    a.g[0] *= sc;
+    a.g[1] *= sc;
+  }
+  static constexpr int kNumAcc = 2;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g[0];
+    vals[1] = a.g[1];
+    th[0] = t.th0;
+    th[1] = t.th1;
+  }
+};
+
 // ---- compile-time chain of terms.  U = samples per lane per trip; inputs are double-buffered in
 //      registers (in[0] = current trip, in[1] = next trip) so the column loads of trip k+1 are in
 //      flight while trip k is being evaluated. ----------------------------------------------------------
@@ -570,7 +664,11 @@ __device__ inline void norm_block(const KArgs& a, int j, const double* s_theta, 
       const Taps b = cubic_taps(tt);
       const double* cf = s_theta + nd.coef_off + k;
       double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-      if ((nd.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
+      if ((nd.flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
+      if (nd.flags & GWI_NORM_LINEAR_SPLINE) {  // BSpline.norm: trapz of the spline itself
+        acc += tw * v;
+        continue;
+      }
       e += v;
     }
     if (tw != 0.0) acc += tw * exp(e);

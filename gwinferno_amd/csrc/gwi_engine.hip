@@ -40,6 +40,8 @@ struct Variant {
 #define K_PZ GWI_TERM_POWERLAW_REDSHIFT
 #define K_SP GWI_TERM_EXP_SPLINE
 #define K_TN GWI_TERM_TRUNCNORM
+#define K_LS GWI_TERM_LINEAR_SPLINE
+#define K_TJ GWI_TERM_TILT_JOINT
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
@@ -71,7 +73,15 @@ const Variant kVariants[] = {
     // mass-only B-spline models: BSplinePrimaryBSplineRatio / BSplinePrimaryPowerlawRatio x PL z
     GWI_VARIANT("plz+spline2", K_PZ, K_SP, K_SP),
     GWI_VARIANT("plq+plz+spline", K_PQ, K_PZ, K_SP),
+    // BSplinePrimaryBSplineRatio x BSplineEffectiveSpinDims (chi_eff, chi_p: separable.py:706-778) x PL z
+    GWI_VARIANT_U("plz+spline2+lspline2", 1, K_PZ, K_SP, K_SP, K_LS, K_LS),
+    // BSplineIID/IndependentComponentMasses (separable.py:533-703): (m2/m1)^beta x p(m1) p(m2) x PL z
+    GWI_VARIANT("pl+plz+spline2", K_PL, K_PZ, K_SP, K_SP),
+    // PL+Peak x PL q x default_spin_tilt (parametric.py:97-102) x PL z
+    GWI_VARIANT("plpeak+plq+plz+tiltjoint", K_PP, K_PQ, K_PZ, K_TJ),
     // single-term sequences (term-level parity tests)
+    GWI_VARIANT("lspline", K_LS),
+    GWI_VARIANT("tiltjoint", K_TJ),
     GWI_VARIANT("pl", K_PL),
     GWI_VARIANT("plpeak", K_PP),
     GWI_VARIANT("plq", K_PQ),
@@ -261,6 +271,8 @@ gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
       case GWI_TERM_TILT_MIXTURE: n_th = 2; break;
       case GWI_TERM_POWERLAW_REDSHIFT: break;
       case GWI_TERM_TRUNCNORM: n_th = 2; break;
+      case GWI_TERM_TILT_JOINT: n_cols = 2; n_th = 2; break;
+      case GWI_TERM_LINEAR_SPLINE:
       case GWI_TERM_EXP_SPLINE:
         n_th = 0;
         if (tm.n_basis < 4 || !theta_ok(tm.coef_off) || !theta_ok(tm.coef_off + tm.n_basis - 1)) return fail(h, GWI_ERR_INVALID, "spline coefficient range invalid");
@@ -294,9 +306,18 @@ void prelude(gwi_engine* h, const double* theta) {
     for (int i = 0; i < kMaxDerived; ++i) d[i] = 0.0;
     switch (tm.kind) {
       case GWI_TERM_POWERLAW: {
+        if (tm.flags & GWI_POWERLAW_UNNORMALISED) break;  // bare x^alpha pairing factor
         double la, dla;
         powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &la, &dla);
         c += la;
+        break;
+      }
+      case GWI_TERM_TILT_JOINT: {
+        double dmu;
+        truncnorm_lognorm(1.0, theta[tm.theta[1]], -1.0, 1.0, &d[0], &dmu, &d[1]);
+        const double sg = theta[tm.theta[1]];
+        d[2] = 1.0 / (sg * sg);
+        d[3] = d[2] / sg;
         break;
       }
       case GWI_TERM_PLPEAK: {
@@ -769,7 +790,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   while (rep & (rep - 1)) rep &= rep - 1;  // power of two
   const int pad = spec->n_theta | 1;        // odd row stride: replicas land in different banks
   bool has_spline = false;
-  for (int t = 0; t < spec->n_terms; ++t) has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE;
+  for (int t = 0; t < spec->n_terms; ++t)
+    has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE;
   if (!has_spline) rep = 1;
   h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
 
@@ -837,7 +859,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     d.p0 = tm.p[0];
     d.p1 = tm.p[1];
     d.p2 = tm.p[2];
-    if (tm.kind == GWI_TERM_EXP_SPLINE) {
+    if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
     }

@@ -22,7 +22,9 @@ __all__ = [
     "powerlaw_pdf", "truncnorm_pdf", "betadist",
     "powerlaw_primary_ratio_pdf", "plpeak_primary_pdf", "plpeak_primary_ratio_pdf",
     "beta_spin_magnitude", "iid_spin_magnitude", "independent_spin_magnitude_beta_dist",
-    "mixture_isoalign_spin_tilt", "iid_spin_tilt", "independent_spin_tilt",
+    "mixture_isoalign_spin_tilt", "iid_spin_tilt", "independent_spin_tilt", "default_spin_tilt",
+    "BSplineChiEffective", "BSplineSymmetricChiEffective", "BSplineChiPrecess", "BSplineEffectiveSpinDims",
+    "BSplineIIDComponentMasses", "BSplineIndependentComponentMasses",
     "PowerlawRedshiftModel", "PowerlawSplineRedshiftModel",
     "Base1DBSplineModel", "BSplineMass", "BSplineRatio", "BSplineSpinMagnitude", "BSplineSpinTilt",
     "BSplineIIDSpinMagnitudes", "BSplineIndependentSpinMagnitudes", "BSplineIIDSpinTilts", "BSplineIndependentSpinTilts",
@@ -141,6 +143,15 @@ def independent_spin_tilt(ct1, ct2, xi_tilt_1, xi_tilt_2, sigma_tilt1, sigma_til
     return mixture_isoalign_spin_tilt(ct1, xi_tilt_1, sigma_tilt1) * mixture_isoalign_spin_tilt(ct2, xi_tilt_2, sigma_tilt2)  # :93-94
 
 
+def default_spin_tilt(ct1, ct2, xi_tilt, sigma_tilt):
+    """parametric.py:97-102: (1-xi) iso(ct1) iso(ct2) + xi TN(ct1) TN(ct2), one mixing fraction."""
+    ct1, ct2 = _f(ct1), _f(ct2)
+    side = side_of(ct1)
+    with np.errstate(all="ignore"):
+        mask = ~((ct1 > 1) | (ct1 < -1)) & ~((ct2 > 1) | (ct2 < -1))
+    return Density([Factor(N.TERM_TILT_JOINT, side, [Column("id", ct1), Column("id", ct2)], [xi_tilt, sigma_tilt], mask=mask)], side)
+
+
 class PowerlawRedshiftModel(object):
     """parametric.py:112-145.  ``zmin``/``zmax`` come from the GLOBAL PE and injection arrays
     (:114-115) -- construct the model before sharding a catalog across GPUs."""
@@ -211,14 +222,16 @@ class PowerlawSplineRedshiftModel(PowerlawRedshiftModel):
 # 1-D B-spline models (gwinferno/models/bsplines/single.py)
 # ================================================================================================
 class Base1DBSplineModel(object):
-    """single.py:16-128.  Only exponentiated bases (LogYBSpline, LogXLogYBSpline) are implemented:
-    they are the defaults of every mass / ratio / spin model (:151, :185, :344, :384)."""
+    """single.py:16-128.  Bases: the exponentiated LogYBSpline / LogXLogYBSpline (defaults of every mass /
+    ratio / spin-component model, :151, :185, :344, :384) and the linear BSpline (defaults of the
+    effective-spin models, :219, :254, :307)."""
 
     def __init__(self, n_splines, xx, xx_inj, xrange=(0.0, 1.0), degree=3, basis=BSpline, **kwargs):
         if degree != 3:
             raise NotImplementedError("only cubic splines are implemented")
-        if basis not in (LogYBSpline, LogXLogYBSpline):
-            raise NotImplementedError(f"basis {getattr(basis, '__name__', basis)} is not implemented for 1-D density models (LogYBSpline / LogXLogYBSpline are)")
+        if basis not in (LogYBSpline, LogXLogYBSpline, BSpline):
+            raise NotImplementedError(f"basis {getattr(basis, '__name__', basis)} is not implemented for 1-D density models (BSpline / LogYBSpline / LogXLogYBSpline are)")
+        self._linear = basis is BSpline
         self.n_splines = int(n_splines)
         self.xmin, self.xmax = xrange
         self.degree = degree
@@ -238,14 +251,14 @@ class Base1DBSplineModel(object):
         self._norm = None
         if it.normalize:
             tw, us = it.grid_tables()
-            self._norm = GridNorm(tw, us=us, n_basis=it.N, lo=it.lo, hi=it.hi)
+            self._norm = GridNorm(tw, us=us, n_basis=it.N, lo=it.lo, hi=it.hi, spline_flags=N.NORM_LINEAR_SPLINE if self._linear else 0)
         self.scale = 1.0
 
     def _factor(self, coefs, pe_samples):
         side = PE if pe_samples else INJ
         it = self.interpolator
-        return Factor(N.TERM_EXP_SPLINE, side, [Column("id", self._coord[side])], coefs=coefs, consts=(it.lo, it.hi), n_basis=it.N, mask=self._mask[side],
-                      norm=self._norm, owner=self)
+        kind = N.TERM_LINEAR_SPLINE if self._linear else N.TERM_EXP_SPLINE
+        return Factor(kind, side, [Column("id", self._coord[side])], coefs=coefs, consts=(it.lo, it.hi), n_basis=it.N, mask=self._mask[side], norm=self._norm, owner=self)
 
     def __call__(self, coefs, pe_samples=True):
         side = PE if pe_samples else INJ
@@ -263,6 +276,25 @@ class BSplineSpinTilt(Base1DBSplineModel):
     def __init__(self, n_splines, ct, ct_inj, basis=LogYBSpline, **kwargs):  # single.py:165-196
         xrange = kwargs.pop("xrange", (-1.0, 1.0))
         super().__init__(n_splines, ct, ct_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+class BSplineChiEffective(Base1DBSplineModel):
+    def __init__(self, n_splines, chieff, chieff_inj, basis=BSpline, **kwargs):  # single.py:199-230
+        xrange = kwargs.pop("xrange", (-1.0, 1.0))
+        super().__init__(n_splines, chieff, chieff_inj, basis=basis, xrange=xrange, **kwargs)
+
+
+class BSplineSymmetricChiEffective(Base1DBSplineModel):
+    def __init__(self, n_splines, chieff, chieff_inj, basis=BSpline, **kwargs):  # single.py:233-284
+        xrange = kwargs.pop("xrange", (0.0, 1.0))
+        super().__init__(n_splines, np.abs(_f(chieff)), np.abs(_f(chieff_inj)), basis=basis, xrange=xrange, **kwargs)
+        self.scale = 0.5  # :284
+
+
+class BSplineChiPrecess(Base1DBSplineModel):
+    def __init__(self, n_splines, chip, chip_inj, basis=BSpline, **kwargs):  # single.py:287-318
+        xrange = kwargs.pop("xrange", (0.0, 1.0))
+        super().__init__(n_splines, chip, chip_inj, basis=basis, xrange=xrange, **kwargs)
 
 
 class BSplineRatio(Base1DBSplineModel):
@@ -321,6 +353,57 @@ class BSplineIndependentSpinTilts(_PairModel):
 
     def __call__(self, pcoefs, scoefs, pe_samples=True):
         return self._pair(pcoefs, scoefs, pe_samples)
+
+
+class BSplineEffectiveSpinDims(object):
+    def __init__(self, n_splines_e, n_splines_p, chieff, chip, chieff_inj, chip_inj, kwargs_e={}, kwargs_p={}, **kwargs):  # separable.py:706-778
+        self.chi_eff_model = BSplineChiEffective(n_splines_e, chieff, chieff_inj, **kwargs_e, **kwargs)
+        self.chi_p_model = BSplineChiPrecess(n_splines_p, chip, chip_inj, **kwargs_p, **kwargs)
+
+    def __call__(self, ecoefs, pcoefs, pe_samples=True):
+        return self.chi_eff_model(ecoefs, pe_samples=pe_samples) * self.chi_p_model(pcoefs, pe_samples=pe_samples)
+
+
+class _ComponentMasses(object):
+    """p(m1) p(m2) (m2/m1)^beta (separable.py:533-703)."""
+
+    mask_ratio = False
+
+    def _setup(self, m1, m2, m1_inj, m2_inj):
+        with np.errstate(all="ignore"):
+            self.qs = [_f(m2_inj) / _f(m1_inj), _f(m2) / _f(m1)]  # :585, :679
+
+    def _pairing(self, beta, pe_samples):
+        q = self.qs[1 if pe_samples else 0]
+        side = PE if pe_samples else INJ
+        mask = None
+        if self.mask_ratio:
+            with np.errstate(all="ignore"):
+                mask = ~((q < 0) | (q > 1))  # :609-613
+        return Density([Factor(N.TERM_POWERLAW, side, [Column("log", q)], [beta], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, mask=mask, owner=self, tag="pairing")], side)
+
+
+class BSplineIIDComponentMasses(_ComponentMasses):
+    mask_ratio = True
+
+    def __init__(self, n_splines, m1, m2, m1_inj, m2_inj, mmin=2, mmax=100, **kwargs):  # separable.py:533-613
+        self.primary_model = BSplineMass(n_splines=n_splines, m=m1, m_inj=m1_inj, mmin=mmin, mmax=mmax, **kwargs)
+        self.secondary_model = BSplineMass(n_splines=n_splines, m=m2, m_inj=m2_inj, mmin=mmin, mmax=mmax, **kwargs)
+        self._setup(m1, m2, m1_inj, m2_inj)
+
+    def __call__(self, coefs, beta=0, pe_samples=True):
+        return self.primary_model(coefs, pe_samples=pe_samples) * self.secondary_model(coefs, pe_samples=pe_samples) * self._pairing(beta, pe_samples)
+
+
+class BSplineIndependentComponentMasses(_ComponentMasses):
+    def __init__(self, n_splines1, n_splines2, m1, m2, m1_inj, m2_inj, mmin1=2, mmax1=100, mmin2=2, mmax2=100, kwargs1={}, kwargs2={}, **kwargs):
+        # separable.py:616-703
+        self.primary_model = BSplineMass(n_splines=n_splines1, m=m1, m_inj=m1_inj, mmin=mmin1, mmax=mmax1, **kwargs1, **kwargs)
+        self.secondary_model = BSplineMass(n_splines=n_splines2, m=m2, m_inj=m2_inj, mmin=mmin2, mmax=mmax2, **kwargs2, **kwargs)
+        self._setup(m1, m2, m1_inj, m2_inj)
+
+    def __call__(self, pcoefs, scoefs, beta=0, pe_samples=True):
+        return self.primary_model(pcoefs, pe_samples=pe_samples) * self.secondary_model(scoefs, pe_samples=pe_samples) * self._pairing(beta, pe_samples)
 
 
 class BSplinePrimaryPowerlawRatio(object):

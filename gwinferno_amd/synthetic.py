@@ -49,7 +49,19 @@ def make_catalog(n_ev, n_pe, n_inj, seed=BASE_SEED, mmin=5.0, mmax=100.0, zmax_d
     # in redshift (cf. reference preprocess/data_collection.py:122-132)
     prior = cosmo.dVc_dz(z) / (1 + z) * (1 + z) ** 2 * m1 / 4.0
     prior = prior / 1e9  # Gpc^3-ish scale so weights are O(1)
+    def derived(m1_, q_, a1_, a2_, ct1_, ct2_):
+        """mass_2, chi_eff, chi_p (reference preprocess/conversions.py:1-110 definitions)."""
+        chi_eff = (a1_ * ct1_ + q_ * a2_ * ct2_) / (1.0 + q_)
+        s1 = a1_ * np.sqrt(np.clip(1.0 - ct1_**2, 0.0, None))
+        s2 = a2_ * np.sqrt(np.clip(1.0 - ct2_**2, 0.0, None))
+        chi_p = np.maximum(s1, q_ * (4.0 * q_ + 3.0) / (4.0 + 3.0 * q_) * s2)
+        return q_ * m1_, chi_eff, chi_p
+
+    m2, chieff, chip = derived(m1, q, a1, a2, ct1, ct2)
     pedict = {
+        "mass_2": m2,
+        "chi_eff": chieff,
+        "chi_p": chip,
         "mass_1": m1,
         "mass_ratio": q,
         "redshift": z,
@@ -76,7 +88,11 @@ def make_catalog(n_ev, n_pe, n_inj, seed=BASE_SEED, mmin=5.0, mmax=100.0, zmax_d
     p_q = qi * 2.0 / (1.0 - (2.0 / m1i) ** 2)
     p_z = cosmo.dVc_dz(zi) * (1 + zi) / znorm
     prior_i = p_m1 * p_q * p_z * 1.0 * 1.0 * 0.5 * 0.5
+    m2i, chieffi, chipi = derived(m1i, qi, a1i, a2i, ct1i, ct2i)
     injdict = {
+        "mass_2": m2i,
+        "chi_eff": chieffi,
+        "chi_p": chipi,
         "mass_1": m1i,
         "mass_ratio": qi,
         "redshift": zi,

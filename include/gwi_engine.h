@@ -80,8 +80,23 @@ enum {
   GWI_TERM_EXP_SPLINE = 7,
   /* truncated normal TN(x; mu, sigma, lo, hi)       distributions.py:122-143 (log=False)
    * cols[0]=x; theta = mu, sigma; p[0]=lo, p[1]=hi */
-  GWI_TERM_TRUNCNORM = 8
+  GWI_TERM_TRUNCNORM = 8,
+  /* sum_k c_k B_k(x) [/ Z(c)]: linear-Y B-spline density (BSpline basis)   interpolation.py:293-317,
+   * models/bsplines/single.py:199-318 (chi_eff, chi_p)
+   * cols[0]=spline coordinate; coef_off/n_basis; p[0]=lo, p[1]=hi; norm = grid normaliser (linear) or -1.
+   * Non-positive values of the spline count as zero density. */
+  GWI_TERM_LINEAR_SPLINE = 9,
+  /* (1-xi)/4 + xi TN(ct1;1,sigma,-1,1) TN(ct2;1,sigma,-1,1)   parametric.py:97-102 (default_spin_tilt)
+   * cols = cos tilt 1, cos tilt 2; theta = xi, sigma */
+  GWI_TERM_TILT_JOINT = 10
 };
+
+/* POWERLAW flag: bare x^alpha with no normaliser and no truncation (the (m2/m1)^beta pairing factor,
+ * models/bsplines/separable.py:609-613, :703). */
+#define GWI_POWERLAW_UNNORMALISED 2
+/* gwi_norm.spline_flags bit: the integrand is the linear spline itself, Z = sum_g tw_g sum_k c_k B_k
+ * (BSpline.norm, interpolation.py:280-291), not exp(...) of it. */
+#define GWI_NORM_LINEAR_SPLINE 4
 
 /* EXP_SPLINE flag: outside [lo,hi] the basis is 0 (BSpline/LogXBSpline.bases,
  * interpolation.py:175) so the factor is exp(0)=1, instead of the sample being excluded

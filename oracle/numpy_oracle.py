@@ -224,6 +224,13 @@ def mixture_isoalign_spin_tilt(ct, xi, sigma):
     return inside * (1 - xi) / 2 + xi * truncnorm_pdf(ct, 1.0, sigma, -1.0, 1.0)
 
 
+def default_spin_tilt(ct1, ct2, xi, sigma):
+    """parametric.py:97-102."""
+    iso1 = np.where((ct1 > 1) | (ct1 < -1), 0.0, 0.5)
+    iso2 = np.where((ct2 > 1) | (ct2 < -1), 0.0, 0.5)
+    return (1 - xi) * iso1 * iso2 + xi * truncnorm_pdf(ct1, 1.0, sigma, -1.0, 1.0) * truncnorm_pdf(ct2, 1.0, sigma, -1.0, 1.0)
+
+
 def independent_spin_tilt(ct1, ct2, xi1, xi2, sig1, sig2):
     """parametric.py:93-94."""
     return mixture_isoalign_spin_tilt(ct1, xi1, sig1) * mixture_isoalign_spin_tilt(ct2, xi2, sig2)
@@ -548,7 +555,74 @@ class BSplineIID(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class PLPeakDefaultTilt(PLPeak):
+    """PL+Peak x PL q x default_spin_tilt x PL z."""
+
+    PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "xi": (), "sig_t": (), "lamb": ()}
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            tilts = default_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+            return _finite_or_zero(self.mass_density(p, d) * tilts * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+
+class BSplineChiEff(Composition):
+    """BSplinePrimaryBSplineRatio x BSplineEffectiveSpinDims (linear 'B' bases, normalised: single.py:199-230,
+    287-318; separable.py:706-778) x PL z."""
+
+    NM, NQ, NE, NP = 12, 8, 10, 8
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.NM,), "q_coefs": (self.NQ,), "e_coefs": (self.NE,), "p_coefs": (self.NP,), "lamb": ()}
+        self.m_model = spline_mass(self.NM, pedict["mass_1"], injdict["mass_1"], self.mmin, self.mmax)
+        self.q_model = spline_ratio(self.NQ, pedict["mass_ratio"], injdict["mass_ratio"], self.mmin / self.mmax)
+        self.e_model = Spline1D(self.NE, pedict["chi_eff"], injdict["chi_eff"], (-1.0, 1.0), "B", normalize=True)
+        self.p_model = Spline1D(self.NP, pedict["chi_p"], injdict["chi_p"], (0.0, 1.0), "B", normalize=True)
+        self.z_model = PowerlawRedshift(pedict["redshift"], injdict["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            mass = self.q_model(p["q_coefs"], pe_samples) * self.m_model(p["m1_coefs"], pe_samples)
+            chi = self.e_model(p["e_coefs"], pe_samples) * self.p_model(p["p_coefs"], pe_samples)
+            return _finite_or_zero(mass * chi * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+class BSplineComponentMasses(Composition):
+    """BSplineIIDComponentMasses (separable.py:533-613) x PL z."""
+
+    NM = 16
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m_coefs": (self.NM,), "beta": (), "lamb": ()}
+        self.m1_model = spline_mass(self.NM, pedict["mass_1"], injdict["mass_1"], 3.0, self.mmax)
+        self.m2_model = spline_mass(self.NM, pedict["mass_2"], injdict["mass_2"], 3.0, self.mmax)
+        with np.errstate(all="ignore"):
+            self.q = {True: pedict["mass_2"] / pedict["mass_1"], False: injdict["mass_2"] / injdict["mass_1"]}  # :585
+        self.z_model = PowerlawRedshift(pedict["redshift"], injdict["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        q = self.q[pe_samples]
+        with np.errstate(all="ignore"):
+            pm = self.m1_model(p["m_coefs"], pe_samples) * self.m2_model(p["m_coefs"], pe_samples)
+            mass = np.where((q < 0) | (q > 1), 0.0, pm) * np.power(q, p["beta"])  # :609-613
+            return _finite_or_zero(mass * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
 COMPOSITIONS = {
+    "plpeak_default_tilt": PLPeakDefaultTilt,
+    "bspline_chieff": BSplineChiEff,
+    "bspline_component_masses": BSplineComponentMasses,
     "pl_test": PLTest,
     "plpeak": PLPeak,
     "plpeak_full": PLPeakFull,

@@ -43,6 +43,9 @@ def norm_values(bm, theta):
         e = np.zeros(len(g.tw)) if g.lb is None else g.lb.copy()
         if expo_theta >= 0:
             e = e + (theta[expo_theta] + g.expo_add) * g.l1
+        if g.n_basis > 0 and (g.spline_flags & N.NORM_LINEAR_SPLINE):
+            out.append(np.sum(g.tw * _spline(g.us, theta[coef_off : coef_off + g.n_basis], g.lo, g.hi, True)))
+            continue
         if g.n_basis > 0:
             e = e + _spline(g.us, theta[coef_off : coef_off + g.n_basis], g.lo, g.hi, bool(g.spline_flags & N.SPLINE_OUTSIDE_ZERO_EXPONENT))
         with np.errstate(all="ignore"):
@@ -66,7 +69,18 @@ def log_weights(bm, theta, include_consts=True):
                 th = [theta[i] for i in t["theta"]]
                 p = t["p"]
                 k = t["kind"]
-                if k == N.TERM_POWERLAW:
+                if k == N.TERM_POWERLAW and (t["flags"] & N.POWERLAW_UNNORMALISED):
+                    ell = ell + th[0] * c[0]
+                elif k == N.TERM_LINEAR_SPLINE:
+                    co = t["coef_off"]
+                    f = _spline(c[0], theta[co : co + t["n_basis"]], p[0], p[1], True)
+                    ell = ell + np.log(np.where(f > 0, f, 0.0))
+                elif k == N.TERM_TILT_JOINT:
+                    xi, sg = th
+                    ln = _tn_lognorm(1.0, sg, -1.0, 1.0)
+                    A = np.exp(-0.5 * ((c[0] - 1) ** 2 + (c[1] - 1) ** 2) / sg**2 + 2 * ln)
+                    ell = ell + np.log(0.25 * (1 - xi) + xi * A)
+                elif k == N.TERM_POWERLAW:
                     ell = ell + th[0] * c[0] + k_const * _pl_lognorm(th[0], p[0], p[1])
                 elif k == N.TERM_PLPEAK:
                     alpha, mu, sg, lam = th

@@ -227,7 +227,77 @@ class BSplineFull(Composition):
         return out
 
 
+class PLPeakDefaultTilt(PLPeak):
+    """PL+Peak x PL q x default_spin_tilt (parametric.py:97-102) x PL z."""
+
+    params = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "xi": (), "sig_t": (), "lamb": ()}
+
+    def weights(self, p, d, pe_samples):
+        P = ref.parametric
+        p_m1q = P.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], MMIN, MMAX, p["mpp"], p["sigpp"], p["lam"])
+        p_ct = P.default_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+        return _guard(p_m1q * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    @staticmethod
+    def draw(rng):
+        out = PLPeak.draw(rng)
+        out.update(xi=rng.uniform(0.0, 1.0), sig_t=rng.uniform(0.3, 4.0))
+        return out
+
+
+class BSplineChiEff(Composition):
+    """BSplinePrimaryBSplineRatio(12, 8) x BSplineEffectiveSpinDims(10, 8, normalize=True) x PowerlawRedshiftModel
+    (separable.py:446-530, 706-778; linear BSpline bases single.py:199-230, 287-318)."""
+
+    NM, NQ, NE, NP = 12, 8, 10, 8
+    params = {"m1_coefs": (NM,), "q_coefs": (NQ,), "e_coefs": (NE,), "p_coefs": (NP,), "lamb": ()}
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        S = ref.separable
+        self.mass_model = S.BSplinePrimaryBSplineRatio(self.NM, self.NQ, pe["mass_1"], inj["mass_1"], pe["mass_ratio"], inj["mass_ratio"], m1min=MMIN, m2min=MMIN, mmax=MMAX)
+        self.chi_model = S.BSplineEffectiveSpinDims(self.NE, self.NP, pe["chi_eff"], pe["chi_p"], inj["chi_eff"], inj["chi_p"], normalize=True)
+        self.z_model = ref.parametric.PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+
+    def weights(self, p, d, pe_samples):
+        w = self.mass_model(p["m1_coefs"], p["q_coefs"], pe_samples=pe_samples) * self.chi_model(p["e_coefs"], p["p_coefs"], pe_samples=pe_samples)
+        return _guard(w * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(lamb=p["lamb"])
+
+    @classmethod
+    def draw(cls, rng):
+        return {"m1_coefs": rng.normal(size=cls.NM), "q_coefs": rng.normal(size=cls.NQ), "e_coefs": rng.uniform(0.1, 1.0, size=cls.NE),
+                "p_coefs": rng.uniform(0.1, 1.0, size=cls.NP), "lamb": rng.normal(2.7, 1.0)}
+
+
+class BSplineComponentMasses(Composition):
+    """BSplineIIDComponentMasses(16, mmin=3) x PowerlawRedshiftModel (separable.py:533-613)."""
+
+    NM = 16
+    params = {"m_coefs": (NM,), "beta": (), "lamb": ()}
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        self.mass_model = ref.separable.BSplineIIDComponentMasses(self.NM, pe["mass_1"], pe["mass_2"], inj["mass_1"], inj["mass_2"], mmin=3.0, mmax=MMAX)
+        self.z_model = ref.parametric.PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+
+    def weights(self, p, d, pe_samples):
+        return _guard(self.mass_model(p["m_coefs"], beta=p["beta"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(lamb=p["lamb"])
+
+    @classmethod
+    def draw(cls, rng):
+        return {"m_coefs": rng.normal(size=cls.NM), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
+
+
 COMPOSITIONS = {
+    "plpeak_default_tilt": PLPeakDefaultTilt,
+    "bspline_chieff": BSplineChiEff,
+    "bspline_component_masses": BSplineComponentMasses,
     "pl_test": PLTest,
     "plpeak": PLPeak,
     "plpeak_full": PLPeakFull,
@@ -454,7 +524,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "gwtc3"]
+    todo = which or ["terms", "bases", "cases", "cases2", "gwtc3"]
     if "terms" in todo:
         make_terms()
     if "bases" in todo:
@@ -468,6 +538,11 @@ def main(which):
         pe, inj, tot = make_catalog(6, 96, 768, seed=BASE_SEED + 12)
         make_case("case_bspline_iid.npz", "bspline_iid", pe, inj, tot, seed=5, n_points=3, n_grad=1)
         make_case("case_bspline_full.npz", "bspline_full", pe, inj, tot, seed=6, n_points=3, n_grad=1)
+    if "cases2" in todo:
+        pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+        make_case("case_plpeak_default_tilt.npz", "plpeak_default_tilt", pe, inj, tot, seed=9, n_points=3, n_grad=1)
+        make_case("case_bspline_chieff.npz", "bspline_chieff", pe, inj, tot, seed=10, n_points=3, n_grad=1)
+        make_case("case_bspline_component_masses.npz", "bspline_component_masses", pe, inj, tot, seed=11, n_points=3, n_grad=1)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

@@ -13,6 +13,9 @@ CASES = [
     "bspline_test",
     "bspline_iid",
     "bspline_full",
+    "plpeak_default_tilt",
+    "bspline_chieff",
+    "bspline_component_masses",
     "gwtc3_pl_test",
     "gwtc3_bspline_test",
 ]
