@@ -56,3 +56,50 @@ def test_model_shapes_and_truncation_like_reference_tests():
     assert np.array_equal(fz.mask, pe["redshift"] <= zm.zmax)
     with pytest.raises(ValueError):
         zm(pe["redshift"][:, :3], 2.0)  # not the array the model was built with
+
+
+def test_smoothing_prior_matches_reference_golden():
+    import os
+
+    from golden_util import GOLDEN_DIR
+
+    from gwinferno_amd.smoothing import apply_difference_prior
+
+    z = np.load(os.path.join(GOLDEN_DIR, "terms.npz"))
+    got = [apply_difference_prior(z["smoothing/coefs"], tau, deg) for tau, deg in ((1.0, 1), (25.0, 2), (5.0, 3))]
+    assert np.allclose(got, z["smoothing/values"], rtol=1e-14)
+    assert apply_difference_prior(np.ones(10), 5) == 0  # tests/models/bsplines/smoothing_test.py:18-21
+
+
+def test_numpyro_distribution_log_prob_faces_bind_like_models():
+    """Powerlaw / PowerlawRedshift .log_prob (numpyro_distributions.py:127-136, 186-195) produce the same
+    bound terms as the corresponding model functions."""
+    from bound_eval import log_weights
+
+    from gwinferno_amd.engine import bind
+    from gwinferno_amd.numpyro_distributions import Powerlaw, PowerlawRedshift
+    from oracle import numpy_oracle as O
+
+    pe, inj, total = make_catalog(3, 16, 40, seed=2)
+    zgrid = np.linspace(1e-9, 1.9, 1000)
+    dV = O.planck15_lvk().dVc_dz(zgrid)
+
+    pm, pz = Powerlaw(-2.3, 5.0, 100.0), PowerlawRedshift(2.7, 1.9, zgrid, dV)  # one object per model call (analysis.py:381-399)
+
+    def w(d):
+        return pm.log_prob(d["mass_1"]) * pz.log_prob(d["redshift"]) / d["prior"]
+
+    wp, wi = w(pe), w(inj)
+    bm = bind(wp, wi)
+    lpe, linj, norms = log_weights(bm, bm.theta_of(wp))
+    # direct evaluation of the reference formulas
+    with np.errstate(all="ignore"):
+        for d, got in ((pe, lpe), (inj, linj)):
+            lp_m = -2.3 * np.log(d["mass_1"]) + np.log((1 - 2.3) / (100.0 ** (1 - 2.3) - 5.0 ** (1 - 2.3)))
+            lp_m = np.where((d["mass_1"] < 5.0) | (d["mass_1"] > 100.0), -np.inf, lp_m)
+            norm = np.trapezoid(dV * (1 + zgrid) ** 1.7, zgrid)
+            lp_z = np.log(np.interp(d["redshift"], zgrid, dV)) + 1.7 * np.log(1 + d["redshift"]) - np.log(norm)
+            ref = lp_m + lp_z - np.log(d["prior"])
+            ok = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), ok)
+            assert np.max(np.abs(got[ok] - ref[ok])) < 1e-11
