@@ -117,7 +117,7 @@ class GwiSummary(C.Structure):
     ]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgwi_engine.so")
+LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgwi_engine.so")
 
 # every symbol include/gwi_engine.h declares
 EXPORTED_SYMBOLS = [

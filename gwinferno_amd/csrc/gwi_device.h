@@ -44,9 +44,11 @@ struct KArgs {
   const double* inj_cols[GWI_MAX_COLS];  // one scalar load away, no pointer-table round trip
   const NormD* norms;
   double* partials;   // [n_scan_blocks][rec_stride]
-  double* norm_out;   // [n_norms]
   double* logw_pe;    // only for the log-weight variant
   double* logw_inj;
+#ifdef GWI_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [n_blocks][kWaves][8] s_memrealtime stamps
+#endif
   long long n_pe;     // samples per event
   long long n_inj;
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
@@ -644,44 +646,24 @@ struct Chain<U, K, Rest...> {
   }
 };
 
-// ---- grid normaliser workgroup (interpolation.py:280-291, parametric.py:123-124,
-//      spline_perturbation.py:323-336): Z = sum_g tw_g exp(lb_g + (theta+add) l1_g + spline(us_g))
-__device__ inline void norm_block(const KArgs& a, int j, const double* s_theta, double* s_red) {
-  const NormD nd = a.norms[j];
-  const int tid = threadIdx.x;
-  double acc = 0.0;
-  const double expo = nd.expo_theta >= 0 ? s_theta[nd.expo_theta] + nd.expo_add : 0.0;
-  const double inv_dx = nd.n_basis > 0 ? (double)(nd.n_basis - 3) / (nd.hi - nd.lo) : 0.0;
-  for (int g = tid; g < nd.n_pts; g += kBlock) {
-    const double tw = nd.tw[g];
-    double e = nd.lb ? nd.lb[g] : 0.0;
-    if (nd.expo_theta >= 0) e += expo * nd.l1[g];
-    if (nd.n_basis > 0) {
-      const double x = nd.us[g];
-      int k;
-      double tt;
-      spline_locate(x, nd.lo, inv_dx, nd.n_basis, k, tt);
-      const Taps b = cubic_taps(tt);
-      const double* cf = s_theta + nd.coef_off + k;
-      double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-      if ((nd.flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
-      if (nd.flags & GWI_NORM_LINEAR_SPLINE) {  // BSpline.norm: trapz of the spline itself
-        acc += tw * v;
-        continue;
-      }
-      e += v;
-    }
-    if (tw != 0.0) acc += tw * exp(e);
-  }
-  acc = wave_sum(acc);
-  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
-  __syncthreads();
-  if (tid == 0) a.norm_out[j] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
+// ---- grid normalisers (interpolation.py:280-291, parametric.py:123-124, spline_perturbation.py:323-336):
+//      Z_j = sum_g tw_g exp(lb_g + (theta+add) l1_g + spline(us_g)), one workgroup per normaliser.
+//      Only the HOST consumes Z (it rescales sites; Z cancels in log_l and its gradient), so this runs
+//      as its own small launch on a second stream, concurrently with the scan, and publishes straight to
+//      pinned host memory -- keeping its registers and LDS out of the scan kernel's budget.
+struct NormArgs {
+  const NormD* norms;
+  double* out_host;    // pinned host [n_norms + 1]: slot 0 = completion stamps counter base, Z_j at 1 + j
+  unsigned long long* stamps_host;  // pinned host [n_norms]
+  unsigned long long seq;
+  int n_theta;
+  double theta[GWI_MAX_THETA];
+};
+
+__global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a);
 
 // ---- the scan kernel -----------------------------------------------------------------------------
-// grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups + n_norms normaliser
-// workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
+// grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
 // belongs to that event's logsumexp; an injection workgroup owns `chunk_inj` consecutive
 // injections.  Loads are coalesced: lane i of a wave reads element base+i of each column; each lane
 // carries kU samples (256 apart) per trip so polynomial constants, the wave maximum and the loop
@@ -703,24 +685,30 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
+#ifdef GWI_STAMPS
+  unsigned long long* stamp_row = a.stamps + ((long long)b * kWaves + wave) * 8;
+#define GWI_STAMP(k)                                                        \
+  do {                                                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();         \
+    if (lane == 0) stamp_row[k] = t_;                                       \
+  } while (0)
+#else
+#define GWI_STAMP(k) \
+  do {               \
+  } while (0)
+#endif
+  GWI_STAMP(0);
   const int n_pe_blocks = a.n_ev * a.tiles_per_event;
-  const int n_scan_blocks = n_pe_blocks + a.n_inj_tiles;
-  const bool is_norm = b >= n_scan_blocks;
 
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
-  if (ChainT::kSpline || is_norm)
+  if (ChainT::kSpline)
     for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
   const int wave_span = a.gacc_rep * a.gacc_pad;
   double* const wave_rows = s_gacc + wave * wave_span;
   if (ChainT::kSpline)
     for (int p = lane; p < wave_span; p += 64) wave_rows[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
-  if (ChainT::kSpline || is_norm) __syncthreads();
-
-  if (is_norm) {
-    norm_block(a, b - n_scan_blocks, s_theta, &s_wrec[0][0]);
-    return;
-  }
+  if (ChainT::kSpline) __syncthreads();
 
   long long start, end, base;
   Ctx ctx;
@@ -765,7 +753,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
     }
   };
   const long long i0 = start + tid;
+  GWI_STAMP(1);
   if (i0 - lane < end) issue_loads(0, i0);
+#ifdef GWI_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
+  GWI_STAMP(2);
+#endif
   for (long long i = i0; i - lane < end; i += kU * kBlock) {
     const long long i_next = i + kU * kBlock;
     const bool has_next = i_next - lane < end;  // wave-uniform
@@ -822,6 +815,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
     }
   }
   if (WRITE_LOGW) return;
+  GWI_STAMP(3);
 
   // ---- workgroup record: common exponent M, then a transposed LDS reduction of every scalar sum
   if (lane == 0) s_wrec[wave][0] = m;
@@ -884,6 +878,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
     }
     out[kRecHeader + p] = g;
   }
+  GWI_STAMP(4);
 }
 
 // ---- stage 2: combine the tile records of one GROUP with a common reference exponent.  Groups
@@ -1020,7 +1015,6 @@ struct FinalArgs {
   const double* ev_grad;
   const double* inj_out;
   const double* inj_grad;
-  const double* norm_out;
   double* record;       // device-visible pinned host buffer (or the device send buffer when sharded)
   int n_ev, n_theta, n_norms, n_inj_groups;
   unsigned long long seq;  // written last to record[0] as a completion stamp
@@ -1091,7 +1085,6 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
     for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * a.inj_grad[(long long)j * a.n_theta + p];
     store_sys(r + off_ginj + p, g);
   }
-  if (tid < a.n_norms) store_sys(r + off_norm + tid, a.norm_out[tid]);
   __syncthreads();
   if (row == 0 && col < a.n_theta) {
     double g = 0.0;
@@ -1105,6 +1098,46 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
 __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered, double* host, int n, unsigned long long seq) {
   for (int i = threadIdx.x + 1; i < n; i += kBlock) store_sys(host + i, gathered[i]);
   publish_stamp(host, seq, threadIdx.x);
+}
+
+__global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a) {
+  __shared__ double s_theta[GWI_MAX_THETA];
+  __shared__ double s_red[kWaves];
+  const int tid = threadIdx.x, j = blockIdx.x;
+  for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
+  __syncthreads();
+  const NormD nd = a.norms[j];
+  double acc = 0.0;
+  const double expo = nd.expo_theta >= 0 ? s_theta[nd.expo_theta] + nd.expo_add : 0.0;
+  const double inv_dx = nd.n_basis > 0 ? (double)(nd.n_basis - 3) / (nd.hi - nd.lo) : 0.0;
+  for (int g = tid; g < nd.n_pts; g += kBlock) {
+    const double tw = nd.tw[g];
+    double e = nd.lb ? nd.lb[g] : 0.0;
+    if (nd.expo_theta >= 0) e += expo * nd.l1[g];
+    if (nd.n_basis > 0) {
+      const double x = nd.us[g];
+      int k;
+      double tt;
+      spline_locate(x, nd.lo, inv_dx, nd.n_basis, k, tt);
+      const Taps b = cubic_taps(tt);
+      const double* cf = s_theta + nd.coef_off + k;
+      double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+      if ((nd.flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
+      if (nd.flags & GWI_NORM_LINEAR_SPLINE) {  // BSpline.norm: trapz of the spline itself
+        acc += tw * v;
+        continue;
+      }
+      e += v;
+    }
+    if (tw != 0.0) acc += tw * exp(e);
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) store_sys(a.out_host + j, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(a.stamps_host + j, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace gwi

@@ -55,6 +55,7 @@ const Variant kVariants[] = {
     // BASELINE config 2 -- PL+Peak m1 x PL q [x PL z]
     GWI_VARIANT("plpeak+plq", K_PP, K_PQ),
     GWI_VARIANT("plpeak+plq+plz", K_PP, K_PQ, K_PZ),
+    GWI_VARIANT_U("plpeak+plq+plz/u1", 1, K_PP, K_PQ, K_PZ),  // 128 VGPRs -> 4 waves/SIMD
     // BASELINE config 1 -- + independent Beta magnitudes + independent tilt mixtures
     GWI_VARIANT("plpeak+plq+beta2+tilt2+plz", K_PP, K_PQ, K_BE, K_BE, K_TI, K_TI, K_PZ),
     // tests/inference_test.py:244-285 -- PL z x {BSpline m1, BSpline q, spline(log z)}
@@ -195,12 +196,13 @@ struct gwi_engine {
   const Variant* variant = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t norm_stream = nullptr;  // normaliser grids run beside the scan
   long long n_ev = 0, n_pe = 0, n_inj = 0;
   // device memory
   std::vector<double*> d_cols_pe, d_cols_inj;
   NormD* d_norms = nullptr;
   std::vector<double*> d_norm_arrays;
-  double *d_partials = nullptr, *d_norm_out = nullptr, *d_ev_out = nullptr, *d_ev_grad = nullptr, *d_inj_out = nullptr, *d_inj_grad = nullptr;
+  double *d_partials = nullptr, *d_ev_out = nullptr, *d_ev_grad = nullptr, *d_inj_out = nullptr, *d_inj_grad = nullptr;
   double *d_logw_pe = nullptr, *d_logw_inj = nullptr;
   // pinned, device-visible host memory
   double *h_record = nullptr, *h_record_dev = nullptr;
@@ -208,7 +210,9 @@ struct gwi_engine {
   // host-final mode: per-group result rows + normaliser values in pinned host memory
   bool host_final = false;
   double *h_rows = nullptr, *h_rows_dev = nullptr;
-  double *h_norm = nullptr, *h_norm_dev = nullptr;
+  double *h_norm = nullptr, *h_norm_dev = nullptr;                    // pinned: Z_j
+  unsigned long long *h_norm_stamp = nullptr, *h_norm_stamp_dev = nullptr;  // pinned: per-normaliser stamps
+  NormArgs nargs;
   // launch geometry
   int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
   int n_inj_groups = 1, tiles_per_inj_group = 1;
@@ -363,7 +367,7 @@ void prelude(gwi_engine* h, const double* theta) {
 }
 
 gwi_status launch_scan(gwi_handle h, bool logw) {
-  const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);
+  const int grid = h->n_scan_blocks;
   ScanFn fn = logw ? h->variant->logw : h->variant->scan;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), h->scan_lds_bytes, h->stream, h->kargs);
   GWI_HIP(hipGetLastError());
@@ -372,6 +376,18 @@ gwi_status launch_scan(gwi_handle h, bool logw) {
 
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf);
 gwi_status wait_for_rows(gwi_handle h);
+gwi_status wait_for_norms(gwi_handle h, double* record);
+
+// Normaliser grids: own stream, beside the scan; launched AFTER the main-stream kernels so that its
+// host-side launch cost is off the critical path.  `seq` is the stamp the waiters will look for.
+gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long seq) {
+  if (h->spec.n_norms == 0) return GWI_OK;
+  std::memcpy(h->nargs.theta, theta, sizeof(double) * h->spec.n_theta);
+  h->nargs.seq = seq;
+  hipLaunchKernelGGL(norm_kernel, dim3(h->spec.n_norms), dim3(kBlock), 0, h->norm_stream, h->nargs);
+  GWI_HIP(hipGetLastError());
+  return GWI_OK;
+}
 
 // launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
 // or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
@@ -405,6 +421,8 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     if (ca.host_rows) {
       ++h->seq;
       if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+      gwi_status sn = launch_norms(h, theta, h->seq);
+      if (sn != GWI_OK) return sn;
       return wait ? wait_for_rows(h) : GWI_OK;
     }
     FinalArgs fa;
@@ -412,7 +430,6 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     fa.ev_grad = h->d_ev_grad;
     fa.inj_out = h->d_inj_out;
     fa.inj_grad = h->d_inj_grad;
-    fa.norm_out = h->host_final ? h->h_norm_dev : h->d_norm_out;
     fa.record = record_dev ? record_dev : h->h_record_dev;
     fa.n_ev = (int)h->n_ev;
     fa.n_theta = h->spec.n_theta;
@@ -423,8 +440,34 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     GWI_HIP(hipGetLastError());
   }
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+  {
+    gwi_status sn = launch_norms(h, theta, h->seq);
+    if (sn != GWI_OK) return sn;
+  }
   if (!wait) return GWI_OK;
-  return wait_for_stamp(h, h->h_record);
+  gwi_status st_ = wait_for_stamp(h, h->h_record);
+  if (st_ != GWI_OK) return st_;
+  return wait_for_norms(h, h->h_record);
+}
+
+// the normaliser launch publishes Z_j + a stamp per normaliser; copy them into rank 0's record slots
+gwi_status wait_for_norms(gwi_handle h, double* record) {
+  const int n = h->spec.n_norms;
+  if (n == 0) return GWI_OK;
+  bool done = false;
+  for (long spin = 0; spin < 400000 && !done; ++spin) {
+    done = true;
+    for (int j = 0; j < n; ++j) done = done && *reinterpret_cast<volatile unsigned long long*>(h->h_norm_stamp + j) == h->seq;
+    if (!done) __builtin_ia32_pause();
+  }
+  if (!done) {
+    GWI_HIP(hipStreamSynchronize(h->norm_stream));
+    for (int j = 0; j < n; ++j)
+      if (h->h_norm_stamp[j] != h->seq) return fail(h, GWI_ERR_HIP, "normaliser stamp mismatch after stream synchronise");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int j = 0; j < n; ++j) record[kRecNormOff + j] = h->h_norm[j];
+  return GWI_OK;
 }
 
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf) {
@@ -598,8 +641,7 @@ gwi_status wait_for_rows(gwi_handle h) {
   r[5] = S1;
   r[6] = S2;
   r[7] = (double)n_ev;
-  for (int j = 0; j < n_norms; ++j) r[kRecNormOff + j] = h->h_norm[j];
-  return GWI_OK;
+  return wait_for_norms(h, r);
 }
 
 void destroy_impl(gwi_engine* h) {
@@ -614,7 +656,6 @@ void destroy_impl(gwi_engine* h) {
   for (double* p : h->d_norm_arrays) (void)hipFree(p);
   (void)hipFree(h->d_norms);
   (void)hipFree(h->d_partials);
-  (void)hipFree(h->d_norm_out);
   (void)hipFree(h->d_ev_out);
   (void)hipFree(h->d_ev_grad);
   (void)hipFree(h->d_inj_out);
@@ -629,6 +670,8 @@ void destroy_impl(gwi_engine* h) {
   if (h->h_ev) (void)hipHostFree(h->h_ev);
   if (h->h_rows) (void)hipHostFree(h->h_rows);
   if (h->h_norm) (void)hipHostFree(h->h_norm);
+  if (h->h_norm_stamp) (void)hipHostFree(h->h_norm_stamp);
+  if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -704,6 +747,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
   GWI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  GWI_HIP(hipStreamCreateWithFlags(&h->norm_stream, hipStreamNonBlocking));
   if (const char* env = std::getenv("GWI_SPIN_WAIT")) h->spin_wait = std::atoi(env) != 0;
   for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
   h->n_ev = n_ev;
@@ -755,14 +799,44 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipMalloc(&h->d_norms, sizeof(NormD) * nd.size()));
   GWI_HIP(hipMemcpy(h->d_norms, nd.data(), sizeof(NormD) * nd.size(), hipMemcpyHostToDevice));
 
-  // ---- launch geometry: ~2048 scan workgroups (8 per CU) unless that would make them tiny
+  // dynamic LDS of the scan kernel (spline-gradient rows), needed by the occupancy query below
+  size_t scan_lds = 0;
+  {
+    int rep0 = 8;
+    if (const char* env = std::getenv("GWI_GACC_REP")) rep0 = std::atoi(env);
+    if (rep0 < 1) rep0 = 1;
+    if (rep0 > 16) rep0 = 16;
+    while (rep0 & (rep0 - 1)) rep0 &= rep0 - 1;
+    bool spl = false;
+    for (int t = 0; t < spec->n_terms; ++t) spl = spl || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE;
+    scan_lds = spl ? sizeof(double) * (size_t)kWaves * rep0 * (spec->n_theta | 1) : 0;
+  }
+  // ---- launch geometry.  Default: ~2048 scan workgroups (8 per CU).  A step lasts only ~10 us, so a
+  // partial second dispatch round (a few workgroups that can only start when the first finishers
+  // retire) costs a large fraction of it: when one round of resident workgroups can hold the whole
+  // catalog with <= 4 trips each, size the workgroups for exactly one round instead.
+  const long long gran = (long long)h->variant->samples_per_lane * kBlock;  // every lane carries U samples per trip
   long long spb = 0;
   if (const char* env = std::getenv("GWI_SAMPLES_PER_BLOCK")) spb = std::atoll(env);
   if (spb <= 0) {
     const long long total = n_ev * n_pe + n_inj;
     spb = (total + 2047) / 2048;
+    int occ = 0;
+    bool single_round = true;
+    if (const char* env = std::getenv("GWI_SINGLE_ROUND")) single_round = std::atoi(env) != 0;
+    if (single_round && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->variant->scan, kBlock, scan_lds) == hipSuccess && occ > 0) {
+      const long long capacity = (long long)prop.multiProcessorCount * occ;
+      for (long long cand = gran; cand <= 4 * gran; cand += gran) {
+        const long long pad = ((n_pe + gran - 1) / gran) * gran;
+        const long long cpe = cand < pad ? cand : pad;
+        const long long blocks = n_ev * ((n_pe + cpe - 1) / cpe) + (n_inj + cand - 1) / cand;
+        if (blocks <= capacity) {
+          if (cand > spb) spb = cand;
+          break;
+        }
+      }
+    }
   }
-  const long long gran = (long long)h->variant->samples_per_lane * kBlock;  // every lane carries U samples per trip
   spb = ((spb + gran - 1) / gran) * gran;
   if (spb < gran) spb = gran;
   const long long n_pe_pad = ((n_pe + gran - 1) / gran) * gran;
@@ -796,7 +870,6 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
 
   GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
-  GWI_HIP(hipMalloc(&h->d_norm_out, sizeof(double) * (spec->n_norms ? spec->n_norms : 1)));
   GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * 4 * (size_t)(n_ev ? n_ev : 1)));
   GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
   GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * 4 * (size_t)h->n_inj_groups));
@@ -818,6 +891,14 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     std::memset(h->h_rows, 0, row_bytes);
     GWI_HIP(hipHostMalloc((void**)&h->h_norm, sizeof(double) * (spec->n_norms ? spec->n_norms : 1), hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_dev, h->h_norm, 0));
+    GWI_HIP(hipHostMalloc((void**)&h->h_norm_stamp, sizeof(unsigned long long) * (spec->n_norms ? spec->n_norms : 1), hipHostMallocMapped));
+    GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_stamp_dev, h->h_norm_stamp, 0));
+    std::memset(h->h_norm_stamp, 0, sizeof(unsigned long long) * (spec->n_norms ? spec->n_norms : 1));
+    std::memset(&h->nargs, 0, sizeof(h->nargs));
+    h->nargs.norms = h->d_norms;
+    h->nargs.out_host = h->h_norm_dev;
+    h->nargs.stamps_host = h->h_norm_stamp_dev;
+    h->nargs.n_theta = spec->n_theta;
   }
 
   // ---- constant part of the kernel-argument block
@@ -829,7 +910,6 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   }
   k.norms = h->d_norms;
   k.partials = h->d_partials;
-  k.norm_out = h->host_final ? h->h_norm_dev : h->d_norm_out;
   k.n_pe = n_pe;
   k.n_inj = n_inj;
   k.n_ev = (int)n_ev;
@@ -842,6 +922,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   k.n_theta = spec->n_theta;
   k.kappa_col = spec->kappa_col;
   k.rec_stride = h->rec_stride;
+#ifdef GWI_STAMPS
+  GWI_HIP(hipMalloc(&k.stamps, sizeof(unsigned long long) * (size_t)(h->n_scan_blocks + spec->n_norms + 1) * kWaves * 8));
+  GWI_HIP(hipMemset(k.stamps, 0, sizeof(unsigned long long) * (size_t)(h->n_scan_blocks + spec->n_norms + 1) * kWaves * 8));
+#endif
   k.gacc_rep = rep;
   k.gacc_pad = pad;
   for (int t = 0; t < spec->n_terms; ++t) {
@@ -983,6 +1067,8 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
   GWI_HIP(hipGetLastError());
   st = wait_for_stamp(h, h->h_gather);
   if (st != GWI_OK) return st;
+  st = wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
+  if (st != GWI_OK) return st;
   gwi_summary s;
   assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms);
   if (summary) *summary = s;
@@ -1007,6 +1093,16 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
   *seconds_per_eval = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n_iter;
   return GWI_OK;
 }
+
+#ifdef GWI_STAMPS
+// diagnostic build only (not part of the ABI): fetch the per-wave phase stamps of the last scan launch
+gwi_status gwi_debug_stamps(gwi_handle h, unsigned long long* out, int64_t n_words) {
+  if (!h || !out) return GWI_ERR_INVALID;
+  const int64_t have = (int64_t)h->n_scan_blocks * kWaves * 8;
+  GWI_HIP(hipMemcpy(out, h->kargs.stamps, sizeof(unsigned long long) * (size_t)(n_words < have ? n_words : have), hipMemcpyDeviceToHost));
+  return GWI_OK;
+}
+#endif
 
 gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, double* inj_logw) {
   if (!h || !theta || !h->variant) return GWI_ERR_INVALID;

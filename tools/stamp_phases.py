@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-wave phase timeline of the scan kernel from s_memrealtime stamps.
+Build the stamped library first:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DGWI_STAMPS -Iinclude \
+        gwinferno_amd/csrc/gwi_engine.hip -o gwinferno_amd/_lib/libgwi_engine_stamps.so -ldl
+  GWI_ENGINE_LIB=gwinferno_amd/_lib/libgwi_engine_stamps.so python tools/stamp_phases.py c2
+Stamps: 0 wave entry, 1 prologue done, 2 first trip's loads landed, 3 loop done, 4 record written."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import CONFIGS  # noqa: E402
+from gwinferno_amd.compositions import COMPOSITIONS, draw_params  # noqa: E402
+from gwinferno_amd.synthetic import make_config_catalog  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+comp_name, cat, _, _ = CONFIGS[cfg]
+pe, inj, total = make_config_catalog(cat)
+comp = COMPOSITIONS[comp_name](pe, inj)
+eng = comp.engine()
+th = comp.theta(draw_params(comp_name, np.random.default_rng(0)))
+for _ in range(20):
+    eng.evaluate(th, total, min_neff_cut=False)
+n_words = 1 << 22
+buf = (C.c_uint64 * n_words)()
+eng.lib.gwi_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
+assert eng.lib.gwi_debug_stamps(eng.handle, buf, n_words) == 0
+st_all = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:, :5].astype(np.int64)
+blk = np.arange(len(st_all)) // 4
+ok = (st_all[:, 0] > 0) & (st_all[:, 4] > 0)
+st, blk = st_all[ok], blk[ok]
+# blocks are dealt round-robin over the 8 XCDs (block b and b+8 share one); each XCD has its own
+# realtime counter phase, so the origin is taken per XCD group
+xcd = blk % 8
+us = np.zeros(st.shape)
+for x in range(8):
+    sel = xcd == x
+    if sel.any():
+        print(f"  xcd-group {x}: first entry tick offset vs global min {(st[sel, 0].min() - st[:, 0].min()) / 100.0:7.2f} us, waves {sel.sum()}")
+        us[sel] = (st[sel] - st[sel, 0].min()) / 100.0
+print(f"{cfg}: {len(st)} waves; kernel span (first entry -> last record) {us[:, 4].max():.2f} us")
+names = ["entry (dispatch skew)", "prologue", "first loads land", "evaluate + accumulate", "epilogue (record)"]
+prev = np.zeros(len(us))
+for k in range(5):
+    d = us[:, k] - (us[:, k - 1] if k else 0.0)
+    print(f"  {names[k]:26s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us   (absolute median end {np.median(us[:, k]):6.2f})")
