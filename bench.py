@@ -33,6 +33,17 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_table(config):
+    """Row of profiles/<latest round>/traffic.json for this config (or {})."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")))
+    try:
+        return json.load(open(files[-1])).get(config, {}) if files else {}
+    except Exception:
+        return {}
+
+
 def pmc_traffic(config):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes of the latest round
     (profiles/<round>/traffic.json, produced by tools/profile_round.sh + tools/summarize_profiles.py:
@@ -220,6 +231,12 @@ def main():
                 "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
                 "timed_launches": len(scan_ms),
+                # second view: the scan is fp64-issue/latency bound, not HBM bound
+                "fp64_vector": {
+                    "peak_tflops": 78.6,
+                    "flop_per_launch_pmc": pmc_table(args.config).get("fp64_flop_per_launch") if world == 1 else None,
+                    "achieved_tflops": (pmc_table(args.config).get("fp64_flop_per_launch", 0.0) / (scan_us * 1e-6) / 1e12) if (world == 1 and scan_ms and pmc_table(args.config).get("fp64_flop_per_launch")) else None,
+                },
             },
             "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
             "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,

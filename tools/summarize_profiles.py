@@ -53,6 +53,23 @@ def main(round_name):
             lines.append(f"| {cfg} | {short} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {f:.1f} | {w:.1f} | {hbm:.0f} |" if hbm else f"| {cfg} | {short} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | - | - | - |")
             if key == "scan_kernel":
                 traffic[cfg] = {"scan_avg_us_rocprof": float(r["AverageNs"]) / 1e3, "fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_per_launch": hbm}
+    # ---- SQ counters of the scan kernel: instruction mix, fp64 rate, where wave time goes
+    sq_lines = ["| config | waves | VALU/wave | SALU/wave | LDS/wave | fp64 GFLOP per launch | fp64 TFLOP/s (of 78.6 peak) | wave time waiting (s_waitcnt/barrier) | issuing | LDS bank-conflict share |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for cfg in sorted(os.listdir(src)):
+        def c(name, part):
+            return mean_counter(os.path.join(src, cfg, part, "*", "*_counter_collection.csv"), "scan_kernel", name)
+        w = c("SQ_WAVES", "sq_a")
+        if not w or cfg not in traffic:
+            continue
+        valu, salu, lds = c("SQ_INSTS_VALU", "sq_a"), c("SQ_INSTS_SALU", "sq_a"), c("SQ_INSTS_LDS", "sq_a")
+        add, mul, fma, tr = c("SQ_INSTS_VALU_ADD_F64", "sq_a"), c("SQ_INSTS_VALU_MUL_F64", "sq_a"), c("SQ_INSTS_VALU_FMA_F64", "sq_a"), c("SQ_INSTS_VALU_TRANS_F64", "sq_a")
+        flop = 64.0 * ((add or 0) + (mul or 0) + 2 * (fma or 0) + (tr or 0))
+        t_us = traffic[cfg]["scan_avg_us_rocprof"]
+        wc, wa, ai = c("SQ_WAVE_CYCLES", "sq_b"), c("SQ_WAIT_ANY", "sq_b"), c("SQ_ACTIVE_INST_ANY", "sq_b")
+        bc, ia = c("SQ_LDS_BANK_CONFLICT", "sq_b"), c("SQ_LDS_IDX_ACTIVE", "sq_b")
+        traffic[cfg].update(fp64_flop_per_launch=flop, fp64_tflops=flop / (t_us * 1e-6) / 1e12)
+        sq_lines.append(f"| {cfg} | {w:.0f} | {valu / w:.0f} | {salu / w:.0f} | {lds / w:.0f} | {flop / 1e9:.2f} | {flop / (t_us * 1e-6) / 1e12:.2f} | {wa / wc:.0%} | {ai / wc:.0%} | {(bc / ia if ia else 0):.0%} |")
+    lines += ["", "Scan-kernel SQ counters (separate `--pmc` passes; fp64 FLOP = 64 x (ADD + MUL + 2 FMA + TRANS) wave-instructions):", ""] + sq_lines
     with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
         fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).\n\n")
         fh.write("\n".join(lines) + "\n")
