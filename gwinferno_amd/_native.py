@@ -123,6 +123,7 @@ LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.p
 EXPORTED_SYMBOLS = [
     "gwi_create",
     "gwi_eval",
+    "gwi_eval_batch",
     "gwi_log_weights",
     "gwi_partial_len",
     "gwi_eval_partial",
@@ -171,6 +172,8 @@ def load_library():
     lib.gwi_create.argtypes = [C.POINTER(GwiSpec), C.POINTER(_DP), C.c_int64, C.c_int64, C.POINTER(_DP), C.c_int64, C.c_int32, C.POINTER(vp)]
     lib.gwi_eval.restype = C.c_int32
     lib.gwi_eval.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_eval_batch.restype = C.c_int32
+    lib.gwi_eval_batch.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_log_weights.restype = C.c_int32
     lib.gwi_log_weights.argtypes = [vp, _DP, _DP, _DP]
     lib.gwi_partial_len.restype = C.c_int64

@@ -39,6 +39,13 @@ struct NormD {
   const double* us;
 };
 
+// hyper-parameter point + its host-precomputed theta-only scalars; a batched launch reads one per
+// blockIdx.y from device memory, a single evaluation reads the copy embedded in the kernel arguments
+struct ThetaBlock {
+  double theta[GWI_MAX_THETA];
+  double derived[GWI_MAX_TERMS][kMaxDerived];
+};
+
 struct KArgs {
   const double* pe_cols[GWI_MAX_COLS];   // column base pointers live in the kernel-argument block:
   const double* inj_cols[GWI_MAX_COLS];  // one scalar load away, no pointer-table round trip
@@ -54,6 +61,7 @@ struct KArgs {
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
   int gacc_rep, gacc_pad;  // spline-gradient LDS rows: replicas per wave (power of two), row stride (odd)
+  const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   TermD terms[GWI_MAX_TERMS];
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
@@ -144,8 +152,9 @@ __device__ __forceinline__ double gload(const double* p, long long idx) { return
 
 // ---- evaluation context --------------------------------------------------------------------
 struct Ctx {
-  const KArgs* a;               // kernel arguments: scalar hyper-parameters are read from here
-                                // (uniform index -> scalar loads), never from LDS
+  const KArgs* a;               // kernel arguments (term descriptors, sizes, column pointers)
+  const double* theta;          // scalar hyper-parameters: uniform index -> scalar loads, never LDS
+  const double (*derived)[kMaxDerived];  // host-precomputed theta-only scalars per term
   const double* coefs;          // LDS copy of theta for the lane-varying spline coefficient reads
   double* gacc;                 // this wave's LDS gradient-numerator row [n_theta]
   const double* const* cols;    // column table of the sample set this workgroup scans
@@ -182,7 +191,7 @@ struct Term<GWI_TERM_POWERLAW> {
   };
   __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
     s.lx = in.x0;
-    return c.a->theta[t.th0] * s.lx;
+    return c.theta[t.th0] * s.lx;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.lx; }
   GWI_ACC1(g0)
@@ -214,7 +223,7 @@ struct Term<GWI_TERM_PLPEAK> {
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
     const double x = in.x0;
     const double lx = in.x1;
-    const double alpha = c.a->theta[t.th0], mu = c.a->theta[t.th1], lam = c.a->theta[t.th3];
+    const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;
     const double e_pl = exp(alpha * lx + d[0]);
@@ -272,7 +281,7 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
     const double lq = in.x0;
     const double lr = t.p0 - in.x1;  // log(mmin/m1) <= 0 for every non-excluded sample
-    const double beta = c.a->theta[t.th0];
+    const double beta = c.theta[t.th0];
     const double b1 = 1.0 + beta;
     if (b1 == 0.0) {  // alpha == -1 branch of the reference: 1/log(high/low)
       s.db = lq - 0.5 * lr;
@@ -314,7 +323,7 @@ struct Term<GWI_TERM_BETA> {
   __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
     s.la = in.x0;
     s.l1 = in.x1;
-    return (c.a->theta[t.th0] - 1.0) * s.la + (c.a->theta[t.th1] - 1.0) * s.l1;
+    return (c.theta[t.th0] - 1.0) * s.la + (c.theta[t.th1] - 1.0) * s.l1;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
     a.g[0] += w * s.la;
@@ -351,7 +360,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
     const double ct = in.x0;
-    const double xi = c.a->theta[t.th0];
+    const double xi = c.theta[t.th0];
     const double dx = ct - 1.0;
     const double dx2 = dx * dx;
     const double e_tn = exp(-0.5 * dx2 * d[2] + d[0]);
@@ -396,7 +405,7 @@ struct Term<GWI_TERM_TRUNCNORM> {
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double&) {
     const double x = in.x0;
-    const double dx = x - c.a->theta[t.th0];
+    const double dx = x - c.theta[t.th0];
     const double dx2 = dx * dx;
     s.dmu = dx * d[0];
     s.dsg = dx2 * d[1];
@@ -436,7 +445,7 @@ struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
   };
   __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
     s.l1pz = in.x0;
-    return (c.a->theta[t.th0] - 1.0) * s.l1pz;
+    return (c.theta[t.th0] - 1.0) * s.l1pz;
   }
   __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.l1pz; }
   GWI_ACC1(g0)
@@ -561,7 +570,7 @@ struct Term<GWI_TERM_TILT_JOINT> {
     double g[2];
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
-    const double xi = c.a->theta[t.th0];
+    const double xi = c.theta[t.th0];
     const double d1 = in.x0 - 1.0, d2 = in.x1 - 1.0;
     const double r2 = d1 * d1 + d2 * d2;
     const double A = exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
@@ -629,7 +638,7 @@ struct Chain<U, K, Rest...> {
     rest.advance();
   }
   __device__ double eval(int u, int ti, const Ctx& c, double& lin) {
-    const double l = Term<K>::eval(c.a->terms[ti], c.a->derived[ti], c, in[0][u], st[u], lin);
+    const double l = Term<K>::eval(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin);
     return l + rest.eval(u, ti + 1, c, lin);
   }
   __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
@@ -656,7 +665,8 @@ struct NormArgs {
   double* out_host;    // pinned host [n_norms + 1]: slot 0 = completion stamps counter base, Z_j at 1 + j
   unsigned long long* stamps_host;  // pinned host [n_norms]
   unsigned long long seq;
-  int n_theta;
+  int n_theta, n_norms;
+  const ThetaBlock* tblocks;  // batched launches: theta of point blockIdx.y; nullptr: the embedded copy
   double theta[GWI_MAX_THETA];
 };
 
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a);
 // overhead are shared between them.
 constexpr int kRedChunk = 8;  // values per pass of the block-level transposed reduction (16 KiB LDS)
 
-template <bool WRITE_LOGW, int U, int... Ks>
+template <bool WRITE_LOGW, bool BATCH, int U, int... Ks>
 __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   using ChainT = Chain<U, Ks...>;
   constexpr int kU = U;
@@ -701,8 +711,11 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   const int n_pe_blocks = a.n_ev * a.tiles_per_event;
 
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
+  // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
+  const int kb = BATCH ? (int)blockIdx.y : 0;
+  const double* theta_src = BATCH ? a.tblocks[kb].theta : a.theta;
   if (ChainT::kSpline)
-    for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
+    for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
   const int wave_span = a.gacc_rep * a.gacc_pad;
   double* const wave_rows = s_gacc + wave * wave_span;
   if (ChainT::kSpline)
@@ -713,6 +726,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   long long start, end, base;
   Ctx ctx;
   ctx.a = &a;
+  ctx.theta = theta_src;
+  ctx.derived = BATCH ? a.tblocks[kb].derived : a.derived;
   ctx.coefs = s_theta;
   ctx.gacc = wave_rows + (lane & (a.gacc_rep - 1)) * a.gacc_pad;
   double* logw;
@@ -834,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   chain.collect(0, ctx, vals + 2, th + 2);
 #pragma unroll
   for (int v = 2; v < kNV; ++v) vals[v] *= f;
-  double* out = a.partials + (long long)b * a.rec_stride;
+  double* out = a.partials + ((long long)kb * gridDim.x + b) * a.rec_stride;
 #pragma unroll
   for (int v0 = 0; v0 < kNV; v0 += kRedChunk) {
     if (v0 > 0) __syncthreads();
@@ -899,6 +914,7 @@ struct CombineArgs {
   double* host_rows;  // nullptr: device-final mode
   unsigned long long seq;
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
+  int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   double n_pe;
 };
 
@@ -936,7 +952,15 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
     n_tiles = a.tiles_per_event;
     first = (long long)e * a.tiles_per_event;
   }
-  const double* rec = a.partials + first * a.rec_stride;
+  const int kb = blockIdx.y;  // hyper-parameter point of a batched launch (0 otherwise)
+  const int n_groups = a.n_ev + a.n_inj_groups;
+  const double* rec = a.partials + ((long long)kb * a.n_scan_blocks + first) * a.rec_stride;
+  double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
+  double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
+  double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
+  double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
+  double* const ev_host = a.ev_host + (long long)kb * 3 * a.n_ev;
+  double* const host_rows = a.host_rows ? a.host_rows + (long long)kb * n_groups * (4 + a.n_theta) : nullptr;
 
   // phase 1, every wave redundantly: lanes <- tiles.  Common exponent M, per-tile factor f_t, S1, S2.
   // (host guarantees n_tiles <= 64 per group)
@@ -955,17 +979,17 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
     const double* col = rec + kRecHeader + p;
 #pragma unroll 4
     for (int t = 0; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
-    if (a.host_rows)
-      store_sys(a.host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
+    if (host_rows)
+      store_sys(host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
     else if (is_inj)
-      a.inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
+      inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
     else
-      a.ev_grad[(long long)e * a.n_theta + p] = acc * inv_s1;
+      ev_grad[(long long)e * a.n_theta + p] = acc * inv_s1;
   }
   if (tid < 64) {
     const double S2 = wave_sum(f * f * r2);
-    if (lane == 0 && a.host_rows) {
-      double* o = a.host_rows + (long long)e * (4 + a.n_theta);
+    if (lane == 0 && host_rows) {
+      double* o = host_rows + (long long)e * (4 + a.n_theta);
       if (is_inj) {
         store_sys(o + 1, M);
         store_sys(o + 2, S1);
@@ -979,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
       }
     } else if (lane == 0) {
       if (is_inj) {
-        double* o = a.inj_out + (long long)(e - a.n_ev) * 4;
+        double* o = inj_out + (long long)(e - a.n_ev) * 4;
         o[0] = M;
         o[1] = S1;
         o[2] = S2;
@@ -989,18 +1013,18 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
         const double log_s1 = log(S1);
         const double log_neff = 2.0 * log_s1 - log(S2);
         const double var = 1.0 / exp(log_neff) - 1.0 / a.n_pe;
-        double* o = a.ev_out + (long long)e * 4;
+        double* o = ev_out + (long long)e * 4;
         o[0] = log_s1 + M;
         o[1] = log_neff;
         o[2] = var;
         o[3] = S1;
-        store_sys(a.ev_host + e, log_s1 + M);
-        store_sys(a.ev_host + a.n_ev + e, log_neff);
-        store_sys(a.ev_host + 2 * a.n_ev + e, var);
+        store_sys(ev_host + e, log_s1 + M);
+        store_sys(ev_host + a.n_ev + e, log_neff);
+        store_sys(ev_host + 2 * a.n_ev + e, var);
       }
     }
   }
-  if (a.host_rows) publish_stamp(a.host_rows + (long long)e * (4 + a.n_theta), a.seq, tid);
+  if (host_rows) publish_stamp(host_rows + (long long)e * (4 + a.n_theta), a.seq, tid);
 }
 
 // ---- stage 3: reduce over events, merge the injection groups, and publish this device's record to
@@ -1017,6 +1041,7 @@ struct FinalArgs {
   const double* inj_grad;
   double* record;       // device-visible pinned host buffer (or the device send buffer when sharded)
   int n_ev, n_theta, n_norms, n_inj_groups;
+  int record_len;          // batched launches: record of point blockIdx.y starts at record + y * record_len
   unsigned long long seq;  // written last to record[0] as a completion stamp
 };
 
@@ -1029,7 +1054,12 @@ __device__ __forceinline__ int pow2_at_least(int v) {
 __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a) {
   __shared__ double s_tile[kFinalThreads];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* r = a.record;
+  const int kb = blockIdx.y;
+  double* r = a.record + (long long)kb * a.record_len;
+  const double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
+  const double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
+  const double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
+  const double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
 
   // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
@@ -1039,7 +1069,7 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
   double acc = 0.0;
   if (col < a.n_theta) {
 #pragma unroll 8
-    for (int e = row; e < a.n_ev; e += rows) acc += a.ev_grad[(long long)e * a.n_theta + col];
+    for (int e = row; e < a.n_ev; e += rows) acc += ev_grad[(long long)e * a.n_theta + col];
   }
   s_tile[tid] = acc;
 
@@ -1047,7 +1077,7 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
   if (wave == 0) {
     double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
     for (int e = lane; e < a.n_ev; e += 64) {
-      const double* o = a.ev_out + (long long)e * 4;
+      const double* o = ev_out + (long long)e * 4;
       sum += o[0];
       var += o[2];
       double le = o[1];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
@@ -1067,12 +1097,12 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
   }
   // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups
   const bool hasg = lane < a.n_inj_groups;
-  const double m_j = hasg ? a.inj_out[lane * 4] : GWI_NEG_INF;
+  const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
   const double Minj = wave_max(m_j);
   const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
   if (wave == 1) {
-    const double S1 = wave_sum(fj * (hasg ? a.inj_out[lane * 4 + 1] : 0.0));
-    const double S2 = wave_sum(fj * fj * (hasg ? a.inj_out[lane * 4 + 2] : 0.0));
+    const double S1 = wave_sum(fj * (hasg ? inj_out[lane * 4 + 1] : 0.0));
+    const double S2 = wave_sum(fj * fj * (hasg ? inj_out[lane * 4 + 2] : 0.0));
     if (lane == 0) {
       store_sys(r + 4, Minj);
       store_sys(r + 5, S1);
@@ -1082,7 +1112,7 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a)
   // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
   for (int p = tid; p < a.n_theta; p += kFinalThreads) {
     double g = 0.0;
-    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * a.inj_grad[(long long)j * a.n_theta + p];
+    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
     store_sys(r + off_ginj + p, g);
   }
   __syncthreads();
@@ -1103,8 +1133,9 @@ __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered,
 __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a) {
   __shared__ double s_theta[GWI_MAX_THETA];
   __shared__ double s_red[kWaves];
-  const int tid = threadIdx.x, j = blockIdx.x;
-  for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = a.theta[p];
+  const int tid = threadIdx.x, j = blockIdx.x, kb = blockIdx.y;
+  const double* theta_src = a.tblocks ? a.tblocks[kb].theta : a.theta;
+  for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
   __syncthreads();
   const NormD nd = a.norms[j];
   double acc = 0.0;
@@ -1134,10 +1165,10 @@ __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a) {
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
-  if (tid == 0) store_sys(a.out_host + j, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  if (tid == 0) store_sys(a.out_host + kb * a.n_norms + j, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(a.stamps_host + j, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(a.stamps_host + kb * a.n_norms + j, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace gwi

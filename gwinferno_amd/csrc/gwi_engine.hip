@@ -30,6 +30,7 @@ struct Variant {
   int samples_per_lane;
   ScanFn scan;
   ScanFn logw;
+  ScanFn scan_batch;
 };
 
 #define K_PL GWI_TERM_POWERLAW
@@ -45,7 +46,8 @@ struct Variant {
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
-  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, U, __VA_ARGS__>, &scan_kernel<true, U, __VA_ARGS__> }
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, false, U, __VA_ARGS__>, \
+    &scan_kernel<true, false, U, __VA_ARGS__>, &scan_kernel<false, true, U, __VA_ARGS__> }
 #define GWI_VARIANT(NAME, ...) GWI_VARIANT_U(NAME, 2, __VA_ARGS__)
 
 // Term sequences are canonical: the host sorts a model's terms by kind id (stable).
@@ -219,8 +221,11 @@ struct gwi_engine {
 
   size_t scan_lds_bytes = 0;
   unsigned long long seq = 0;
-  // results of the last prelude
-  double host_const = 0.0;
+  // results of the last prelude (one per hyper-parameter point of the last launch)
+  std::vector<double> host_consts = std::vector<double>(1, 0.0);
+  // batched evaluation: up to max_batch hyper-parameter points per launch (blockIdx.y)
+  int max_batch = 16;
+  ThetaBlock *d_tblocks = nullptr, *h_tblocks = nullptr;
   // timing
   bool timing = false;
   bool spin_wait = true;
@@ -231,6 +236,7 @@ struct gwi_engine {
   double *d_send = nullptr, *d_recv = nullptr;
   double *h_gather = nullptr, *h_gather_dev = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_tblocks = nullptr;
   float last_ms[3] = {0, 0, 0};
   std::string err;
   KArgs kargs;
@@ -301,12 +307,11 @@ gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
 }
 
 // theta -> derived scalars of every term + the sample-independent log-normaliser total
-void prelude(gwi_engine* h, const double* theta) {
-  KArgs& k = h->kargs;
+void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*derived_out)[kMaxDerived], double* host_const) {
   double c = 0.0;
   for (int t = 0; t < h->spec.n_terms; ++t) {
     const gwi_term& tm = h->spec.terms[t];
-    double* d = k.derived[t];
+    double* d = derived_out[t];
     for (int i = 0; i < kMaxDerived; ++i) d[i] = 0.0;
     switch (tm.kind) {
       case GWI_TERM_POWERLAW: {
@@ -362,39 +367,52 @@ void prelude(gwi_engine* h, const double* theta) {
       default: break;
     }
   }
-  h->host_const = c;
-  std::memcpy(k.theta, theta, sizeof(double) * h->spec.n_theta);
+  *host_const = c;
+  std::memcpy(theta_out, theta, sizeof(double) * h->spec.n_theta);
 }
 
-gwi_status launch_scan(gwi_handle h, bool logw) {
+gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   const int grid = h->n_scan_blocks;
-  ScanFn fn = logw ? h->variant->logw : h->variant->scan;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), h->scan_lds_bytes, h->stream, h->kargs);
+  ScanFn fn = logw ? h->variant->logw : (batch ? h->variant->scan_batch : h->variant->scan);
+  hipLaunchKernelGGL(fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->stream, h->kargs);
   GWI_HIP(hipGetLastError());
   return GWI_OK;
 }
 
-gwi_status wait_for_stamp(gwi_handle h, double* host_buf);
-gwi_status wait_for_rows(gwi_handle h);
-gwi_status wait_for_norms(gwi_handle h, double* record);
+gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K = 1);
+gwi_status wait_for_rows(gwi_handle h, int K = 1);
+gwi_status wait_for_norms(gwi_handle h, double* record, int K = 1);
 
 // Normaliser grids: own stream, beside the scan; launched AFTER the main-stream kernels so that its
 // host-side launch cost is off the critical path.  `seq` is the stamp the waiters will look for.
-gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long seq) {
+gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long seq, int K = 1, bool batch = false) {
   if (h->spec.n_norms == 0) return GWI_OK;
-  std::memcpy(h->nargs.theta, theta, sizeof(double) * h->spec.n_theta);
+  if (!batch) std::memcpy(h->nargs.theta, theta, sizeof(double) * h->spec.n_theta);
+  h->nargs.tblocks = batch ? h->d_tblocks : nullptr;
   h->nargs.seq = seq;
-  hipLaunchKernelGGL(norm_kernel, dim3(h->spec.n_norms), dim3(kBlock), 0, h->norm_stream, h->nargs);
+  if (batch) GWI_HIP(hipStreamWaitEvent(h->norm_stream, h->ev_tblocks, 0));  // theta blocks are uploaded on the main stream
+  hipLaunchKernelGGL(norm_kernel, dim3(h->spec.n_norms, batch ? K : 1), dim3(kBlock), 0, h->norm_stream, h->nargs);
   GWI_HIP(hipGetLastError());
   return GWI_OK;
 }
 
 // launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
 // or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
-gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true) {
-  prelude(h, theta);
+gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false) {
+  const int n_theta = h->spec.n_theta;
+  if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
+  if (!batch) {
+    prelude(h, theta, h->kargs.theta, h->kargs.derived, &h->host_consts[0]);
+    h->kargs.tblocks = nullptr;
+  } else {
+    for (int k = 0; k < K; ++k) prelude(h, theta + (size_t)k * n_theta, h->h_tblocks[k].theta, h->h_tblocks[k].derived, &h->host_consts[k]);
+    GWI_HIP(hipMemcpyAsync(h->d_tblocks, h->h_tblocks, sizeof(ThetaBlock) * K, hipMemcpyHostToDevice, h->stream));
+    GWI_HIP(hipEventRecord(h->ev_tblocks, h->stream));
+    h->kargs.tblocks = h->d_tblocks;
+  }
+  const unsigned gy = batch ? (unsigned)K : 1u;
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[0], h->stream));
-  gwi_status st = launch_scan(h, false);
+  gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[1], h->stream));
   {
@@ -409,21 +427,22 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     ca.n_inj_tiles = h->n_inj_tiles;
     ca.n_inj_groups = h->n_inj_groups;
     ca.tiles_per_inj_group = h->tiles_per_inj_group;
-    ca.n_theta = h->spec.n_theta;
+    ca.n_theta = n_theta;
     ca.rec_stride = h->rec_stride;
+    ca.n_scan_blocks = h->n_scan_blocks;
     ca.n_pe = (double)h->n_pe;
     ca.ev_host = h->h_ev_dev;
     ca.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
     ca.seq = h->seq + 1;
-    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups)), dim3(kBlock), 0, h->stream, ca);
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(kBlock), 0, h->stream, ca);
     GWI_HIP(hipGetLastError());
     if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
     if (ca.host_rows) {
       ++h->seq;
       if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
-      gwi_status sn = launch_norms(h, theta, h->seq);
+      gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
       if (sn != GWI_OK) return sn;
-      return wait ? wait_for_rows(h) : GWI_OK;
+      return wait ? wait_for_rows(h, K) : GWI_OK;
     }
     FinalArgs fa;
     fa.ev_out = h->d_ev_out;
@@ -432,63 +451,68 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     fa.inj_grad = h->d_inj_grad;
     fa.record = record_dev ? record_dev : h->h_record_dev;
     fa.n_ev = (int)h->n_ev;
-    fa.n_theta = h->spec.n_theta;
+    fa.n_theta = n_theta;
     fa.n_norms = h->spec.n_norms;
     fa.n_inj_groups = h->n_inj_groups;
+    fa.record_len = record_len(h);
     fa.seq = ++h->seq;
-    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(kFinalThreads), 0, h->stream, fa);
+    hipLaunchKernelGGL(final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, h->stream, fa);
     GWI_HIP(hipGetLastError());
   }
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
   {
-    gwi_status sn = launch_norms(h, theta, h->seq);
+    gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
     if (sn != GWI_OK) return sn;
   }
   if (!wait) return GWI_OK;
-  gwi_status st_ = wait_for_stamp(h, h->h_record);
+  gwi_status st_ = wait_for_stamp(h, h->h_record, K);
   if (st_ != GWI_OK) return st_;
-  return wait_for_norms(h, h->h_record);
+  return wait_for_norms(h, h->h_record, K);
 }
 
 // the normaliser launch publishes Z_j + a stamp per normaliser; copy them into rank 0's record slots
-gwi_status wait_for_norms(gwi_handle h, double* record) {
+gwi_status wait_for_norms(gwi_handle h, double* record, int K) {
   const int n = h->spec.n_norms;
   if (n == 0) return GWI_OK;
+  const int total = n * K;
   bool done = false;
   for (long spin = 0; spin < 400000 && !done; ++spin) {
     done = true;
-    for (int j = 0; j < n; ++j) done = done && *reinterpret_cast<volatile unsigned long long*>(h->h_norm_stamp + j) == h->seq;
+    for (int j = 0; j < total; ++j) done = done && *reinterpret_cast<volatile unsigned long long*>(h->h_norm_stamp + j) == h->seq;
     if (!done) __builtin_ia32_pause();
   }
   if (!done) {
     GWI_HIP(hipStreamSynchronize(h->norm_stream));
-    for (int j = 0; j < n; ++j)
+    for (int j = 0; j < total; ++j)
       if (h->h_norm_stamp[j] != h->seq) return fail(h, GWI_ERR_HIP, "normaliser stamp mismatch after stream synchronise");
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (int j = 0; j < n; ++j) record[kRecNormOff + j] = h->h_norm[j];
+  const int len = record_len(h);
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < n; ++j) record[(size_t)k * len + kRecNormOff + j] = h->h_norm[k * n + j];
   return GWI_OK;
 }
 
-gwi_status wait_for_stamp(gwi_handle h, double* host_buf) {
+gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K) {
   // Completion: final_kernel stores the sequence stamp into pinned host memory LAST (system-scope
   // release after __threadfence_system), so the host can poll it instead of paying a stream
   // synchronise; after ~2 ms of polling fall back to the blocking call (and surface any error).
-  volatile unsigned long long* stamp = reinterpret_cast<volatile unsigned long long*>(host_buf);
+  const size_t len = (size_t)record_len(h);
+  auto stamp_of = [&](int k) { return *reinterpret_cast<volatile unsigned long long*>(host_buf + (size_t)k * len); };
   bool done = false;
   if (!h->timing && h->spin_wait) {
-    for (long spin = 0; spin < 400000; ++spin) {
-      if (*stamp == h->seq) {
-        done = true;
-        break;
-      }
-      __builtin_ia32_pause();
+    int k = 0;
+    for (long spin = 0; spin < 400000 && !done; ++spin) {
+      while (k < K && stamp_of(k) == h->seq) ++k;
+      done = k == K;
+      if (!done) __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
-    if (*stamp != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
+    for (int k = 0; k < K; ++k)
+      if (stamp_of(k) != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
   }
   if (h->timing) {
     for (int i = 0; i < 3; ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
@@ -497,7 +521,8 @@ gwi_status wait_for_stamp(gwi_handle h, double* host_buf) {
 }
 
 // Assemble the sites of analysis.py:259-319 from gathered per-rank records.
-void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi_options* opt, gwi_summary* out, double* grad, double* norms) {
+void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi_options* opt, gwi_summary* out, double* grad, double* norms,
+              double host_const) {
   const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
   const int len = record_len(h);
   const double NEG_BIG = -1.7976931348623157e308;  // jnp.nan_to_num(-inf)
@@ -525,7 +550,7 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
     }
   }
   const double* nrm = records + kRecNormOff;  // every rank integrates the same grids
-  double log_const = h->host_const;
+  double log_const = host_const;
   for (int t = 0; t < h->spec.n_terms; ++t)
     if (h->spec.terms[t].norm >= 0) log_const -= std::log(nrm[h->spec.terms[t].norm]);
   if (norms)
@@ -583,65 +608,70 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
 
 // Host-final mode: poll every group's stamp, then do what final_kernel does (fixed summation order)
 // into h_record so that assemble() is shared with the device-final and sharded paths.
-gwi_status wait_for_rows(gwi_handle h) {
+gwi_status wait_for_rows(gwi_handle h, int K) {
   const int n_groups = (int)h->n_ev + h->n_inj_groups;
   const int stride = 4 + h->spec.n_theta, n_theta = h->spec.n_theta;
+  const int total = n_groups * K;
   bool done = false;
   if (!h->timing && h->spin_wait) {
     int g = 0;
     for (long spin = 0; spin < 400000 && !done; ++spin) {
-      while (g < n_groups && *reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) == h->seq) ++g;
-      done = g == n_groups;
+      while (g < total && *reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) == h->seq) ++g;
+      done = g == total;
       if (!done) __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
-    for (int g = 0; g < n_groups; ++g)
+    for (int g = 0; g < total; ++g)
       if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq)
         return fail(h, GWI_ERR_HIP, "group stamp mismatch after stream synchronise");
   }
   if (h->timing) {
     for (int i = 0; i < 3; ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
   }
-  double* r = h->h_record;
-  const int n_ev = (int)h->n_ev, n_norms = h->spec.n_norms;
-  double sum = 0.0, var = 0.0, mn = INFINITY;
-  double* gpe = r + kRecNormOff + n_norms;
-  double* ginj = gpe + n_theta;
-  for (int p = 0; p < n_theta; ++p) gpe[p] = ginj[p] = 0.0;
-  for (int e = 0; e < n_ev; ++e) {
-    const double* row = h->h_rows + (size_t)e * stride;
-    sum += row[1];
-    var += row[3];
-    double le = row[2];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
-    if (le != le) le = 0.0;
-    le = std::fmin(std::fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
-    mn = std::fmin(mn, le);
-    h->h_ev[e] = row[1];
-    h->h_ev[n_ev + e] = row[2];
-    h->h_ev[2 * n_ev + e] = row[3];
-    for (int p = 0; p < n_theta; ++p) gpe[p] += row[4 + p];
+  const int n_ev = (int)h->n_ev, n_norms = h->spec.n_norms, len = record_len(h);
+  for (int k = 0; k < K; ++k) {
+    double* r = h->h_record + (size_t)k * len;
+    const double* rows = h->h_rows + (size_t)k * n_groups * stride;
+    double* ev = h->h_ev + (size_t)k * 3 * n_ev;
+    double sum = 0.0, var = 0.0, mn = INFINITY;
+    double* gpe = r + kRecNormOff + n_norms;
+    double* ginj = gpe + n_theta;
+    for (int p = 0; p < n_theta; ++p) gpe[p] = ginj[p] = 0.0;
+    for (int e = 0; e < n_ev; ++e) {
+      const double* row = rows + (size_t)e * stride;
+      sum += row[1];
+      var += row[3];
+      double le = row[2];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+      if (le != le) le = 0.0;
+      le = std::fmin(std::fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
+      mn = std::fmin(mn, le);
+      ev[e] = row[1];
+      ev[n_ev + e] = row[2];
+      ev[2 * n_ev + e] = row[3];
+      for (int p = 0; p < n_theta; ++p) gpe[p] += row[4 + p];
+    }
+    double M = -INFINITY;
+    for (int j = 0; j < h->n_inj_groups; ++j) M = std::fmax(M, rows[(size_t)(n_ev + j) * stride + 1]);
+    double S1 = 0.0, S2 = 0.0;
+    for (int j = 0; j < h->n_inj_groups; ++j) {
+      const double* row = rows + (size_t)(n_ev + j) * stride;
+      const double f = (row[1] == -INFINITY) ? 0.0 : std::exp(row[1] - M);
+      S1 += f * row[2];
+      S2 += f * f * row[3];
+      for (int p = 0; p < n_theta; ++p) ginj[p] += f * row[4 + p];
+    }
+    r[1] = sum;
+    r[2] = var;
+    r[3] = mn;
+    r[4] = M;
+    r[5] = S1;
+    r[6] = S2;
+    r[7] = (double)n_ev;
   }
-  double M = -INFINITY;
-  for (int j = 0; j < h->n_inj_groups; ++j) M = std::fmax(M, h->h_rows[(size_t)(n_ev + j) * stride + 1]);
-  double S1 = 0.0, S2 = 0.0;
-  for (int j = 0; j < h->n_inj_groups; ++j) {
-    const double* row = h->h_rows + (size_t)(n_ev + j) * stride;
-    const double f = (row[1] == -INFINITY) ? 0.0 : std::exp(row[1] - M);
-    S1 += f * row[2];
-    S2 += f * f * row[3];
-    for (int p = 0; p < n_theta; ++p) ginj[p] += f * row[4 + p];
-  }
-  r[1] = sum;
-  r[2] = var;
-  r[3] = mn;
-  r[4] = M;
-  r[5] = S1;
-  r[6] = S2;
-  r[7] = (double)n_ev;
-  return wait_for_norms(h, r);
+  return wait_for_norms(h, h->h_record, K);
 }
 
 void destroy_impl(gwi_engine* h) {
@@ -674,6 +704,9 @@ void destroy_impl(gwi_engine* h) {
   if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->ev_tblocks) (void)hipEventDestroy(h->ev_tblocks);
+  (void)hipFree(h->d_tblocks);
+  if (h->h_tblocks) (void)hipHostFree(h->h_tblocks);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -750,6 +783,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipStreamCreateWithFlags(&h->norm_stream, hipStreamNonBlocking));
   if (const char* env = std::getenv("GWI_SPIN_WAIT")) h->spin_wait = std::atoi(env) != 0;
   for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
+  GWI_HIP(hipEventCreateWithFlags(&h->ev_tblocks, hipEventDisableTiming));
+  if (const char* env = std::getenv("GWI_MAX_BATCH")) h->max_batch = std::atoi(env);
+  if (h->max_batch < 1) h->max_batch = 1;
+  if (h->max_batch > 64) h->max_batch = 64;
   h->n_ev = n_ev;
   h->n_pe = n_pe;
   h->n_inj = n_inj;
@@ -869,16 +906,19 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (!has_spline) rep = 1;
   h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
 
-  GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
-  GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * 4 * (size_t)(n_ev ? n_ev : 1)));
-  GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
-  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * 4 * (size_t)h->n_inj_groups));
-  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * (size_t)h->n_inj_groups * spec->n_theta));
-  GWI_HIP(hipHostMalloc((void**)&h->h_record, sizeof(double) * record_len(h), hipHostMallocMapped));
+  const size_t KB = (size_t)h->max_batch;  // every per-evaluation buffer holds max_batch hyper-parameter points
+  GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * KB * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
+  GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * KB * 4 * (size_t)(n_ev ? n_ev : 1)));
+  GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * KB * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
+  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * KB * 4 * (size_t)h->n_inj_groups));
+  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * KB * (size_t)h->n_inj_groups * spec->n_theta));
+  GWI_HIP(hipMalloc(&h->d_tblocks, sizeof(ThetaBlock) * KB));
+  GWI_HIP(hipHostMalloc((void**)&h->h_tblocks, sizeof(ThetaBlock) * KB, hipHostMallocDefault));
+  GWI_HIP(hipHostMalloc((void**)&h->h_record, sizeof(double) * KB * record_len(h), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_record_dev, h->h_record, 0));
-  GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
+  GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * KB * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_ev_dev, h->h_ev, 0));
-  std::memset(h->h_record, 0, sizeof(double) * record_len(h));
+  std::memset(h->h_record, 0, sizeof(double) * KB * record_len(h));
   // host-final mode for small problems: the per-group rows fit a few KiB, so the host sums them and
   // the third launch (final_kernel: ~1.5 us boundary + ~6-9 us of latency chain) disappears
   {
@@ -886,19 +926,21 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     const size_t row_bytes = sizeof(double) * n_groups * (4 + spec->n_theta);
     h->host_final = row_bytes <= 32 * 1024;
     if (const char* env = std::getenv("GWI_HOST_FINAL")) h->host_final = h->host_final && std::atoi(env) != 0;
-    GWI_HIP(hipHostMalloc((void**)&h->h_rows, row_bytes, hipHostMallocMapped));
+    GWI_HIP(hipHostMalloc((void**)&h->h_rows, KB * row_bytes, hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_rows_dev, h->h_rows, 0));
-    std::memset(h->h_rows, 0, row_bytes);
-    GWI_HIP(hipHostMalloc((void**)&h->h_norm, sizeof(double) * (spec->n_norms ? spec->n_norms : 1), hipHostMallocMapped));
+    std::memset(h->h_rows, 0, KB * row_bytes);
+    const size_t nn = KB * (size_t)(spec->n_norms ? spec->n_norms : 1);
+    GWI_HIP(hipHostMalloc((void**)&h->h_norm, sizeof(double) * nn, hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_dev, h->h_norm, 0));
-    GWI_HIP(hipHostMalloc((void**)&h->h_norm_stamp, sizeof(unsigned long long) * (spec->n_norms ? spec->n_norms : 1), hipHostMallocMapped));
+    GWI_HIP(hipHostMalloc((void**)&h->h_norm_stamp, sizeof(unsigned long long) * nn, hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_stamp_dev, h->h_norm_stamp, 0));
-    std::memset(h->h_norm_stamp, 0, sizeof(unsigned long long) * (spec->n_norms ? spec->n_norms : 1));
+    std::memset(h->h_norm_stamp, 0, sizeof(unsigned long long) * nn);
     std::memset(&h->nargs, 0, sizeof(h->nargs));
     h->nargs.norms = h->d_norms;
     h->nargs.out_host = h->h_norm_dev;
     h->nargs.stamps_host = h->h_norm_stamp_dev;
     h->nargs.n_theta = spec->n_theta;
+    h->nargs.n_norms = spec->n_norms;
   }
 
   // ---- constant part of the kernel-argument block
@@ -967,7 +1009,7 @@ int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
 
 gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
   if (!h || !theta) return GWI_ERR_INVALID;
-  prelude(h, theta);
+  prelude(h, theta, h->kargs.theta, h->kargs.derived, &h->host_consts[0]);
   return GWI_OK;
 }
 
@@ -992,7 +1034,7 @@ gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, con
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (opt->marginalize_selection && grad)
     return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
-  assemble(h, records, n_ranks, opt, summary, grad, norms);
+  assemble(h, records, n_ranks, opt, summary, grad, norms, h->host_consts[0]);
   return GWI_OK;
 }
 
@@ -1008,7 +1050,7 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
   gwi_status st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_record, 1, opt, &s, grad, norms);
+  assemble(h, h->h_record, 1, opt, &s, grad, norms, h->host_consts[0]);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1016,6 +1058,34 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
     for (size_t i = 0; i < n; ++i) log_bfs[i] = h->h_ev[i] + shift;  // logBF_i = logsumexp_i - log N_pe (analysis.py:80)
   if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
   if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
+  return GWI_OK;
+}
+
+gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries, double* grads,
+                          double* log_bfs, double* log_neffs, double* variances, double* norms) {
+  if (!h || !thetas || !opt || !h->variant || k_batch < 1) return GWI_ERR_INVALID;
+  if (k_batch > h->max_batch) return fail(h, GWI_ERR_INVALID, "k_batch exceeds the engine's max_batch (GWI_MAX_BATCH, default 16)");
+  if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
+    return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
+  if (opt->marginalize_selection && grads)
+    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
+  GWI_HIP(hipSetDevice(h->device));
+  gwi_status st = run_pipeline(h, thetas, nullptr, true, k_batch, true);
+  if (st != GWI_OK) return st;
+  const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
+  const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
+  for (int k = 0; k < k_batch; ++k) {
+    gwi_summary s;
+    assemble(h, h->h_record + k * len, 1, opt, &s, grads ? grads + (size_t)k * n_theta : nullptr, norms ? norms + (size_t)k * n_norms : nullptr, h->host_consts[k]);
+    if (summaries) summaries[k] = s;
+    const double* ev = h->h_ev + (size_t)k * 3 * n;
+    const double shift = s.log_norm_const - std::log((double)h->n_pe);
+    if (log_bfs)
+      for (size_t i = 0; i < n; ++i) log_bfs[k * n + i] = ev[i] + shift;
+    if (log_neffs) std::memcpy(log_neffs + k * n, ev + n, sizeof(double) * n);
+    if (variances) std::memcpy(variances + k * n, ev + 2 * n, sizeof(double) * n);
+  }
   return GWI_OK;
 }
 
@@ -1070,7 +1140,7 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
   st = wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms);
+  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms, h->host_consts[0]);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1114,7 +1184,7 @@ gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, d
   // normaliser values come from a regular evaluation
   gwi_status st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
-  double log_const = h->host_const;
+  double log_const = h->host_consts[0];
   const double* nrm = h->h_record + kRecNormOff;
   for (int t = 0; t < h->spec.n_terms; ++t)
     if (h->spec.terms[t].norm >= 0) log_const -= std::log(nrm[h->spec.terms[t].norm]);

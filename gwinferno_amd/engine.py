@@ -324,6 +324,23 @@ class NativePopulationLikelihood:
         return EvalResult(log_likelihood=b.summ.log_likelihood, grad=b.grad if want_grad else None, summary=b.summ, log_bfs=b.lb, log_neffs=b.ln, variances=b.lv,
                           norms=b.norms[:n_norms])
 
+    def evaluate_batch(self, thetas, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True):
+        """K hyper-parameter points in one set of launches (vectorised chains).  ``thetas``: (K, n_theta).
+        Returns a list of K :class:`EvalResult`."""
+        thetas = N.f64(thetas)
+        if thetas.ndim != 2 or thetas.shape[1] != self.n_theta:
+            raise ValueError(f"thetas must have shape (K, {self.n_theta})")
+        K = thetas.shape[0]
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        summ = (N.GwiSummary * K)()
+        grads = np.zeros((K, self.n_theta)) if want_grad else None
+        lb, ln, lv = np.zeros((K, self.n_ev)), np.zeros((K, self.n_ev)), np.zeros((K, self.n_ev))
+        n_norms = len(self.bound.norms)
+        norms = np.zeros((K, max(n_norms, 1)))
+        self._check(self.lib.gwi_eval_batch(self.handle, N.as_dp(thetas), K, C.byref(opt), summ, N.as_dp(grads), N.as_dp(lb), N.as_dp(ln), N.as_dp(lv), N.as_dp(norms)))
+        return [EvalResult(log_likelihood=summ[k].log_likelihood, grad=grads[k] if want_grad else None, summary=summ[k], log_bfs=lb[k], log_neffs=ln[k], variances=lv[k],
+                           norms=norms[k, :n_norms]) for k in range(K)]
+
     def configure(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
         """Fix the likelihood options once; :meth:`value_and_grad` then has the smallest possible
         per-call overhead (what a sampler's inner loop wants)."""

@@ -195,6 +195,15 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
 gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
                     double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
+/* k_batch hyper-parameter points in ONE set of launches (blockIdx.y = point): what vectorised
+ * multi-chain NUTS evaluates per step.  thetas[k_batch][n_theta] row-major; outputs are arrays of
+ * k_batch entries (summaries[k], grads[k][n_theta], log_bfs[k][n_ev], ..., norms[k][n_norms]; any may
+ * be NULL).  The catalog is streamed from HBM once per workgroup tile and re-read from L2/Infinity
+ * Cache for the other points; launch, combine and host latencies are paid once per batch.
+ * k_batch <= GWI_MAX_BATCH (environment, default 16, at most 64). */
+gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries,
+                          double* grads, double* log_bfs, double* log_neffs, double* variances, double* norms);
+
 /* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the
  * reference passes to hierarchical_likelihood as pe_weights / inj_weights (tests/inference_test.py:
  * 174-175).  Diagnostic / parity entry point; not used on the sampling path. */
