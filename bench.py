@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event kernel timing on every n-th timed step")
     args = ap.parse_args()
 
@@ -241,6 +242,19 @@ def main():
             "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
             "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,
         }
+        if dist is None and args.k_batch > 1:
+            # secondary number: vectorised chains -- K hyper-points per launch (not the headline `value`,
+            # which is one sequential chain)
+            K = args.k_batch
+            tb = np.stack(thetas[:K] if len(thetas) >= K else (thetas * K)[:K])
+            for _ in range(30):
+                eng.evaluate_batch(tb, total, min_neff_cut=False)
+            n_b = max(20, args.steps // (4 * K))
+            t0 = time.perf_counter()
+            for _ in range(n_b):
+                eng.evaluate_batch(tb, total, min_neff_cut=False)
+            dt = time.perf_counter() - t0
+            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(comp_name, pe, inj, total, pool)
     if dist is not None:
