@@ -1,9 +1,9 @@
 // gwi_device.h -- device side of the population-likelihood engine (gfx950 / CDNA4 only).
 //
 // One fused "scan" launch streams the catalog columns once and produces, per workgroup, a partial
-// record (running max m, S1 = sum e^{l-m}, S2 = sum e^{2(l-m)}, G[p] = sum e^{l-m} dl/dtheta_p);
-// extra workgroups of the same launch integrate the grid normalisers.  Two tiny launches then
-// combine records per event and over events.  Everything is fp64.
+// record (running max m, S1 = sum e^{l-m}, S2 = sum e^{2(l-m)}, G[p] = sum e^{l-m} dl/dtheta_p).
+// A small launch then combines records per event (and, for large problems, a third sums over
+// events); the grid normalisers are integrated by norm_kernel on a side stream.  Everything is fp64.
 //
 // Reference arithmetic being replaced (paths relative to the reference root):
 //   per-sample densities      gwinferno/distributions.py:100-162, models/parametric/parametric.py:27-145
