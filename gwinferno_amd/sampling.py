@@ -1,0 +1,160 @@
+"""A small Hamiltonian Monte Carlo driver for environments without jax/numpyro.
+
+The reference drives its model with ``numpyro.infer.NUTS`` (examples/utils.py:63-85), which needs
+``jit(value_and_grad(potential_fn))``.  Where numpyro is installed the drop-in
+``gwinferno_amd.likelihood.hierarchical_likelihood`` serves that unchanged; this module exists so that
+the engine can be exercised end to end -- prior + likelihood + sampler -- with NumPy only.  It is a plain
+HMC with dual-averaging step-size adaptation and a diagonal mass matrix estimated during warm-up; every
+leapfrog step costs exactly one engine evaluation (value + gradient), as in NUTS.
+
+``log_prob_and_grad(theta) -> (float, ndarray)`` is the full target: engine log-likelihood plus the
+user's log-prior, e.g. the Normal priors and P-spline smoothing priors of
+gwinferno/pipeline/utils.py:163-216.
+"""
+import numpy as np
+
+from .smoothing import apply_difference_prior
+
+
+class GaussianSmoothingPrior:
+    """Independent Normal(0, sigma) priors on named slices of theta plus optional P-spline difference
+    penalties (pipeline/utils.py:163-216): ``-0.5 * tau * ||D^deg c||^2``."""
+
+    def __init__(self, n_theta):
+        self.n_theta = n_theta
+        self.sigmas = np.full(n_theta, np.inf)
+        self.penalties = []  # (slice, tau, degree)
+
+    def normal(self, sl, sigma):
+        self.sigmas[sl] = sigma
+        return self
+
+    def smoothing(self, sl, tau, degree):
+        self.penalties.append((sl, float(tau), int(degree)))
+        return self
+
+    def __call__(self, theta):
+        with np.errstate(divide="ignore"):
+            inv_var = np.where(np.isfinite(self.sigmas), 1.0 / self.sigmas**2, 0.0)
+        lp = -0.5 * np.sum(inv_var * theta**2)
+        grad = -inv_var * theta
+        for sl, tau, deg in self.penalties:
+            c = theta[sl]
+            lp += apply_difference_prior(c, tau, deg)
+            d = c
+            for _ in range(deg):
+                d = d[1:] - d[:-1]
+            # gradient of -0.5 tau ||D^deg c||^2 = -tau (D^deg)^T (D^deg c)
+            g = d
+            for _ in range(deg):
+                g = np.concatenate([[-g[0]], g[:-1] - g[1:], [g[-1]]])
+            grad[sl] -= tau * g
+        return lp, grad
+
+
+class Bijector:
+    """Unconstrained u -> constrained theta, elementwise, with log|d theta/d u| (what numpyro's
+    ``biject_to(support)`` does for Uniform / HalfNormal / positive sites, e.g.
+    examples/simple_powerlaw_peak_example.py:52-77)."""
+
+    def __init__(self, n_theta):
+        self.kind = np.zeros(n_theta, dtype=int)  # 0 identity, 1 interval(lo, hi), 2 positive
+        self.lo = np.zeros(n_theta)
+        self.hi = np.ones(n_theta)
+
+    def interval(self, idx, lo, hi):
+        self.kind[idx], self.lo[idx], self.hi[idx] = 1, lo, hi
+        return self
+
+    def positive(self, idx):
+        self.kind[idx] = 2
+        return self
+
+    def forward(self, u):
+        """theta, d theta/d u, d log|J| / d u, log|J|"""
+        sig = 1.0 / (1.0 + np.exp(-u))
+        width = self.hi - self.lo
+        theta = np.where(self.kind == 1, self.lo + width * sig, np.where(self.kind == 2, np.exp(u), u))
+        dth = np.where(self.kind == 1, width * sig * (1 - sig), np.where(self.kind == 2, np.exp(u), 1.0))
+        with np.errstate(divide="ignore"):
+            logj = np.where(self.kind == 1, np.log(width * sig * (1 - sig)), np.where(self.kind == 2, u, 0.0))
+        dlogj = np.where(self.kind == 1, 1 - 2 * sig, np.where(self.kind == 2, 1.0, 0.0))
+        return theta, dth, dlogj, float(np.sum(logj))
+
+    def inverse(self, theta):
+        with np.errstate(all="ignore"):
+            x = (theta - self.lo) / (self.hi - self.lo)
+            return np.where(self.kind == 1, np.log(x / (1 - x)), np.where(self.kind == 2, np.log(theta), theta))
+
+
+def make_target(engine, total_inj, prior, bijector=None, **likelihood_flags):
+    """u -> (log posterior, gradient) in the sampler's (unconstrained) coordinates, using the engine's
+    lean value_and_grad entry; ``prior`` acts on the constrained theta."""
+    vg = engine.configure(total_inj, **likelihood_flags)
+
+    def target(u):
+        if bijector is None:
+            theta, dth, dlogj, logj = u, 1.0, 0.0, 0.0
+        else:
+            theta, dth, dlogj, logj = bijector.forward(u)
+        ll, g = vg(theta)
+        lp, gp = prior(theta)
+        return ll + lp + logj, (g + gp) * dth + dlogj
+
+    return target
+
+
+def hmc(target, theta0, n_warmup=200, n_samples=200, n_leapfrog=8, target_accept=0.8, seed=0, progress=None):
+    """Returns dict(samples, log_prob, accept_rate, step_size, n_evals)."""
+    rng = np.random.default_rng(seed)
+    theta = np.array(theta0, dtype=np.float64)
+    dim = theta.size
+    lp, grad = target(theta)
+    n_evals = 1
+    inv_mass = np.ones(dim)
+    # dual averaging (Hoffman & Gelman 2014, algorithm 5)
+    eps = 0.01
+    mu, log_eps_bar, h_bar, gamma, t0, kappa = np.log(10 * eps), 0.0, 0.0, 0.05, 10.0, 0.75
+    samples, lps, accepts = [], [], []
+    warm = []
+    for it in range(n_warmup + n_samples):
+        p0 = rng.normal(size=dim) / np.sqrt(inv_mass)
+        th, g, p = theta.copy(), grad.copy(), p0.copy()
+        cur_lp = lp
+        h0 = -cur_lp + 0.5 * np.sum(inv_mass * p0**2)
+        ok = True
+        for _ in range(n_leapfrog):
+            p = p + 0.5 * eps * g
+            th = th + eps * inv_mass * p
+            new_lp, g = target(th)
+            n_evals += 1
+            if not np.isfinite(new_lp) or new_lp < -1e300 or not np.all(np.isfinite(g)):
+                ok = False
+                break
+            p = p + 0.5 * eps * g
+        if ok:
+            h1 = -new_lp + 0.5 * np.sum(inv_mass * p**2)
+            acc = float(min(1.0, np.exp(min(0.0, h0 - h1))))
+        else:
+            acc = 0.0
+        if rng.uniform() < acc:
+            theta, lp, grad = th, new_lp, g
+        if it < n_warmup:
+            m = it + 1
+            h_bar = (1 - 1 / (m + t0)) * h_bar + (target_accept - acc) / (m + t0)
+            log_eps = mu - np.sqrt(m) / gamma * h_bar
+            log_eps_bar = m**-kappa * log_eps + (1 - m**-kappa) * log_eps_bar
+            eps = float(np.exp(log_eps))
+            warm.append(theta.copy())
+            if m == n_warmup // 2 and len(warm) > 20:  # one diagonal mass-matrix update mid warm-up
+                var = np.var(np.array(warm[len(warm) // 2 :]), axis=0)
+                inv_mass = np.where(var > 1e-12, var, 1.0)
+            if m == n_warmup:
+                eps = float(np.exp(log_eps_bar))
+        else:
+            samples.append(theta.copy())
+            lps.append(lp)
+            accepts.append(acc)
+        if progress and (it + 1) % progress == 0:
+            print(f"[hmc] iter {it + 1}: log_prob {lp:.3f} step {eps:.4g}", flush=True)
+    return {"samples": np.array(samples), "log_prob": np.array(lps), "accept_rate": float(np.mean(accepts)) if accepts else 0.0, "step_size": eps, "n_evals": n_evals}

@@ -103,3 +103,34 @@ def test_numpyro_distribution_log_prob_faces_bind_like_models():
             ok = np.isfinite(ref)
             assert np.array_equal(np.isfinite(got), ok)
             assert np.max(np.abs(got[ok] - ref[ok])) < 1e-11
+
+
+def test_prior_gradient_matches_finite_differences():
+    from gwinferno_amd.sampling import GaussianSmoothingPrior
+
+    rng = np.random.default_rng(0)
+    th = rng.normal(size=20)
+    prior = GaussianSmoothingPrior(20).normal(slice(0, 20), 3.0).smoothing(slice(2, 14), 5.0, 1).smoothing(slice(4, 20), 25.0, 2)
+    lp, g = prior(th)
+    for i in range(20):
+        e = np.zeros(20)
+        e[i] = 1e-6
+        fd = (prior(th + e)[0] - prior(th - e)[0]) / 2e-6
+        assert abs(fd - g[i]) < 1e-6 * max(1.0, abs(g[i]))
+
+
+def test_bijector_roundtrip_and_jacobian():
+    from gwinferno_amd.sampling import Bijector
+
+    b = Bijector(4).interval(1, 5.0, 100.0).positive(2).interval(3, 0.0, 1.0)
+    th = np.array([-2.5, 35.0, 4.0, 0.1])
+    u = b.inverse(th)
+    th2, dth, dlogj, logj = b.forward(u)
+    assert np.allclose(th2, th)
+    for i in range(4):
+        e = np.zeros(4)
+        e[i] = 1e-6
+        fd = (b.forward(u + e)[0][i] - b.forward(u - e)[0][i]) / 2e-6
+        assert abs(fd - dth[i]) < 1e-6
+        fdj = (b.forward(u + e)[3] - b.forward(u - e)[3]) / 2e-6
+        assert abs(fdj - dlogj[i]) < 1e-6
