@@ -1,0 +1,376 @@
+/* gwpop_oracle.c -- CPU ORACLE / BASELINE, TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Plain-C (OpenMP) restatement of the hierarchical population likelihood hot path for the flat model
+ * description of include/gwi_engine.h: per-sample densities (gwinferno/distributions.py:100-162,
+ * models/parametric/parametric.py:27-145), uniform cubic B-spline projection
+ * (gwinferno/interpolation.py:98-149, 293-317, 381-394), grid normalisers (:280-291,
+ * parametric.py:123-124, spline_perturbation.py:323-336), importance-sampling reductions
+ * (pipeline/analysis.py:50-136) and the assembly of log_l with its cuts (:259-319), value AND gradient.
+ * It is pinned against the golden vectors of the unmodified reference through
+ * tests/test_c_oracle.py, and is what bench.py times as `cpu_baseline` (kind "port") on all host cores.
+ * Only tests/, __graft_entry__ and bench.py's cpu_baseline leg may load it; the product never does.
+ *
+ * Scalar straight-line code on purpose: one sample at a time, libm transcendentals, a running
+ * maximum with rescaling -- no relation to the GPU kernels' organisation.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/gwi_engine.h"
+
+#define NEG_BIG (-1.7976931348623157e308)
+
+typedef struct {
+  double m, s1, s2;
+  double g[GWI_MAX_THETA];
+} acc_t;
+
+static void acc_init(acc_t* a) {
+  a->m = -INFINITY;
+  a->s1 = a->s2 = 0.0;
+  memset(a->g, 0, sizeof(a->g));
+}
+
+static void acc_rescale(acc_t* a, double new_m, int n_theta) {
+  if (a->m == -INFINITY) {
+    a->m = new_m;
+    return;
+  }
+  const double sc = exp(a->m - new_m);
+  a->s1 *= sc;
+  a->s2 *= sc * sc;
+  for (int p = 0; p < n_theta; ++p) a->g[p] *= sc;
+  a->m = new_m;
+}
+
+static void acc_merge(acc_t* dst, const acc_t* src, int n_theta) {
+  if (src->m == -INFINITY) return;
+  if (src->m > dst->m) acc_rescale(dst, src->m, n_theta);
+  const double f = exp(src->m - dst->m);
+  dst->s1 += f * src->s1;
+  dst->s2 += f * f * src->s2;
+  for (int p = 0; p < n_theta; ++p) dst->g[p] += f * src->g[p];
+}
+
+static void pl_lognorm(double alpha, double lo, double hi, double* la, double* dla) {
+  const double a1 = 1.0 + alpha, llo = log(lo), lhi = log(hi);
+  if (a1 == 0.0) {
+    *la = -log(lhi - llo);
+    *dla = -0.5 * (lhi + llo);
+    return;
+  }
+  const double ph = pow(hi, a1), pw = pow(lo, a1);
+  *la = log(a1 / (ph - pw)); /* distributions.py:115 */
+  *dla = 1.0 / a1 - (ph * lhi - pw * llo) / (ph - pw);
+}
+
+static void tn_lognorm(double mu, double sg, double lo, double hi, double* lc, double* dmu, double* dsg) {
+  const double r2 = sqrt(2.0), a = (lo - mu) / sg, b = (hi - mu) / sg;
+  const double dphi = 0.5 * (1.0 + erf(b / r2)) - 0.5 * (1.0 + erf(a / r2)); /* distributions.py:138-140 */
+  const double c = 1.0 / sqrt(2.0 * M_PI);
+  const double pa = exp(-0.5 * a * a) * c, pb = exp(-0.5 * b * b) * c;
+  *lc = -log(sg) - 0.5 * log(2.0 * M_PI) - log(dphi);
+  *dmu = (pb - pa) / (sg * dphi);
+  *dsg = -1.0 / sg + (b * pb - a * pa) / (sg * dphi);
+}
+
+static void taps(double t, double b[4]) {
+  const double o = 1.0 - t;
+  b[0] = o * o * o / 6.0;
+  b[1] = (3.0 * t * t * t - 6.0 * t * t + 4.0) / 6.0;
+  b[2] = (-3.0 * t * t * t + 3.0 * t * t + 3.0 * t + 1.0) / 6.0;
+  b[3] = t * t * t / 6.0;
+}
+
+static int locate(double x, double lo, double hi, int n_basis, double* t) {
+  const int n_int = n_basis - 3;
+  const double u = (x - lo) * ((double)n_int / (hi - lo));
+  int k = (int)floor(u);
+  if (k < 0) k = 0;
+  if (k > n_int - 1) k = n_int - 1;
+  *t = u - (double)k;
+  return k;
+}
+
+/* log weight (without sample-independent constants) and d(log weight)/d theta of ONE sample */
+static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t idx, const double* th, const double (*der)[8], double* d) {
+  double ell = cols[sp->kappa_col][idx];
+  for (int t = 0; t < sp->n_terms && ell > -INFINITY; ++t) {
+    const gwi_term* tm = &sp->terms[t];
+    const double x0 = cols[tm->cols[0]][idx];
+    switch (tm->kind) {
+      case GWI_TERM_POWERLAW:
+        ell += th[tm->theta[0]] * x0;
+        d[tm->theta[0]] += x0;
+        break;
+      case GWI_TERM_PLPEAK: {
+        const double lx = cols[tm->cols[1]][idx];
+        const double al = th[tm->theta[0]], mu = th[tm->theta[1]], sg = th[tm->theta[2]], lam = th[tm->theta[3]];
+        const double epl = exp(al * lx + der[t][0]), etn = exp(-0.5 * (x0 - mu) * (x0 - mu) / (sg * sg) + der[t][2]);
+        const double P = (1.0 - lam) * epl, T = lam * etn, p = P + T;
+        ell += log(p);
+        d[tm->theta[0]] += P * (lx + der[t][1]) / p;
+        d[tm->theta[1]] += T * ((x0 - mu) / (sg * sg) + der[t][3]) / p;
+        d[tm->theta[2]] += T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p;
+        d[tm->theta[3]] += (etn - epl) / p;
+        break;
+      }
+      case GWI_TERM_POWERLAW_RATIO: {
+        const double lr = tm->p[0] - cols[tm->cols[1]][idx], beta = th[tm->theta[0]], b1 = 1.0 + beta;
+        if (b1 == 0.0) {
+          ell += -x0 - log(-lr);
+          d[tm->theta[0]] += x0 - 0.5 * lr;
+        } else {
+          const double E = exp(b1 * lr);
+          ell += beta * x0 + log(b1 / (1.0 - E));
+          d[tm->theta[0]] += x0 + 1.0 / b1 + E * lr / (1.0 - E);
+        }
+        break;
+      }
+      case GWI_TERM_BETA: {
+        const double l1 = cols[tm->cols[1]][idx];
+        ell += (th[tm->theta[0]] - 1.0) * x0 + (th[tm->theta[1]] - 1.0) * l1;
+        d[tm->theta[0]] += x0;
+        d[tm->theta[1]] += l1;
+        break;
+      }
+      case GWI_TERM_TILT_MIXTURE: {
+        const double xi = th[tm->theta[0]], sg = th[tm->theta[1]];
+        const double e = exp(-0.5 * (x0 - 1.0) * (x0 - 1.0) / (sg * sg) + der[t][0]);
+        const double p = 0.5 * (1.0 - xi) + xi * e;
+        ell += log(p);
+        d[tm->theta[0]] += (e - 0.5) / p;
+        d[tm->theta[1]] += xi * e * ((x0 - 1.0) * (x0 - 1.0) / (sg * sg * sg) + der[t][1]) / p;
+        break;
+      }
+      case GWI_TERM_TILT_JOINT: {
+        const double x1 = cols[tm->cols[1]][idx], xi = th[tm->theta[0]], sg = th[tm->theta[1]];
+        const double r2 = (x0 - 1.0) * (x0 - 1.0) + (x1 - 1.0) * (x1 - 1.0);
+        const double A = exp(-0.5 * r2 / (sg * sg) + 2.0 * der[t][0]);
+        const double p = 0.25 * (1.0 - xi) + xi * A;
+        ell += log(p);
+        d[tm->theta[0]] += (A - 0.25) / p;
+        d[tm->theta[1]] += xi * A * (r2 / (sg * sg * sg) + 2.0 * der[t][1]) / p;
+        break;
+      }
+      case GWI_TERM_TRUNCNORM: {
+        const double mu = th[tm->theta[0]], sg = th[tm->theta[1]];
+        ell += -0.5 * (x0 - mu) * (x0 - mu) / (sg * sg);
+        d[tm->theta[0]] += (x0 - mu) / (sg * sg);
+        d[tm->theta[1]] += (x0 - mu) * (x0 - mu) / (sg * sg * sg);
+        break;
+      }
+      case GWI_TERM_POWERLAW_REDSHIFT:
+        ell += (th[tm->theta[0]] - 1.0) * x0;
+        d[tm->theta[0]] += x0;
+        break;
+      case GWI_TERM_EXP_SPLINE:
+      case GWI_TERM_LINEAR_SPLINE: {
+        double tt, b[4];
+        const int inside = (x0 >= tm->p[0]) && (x0 <= tm->p[1]);
+        const int k = locate(x0, tm->p[0], tm->p[1], tm->n_basis, &tt);
+        taps(tt, b);
+        const double* c = th + tm->coef_off + k;
+        const double v = c[0] * b[0] + c[1] * b[1] + c[2] * b[2] + c[3] * b[3];
+        if (tm->kind == GWI_TERM_EXP_SPLINE) {
+          if ((tm->flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) && !inside) break; /* basis 0 outside: factor 1 */
+          ell += v;
+          for (int j = 0; j < 4; ++j) d[tm->coef_off + k + j] += b[j];
+        } else {
+          if (!inside || !(v > 0.0)) {
+            ell = -INFINITY;
+            break;
+          }
+          ell += log(v);
+          for (int j = 0; j < 4; ++j) d[tm->coef_off + k + j] += b[j] / v;
+        }
+        break;
+      }
+      default: ell = NAN;
+    }
+  }
+  if (!(ell < INFINITY)) ell = -INFINITY; /* NaN / +inf weights count as zero (tests/inference_test.py:172) */
+  return ell;
+}
+
+static void scan_range(const gwi_spec* sp, const double* const* cols, int64_t lo, int64_t hi, const double* th, const double (*der)[8], acc_t* out) {
+  const int n_theta = sp->n_theta;
+  acc_init(out);
+  double d[GWI_MAX_THETA];
+  for (int64_t i = lo; i < hi; ++i) {
+    memset(d, 0, sizeof(double) * n_theta);
+    const double ell = sample_logw(sp, cols, i, th, der, d);
+    if (ell == -INFINITY) continue;
+    if (ell > out->m) acc_rescale(out, ell, n_theta);
+    const double w = exp(ell - out->m);
+    out->s1 += w;
+    out->s2 += w * w;
+    for (int p = 0; p < n_theta; ++p) out->g[p] += w * d[p];
+  }
+}
+
+static double grid_norm(const gwi_norm* nm, const double* th) {
+  double z = 0.0;
+  for (int g = 0; g < nm->n_pts; ++g) {
+    double e = nm->lb ? nm->lb[g] : 0.0;
+    if (nm->expo_theta >= 0) e += (th[nm->expo_theta] + nm->expo_add) * nm->l1[g];
+    if (nm->n_basis > 0) {
+      double tt, b[4];
+      const double x = nm->us[g];
+      const int k = locate(x, nm->lo, nm->hi, nm->n_basis, &tt);
+      taps(tt, b);
+      const double* c = th + nm->coef_off + k;
+      double v = c[0] * b[0] + c[1] * b[1] + c[2] * b[2] + c[3] * b[3];
+      if ((nm->spline_flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nm->lo) && (x <= nm->hi))) v = 0.0;
+      if (nm->spline_flags & GWI_NORM_LINEAR_SPLINE) {
+        z += nm->tw[g] * v;
+        continue;
+      }
+      e += v;
+    }
+    if (nm->tw[g] != 0.0) z += nm->tw[g] * exp(e);
+  }
+  return z;
+}
+
+/* One value-and-gradient evaluation.  Outputs as gwi_eval (include/gwi_engine.h). */
+int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
+             const double* th, const gwi_options* opt, gwi_summary* out, double* grad, double* log_bfs, double* log_neffs, double* variances,
+             double* norms_out, int n_threads) {
+  const int n_theta = sp->n_theta;
+  double der[GWI_MAX_TERMS][8];
+  memset(der, 0, sizeof(der));
+  double host_const = 0.0;
+  for (int t = 0; t < sp->n_terms; ++t) {
+    const gwi_term* tm = &sp->terms[t];
+    double a, b, c;
+    switch (tm->kind) {
+      case GWI_TERM_POWERLAW:
+        if (!(tm->flags & GWI_POWERLAW_UNNORMALISED)) {
+          pl_lognorm(th[tm->theta[0]], tm->p[0], tm->p[1], &a, &b);
+          host_const += a;
+        }
+        break;
+      case GWI_TERM_PLPEAK:
+        pl_lognorm(th[tm->theta[0]], tm->p[0], tm->p[1], &der[t][0], &der[t][1]);
+        tn_lognorm(th[tm->theta[1]], th[tm->theta[2]], tm->p[0], tm->p[1], &der[t][2], &der[t][3], &der[t][4]);
+        break;
+      case GWI_TERM_BETA: host_const -= lgamma(th[tm->theta[0]]) + lgamma(th[tm->theta[1]]) - lgamma(th[tm->theta[0]] + th[tm->theta[1]]); break;
+      case GWI_TERM_TILT_MIXTURE:
+      case GWI_TERM_TILT_JOINT: tn_lognorm(1.0, th[tm->theta[1]], -1.0, 1.0, &der[t][0], &a, &der[t][1]); break;
+      case GWI_TERM_TRUNCNORM:
+        tn_lognorm(th[tm->theta[0]], th[tm->theta[1]], tm->p[0], tm->p[1], &a, &b, &c);
+        host_const += a;
+        break;
+      default: break;
+    }
+  }
+  double norms[GWI_MAX_NORMS];
+  for (int j = 0; j < sp->n_norms; ++j) norms[j] = grid_norm(&sp->norms[j], th);
+  double log_const = host_const;
+  for (int t = 0; t < sp->n_terms; ++t)
+    if (sp->terms[t].norm >= 0) log_const -= log(norms[sp->terms[t].norm]);
+  if (norms_out) memcpy(norms_out, norms, sizeof(double) * sp->n_norms);
+
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+  /* events in parallel; injections in parallel chunks merged in chunk order */
+  double* ev = (double*)malloc(sizeof(double) * (size_t)n_ev * (3 + n_theta));
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t e = 0; e < n_ev; ++e) {
+    acc_t a;
+    scan_range(sp, pe_cols, e * n_pe, (e + 1) * n_pe, th, der, &a);
+    double* row = ev + e * (3 + n_theta);
+    const double log_s1 = log(a.s1);
+    row[0] = log_s1 + a.m;                 /* logsumexp */
+    row[1] = 2.0 * log_s1 - log(a.s2);     /* log n_eff (analysis.py:79) */
+    row[2] = 1.0 / exp(row[1]) - 1.0 / (double)n_pe;
+    for (int p = 0; p < n_theta; ++p) row[3 + p] = a.s1 > 0.0 ? a.g[p] / a.s1 : 0.0;
+  }
+  const int n_chunks = 64;
+  acc_t* parts = (acc_t*)malloc(sizeof(acc_t) * n_chunks);
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < n_chunks; ++c) scan_range(sp, inj_cols, n_inj * c / n_chunks, n_inj * (c + 1) / n_chunks, th, der, &parts[c]);
+  acc_t inj;
+  acc_init(&inj);
+  for (int c = 0; c < n_chunks; ++c) acc_merge(&inj, &parts[c], n_theta);
+  free(parts);
+
+  /* assembly: analysis.py:259-319 */
+  const double n_obs = opt->n_obs, n_tot = opt->total_inj;
+  double sum_lse = 0.0, sum_var = 0.0, min_lneff = INFINITY;
+  for (int64_t e = 0; e < n_ev; ++e) {
+    const double* row = ev + e * (3 + n_theta);
+    sum_lse += row[0];
+    sum_var += row[2];
+    double le = row[1];
+    if (le != le) le = 0.0;
+    le = fmin(fmax(le, NEG_BIG), -NEG_BIG);
+    min_lneff = fmin(min_lneff, le);
+    if (log_bfs) log_bfs[e] = row[0] - log((double)n_pe) + log_const;
+    if (log_neffs) log_neffs[e] = row[1];
+    if (variances) variances[e] = row[2];
+  }
+  gwi_summary s;
+  memset(&s, 0, sizeof(s));
+  s.log_norm_const = log_const;
+  s.sum_logBFs = sum_lse + (double)n_ev * (log_const - log((double)n_pe));
+  const double log_mu = log(inj.s1) + inj.m - log(n_tot) + log_const;
+  const double log_neff_inj = 2.0 * log(inj.s1) - log(inj.s2 - inj.s1 * inj.s1 / n_tot);
+  const double var_mu = 1.0 / exp(log_neff_inj) - 1.0 / n_tot;
+  s.log_det_eff = log_mu;
+  s.log_nEff_inj = log_neff_inj;
+  s.variance_log_detection_efficiency = var_mu;
+  s.min_log_nEff = min_lneff;
+  s.surveyed_hypervolume_norm = sp->vt_norm >= 0 ? norms[sp->vt_norm] : NAN;
+  double lde = log_mu;
+  int cut = 0;
+  if (opt->marginalize_selection) lde -= (3.0 + n_obs) / (2.0 * exp(log_neff_inj));
+  if (opt->min_neff_cut && !(log_neff_inj >= log(4.0 * n_obs))) lde = INFINITY;
+  s.selection_factor = isinf(lde) ? NEG_BIG : -n_obs * lde;
+  if (isinf(lde)) cut = 1;
+  double log_l = s.selection_factor + s.sum_logBFs;
+  if (isnan(log_l)) {
+    log_l = NEG_BIG;
+    cut = 1;
+  } else if (isinf(log_l)) {
+    log_l = log_l > 0 ? -NEG_BIG : NEG_BIG;
+    cut = 1;
+  }
+  s.log_l = log_l;
+  if (opt->min_neff_cut && exp(min_lneff) <= n_obs) {
+    log_l = NEG_BIG;
+    cut = 1;
+  }
+  s.variance_log_likelihood = n_obs * n_obs * var_mu + sum_var;
+  if (opt->max_variance_cut && !(s.variance_log_likelihood <= 1.0)) {
+    log_l = NEG_BIG;
+    cut = 1;
+  }
+  s.log_likelihood = log_l;
+  if (out) *out = s;
+  if (grad) {
+    for (int p = 0; p < n_theta; ++p) {
+      double g = 0.0;
+      for (int64_t e = 0; e < n_ev; ++e) g += ev[e * (3 + n_theta) + 3 + p];
+      grad[p] = cut ? 0.0 : g - n_obs * (inj.s1 > 0.0 ? inj.g[p] / inj.s1 : 0.0);
+    }
+  }
+  free(ev);
+  return 0;
+}
+
+int gwo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,49 @@
+"""CPU: pin the C/OpenMP restatement (oracle/gwpop_oracle.c, the `cpu_baseline` of bench.py) against
+the golden vectors of the unmodified reference: every site of every case / hyper-point, and the
+gradient against the reference's finite differences."""
+import numpy as np
+import pytest
+from golden_util import CASES, GoldenCase, rel_err
+
+from gwinferno_amd.compositions import COMPOSITIONS
+from gwinferno_amd.engine import bind
+from oracle.c_oracle import COracle
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_oracle_sites_and_gradient(name):
+    case = GoldenCase(name)
+    comp = COMPOSITIONS[case.composition](case.pe, case.inj, mmin=case.meta["mmin"], mmax=case.meta["mmax"])
+    p0 = case.point(0)
+    bm = bind(comp.weights(p0, True), comp.weights(p0, False), comp.hypervolume(p0))
+    orc = COracle(bm)
+    comp._engine = type("E", (), {"bound": bm})()
+    for fs, flags in case.flagsets.items():
+        flags = {k: v for k, v in flags.items() if k != "log"}
+        for i in range(case.n_points):
+            got = orc.evaluate(bm.theta_of(comp.weights(case.point(i), True)), case.total_inj, **flags)
+            s = got["summary"]
+            pairs = {
+                "log_likelihood": s.log_likelihood, "log_l": s.log_l, "sum_logBFs": s.sum_logBFs, "selection_factor": s.selection_factor,
+                "log_nEff_inj": s.log_nEff_inj, "detection_efficiency": np.exp(s.log_det_eff), "logBFs": got["logBFs"], "log_nEffs": got["log_nEffs"],
+                "surveyed_hypervolume": s.surveyed_hypervolume_norm / 1e9 * case.tobs,
+            }
+            for site, val in pairs.items():
+                assert rel_err(val, case.sites[fs][site][i]) < 1e-9, (name, fs, i, site)
+            assert np.allclose(s.variance_log_likelihood, case.sites[fs]["variance_log_likelihood"][i], rtol=1e-8, atol=1e-12)
+    for i, fd in case.fdgrad.items():
+        g = comp.named_gradient(orc.evaluate(bm.theta_of(comp.weights(case.point(i), True)), case.total_inj, min_neff_cut=False)["grad"])
+        for pname, ref in fd.items():
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname)
+
+
+def test_thread_count_does_not_change_values():
+    case = GoldenCase("bspline_full")
+    comp = COMPOSITIONS[case.composition](case.pe, case.inj)
+    p0 = case.point(0)
+    bm = bind(comp.weights(p0, True), comp.weights(p0, False), comp.hypervolume(p0))
+    orc = COracle(bm)
+    th = bm.theta_of(comp.weights(p0, True))
+    a, b = orc.evaluate(th, case.total_inj, min_neff_cut=False, n_threads=1), orc.evaluate(th, case.total_inj, min_neff_cut=False, n_threads=4)
+    assert a["log_likelihood"] == b["log_likelihood"] and np.array_equal(a["grad"], b["grad"])
