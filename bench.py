@@ -67,10 +67,27 @@ def cpu_baseline(comp, thetas, total, budget_s=10.0):
     from oracle.c_oracle import COracle
 
     orc = COracle(comp.engine().bound)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota of the container, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = max(1, min(avail, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    # the visible CPU count can exceed what the container may really use: probe a few thread counts
+    # (one evaluation each) and keep the fastest
+    best, cores = None, 1
+    for nt in sorted({1, 2, 4, 8, 16, 32, 64, 128, avail}):
+        if nt > avail:
+            continue
+        orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
+        t0 = time.perf_counter()
+        orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, nt
     n, t_used = 0, 0.0
-    while t_used < budget_s and n < 4 * len(thetas):
+    while t_used < budget_s:
         t0 = time.perf_counter()
         orc.evaluate(thetas[n % len(thetas)], total, min_neff_cut=False, n_threads=cores)
         t_used += time.perf_counter() - t0
