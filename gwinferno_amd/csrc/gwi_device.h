@@ -46,6 +46,27 @@ struct ThetaBlock {
   double derived[GWI_MAX_TERMS][kMaxDerived];
 };
 
+// Arguments of the two launches after the scan: combine_kernel (tile records of a group -- an event,
+// or a run of injection tiles -- to one result per group) and final_kernel (sum over groups).
+struct TailArgs {
+  const double* partials;
+  double* ev_out;     // [n_ev][4]: logsumexp (= log sum_j w_ij, no -log N_pe), log n_eff, variance, S1
+  double* ev_grad;    // [n_ev][n_theta]: G_p / S1
+  double* inj_out;    // [n_inj_groups][4]: M, S1, S2
+  double* inj_grad;   // [n_inj_groups][n_theta]: G_p relative to that group's M
+  double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
+  // host-final mode (small problems): every group publishes its whole result row
+  // [stamp, a, b, c, grad[n_theta]] to pinned host memory and the HOST sums over groups;
+  // a = logsumexp | M, b = log n_eff | S1, c = variance | S2
+  double* host_rows;  // nullptr: device-final mode
+  double* record;     // device-final mode: pinned host record (or the device send buffer when sharded)
+  unsigned long long seq;        // completion stamp of this evaluation
+  int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
+  int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
+  int n_norms, record_len;
+  double n_pe;
+};
+
 struct KArgs {
   const double* pe_cols[GWI_MAX_COLS];   // column base pointers live in the kernel-argument block:
   const double* inj_cols[GWI_MAX_COLS];  // one scalar load away, no pointer-table round trip
@@ -116,6 +137,57 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = fma(r, e, r);
   e = fma(-x, r, 1.0);
   return fma(r, e, r);
+}
+
+// ---- exp / expm1 for the scan loop ---------------------------------------------------------
+// exp(x) = 2^n (1 + r q(r)),  n = rint(x log2 e),  r = x - n ln2 (two-piece ln2),  |r| <= 0.3466,
+// q = Taylor series of (e^r - 1)/r to r^12 (truncation 0.3466^14/14! = 4e-18 relative).  Every Horner
+// step is ONE v_fma_f64 whose addend is a scalar-register constant: left to itself the compiler parks
+// the constants in vector registers and spends a v_mov_b64 + v_fmac_f64 per step (two-address form).
+// The argument is clamped to [-1000, 710]: exp(-inf) = 0 and exp(>709.8) = +inf fall out of ldexp.
+// v_max/v_min return the non-NaN operand, so a NaN argument gives 0: NaN can only enter through a
+// non-finite hyper-parameter, which the host rejects before launching (theta_finite in the engine);
+// data NaNs sit in samples already excluded by kappa = -inf.  expm1 shares the core: 2^n (1 + rq) - 1 = fma(2^n, rq, 2^n - 1), exact for n = 0.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+struct ExpParts {
+  double rq;  // e^r - 1
+  int n;
+};
+__device__ __forceinline__ ExpParts exp_parts(double x) {
+  x = fmin(fmax(x, -1000.0), 710.0);
+  const double nf = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(nf, -6.93147180369123816490e-01, x);
+  r = fma(nf, -1.90821492927058770002e-10, r);
+  double q = 1.0 / 6227020800.0;          // 1/13!
+  q = fma_sc(q, r, 1.0 / 479001600.0);    // 1/12!
+  q = fma_sc(q, r, 1.0 / 39916800.0);
+  q = fma_sc(q, r, 1.0 / 3628800.0);
+  q = fma_sc(q, r, 1.0 / 362880.0);
+  q = fma_sc(q, r, 1.0 / 40320.0);
+  q = fma_sc(q, r, 1.0 / 5040.0);
+  q = fma_sc(q, r, 1.0 / 720.0);
+  q = fma_sc(q, r, 1.0 / 120.0);
+  q = fma_sc(q, r, 1.0 / 24.0);
+  q = fma_sc(q, r, 1.0 / 6.0);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  ExpParts p;
+  p.rq = q * r;
+  p.n = (int)nf;
+  return p;
+}
+__device__ __forceinline__ double fast_exp(double x) {
+  const ExpParts p = exp_parts(x);
+  return ldexp(p.rq + 1.0, p.n);
+}
+__device__ __forceinline__ double fast_expm1(double x) {
+  const ExpParts p = exp_parts(x);
+  const double s = ldexp(1.0, p.n);
+  return fma(s, p.rq, s - 1.0);
 }
 
 // ---- uniform cubic B-spline: 4 taps from the fractional knot coordinate --------------------
@@ -226,8 +298,8 @@ struct Term<GWI_TERM_PLPEAK> {
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;
-    const double e_pl = exp(alpha * lx + d[0]);
-    const double e_tn = exp(-0.5 * dx2 * d[5] + d[2]);
+    const double e_pl = fast_exp(alpha * lx + d[0]);
+    const double e_tn = fast_exp(-0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
     const double ip = fast_rcp(p);
@@ -288,7 +360,7 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
       lin *= -fast_rcp(lr);
       return -lq;
     }
-    const double em1 = expm1(b1 * lr);   // r^(1+beta) - 1
+    const double em1 = fast_expm1(b1 * lr);   // r^(1+beta) - 1
     const double inv_den = -fast_rcp(em1);  // 1/(1 - r^(1+beta))
     s.db = lq + d[0] + (em1 + 1.0) * lr * inv_den;
     lin *= b1 * inv_den;
@@ -363,7 +435,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
     const double xi = c.theta[t.th0];
     const double dx = ct - 1.0;
     const double dx2 = dx * dx;
-    const double e_tn = exp(-0.5 * dx2 * d[2] + d[0]);
+    const double e_tn = fast_exp(-0.5 * dx2 * d[2] + d[0]);
     const double p = 0.5 * (1.0 - xi) + xi * e_tn;
     const double ip = fast_rcp(p);
     s.dxi = (e_tn - 0.5) * ip;
@@ -490,6 +562,9 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     return v;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
+#ifdef GWI_ABLATE_ATOMICS
+    return;
+#endif
     if (s.k >= 0 && w != 0.0) {
       const Taps b = cubic_taps(s.t);
       double* g = c.gacc + t.th0 + s.k;
@@ -573,7 +648,7 @@ struct Term<GWI_TERM_TILT_JOINT> {
     const double xi = c.theta[t.th0];
     const double d1 = in.x0 - 1.0, d2 = in.x1 - 1.0;
     const double r2 = d1 * d1 + d2 * d2;
-    const double A = exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
+    const double A = fast_exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
     const double p = 0.25 * (1.0 - xi) + xi * A;
     const double ip = fast_rcp(p);
     s.dxi = (A - 0.25) * ip;
@@ -672,6 +747,200 @@ struct NormArgs {
 
 __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a);
 
+// ---- publishing to pinned host memory without a system-scope fence ---------------------------------
+// __threadfence_system() = write back the whole L2 + invalidate (several us).  Results bound for the
+// host are instead stored write-through at system scope (global_store ... sc0 sc1: they bypass the
+// caches), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
+// barrier, and only then one lane stores the completion stamp, also write-through
+// (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag" hand-off form).
+__device__ __forceinline__ void store_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void publish_stamp(double* slot, unsigned long long seq, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- stage 2: combine the tile records of one GROUP with a common reference exponent.  Groups
+//      0..n_ev-1 are the events (all tiles of one event); groups n_ev.. split the injection tiles
+//      into runs of <= tiles_per_inj_group.  Latency is everything here (a few KB per group), so there
+//      is NO workgroup barrier: tiles run across the lanes of a wave, record values across the
+//      waves; every wave derives the group's exponent and S1 itself (DPP reductions, fixed order).
+//      One workgroup of kBlock threads per group (e = group, kb = hyper-parameter point).
+__device__ __forceinline__ void combine_group(const TailArgs& a, const int e, const int kb, const int tid) {
+  const int lane = tid & 63;
+  const bool is_inj = e >= a.n_ev;
+  int n_tiles;
+  long long first;
+  if (is_inj) {
+    const int j = e - a.n_ev;
+    const int t0 = j * a.tiles_per_inj_group;
+    n_tiles = a.n_inj_tiles - t0 < a.tiles_per_inj_group ? a.n_inj_tiles - t0 : a.tiles_per_inj_group;
+    first = (long long)a.n_ev * a.tiles_per_event + t0;
+  } else {
+    n_tiles = a.tiles_per_event;
+    first = (long long)e * a.tiles_per_event;
+  }
+  const int n_groups = a.n_ev + a.n_inj_groups;
+  const double* rec = a.partials + ((long long)kb * a.n_scan_blocks + first) * a.rec_stride;
+  double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
+  double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
+  double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
+  double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
+  double* const ev_host = a.ev_host + (long long)kb * 3 * a.n_ev;
+  double* const host_rows = a.host_rows ? a.host_rows + (long long)kb * n_groups * (4 + a.n_theta) : nullptr;
+
+  // phase 1, every wave redundantly: lanes <- tiles.  Common exponent M, per-tile factor f_t, S1, S2.
+  // (host guarantees n_tiles <= 64 per group)
+  const bool has = lane < n_tiles;
+  const double* mine = rec + (long long)(has ? lane : 0) * a.rec_stride;
+  const double m_t = has ? mine[0] : GWI_NEG_INF;
+  const double r1 = has ? mine[1] : 0.0, r2 = has ? mine[2] : 0.0;
+  const double M = wave_max(m_t);
+  const double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
+  const double S1 = wave_sum(f * r1);
+  const double inv_s1 = S1 > 0.0 ? 1.0 / S1 : 0.0;
+  // phase 2: threads <- gradient slots (coalesced across p), tiles in order with f_t broadcast from
+  // its lane: no cross-lane reduction, no barrier, fixed summation order
+  for (int p = tid; p < a.n_theta; p += kBlock) {
+    double acc = 0.0;
+    const double* col = rec + kRecHeader + p;
+#pragma unroll 4
+    for (int t = 0; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
+    if (host_rows)
+      store_sys(host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
+    else if (is_inj)
+      inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
+    else
+      ev_grad[(long long)e * a.n_theta + p] = acc * inv_s1;
+  }
+  if (tid < 64) {
+    const double S2 = wave_sum(f * f * r2);
+    if (lane == 0 && host_rows) {
+      double* o = host_rows + (long long)e * (4 + a.n_theta);
+      if (is_inj) {
+        store_sys(o + 1, M);
+        store_sys(o + 2, S1);
+        store_sys(o + 3, S2);
+      } else {
+        const double log_s1 = log(S1);
+        const double log_neff = 2.0 * log_s1 - log(S2);  // analysis.py:79
+        store_sys(o + 1, log_s1 + M);
+        store_sys(o + 2, log_neff);
+        store_sys(o + 3, 1.0 / exp(log_neff) - 1.0 / a.n_pe);  // :87
+      }
+    } else if (lane == 0) {
+      if (is_inj) {
+        double* o = inj_out + (long long)(e - a.n_ev) * 4;
+        o[0] = M;
+        o[1] = S1;
+        o[2] = S2;
+      } else {
+        // analysis.py:78-87: logBF = logsumexp - log N_pe (constant added on the host),
+        // log n_eff = 2 logsumexp(l) - logsumexp(2 l), variance = 1/n_eff - 1/N_pe
+        const double log_s1 = log(S1);
+        const double log_neff = 2.0 * log_s1 - log(S2);
+        const double var = 1.0 / exp(log_neff) - 1.0 / a.n_pe;
+        double* o = ev_out + (long long)e * 4;
+        o[0] = log_s1 + M;
+        o[1] = log_neff;
+        o[2] = var;
+        o[3] = S1;
+        store_sys(ev_host + e, log_s1 + M);
+        store_sys(ev_host + a.n_ev + e, log_neff);
+        store_sys(ev_host + 2 * a.n_ev + e, var);
+      }
+    }
+  }
+  if (host_rows) publish_stamp(host_rows + (long long)e * (4 + a.n_theta), a.seq, tid);
+}
+
+// ---- stage 3: reduce over events, merge the injection groups, and publish this device's record to
+//      pinned host memory.  One workgroup of THREADS; events (or injection groups) run across the
+//      lanes, output values across the waves; one barrier, before the completion stamp.
+//      record layout (doubles): see kRecNormOff in gwi_engine.hip -------------------------------------
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, const int tid, double* s_tile /* [THREADS] */) {
+  const int lane = tid & 63, wave = tid >> 6;
+  double* r = a.record + (long long)kb * a.record_len;
+  const double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
+  const double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
+  const double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
+  const double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
+  const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
+
+  // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
+  const int vp = pow2_at_least(a.n_theta < 8 ? 8 : a.n_theta);  // <= 256 (GWI_MAX_THETA = 160)
+  const int rows = THREADS / vp;
+  const int row = tid / vp, col = tid - row * vp;
+  double acc = 0.0;
+  if (col < a.n_theta) {
+#pragma unroll 8
+    for (int e = row; e < a.n_ev; e += rows) acc += ev_grad[(long long)e * a.n_theta + col];
+  }
+  s_tile[tid] = acc;
+
+  // ---- meanwhile wave 0: scalar sums over events; wave 1: injection groups
+  if (wave == 0) {
+    double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
+    for (int e = lane; e < a.n_ev; e += 64) {
+      const double* o = ev_out + (long long)e * 4;
+      sum += o[0];
+      var += o[2];
+      double le = o[1];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+      if (le != le) le = 0.0;
+      le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
+      mn = fmin(mn, le);
+    }
+    sum = wave_sum(sum);
+    var = wave_sum(var);
+    mn = -wave_max(-mn);
+    if (lane == 0) {
+      store_sys(r + 1, sum);
+      store_sys(r + 2, var);
+      store_sys(r + 3, mn);
+      store_sys(r + 7, (double)a.n_ev);
+    }
+  }
+  // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups
+  const bool hasg = lane < a.n_inj_groups;
+  const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
+  const double Minj = wave_max(m_j);
+  const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
+  if (wave == 1) {
+    const double S1 = wave_sum(fj * (hasg ? inj_out[lane * 4 + 1] : 0.0));
+    const double S2 = wave_sum(fj * fj * (hasg ? inj_out[lane * 4 + 2] : 0.0));
+    if (lane == 0) {
+      store_sys(r + 4, Minj);
+      store_sys(r + 5, S1);
+      store_sys(r + 6, S2);
+    }
+  }
+  // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
+  for (int p = tid; p < a.n_theta; p += THREADS) {
+    double g = 0.0;
+    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
+    store_sys(r + off_ginj + p, g);
+  }
+  __syncthreads();
+  if (row == 0 && col < a.n_theta) {
+    double g = 0.0;
+    for (int q = 0; q < rows; ++q) g += s_tile[q * vp + col];  // fixed order
+    store_sys(r + off_gpe + col, g);
+  }
+  publish_stamp(r, a.seq, tid);
+}
+
 // ---- the scan kernel -----------------------------------------------------------------------------
 // grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
 // belongs to that event's logsumexp; an injection workgroup owns `chunk_inj` consecutive
@@ -680,8 +949,11 @@ __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a);
 // overhead are shared between them.
 constexpr int kRedChunk = 8;  // values per pass of the block-level transposed reduction (16 KiB LDS)
 
+#ifndef GWI_SCAN_WAVES_PER_EU
+#define GWI_SCAN_WAVES_PER_EU 1
+#endif
 template <bool WRITE_LOGW, bool BATCH, int U, int... Ks>
-__global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(const KArgs a) {
   using ChainT = Chain<U, Ks...>;
   constexpr int kU = U;
   // Spline-coefficient gradient numerators: per wave, gacc_rep replicas of a row of gacc_pad
@@ -769,15 +1041,22 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   };
   const long long i0 = start + tid;
   GWI_STAMP(1);
+#ifndef GWI_NO_PREFETCH
   if (i0 - lane < end) issue_loads(0, i0);
+#endif
 #ifdef GWI_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
   GWI_STAMP(2);
 #endif
   for (long long i = i0; i - lane < end; i += kU * kBlock) {
     const long long i_next = i + kU * kBlock;
+#ifdef GWI_NO_PREFETCH
+    const bool has_next = false;
+    issue_loads(0, i);
+#else
     const bool has_next = i_next - lane < end;  // wave-uniform
     if (has_next) issue_loads(1, i_next);
+#endif
     double ell[kU], lin[kU];
     bool live[kU];
     double mx_lane = GWI_NEG_INF;
@@ -805,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
       const double mx = wave_max(mx_lane);
       if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
         if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
-          const double sc = exp(m - mx);
+          const double sc = fast_exp(m - mx);
           s1 *= sc;
           s2 *= sc * sc;
           chain.rescale(sc);
@@ -817,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
-        const double w = live[u] ? lin[u] * exp(ell[u] - m) : 0.0;
+        const double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
         s1 += w;
         s2 += w * w;
         chain.accumulate(u, 0, ctx, w);
@@ -838,7 +1117,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   double M = s_wrec[0][0];
 #pragma unroll
   for (int w_ = 1; w_ < kWaves; ++w_) M = fmax(M, s_wrec[w_][0]);
-  const double f = (m == GWI_NEG_INF) ? 0.0 : exp(m - M);  // this wave's rescale factor
+  const double f = (m == GWI_NEG_INF) ? 0.0 : fast_exp(m - M);  // this wave's rescale factor
 
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
@@ -878,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   double fw[kWaves];
   if (ChainT::kSpline) {
 #pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : exp(s_wrec[w_][0] - M);
+    for (int w_ = 0; w_ < kWaves; ++w_) fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : fast_exp(s_wrec[w_][0] - M);
   }
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double g = s_out[p];
@@ -896,232 +1175,13 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const KArgs a) {
   GWI_STAMP(4);
 }
 
-// ---- stage 2: combine the tile records of one GROUP with a common reference exponent.  Groups
-//      0..n_ev-1 are the events (all tiles of one event); groups n_ev.. split the injection tiles
-//      into runs of <= tiles_per_inj_group.  Latency is everything here (a few KB per group), so the
-//      kernel has NO workgroup barrier: tiles run across the lanes of a wave, record values across the
-//      waves; every wave derives the group's exponent and S1 itself (DPP reductions, fixed order).
-struct CombineArgs {
-  const double* partials;
-  double* ev_out;     // [n_ev][4]: logsumexp (= log sum_j w_ij, no -log N_pe), log n_eff, variance, S1
-  double* ev_grad;    // [n_ev][n_theta]: G_p / S1
-  double* inj_out;    // [n_inj_groups][4]: M, S1, S2
-  double* inj_grad;   // [n_inj_groups][n_theta]: G_p relative to that group's M
-  double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
-  // host-final mode (small problems): every group publishes its whole result row
-  // [stamp, a, b, c, grad[n_theta]] to pinned host memory and the HOST sums over groups, which
-  // removes the third launch; a = logsumexp | M, b = log n_eff | S1, c = variance | S2
-  double* host_rows;  // nullptr: device-final mode
-  unsigned long long seq;
-  int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
-  int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
-  double n_pe;
-};
+// ---- the tail as separate launches (GWI_FUSED_TAIL=0, and the reference point for A/B timing) -------
+__global__ __launch_bounds__(kBlock) void combine_kernel(const TailArgs a) { combine_group(a, blockIdx.x, blockIdx.y, threadIdx.x); }
 
-__device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
-// ---- publishing to pinned host memory without a system-scope fence ---------------------------------
-// __threadfence_system() = write back the whole L2 + invalidate (several us).  Results bound for the
-// host are instead stored write-through at system scope (global_store ... sc0 sc1: they bypass the
-// caches), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
-// barrier, and only then one lane stores the completion stamp, also write-through
-// (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag" hand-off form).
-__device__ __forceinline__ void store_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void publish_stamp(double* slot, unsigned long long seq, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(kBlock) void combine_kernel(const CombineArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int e = blockIdx.x;
-  const bool is_inj = e >= a.n_ev;
-  int n_tiles;
-  long long first;
-  if (is_inj) {
-    const int j = e - a.n_ev;
-    const int t0 = j * a.tiles_per_inj_group;
-    n_tiles = a.n_inj_tiles - t0 < a.tiles_per_inj_group ? a.n_inj_tiles - t0 : a.tiles_per_inj_group;
-    first = (long long)a.n_ev * a.tiles_per_event + t0;
-  } else {
-    n_tiles = a.tiles_per_event;
-    first = (long long)e * a.tiles_per_event;
-  }
-  const int kb = blockIdx.y;  // hyper-parameter point of a batched launch (0 otherwise)
-  const int n_groups = a.n_ev + a.n_inj_groups;
-  const double* rec = a.partials + ((long long)kb * a.n_scan_blocks + first) * a.rec_stride;
-  double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
-  double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
-  double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
-  double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
-  double* const ev_host = a.ev_host + (long long)kb * 3 * a.n_ev;
-  double* const host_rows = a.host_rows ? a.host_rows + (long long)kb * n_groups * (4 + a.n_theta) : nullptr;
-
-  // phase 1, every wave redundantly: lanes <- tiles.  Common exponent M, per-tile factor f_t, S1, S2.
-  // (host guarantees n_tiles <= 64 per group)
-  const bool has = lane < n_tiles;
-  const double* mine = rec + (long long)(has ? lane : 0) * a.rec_stride;
-  const double m_t = has ? mine[0] : GWI_NEG_INF;
-  const double r1 = has ? mine[1] : 0.0, r2 = has ? mine[2] : 0.0;
-  const double M = wave_max(m_t);
-  const double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
-  const double S1 = wave_sum(f * r1);
-  const double inv_s1 = S1 > 0.0 ? 1.0 / S1 : 0.0;
-  // phase 2: threads <- gradient slots (coalesced across p), tiles in order with f_t broadcast from
-  // its lane: no cross-lane reduction, no barrier, fixed summation order
-  for (int p = tid; p < a.n_theta; p += kBlock) {
-    double acc = 0.0;
-    const double* col = rec + kRecHeader + p;
-#pragma unroll 4
-    for (int t = 0; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
-    if (host_rows)
-      store_sys(host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
-    else if (is_inj)
-      inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
-    else
-      ev_grad[(long long)e * a.n_theta + p] = acc * inv_s1;
-  }
-  if (tid < 64) {
-    const double S2 = wave_sum(f * f * r2);
-    if (lane == 0 && host_rows) {
-      double* o = host_rows + (long long)e * (4 + a.n_theta);
-      if (is_inj) {
-        store_sys(o + 1, M);
-        store_sys(o + 2, S1);
-        store_sys(o + 3, S2);
-      } else {
-        const double log_s1 = log(S1);
-        const double log_neff = 2.0 * log_s1 - log(S2);  // analysis.py:79
-        store_sys(o + 1, log_s1 + M);
-        store_sys(o + 2, log_neff);
-        store_sys(o + 3, 1.0 / exp(log_neff) - 1.0 / a.n_pe);  // :87
-      }
-    } else if (lane == 0) {
-      if (is_inj) {
-        double* o = inj_out + (long long)(e - a.n_ev) * 4;
-        o[0] = M;
-        o[1] = S1;
-        o[2] = S2;
-      } else {
-        // analysis.py:78-87: logBF = logsumexp - log N_pe (constant added on the host),
-        // log n_eff = 2 logsumexp(l) - logsumexp(2 l), variance = 1/n_eff - 1/N_pe
-        const double log_s1 = log(S1);
-        const double log_neff = 2.0 * log_s1 - log(S2);
-        const double var = 1.0 / exp(log_neff) - 1.0 / a.n_pe;
-        double* o = ev_out + (long long)e * 4;
-        o[0] = log_s1 + M;
-        o[1] = log_neff;
-        o[2] = var;
-        o[3] = S1;
-        store_sys(ev_host + e, log_s1 + M);
-        store_sys(ev_host + a.n_ev + e, log_neff);
-        store_sys(ev_host + 2 * a.n_ev + e, var);
-      }
-    }
-  }
-  if (host_rows) publish_stamp(host_rows + (long long)e * (4 + a.n_theta), a.seq, tid);
-}
-
-// ---- stage 3: reduce over events, merge the injection groups, and publish this device's record to
-//      pinned host memory.  One workgroup of 16 waves; events (or injection groups) run across the
-//      lanes, output values across the waves; one barrier, before the completion stamp.
-//      record layout (doubles): see kRecNormOff in gwi_engine.hip -------------------------------------
 constexpr int kFinalThreads = 1024;
-constexpr int kFinalWaves = kFinalThreads / 64;
-
-struct FinalArgs {
-  const double* ev_out;
-  const double* ev_grad;
-  const double* inj_out;
-  const double* inj_grad;
-  double* record;       // device-visible pinned host buffer (or the device send buffer when sharded)
-  int n_ev, n_theta, n_norms, n_inj_groups;
-  int record_len;          // batched launches: record of point blockIdx.y starts at record + y * record_len
-  unsigned long long seq;  // written last to record[0] as a completion stamp
-};
-
-__device__ __forceinline__ int pow2_at_least(int v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
-__global__ __launch_bounds__(kFinalThreads) void final_kernel(const FinalArgs a) {
+__global__ __launch_bounds__(kFinalThreads) void final_kernel(const TailArgs a) {
   __shared__ double s_tile[kFinalThreads];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kb = blockIdx.y;
-  double* r = a.record + (long long)kb * a.record_len;
-  const double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
-  const double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
-  const double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
-  const double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
-  const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
-
-  // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
-  const int vp = pow2_at_least(a.n_theta < 8 ? 8 : a.n_theta);  // <= 256 (GWI_MAX_THETA = 160)
-  const int rows = kFinalThreads / vp;
-  const int row = tid / vp, col = tid - row * vp;
-  double acc = 0.0;
-  if (col < a.n_theta) {
-#pragma unroll 8
-    for (int e = row; e < a.n_ev; e += rows) acc += ev_grad[(long long)e * a.n_theta + col];
-  }
-  s_tile[tid] = acc;
-
-  // ---- meanwhile wave 0: scalar sums over events; wave 1: injection groups
-  if (wave == 0) {
-    double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
-    for (int e = lane; e < a.n_ev; e += 64) {
-      const double* o = ev_out + (long long)e * 4;
-      sum += o[0];
-      var += o[2];
-      double le = o[1];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
-      if (le != le) le = 0.0;
-      le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
-      mn = fmin(mn, le);
-    }
-    sum = wave_sum(sum);
-    var = wave_sum(var);
-    mn = -wave_max(-mn);
-    if (lane == 0) {
-      store_sys(r + 1, sum);
-      store_sys(r + 2, var);
-      store_sys(r + 3, mn);
-      store_sys(r + 7, (double)a.n_ev);
-    }
-  }
-  // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups
-  const bool hasg = lane < a.n_inj_groups;
-  const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
-  const double Minj = wave_max(m_j);
-  const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
-  if (wave == 1) {
-    const double S1 = wave_sum(fj * (hasg ? inj_out[lane * 4 + 1] : 0.0));
-    const double S2 = wave_sum(fj * fj * (hasg ? inj_out[lane * 4 + 2] : 0.0));
-    if (lane == 0) {
-      store_sys(r + 4, Minj);
-      store_sys(r + 5, S1);
-      store_sys(r + 6, S2);
-    }
-  }
-  // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
-  for (int p = tid; p < a.n_theta; p += kFinalThreads) {
-    double g = 0.0;
-    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
-    store_sys(r + off_ginj + p, g);
-  }
-  __syncthreads();
-  if (row == 0 && col < a.n_theta) {
-    double g = 0.0;
-    for (int q = 0; q < rows; ++q) g += s_tile[q * vp + col];  // fixed order
-    store_sys(r + off_gpe + col, g);
-  }
-  publish_stamp(r, a.seq, tid);
+  final_reduce<kFinalThreads>(a, blockIdx.y, threadIdx.x, s_tile);
 }
 
 // ---- after the all-gather: copy the gathered records to pinned host memory and stamp completion -----
@@ -1160,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a) {
       }
       e += v;
     }
-    if (tw != 0.0) acc += tw * exp(e);
+    if (tw != 0.0) acc += tw * fast_exp(e);
   }
   acc = wave_sum(acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;

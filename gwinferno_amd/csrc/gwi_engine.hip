@@ -367,7 +367,12 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
       default: break;
     }
   }
-  *host_const = c;
+  // A non-finite hyper-parameter makes every weight NaN in the reference, i.e. log_l = nan_to_num(-inf)
+  // and a zero gradient (analysis.py:287-289).  The device exp clamps its argument (NaN -> 0), so the
+  // case is decided here: a NaN constant routes assemble() down exactly that branch.
+  bool theta_finite = true;
+  for (int p = 0; p < h->spec.n_theta; ++p) theta_finite = theta_finite && std::isfinite(theta[p]);
+  *host_const = theta_finite ? c : NAN;
   std::memcpy(theta_out, theta, sizeof(double) * h->spec.n_theta);
 }
 
@@ -398,6 +403,10 @@ gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long se
 
 // launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
 // or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
+// (Folding the two tail stages into the scan launch -- the workgroup that completes a group combines
+// it -- was measured and lost: every workgroup then has to drain agent-scope write-through stores and
+// wait for an atomic round trip across the XCDs' separate L2s, ~5 us of a resident slot each, more than
+// the two launch boundaries cost.  See DESIGN.md.)
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false) {
   const int n_theta = h->spec.n_theta;
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
@@ -411,54 +420,43 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     h->kargs.tblocks = h->d_tblocks;
   }
   const unsigned gy = batch ? (unsigned)K : 1u;
+  TailArgs ta;
+  ta.partials = h->d_partials;
+  ta.ev_out = h->d_ev_out;
+  ta.ev_grad = h->d_ev_grad;
+  ta.inj_out = h->d_inj_out;
+  ta.inj_grad = h->d_inj_grad;
+  ta.ev_host = h->h_ev_dev;
+  ta.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
+  ta.record = record_dev ? record_dev : h->h_record_dev;
+  ta.seq = h->seq + 1;
+  ta.n_ev = (int)h->n_ev;
+  ta.tiles_per_event = h->tiles_per_event;
+  ta.n_inj_tiles = h->n_inj_tiles;
+  ta.n_inj_groups = h->n_inj_groups;
+  ta.tiles_per_inj_group = h->tiles_per_inj_group;
+  ta.n_theta = n_theta;
+  ta.rec_stride = h->rec_stride;
+  ta.n_scan_blocks = h->n_scan_blocks;
+  ta.n_norms = h->spec.n_norms;
+  ta.record_len = record_len(h);
+  ta.n_pe = (double)h->n_pe;
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[0], h->stream));
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[1], h->stream));
-  {
-    CombineArgs ca;
-    ca.partials = h->d_partials;
-    ca.ev_out = h->d_ev_out;
-    ca.ev_grad = h->d_ev_grad;
-    ca.inj_out = h->d_inj_out;
-    ca.inj_grad = h->d_inj_grad;
-    ca.n_ev = (int)h->n_ev;
-    ca.tiles_per_event = h->tiles_per_event;
-    ca.n_inj_tiles = h->n_inj_tiles;
-    ca.n_inj_groups = h->n_inj_groups;
-    ca.tiles_per_inj_group = h->tiles_per_inj_group;
-    ca.n_theta = n_theta;
-    ca.rec_stride = h->rec_stride;
-    ca.n_scan_blocks = h->n_scan_blocks;
-    ca.n_pe = (double)h->n_pe;
-    ca.ev_host = h->h_ev_dev;
-    ca.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
-    ca.seq = h->seq + 1;
-    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(kBlock), 0, h->stream, ca);
-    GWI_HIP(hipGetLastError());
-    if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
-    if (ca.host_rows) {
-      ++h->seq;
-      if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
-      gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
-      if (sn != GWI_OK) return sn;
-      return wait ? wait_for_rows(h, K) : GWI_OK;
-    }
-    FinalArgs fa;
-    fa.ev_out = h->d_ev_out;
-    fa.ev_grad = h->d_ev_grad;
-    fa.inj_out = h->d_inj_out;
-    fa.inj_grad = h->d_inj_grad;
-    fa.record = record_dev ? record_dev : h->h_record_dev;
-    fa.n_ev = (int)h->n_ev;
-    fa.n_theta = n_theta;
-    fa.n_norms = h->spec.n_norms;
-    fa.n_inj_groups = h->n_inj_groups;
-    fa.record_len = record_len(h);
-    fa.seq = ++h->seq;
-    hipLaunchKernelGGL(final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, h->stream, fa);
-    GWI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(kBlock), 0, h->stream, ta);
+  GWI_HIP(hipGetLastError());
+  if (h->timing) GWI_HIP(hipEventRecord(h->ev[2], h->stream));
+  ++h->seq;
+  if (ta.host_rows) {
+    if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
+    gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
+    if (sn != GWI_OK) return sn;
+    return wait ? wait_for_rows(h, K) : GWI_OK;
   }
+  hipLaunchKernelGGL(final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, h->stream, ta);
+  GWI_HIP(hipGetLastError());
   if (h->timing) GWI_HIP(hipEventRecord(h->ev[3], h->stream));
   {
     gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
@@ -924,7 +922,9 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   {
     const size_t n_groups = (size_t)n_ev + h->n_inj_groups;
     const size_t row_bytes = sizeof(double) * n_groups * (4 + spec->n_theta);
-    h->host_final = row_bytes <= 32 * 1024;
+    size_t host_final_limit = 32 * 1024;
+    if (const char* env = std::getenv("GWI_HOST_FINAL_BYTES")) host_final_limit = (size_t)std::atoll(env);
+    h->host_final = row_bytes <= host_final_limit;
     if (const char* env = std::getenv("GWI_HOST_FINAL")) h->host_final = h->host_final && std::atoi(env) != 0;
     GWI_HIP(hipHostMalloc((void**)&h->h_rows, KB * row_bytes, hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_rows_dev, h->h_rows, 0));
