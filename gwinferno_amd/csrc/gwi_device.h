@@ -82,6 +82,8 @@ struct KArgs {
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
   int gacc_rep, gacc_pad;  // spline-gradient LDS rows: replicas per wave (power of two), row stride (odd)
+  int square, pad_;        // square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
+                           // the gradient of marginalize_selection needs); records then carry 2M as exponent
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   TermD terms[GWI_MAX_TERMS];
   double derived[GWI_MAX_TERMS][kMaxDerived];
@@ -1084,7 +1086,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       const double mx = wave_max(mx_lane);
       if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
         if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
-          const double sc = fast_exp(m - mx);
+          double sc = fast_exp(m - mx);
+          if (a.square) sc *= sc;
           s1 *= sc;
           s2 *= sc * sc;
           chain.rescale(sc);
@@ -1096,7 +1099,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
-        const double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+        double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+        if (a.square) w *= w;
         s1 += w;
         s2 += w * w;
         chain.accumulate(u, 0, ctx, w);
@@ -1117,7 +1121,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   double M = s_wrec[0][0];
 #pragma unroll
   for (int w_ = 1; w_ < kWaves; ++w_) M = fmax(M, s_wrec[w_][0]);
-  const double f = (m == GWI_NEG_INF) ? 0.0 : fast_exp(m - M);  // this wave's rescale factor
+  double f = (m == GWI_NEG_INF) ? 0.0 : fast_exp(m - M);  // this wave's rescale factor
+  if (a.square) f *= f;
 
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
@@ -1151,13 +1156,16 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       }
     }
   }
-  if (tid == 0) out[0] = M;
+  if (tid == 0) out[0] = a.square ? 2.0 * M : M;
   __syncthreads();
   // gradient numerators: scalar sums from s_out, spline-coefficient sums from the per-wave rows
   double fw[kWaves];
   if (ChainT::kSpline) {
 #pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : fast_exp(s_wrec[w_][0] - M);
+    for (int w_ = 0; w_ < kWaves; ++w_) {
+      fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : fast_exp(s_wrec[w_][0] - M);
+      if (a.square) fw[w_] *= fw[w_];
+    }
   }
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double g = s_out[p];

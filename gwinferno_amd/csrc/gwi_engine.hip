@@ -205,6 +205,7 @@ struct gwi_engine {
   NormD* d_norms = nullptr;
   std::vector<double*> d_norm_arrays;
   double *d_partials = nullptr, *d_ev_out = nullptr, *d_ev_grad = nullptr, *d_inj_out = nullptr, *d_inj_grad = nullptr;
+  std::vector<double> sq_records;  // records of the squared-weight pass (marginalize_selection gradient)
   double *d_logw_pe = nullptr, *d_logw_inj = nullptr;
   // pinned, device-visible host memory
   double *h_record = nullptr, *h_record_dev = nullptr;
@@ -407,8 +408,9 @@ gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long se
 // it -- was measured and lost: every workgroup then has to drain agent-scope write-through stores and
 // wait for an atomic round trip across the XCDs' separate L2s, ~5 us of a resident slot each, more than
 // the two launch boundaries cost.  See DESIGN.md.)
-gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false) {
+gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
   const int n_theta = h->spec.n_theta;
+  h->kargs.square = square ? 1 : 0;
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
   if (!batch) {
     prelude(h, theta, h->kargs.theta, h->kargs.derived, &h->host_consts[0]);
@@ -519,8 +521,10 @@ gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K) {
 }
 
 // Assemble the sites of analysis.py:259-319 from gathered per-rank records.
+// `records_sq` (same layout, from a pass run with KArgs::square): its injection slots hold the sums
+// weighted by w^2, which the gradient of the marginalised selection term needs; nullptr otherwise.
 void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi_options* opt, gwi_summary* out, double* grad, double* norms,
-              double host_const) {
+              double host_const, const double* records_sq = nullptr) {
   const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
   const int len = record_len(h);
   const double NEG_BIG = -1.7976931348623157e308;  // jnp.nan_to_num(-inf)
@@ -601,6 +605,25 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
     // d log_l / d theta = sum_i sum_j s_ij dl_ij - N_obs sum_j s_j dl_j  (SURVEY.md appendix A);
     // a cut replaces log_l by a constant, whose gradient is zero.
     for (int p = 0; p < n_theta; ++p) grad[p] = cut ? 0.0 : g_pe[p] - n_obs * (S1 > 0 ? g_inj[p] / S1 : 0.0);
+    if (opt->marginalize_selection && records_sq && !cut && S1 > 0) {
+      // lde = log mu - c / n_eff, c = (3 + N_obs)/2 (analysis.py:271);  log n_eff = 2 log S1 - log V,
+      // V = S2 - S1^2/N_tot;  dS1 = G (sum w dl), dS2 = 2 H (H = sum w^2 dl, from the squared pass)
+      double M2 = -INFINITY;
+      for (int r = 0; r < n_ranks; ++r) M2 = std::fmax(M2, records_sq[(size_t)r * len + 4]);
+      std::vector<double> H(n_theta, 0.0);
+      for (int r = 0; r < n_ranks; ++r) {
+        const double* rec = records_sq + (size_t)r * len;
+        const double f2 = (rec[4] == -INFINITY) ? 0.0 : std::exp(rec[4] - M2);  // M2 = 2 M
+        const double* gi = rec + kRecNormOff + n_norms + n_theta;
+        for (int p = 0; p < n_theta; ++p) H[p] += f2 * gi[p];
+      }
+      const double V = S2 - S1 * S1 / n_tot;
+      const double c_over_neff = (3.0 + n_obs) / (2.0 * std::exp(log_neff_inj));
+      for (int p = 0; p < n_theta; ++p) {
+        const double dlog_neff = 2.0 * g_inj[p] / S1 - (2.0 * H[p] - 2.0 * S1 * g_inj[p] / n_tot) / V;
+        grad[p] -= n_obs * c_over_neff * dlog_neff;
+      }
+    }
   }
 }
 
@@ -1033,7 +1056,7 @@ gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, con
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (opt->marginalize_selection && grad)
-    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
+    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True needs the squared-weight records, which the caller-exchanged path (gwi_eval_partial / gwi_combine) does not carry: use gwi_eval or gwi_eval_sharded");
   assemble(h, records, n_ranks, opt, summary, grad, norms, h->host_consts[0]);
   return GWI_OK;
 }
@@ -1043,14 +1066,19 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
   if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
-  if (opt->marginalize_selection && grad)
-    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
-  gwi_status st = run_pipeline(h, theta);
+  gwi_status st;
+  const bool need_sq = opt->marginalize_selection && grad;
+  if (need_sq) {  // squared-weight pass first: the regular pass then leaves its per-event arrays in place
+    st = run_pipeline(h, theta, nullptr, true, 1, false, /*square=*/true);
+    if (st != GWI_OK) return st;
+    h->sq_records.assign(h->h_record, h->h_record + record_len(h));
+  }
+  st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_record, 1, opt, &s, grad, norms, h->host_consts[0]);
+  assemble(h, h->h_record, 1, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1067,17 +1095,23 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
   if (k_batch > h->max_batch) return fail(h, GWI_ERR_INVALID, "k_batch exceeds the engine's max_batch (GWI_MAX_BATCH, default 16)");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
-  if (opt->marginalize_selection && grads)
-    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
-  gwi_status st = run_pipeline(h, thetas, nullptr, true, k_batch, true);
-  if (st != GWI_OK) return st;
+  gwi_status st;
   const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
+  const bool need_sq = opt->marginalize_selection && grads;
+  if (need_sq) {
+    st = run_pipeline(h, thetas, nullptr, true, k_batch, true, /*square=*/true);
+    if (st != GWI_OK) return st;
+    h->sq_records.assign(h->h_record, h->h_record + len * k_batch);
+  }
+  st = run_pipeline(h, thetas, nullptr, true, k_batch, true);
+  if (st != GWI_OK) return st;
   const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
   for (int k = 0; k < k_batch; ++k) {
     gwi_summary s;
-    assemble(h, h->h_record + k * len, 1, opt, &s, grads ? grads + (size_t)k * n_theta : nullptr, norms ? norms + (size_t)k * n_norms : nullptr, h->host_consts[k]);
+    assemble(h, h->h_record + k * len, 1, opt, &s, grads ? grads + (size_t)k * n_theta : nullptr, norms ? norms + (size_t)k * n_norms : nullptr, h->host_consts[k],
+             need_sq ? h->sq_records.data() + k * len : nullptr);
     if (summaries) summaries[k] = s;
     const double* ev = h->h_ev + (size_t)k * 3 * n;
     const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1124,23 +1158,31 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
   if (!h->nccl_comm) return fail(h, GWI_ERR_INVALID, "gwi_comm_init has not been called");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
-  if (opt->marginalize_selection && grad)
-    return fail(h, GWI_ERR_UNSUPPORTED, "gradient with marginalize_selection=True is not implemented (needs sum w^2 dl accumulators)");
   GWI_HIP(hipSetDevice(h->device));
-  // scan -> combine -> final (record stays on the device) -> all-gather -> publish, all on one stream
-  gwi_status st = run_pipeline(h, theta, h->d_send, /*wait=*/false);
-  if (st != GWI_OK) return st;
   const size_t len = (size_t)record_len(h);
-  const int rc = g_nccl.AllGather(h->d_send, h->d_recv, len, kNcclDouble, h->nccl_comm, h->stream);
-  if (rc != 0) return fail(h, GWI_ERR_HIP, std::string("ncclAllGather: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "error"));
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_recv, h->h_gather_dev, (int)(len * h->comm_world), h->seq);
-  GWI_HIP(hipGetLastError());
-  st = wait_for_stamp(h, h->h_gather);
-  if (st != GWI_OK) return st;
-  st = wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
+  // scan -> combine -> final (record stays on the device) -> all-gather -> publish, all on one stream
+  auto exchange = [&](bool square) -> gwi_status {
+    gwi_status st = run_pipeline(h, theta, h->d_send, /*wait=*/false, 1, false, square);
+    if (st != GWI_OK) return st;
+    const int rc = g_nccl.AllGather(h->d_send, h->d_recv, len, kNcclDouble, h->nccl_comm, h->stream);
+    if (rc != 0) return fail(h, GWI_ERR_HIP, std::string("ncclAllGather: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "error"));
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_recv, h->h_gather_dev, (int)(len * h->comm_world), h->seq);
+    GWI_HIP(hipGetLastError());
+    st = wait_for_stamp(h, h->h_gather);
+    if (st != GWI_OK) return st;
+    return wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
+  };
+  gwi_status st;
+  const bool need_sq = opt->marginalize_selection && grad;
+  if (need_sq) {  // a second exchange carries the squared-weight numerators
+    st = exchange(true);
+    if (st != GWI_OK) return st;
+    h->sq_records.assign(h->h_gather, h->h_gather + len * h->comm_world);
+  }
+  st = exchange(false);
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms, h->host_consts[0]);
+  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);

@@ -19,7 +19,7 @@ posterior-predictive-check branch (:321-355) raise NotImplementedError.
 import numpy as np
 
 from .engine import NEG_BIG, NativePopulationLikelihood, structure_key
-from .lazy import Density, LazyNorm
+from .lazy import INJ, PE, Column, Density, Factor, LazyNorm, side_of
 
 _ENGINES = {}
 _LAST_SITES = {}
@@ -44,6 +44,9 @@ def clear_engine_cache():
     for eng in _ENGINES.values():
         eng.close()
     _ENGINES.clear()
+    for _, eng, _ in _ONE_SIDED.values():
+        eng.close()
+    _ONE_SIDED.clear()
 
 
 def _is_traced(values):
@@ -104,7 +107,7 @@ _SUMMARY_FIELDS = ("log_likelihood", "log_l", "sum_logBFs", "selection_factor", 
 
 def _evaluate_numpy(eng, theta, total_inj, Nobs, flags, want_grad=True):
     r = eng.evaluate(theta, total_inj, nobs=Nobs, marginalize_selection=flags["marginalize_selection"], min_neff_cut=flags["min_neff_cut"],
-                     max_variance_cut=flags["max_variance_cut"], want_grad=want_grad and not flags["marginalize_selection"])
+                     max_variance_cut=flags["max_variance_cut"], want_grad=want_grad)
     return {"summary": {k: getattr(r.summary, k) for k in _SUMMARY_FIELDS}, "log_bfs": r.log_bfs, "log_neffs": r.log_neffs, "variances": r.variances, "grad": r.grad}
 
 
@@ -230,17 +233,68 @@ def hierarchical_likelihood(
     return sites.get("rate")
 
 
+_ONE_SIDED = {}
+
+
+def _cut(arr, side):
+    """This side's array -> a small stand-in for the OTHER side (first event's samples as a 1-D
+    'injection' set; the first <= 256 injections as a one-event PE tensor)."""
+    a = np.asarray(arr)
+    if side == PE:
+        return np.ascontiguousarray(a[0])
+    return np.ascontiguousarray(a[None, : min(a.shape[0], 256)])
+
+
+def _mirror(density, side):
+    """A structure-identical density for the other side, cut from ``density``'s own data.  The engine
+    always scans a PE tensor and an injection set together; for the one-sided reference functions
+    below the mirrored side is ballast (a few hundred samples) whose results are discarded."""
+    other = INJ if side == PE else PE
+    factors = []
+    for f in density.factors:
+        factors.append(Factor(f.kind, other, [Column(c.transform, _cut(c.source, side)) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
+                              n_basis=f.n_basis, flags=f.flags, mask=None if f.mask is None else _cut(f.mask, side),
+                              static_log=None if f.static_log is None else _cut(f.static_log, side), norm=f.norm, owner=f.owner, norm_owner=f.norm_owner, tag=f.tag))
+    return Density(factors, other, [(sgn, _cut(a, side)) for sgn, a in density.log_static], density.log_const)
+
+
+def _one_sided(weights):
+    if not isinstance(weights, Density) or not weights.factors:
+        raise TypeError("weights must be a lazy density from gwinferno_amd.models")
+    side = weights.side if weights.side is not None else side_of(weights.factors[0].columns[0].source)
+    key = (side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in weights.factors), tuple((sgn, id(a)) for sgn, a in weights.log_static))
+    hit = _ONE_SIDED.get(key)
+    if hit is None:
+        mirror = _mirror(weights, side)
+        eng = NativePopulationLikelihood(weights, mirror) if side == PE else NativePopulationLikelihood(mirror, weights)
+        hit = _ONE_SIDED[key] = (mirror, eng, weights)  # the originals stay referenced: keys are object ids
+    eng = hit[1]
+    theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in _collect_params(eng.bound, weights)])
+    return side, eng, theta
+
+
 def per_event_log_bayes_factors(weights, log=False):
-    """analysis.py:50-88 for a lazy PE product: not evaluable on its own (the engine fuses it with the
-    rest of the likelihood); use hierarchical_likelihood and read sites logBFs / log_nEffs /
-    variance_log_BFs."""
-    raise NotImplementedError(per_event_log_bayes_factors.__doc__)
+    """analysis.py:50-88 for a lazy PE product ``(N_ev, N_pe)``: returns ``(logBFs, logn_effs,
+    variances)``, each ``(N_ev,)``.  ``log`` is accepted for signature compatibility (the engine works
+    in the log domain with an online maximum, where the reference's two branches coincide).  Inside a
+    likelihood prefer :func:`hierarchical_likelihood`, which produces the same arrays as sites from
+    the one fused scan."""
+    side, eng, theta = _one_sided(weights)
+    if side != PE:
+        raise ValueError("per_event_log_bayes_factors expects the (N_events, N_samples) PE product")
+    r = eng.evaluate(theta, float(eng.n_inj), min_neff_cut=False, want_grad=False)
+    return r.log_bfs, r.log_neffs, r.variances
 
 
 def detection_efficiency(weights, Ninj, log=False):
-    """analysis.py:91-136 for a lazy injection product: fused into hierarchical_likelihood; read sites
-    detection_efficiency / log_nEff_inj / variance_log_detection_efficiency."""
-    raise NotImplementedError(detection_efficiency.__doc__)
+    """analysis.py:91-136 for a lazy injection product ``(N_found,)``: returns ``(logmu, logn_eff,
+    variance)``."""
+    side, eng, theta = _one_sided(weights)
+    if side != INJ:
+        raise ValueError("detection_efficiency expects the (N_found_injections,) injection product")
+    r = eng.evaluate(theta, float(Ninj), min_neff_cut=False, want_grad=False)
+    s = r.summary
+    return s.log_det_eff, s.log_nEff_inj, s.variance_log_detection_efficiency
 
 
-__all__ = ["hierarchical_likelihood", "last_sites", "engine_for", "clear_engine_cache", "SAMPLE_VALUES", "NEG_BIG"]
+__all__ = ["hierarchical_likelihood", "per_event_log_bayes_factors", "detection_efficiency", "last_sites", "engine_for", "clear_engine_cache", "SAMPLE_VALUES", "NEG_BIG"]

@@ -86,6 +86,49 @@ def test_reference_style_model_functions(name, builder):
     L.clear_engine_cache()
 
 
+def _weights(name, case, point):
+    """PE and injection products of the two reference test models (inference_test.py:168-175, 255-262)."""
+    from gwinferno_amd.lazy import where_finite
+    from gwinferno_amd.models import BSplinePrimaryBSplineRatio, PowerlawRedshiftModel, PowerlawSplineRedshiftModel, powerlaw_primary_ratio_pdf
+
+    pe, inj = case.pe, case.inj
+    mmin, mmax = case.meta["mmin"], case.meta["mmax"]
+    if "bspline" in name:
+        mass_model = BSplinePrimaryBSplineRatio(10, 5, pe["mass_1"], inj["mass_1"], pe["mass_ratio"], inj["mass_ratio"], m1min=mmin, m2min=mmin, mmax=mmax)
+        z_model = PowerlawSplineRedshiftModel(5, pe["redshift"], inj["redshift"])
+        w = lambda d, flag: where_finite(mass_model(point["m1_coefs"], point["q_coefs"], pe_samples=flag) * z_model(d["redshift"], point["lamb"], point["z_coefs"]) / d["prior"])  # noqa: E731
+        return w(pe, True), w(inj, False)
+    z_model = PowerlawRedshiftModel(z_pe=pe["redshift"], z_inj=inj["redshift"])
+    w = lambda d: where_finite(powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=point["alpha"], beta=point["beta"], mmin=mmin, mmax=mmax)  # noqa: E731
+                               * z_model(d["redshift"], point["lamb"]) / d["prior"])
+    return w(pe), w(inj)
+
+
+@pytest.mark.parametrize("name", ["pl_test", "bspline_test"])
+def test_one_sided_reference_functions(name):
+    """per_event_log_bayes_factors / detection_efficiency (analysis.py:50-136) called on their own with
+    a lazy product, as a user's diagnostics code would: same arrays as the golden sites."""
+    from gwinferno_amd import likelihood as L
+
+    case = GoldenCase(name)
+    ref = case.sites["lin"]
+    for i in range(min(case.n_points, 4)):
+        pew, injw = _weights(name, case, case.point(i))
+        log_bfs, log_neffs, variances = L.per_event_log_bayes_factors(pew)
+        assert rel_err(log_bfs, ref["logBFs"][i]) < 1e-9
+        assert rel_err(log_neffs, ref["log_nEffs"][i]) < 1e-9
+        assert np.allclose(variances, ref["variance_log_BFs"][i], rtol=1e-8, atol=1e-12)
+        logmu, logneff, var = L.detection_efficiency(injw, case.total_inj)
+        assert rel_err(np.exp(logmu), ref["detection_efficiency"][i]) < 1e-9
+        assert rel_err(logneff, ref["log_nEff_inj"][i]) < 1e-9
+        assert np.allclose(var, ref["variance_log_detection_efficiency"][i], rtol=1e-8, atol=1e-12)
+    with pytest.raises(ValueError):
+        L.per_event_log_bayes_factors(injw)
+    with pytest.raises(ValueError):
+        L.detection_efficiency(pew, case.total_inj)
+    L.clear_engine_cache()
+
+
 def test_engine_is_cached_across_calls():
     from gwinferno_amd import likelihood as L
 

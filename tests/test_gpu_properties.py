@@ -108,3 +108,25 @@ def test_oracle_spot_check_config2_full_size():
     assert abs(res.log_likelihood - float(ref["log_likelihood"])) <= 1e-9 * abs(float(ref["log_likelihood"]))
     assert np.max(np.abs(res.log_bfs - ref["logBFs"])) < 1e-9
     assert abs(res.summary.log_nEff_inj - float(ref["log_nEff_inj"])) < 1e-9
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_hyper_parameter_takes_the_nan_branch(bad):
+    """A non-finite hyper-parameter makes every weight NaN in the reference -> log_l = nan_to_num(-inf)
+    (analysis.py:287-289); the gradient of that constant is zero.  Evaluations before and after are
+    unaffected."""
+    from gwinferno_amd.engine import NEG_BIG
+
+    comp_name, pe, inj, total, p, C = _setup("c1")
+    comp = C[comp_name](pe, inj)
+    eng = comp.engine()
+    th = comp.theta(p)
+    good = eng.evaluate(th, total, min_neff_cut=False)
+    th_bad = th.copy()
+    th_bad[0] = bad
+    r = eng.evaluate(th_bad, total, min_neff_cut=False)
+    assert r.log_likelihood == NEG_BIG
+    assert np.all(r.grad == 0.0)
+    again = eng.evaluate(th, total, min_neff_cut=False)
+    assert again.log_likelihood == good.log_likelihood
+    assert np.array_equal(again.grad, good.grad)
