@@ -62,9 +62,10 @@ class Composition:
         """Flat theta for parameter dict ``p`` (layout = order in which the factors consume parameters)."""
         return np.array([np.asarray(p[name], dtype=np.float64).flat[i] for name, i in self._theta_map()])
 
-    def named_gradient(self, grad):
+    def named_gradient(self, grad, p=None):
         """Scatter a flat gradient back onto parameter names (a parameter feeding several theta
-        slots receives the sum, as autodiff would give)."""
+        slots receives the sum, as autodiff would give).  ``p`` (the point) only matters to
+        compositions whose theta is a non-trivial function of the parameters."""
         out = {name: np.zeros(int(np.prod(shape)) if shape else 1) for name, shape in self.PARAMS.items()}
         for g, (name, i) in zip(grad, self._theta_map()):
             out[name][i] += g
@@ -251,7 +252,73 @@ class BSplineComponentMasses(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class BSplineRedshiftCase(Composition):
+    """powerlaw_primary_ratio_pdf x BSplineRedshift(8) with the class defaults (single.py:398-492: LogXBSpline,
+    ``normalize=True``).  The engine's theta holds the SCALED exponent coefficients c / (c . I) and, for the
+    grid normaliser, the raw ones (models.BSplineRedshift), so theta()/named_gradient() apply that map and
+    its chain rule instead of the value-coded lookup of the base class."""
+
+    NZ, KW = 8, {}
+    PARAMS = {"alpha": (), "beta": (), "z_coefs": (NZ,)}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        from .cosmology import planck15_lvk
+
+        cosmo = planck15_lvk()
+        self._last_p = None
+        self.z_model = M.BSplineRedshift(self.NZ, self.pe["redshift"], self.inj["redshift"], cosmo.dVc_dz(self.pe["redshift"]), cosmo.dVc_dz(self.inj["redshift"]), **self.KW)
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_m1q = M.powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=p["alpha"], beta=p["beta"], mmin=self.mmin, mmax=self.mmax)
+        return where_finite(p_m1q * self.z_model(np.asarray(p["z_coefs"], dtype=np.float64), pe_samples=pe_samples) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["z_coefs"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q["z_coefs"] = np.ones(self.NZ)
+        return q
+
+    def theta(self, p):
+        self._last_p = p
+        return self.engine().bound.theta_of(self.weights(p, True))
+
+    def named_gradient(self, grad, p=None):
+        """Gradient with respect to (alpha, beta, z_coefs) from the engine's gradient; the chain rule
+        through c' = c / (c . I) needs the point: ``p``, or the one last passed to :meth:`theta`."""
+        p = self._last_p if p is None else p
+        eng = self.engine()
+        out = {}
+        slots = {}
+        for fi, what, k, off in eng.bound.layout:
+            slots.setdefault(what, []).append((off, k))
+        scal = [off for off, _ in slots["scalar"]]
+        # scalar order follows the sorted term kinds: powerlaw (alpha) then powerlaw-ratio (beta)
+        out["alpha"], out["beta"] = float(grad[scal[0]]), float(grad[scal[1]])
+        off, k = slots["coefs"][0]
+        g_eff = np.asarray(grad[off : off + k])
+        integ = self.z_model._basis_integrals
+        if integ is None:
+            out["z_coefs"] = g_eff.copy()
+        else:
+            c = np.asarray(p["z_coefs"], dtype=np.float64)
+            n = 1.0 / (c @ integ)
+            out["z_coefs"] = n * g_eff - n * n * integ * (c @ g_eff)
+            noff, nk = slots["norm_coefs"][0]
+            out["z_coefs"] = out["z_coefs"] + np.asarray(grad[noff : noff + nk])  # zero: normalisers cancel in log_l
+        return out
+
+
+class BSplineRedshiftRawCase(BSplineRedshiftCase):
+    KW = {"normalize": False}
+
+
 COMPOSITIONS = {
+    "bspline_redshift": BSplineRedshiftCase,
+    "bspline_redshift_raw": BSplineRedshiftRawCase,
     "pl_test": PLTest,
     "plpeak": PLPeak,
     "plpeak_full": PLPeakFull,
@@ -280,6 +347,10 @@ def draw_params(name, rng):
         p = draw_params("plpeak", rng)
         p.update(xi=rng.uniform(0.0, 1.0), sig_t=rng.uniform(0.3, 4.0))
         return {k: p[k] for k in cls.PARAMS}
+    if name == "bspline_redshift":
+        return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.uniform(0.3, 2.0, size=cls.NZ)}
+    if name == "bspline_redshift_raw":
+        return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.normal(size=cls.NZ)}
     if name == "bspline_chieff":
         return {"m1_coefs": rng.normal(size=12), "q_coefs": rng.normal(size=8), "e_coefs": rng.uniform(0.1, 1.0, size=10), "p_coefs": rng.uniform(0.1, 1.0, size=8),
                 "lamb": rng.normal(2.7, 1.0)}

@@ -82,6 +82,10 @@ const Variant kVariants[] = {
     GWI_VARIANT("pl+plz+spline2", K_PL, K_PZ, K_SP, K_SP),
     // PL+Peak x PL q x default_spin_tilt (parametric.py:97-102) x PL z
     GWI_VARIANT("plpeak+plq+plz+tiltjoint", K_PP, K_PQ, K_PZ, K_TJ),
+    // BSplineRedshift (single.py:398-492) in place of the power-law redshift factor: with the parametric
+    // mass pair, and with BSplinePrimaryBSplineRatio
+    GWI_VARIANT("pl+plq+spline", K_PL, K_PQ, K_SP),
+    GWI_VARIANT("spline3", K_SP, K_SP, K_SP),
     // single-term sequences (term-level parity tests)
     GWI_VARIANT("lspline", K_LS),
     GWI_VARIANT("tiltjoint", K_TJ),

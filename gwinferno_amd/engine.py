@@ -25,7 +25,7 @@ class BoundModel:
         self.terms = []         # dicts mirroring gwi_term
         self.norms = []         # (GridNorm, expo_theta, coef_off)
         self.norm_keys = []
-        self.layout = []        # [(factor_index, "scalar", k, offset) | (factor_index, "coefs", n, offset)]
+        self.layout = []        # [(factor_index, "scalar", k, offset) | (factor_index, "coefs" | "norm_coefs", n, offset)]
         self.n_theta = 0
         self.kappa_col = -1
         self.vt_norm = -1
@@ -39,6 +39,8 @@ class BoundModel:
             f = density.factors[fi]
             if what == "scalar":
                 theta[off] = float(np.asarray(f.scalars[k]))
+            elif what == "norm_coefs":
+                theta[off : off + k] = np.asarray(f.norm.coefs, dtype=np.float64).ravel()
             else:
                 theta[off : off + k] = np.asarray(f.coefs, dtype=np.float64).ravel()
         return theta
@@ -159,8 +161,17 @@ def bind(pe, inj, hypervolume=None):
                 if g.expo_param is not None:
                     ref_factor, k = g.expo_param
                     expo_theta = factor_theta[factor_index[id(ref_factor)]][0][k]
+                norm_coef_off = coef_off
+                if g.coefs is not None:  # the normaliser integrates a coefficient vector of its own
+                    if int(np.size(g.coefs)) != g.n_basis:
+                        raise ValueError(f"factor {fi}: normaliser expects {g.n_basis} coefficients")
+                    norm_coef_off = bm.n_theta
+                    bm.layout.append((fi, "norm_coefs", g.n_basis, norm_coef_off))
+                    bm.n_theta += g.n_basis
+                    if bm.n_theta > N.GWI_MAX_THETA:
+                        raise ValueError(f"{bm.n_theta} hyper-parameters exceed GWI_MAX_THETA={N.GWI_MAX_THETA}")
                 bm.norm_keys.append(nkey)
-                bm.norms.append((g, expo_theta, coef_off if g.n_basis > 0 else 0))
+                bm.norms.append((g, expo_theta, norm_coef_off if g.n_basis > 0 else 0))
                 norm_idx = len(bm.norms) - 1
         bm.terms.append(dict(kind=fp.kind, cols=cols, theta=slots, n_basis=fp.n_basis, coef_off=max(coef_off, 0), flags=fp.flags, norm=norm_idx, p=fp.consts,
                              owner=fp.norm_owner))

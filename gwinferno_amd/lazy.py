@@ -64,9 +64,11 @@ class Column:
 class GridNorm:
     """A grid normaliser Z(theta) (see gwi_norm in include/gwi_engine.h).  ``expo_param`` is the index
     (within the owning factor's ``scalars``) of the power-law exponent, ``coefs`` marks that the
-    owning factor's spline coefficients enter the integrand."""
+    owning factor's spline coefficients enter the integrand -- or ``coefs``, when the integrand uses a
+    different coefficient vector from the per-sample term (BSplineRedshift with a normalised basis)."""
 
-    def __init__(self, tw, lb=None, l1=None, expo_param=None, expo_add=0.0, us=None, n_basis=0, lo=0.0, hi=1.0, spline_flags=0):
+    def __init__(self, tw, lb=None, l1=None, expo_param=None, expo_add=0.0, us=None, n_basis=0, lo=0.0, hi=1.0, spline_flags=0, coefs=None):
+        self.coefs = coefs
         self.tw = np.ascontiguousarray(tw, dtype=np.float64)
         self.lb = None if lb is None else np.ascontiguousarray(lb, dtype=np.float64)
         self.l1 = None if l1 is None else np.ascontiguousarray(l1, dtype=np.float64)

@@ -62,7 +62,7 @@ def _collect_params(bound, density):
     out = []
     for fi, what, k, off in bound.layout:
         f = density.factors[fi]
-        out.append(f.scalars[k] if what == "scalar" else f.coefs)
+        out.append(f.scalars[k] if what == "scalar" else (f.norm.coefs if what == "norm_coefs" else f.coefs))
     return out
 
 

@@ -309,6 +309,62 @@ class BSplineMass(Base1DBSplineModel):
         super().__init__(n_splines, m, m_inj, basis=basis, xrange=xrange, **kwargs)
 
 
+class BSplineRedshift(object):
+    """single.py:398-492: ``exp(f(z)) dVc/dz / (1+z) / normalization(coefs)`` with ``f`` a LogXBSpline on
+    ``xrange = (1e-4, zmax)``, exponent 0 outside that range (the masked scatter of :77-109), normalised
+    by ``trapz(dVc/dz/(1+z) exp(sum c_k B_k), zgrid)`` on a 1000-point grid between the common redshift
+    bounds of the PE and injection sets (:447-451, :454-472).
+
+    The reference's default basis is LogXBSpline with ``normalize=True``: ``funcs`` then evaluate
+    ``project`` = ``sum c_k B_k / trapz(sum c_k B_k(grid), grid)`` (interpolation.py:280-317), i.e. the
+    per-sample exponent uses the coefficients scaled by ``1 / (c . I)``, ``I_k = trapz(B_k(grid), grid)``,
+    while ``normalization`` uses the raw ones (:471).  That scaling is theta-only, so it is applied here,
+    on the host, to the coefficient vector handed to the engine (``c / (c @ I)`` also traces under JAX,
+    whose autodiff then supplies the chain rule); the grid normaliser gets the raw vector."""
+
+    def __init__(self, n_splines, z, z_inj, dVdc, dVdc_inj, zmax=2.3, basis=LogXBSpline, **kwargs):
+        if basis is not LogXBSpline:
+            raise NotImplementedError("only the default LogXBSpline basis is implemented")
+        xrange = kwargs.pop("xrange", (1e-4, zmax))
+        degree = kwargs.pop("degree", 3)
+        if degree != 3:
+            raise NotImplementedError("only cubic splines are implemented")
+        kwargs.setdefault("normalize", True)  # LogXBSpline's default (interpolation.py:320)
+        self.n_splines = int(n_splines)
+        self.xmin, self.xmax = xrange
+        self.interpolator = it = LogXBSpline(self.n_splines, xrange=xrange, k=4, **kwargs)
+        z, z_inj = _f(z), _f(z_inj)
+        self._z = {PE: z, INJ: z_inj}
+        self.zmin = max(np.min(z), np.min(z_inj))
+        self.zmax = min(np.max(z), np.max(z_inj))
+        self.zgrid = np.linspace(self.zmin, self.zmax, 1000)
+        self.dVcdzgrid = planck15_lvk().dVc_dz(self.zgrid)
+        with np.errstate(all="ignore"):
+            self._static = {PE: np.log(_f(dVdc)) - np.log1p(z), INJ: np.log(_f(dVdc_inj)) - np.log1p(z_inj)}
+            self._grid_lb = np.log(self.dVcdzgrid) - np.log1p(self.zgrid)
+        self._grid_tw = trapezoid_weights(self.zgrid)
+        self._grid_us = it.coordinate(self.zgrid)
+        # integrals of the basis functions over the basis's own normalisation grid (linear in z, :343)
+        self._basis_integrals = it.bases(it.grid) @ trapezoid_weights(it.grid) if it.normalize else None
+
+    def _exponent_coefs(self, coefs):
+        if self._basis_integrals is None:
+            return coefs
+        return coefs / (coefs @ self._basis_integrals)
+
+    def normalization(self, cs):
+        return LazyNorm(self, [], cs)
+
+    def __call__(self, coefs, pe_samples=True):
+        side = PE if pe_samples else INJ
+        it = self.interpolator
+        f = Factor(N.TERM_EXP_SPLINE, side, [Column("log", self._z[side])], coefs=self._exponent_coefs(coefs), consts=(it.lo, it.hi), n_basis=it.N,
+                   flags=N.SPLINE_OUTSIDE_ZERO_EXPONENT, static_log=self._static[side], owner=self, tag="zspline")
+        f.norm = GridNorm(self._grid_tw, lb=self._grid_lb, us=self._grid_us, n_basis=it.N, lo=it.lo, hi=it.hi, spline_flags=N.SPLINE_OUTSIDE_ZERO_EXPONENT,
+                          coefs=coefs if it.normalize else None)
+        return Density([f], side)
+
+
 # ================================================================================================
 # separable products (gwinferno/models/bsplines/separable.py)
 # ================================================================================================

@@ -414,6 +414,29 @@ def _finite_or_zero(w):
     return np.where(np.isnan(w) | np.isinf(w), 0.0, w)
 
 
+class SplineRedshift(Spline1D):
+    """BSplineRedshift (single.py:398-492): LogXBSpline on (1e-4, zmax=2.3) by default WITH the basis's own
+    normalisation (interpolation.py:320: ``normalize=True``), so ``funcs`` return project() = spline / trapz(spline)
+    (:280-317) scattered into zeros; R(z) = exp(funcs) dVc/dz / (1+z) / normalization(cs), where normalization
+    integrates exp of the RAW spline (einsum, :471) over a 1000-point grid between the common z bounds (:447-451)."""
+
+    def __init__(self, n_basis, z_pe, z_inj, dVdc_pe, dVdc_inj, zmax=2.3, normalize=True):
+        super().__init__(n_basis, z_pe, z_inj, (1e-4, zmax), "logX", normalize=normalize)
+        self.zmin = max(np.min(z_pe), np.min(z_inj))
+        self.zmax = min(np.max(z_pe), np.max(z_inj))
+        self.zgrid = np.linspace(self.zmin, self.zmax, 1000)
+        self.dVcdzgrid = planck15_lvk().dVc_dz(self.zgrid)
+        self.grid_bases = self.basis.design(self.zgrid)
+        self.dV = {True: dVdc_pe, False: dVdc_inj}
+        self.z = {True: z_pe, False: z_inj}
+
+    def normalization(self, cs):
+        return np.trapezoid(self.dVcdzgrid / (1 + self.zgrid) * np.exp(np.tensordot(np.asarray(cs, dtype=np.float64), self.grid_bases, axes=(0, 0))), self.zgrid)
+
+    def __call__(self, coefs, pe_samples=True):
+        return np.exp(super().__call__(coefs, pe_samples)) * self.dV[pe_samples] / (1 + self.z[pe_samples]) / self.normalization(coefs)
+
+
 class Composition:
     """A population model bound to one catalog: ``weights(params, pe_samples)`` returns the
     linear importance weights p(theta|Lambda)/prior, ``hypervolume(params)`` the redshift
@@ -619,7 +642,35 @@ class BSplineComponentMasses(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class BSplineRedshiftCase(Composition):
+    """powerlaw_primary_ratio_pdf x BSplineRedshift(8) with the class defaults (single.py:398-492)."""
+
+    NZ, NORMALIZE = 8, True
+    PARAMS = {"alpha": (), "beta": (), "z_coefs": (NZ,)}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        cosmo = planck15_lvk()
+        self.z_model = SplineRedshift(self.NZ, pedict["redshift"], injdict["redshift"], cosmo.dVc_dz(pedict["redshift"]), cosmo.dVc_dz(injdict["redshift"]),
+                                      normalize=self.NORMALIZE)
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            dens = powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], self.mmin, self.mmax)
+            return _finite_or_zero(dens * self.z_model(p["z_coefs"], pe_samples=pe_samples) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["z_coefs"])
+
+
+class BSplineRedshiftRawCase(BSplineRedshiftCase):
+    NORMALIZE = False
+
+
 COMPOSITIONS = {
+    "bspline_redshift": BSplineRedshiftCase,
+    "bspline_redshift_raw": BSplineRedshiftRawCase,
     "plpeak_default_tilt": PLPeakDefaultTilt,
     "bspline_chieff": BSplineChiEff,
     "bspline_component_masses": BSplineComponentMasses,

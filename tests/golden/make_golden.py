@@ -294,7 +294,44 @@ class BSplineComponentMasses(Composition):
         return {"m_coefs": rng.normal(size=cls.NM), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
 
 
+class BSplineRedshiftCase(Composition):
+    """powerlaw_primary_ratio_pdf x BSplineRedshift(8, z, z_inj, dVc/dz, dVc/dz_inj) (single.py:398-492) with
+    the class defaults: LogXBSpline(normalize=True) on (1e-4, 2.3)."""
+
+    NZ = 8
+    KW = {}
+    params = {"alpha": (), "beta": (), "z_coefs": (NZ,)}
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        cosmo = ref.cosmology.PLANCK_2015_LVK_Cosmology
+        self.z_model = ref.single.BSplineRedshift(self.NZ, pe["redshift"], inj["redshift"], cosmo.dVcdz(pe["redshift"]), cosmo.dVcdz(inj["redshift"]), **self.KW)
+
+    def weights(self, p, d, pe_samples):
+        p_m1q = ref.parametric.powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=p["alpha"], beta=p["beta"], mmin=MMIN, mmax=MMAX)
+        return _guard(p_m1q * self.z_model(p["z_coefs"], pe_samples=pe_samples) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["z_coefs"])
+
+    @classmethod
+    def draw(cls, rng):
+        return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.uniform(0.3, 2.0, size=cls.NZ)}
+
+
+class BSplineRedshiftRawCase(BSplineRedshiftCase):
+    """The same with ``normalize=False`` passed through to the basis: plain exp(B-spline in log z)."""
+
+    KW = {"normalize": False}
+
+    @classmethod
+    def draw(cls, rng):
+        return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.normal(size=cls.NZ)}
+
+
 COMPOSITIONS = {
+    "bspline_redshift": BSplineRedshiftCase,
+    "bspline_redshift_raw": BSplineRedshiftRawCase,
     "plpeak_default_tilt": PLPeakDefaultTilt,
     "bspline_chieff": BSplineChiEff,
     "bspline_component_masses": BSplineComponentMasses,
@@ -524,7 +561,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "gwtc3"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3"]
     if "terms" in todo:
         make_terms()
     if "bases" in todo:
@@ -543,6 +580,10 @@ def main(which):
         make_case("case_plpeak_default_tilt.npz", "plpeak_default_tilt", pe, inj, tot, seed=9, n_points=3, n_grad=1)
         make_case("case_bspline_chieff.npz", "bspline_chieff", pe, inj, tot, seed=10, n_points=3, n_grad=1)
         make_case("case_bspline_component_masses.npz", "bspline_component_masses", pe, inj, tot, seed=11, n_points=3, n_grad=1)
+    if "cases3" in todo:
+        pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+        make_case("case_bspline_redshift.npz", "bspline_redshift", pe, inj, tot, seed=12, n_points=3, n_grad=1)
+        make_case("case_bspline_redshift_raw.npz", "bspline_redshift_raw", pe, inj, tot, seed=13, n_points=3, n_grad=1)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

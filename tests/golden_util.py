@@ -16,6 +16,8 @@ CASES = [
     "plpeak_default_tilt",
     "bspline_chieff",
     "bspline_component_masses",
+    "bspline_redshift",
+    "bspline_redshift_raw",
     "gwtc3_pl_test",
     "gwtc3_bspline_test",
 ]

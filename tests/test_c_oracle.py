@@ -32,7 +32,7 @@ def test_c_oracle_sites_and_gradient(name):
                 assert rel_err(val, case.sites[fs][site][i]) < 1e-9, (name, fs, i, site)
             assert np.allclose(s.variance_log_likelihood, case.sites[fs]["variance_log_likelihood"][i], rtol=1e-8, atol=1e-12)
     for i, fd in case.fdgrad.items():
-        g = comp.named_gradient(orc.evaluate(bm.theta_of(comp.weights(case.point(i), True)), case.total_inj, min_neff_cut=False)["grad"])
+        g = comp.named_gradient(orc.evaluate(bm.theta_of(comp.weights(case.point(i), True)), case.total_inj, min_neff_cut=False)["grad"], p=case.point(i))
         for pname, ref in fd.items():
             scale = max(1.0, float(np.max(np.abs(ref))))
             assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname)

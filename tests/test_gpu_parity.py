@@ -81,7 +81,7 @@ def test_gradient_matches_finite_differences_of_reference(name):
     comp, eng = _engine(case)
     for i, fd in case.fdgrad.items():
         res = eng.evaluate(comp.theta(case.point(i)), case.total_inj, min_neff_cut=False)
-        g = comp.named_gradient(res.grad)
+        g = comp.named_gradient(res.grad, p=case.point(i))
         for pname, ref in fd.items():
             scale = max(1.0, float(np.max(np.abs(ref))))
             assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname, g[pname], ref)
@@ -274,7 +274,7 @@ def test_gradient_with_marginalised_selection(comp_name):
         p_hi[first] = (np.atleast_1d(p[first]) + bump).reshape(np.shape(p[first]))
         p_lo[first] = (np.atleast_1d(p[first]) - bump).reshape(np.shape(p[first]))
         fd_orc = (float(orc.evaluate(p_hi, total, **flags)["log_likelihood"]) - float(orc.evaluate(p_lo, total, **flags)["log_likelihood"])) / (2 * step)
-        g_named = comp.named_gradient(res.grad)
+        g_named = comp.named_gradient(res.grad, p=p)
         assert abs(np.atleast_1d(g_named[first])[0] - fd_orc) < 1e-5 * max(1.0, abs(fd_orc))
     thetas = np.stack([comp.theta(draw_params(comp_name, rng)) for _ in range(3)])
     batch = eng.evaluate_batch(thetas, total, **flags)
