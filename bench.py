@@ -254,6 +254,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
+                "median_scan_us": 1e3 * float(np.median(scan_ms)) if scan_ms else None,
+                "timing": "HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's stream, every 16th timed step",
                 "timed_launches": len(scan_ms),
                 # second view: the scan is fp64-issue/latency bound, not HBM bound
                 "fp64_vector": {

@@ -45,3 +45,18 @@ def load_reference():
     ns.numpyro = importlib.import_module("numpyro")
     ns.jnp = importlib.import_module("jax.numpy")
     return ns
+
+
+def load_preprocess():
+    """The reference's injection-selection and PE-prior helpers (preprocess/selection.py,
+    preprocess/data_collection.py) under in-memory h5py / xarray / arviz stand-ins (refstub/)."""
+    load_reference()
+    if "gwinferno.preprocess" not in sys.modules:
+        mod = types.ModuleType("gwinferno.preprocess")
+        mod.__path__ = [os.path.join(REFERENCE_ROOT, "gwinferno/preprocess")]
+        sys.modules["gwinferno.preprocess"] = mod
+    ns = types.SimpleNamespace()
+    ns.h5py = importlib.import_module("h5py")
+    ns.selection = importlib.import_module("gwinferno.preprocess.selection")
+    ns.data_collection = importlib.import_module("gwinferno.preprocess.data_collection")
+    return ns
