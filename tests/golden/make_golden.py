@@ -548,6 +548,73 @@ def make_bases():
     print("wrote bases.npz")
 
 
+def make_catalog_fixture():
+    """Injection selection + prior construction (preprocess/selection.py:12-80, 82-142) and the redshift
+    PE prior (preprocess/data_collection.py:93-98) run UNMODIFIED on a seeded synthetic injection table
+    served through the in-memory h5py stand-in.  Inputs and outputs are stored."""
+    from ref_import import load_preprocess
+
+    pp = load_preprocess()
+    rng = np.random.default_rng(BASE_SEED + 21)
+    n = 800
+    m1 = rng.uniform(5.0, 90.0, n)
+    tab = {
+        "mass1_source": m1,
+        "mass2_source": m1 * rng.uniform(0.1, 1.0, n),
+        "redshift": rng.uniform(0.01, 1.8, n),
+        "sampling_pdf": rng.uniform(1e-6, 1e-3, n),
+        "ifar_gstlal": 10.0 ** rng.uniform(-3, 1, n),
+        "ifar_pycbc_bbh": 10.0 ** rng.uniform(-3, 1, n),
+        "optimal_snr_net": rng.uniform(4.0, 16.0, n),
+        "name": rng.choice(np.array([b"o1", b"o2", b"o3"]), n),
+        "pastro_cwb": rng.uniform(0.0, 1.0, n),
+    }
+    for ii in (1, 2):
+        for ax in "xyz":
+            tab[f"spin{ii}{ax}"] = rng.uniform(-0.5, 0.5, n)
+    out = {f"o3_in/{k}": (v.astype("S2") if v.dtype.kind == "S" else v) for k, v in tab.items()}
+    out["o3_attrs"] = np.array([7.7e7, 3.1e7])  # total_generated, analysis_time_s
+    pp.h5py.REGISTRY["o3.h5"] = {"attrs": {"analysis_time_s": 3.1e7}, "groups": {"injections": {"attrs": {"total_generated": 7.7e7}, "data": tab}}}
+    variants = {
+        "mq": (["mass_1", "mass_ratio", "redshift"], {}),
+        "spins": (["mass_1", "mass_ratio", "redshift", "a_1", "a_2", "cos_tilt_1", "cos_tilt_2"], {"ifar": 2.0, "snr": 12.0}),
+        "cuts": (["mass_1", "redshift"], {"additional_cuts": {"pastro_cwb": 0.9}}),
+    }
+    for tag, (names, kw) in variants.items():
+        arr = pp.selection.get_o3_cumulative_injection_dict("o3.h5", names, **kw)
+        out[f"o3_out/{tag}/data"] = np.asarray(arr.data, dtype=np.float64)
+        out[f"o3_out/{tag}/params"] = np.array(list(arr.coords["param"]))
+        out[f"o3_out/{tag}/attrs"] = np.array([float(arr.attrs["total_generated"]), float(arr.attrs["analysis_time"])])
+    # O4a-style structured table (selection.py:12-80)
+    lnp = "lnpdraw_mass1_source_mass2_source_redshift_spin1x_spin1y_spin1z_spin2x_spin2y_spin2z"
+    fields = ["mass1_source", "mass2_source", "redshift", "weights", lnp, "semianalytic_observed_phase_maximized_snr_net", "far_gstlal", "far_pycbc"] + [
+        f"spin{ii}{ax}" for ii in (1, 2) for ax in "xyz"]
+    ev = np.zeros(n, dtype=[(f, "f8") for f in fields])
+    ev["mass1_source"], ev["mass2_source"], ev["redshift"] = tab["mass1_source"], tab["mass2_source"], tab["redshift"]
+    ev["weights"] = rng.uniform(0.5, 2.0, n)
+    ev[lnp] = rng.uniform(-12.0, -4.0, n)
+    ev["semianalytic_observed_phase_maximized_snr_net"] = rng.uniform(4.0, 14.0, n)
+    ev["far_gstlal"], ev["far_pycbc"] = 10.0 ** rng.uniform(-1, 3, n), 10.0 ** rng.uniform(-1, 3, n)
+    for ii in (1, 2):
+        for ax in "xyz":
+            ev[f"spin{ii}{ax}"] = tab[f"spin{ii}{ax}"]
+    for f in fields:
+        out[f"o4a_in/{f}"] = np.asarray(ev[f])
+    pp.h5py.REGISTRY["o4a.h5"] = {"attrs": {"total_generated": 5.5e7, "analysis_time": 2.2e7}, "datasets": {"events": ev}}
+    for tag, (names, kw) in {"mq": (["mass_1", "mass_ratio", "redshift"], {}), "spins": (["mass_1", "mass_ratio", "redshift", "a_1"], {"ifar": 0.5, "snr": 11.0})}.items():
+        arr = pp.selection.get_o4a_cumulative_injection_dict("o4a.h5", names, **kw)
+        out[f"o4a_out/{tag}/data"] = np.asarray(arr.data, dtype=np.float64)
+        out[f"o4a_out/{tag}/params"] = np.array(list(arr.coords["param"]))
+        out[f"o4a_out/{tag}/attrs"] = np.array([float(arr.attrs["total_generated"]), float(arr.attrs["analysis_time"])])
+    zs = np.linspace(1e-3, 2.2, 257)
+    out["pz/z"] = zs
+    out["pz/comoving"] = np.asarray(pp.data_collection.dl_2_prior_on_z(zs), dtype=np.float64)
+    out["pz/euclidean"] = np.asarray(pp.data_collection.dl_2_prior_on_z(zs, euclidean=True), dtype=np.float64)
+    path = os.path.join(HERE, "catalog.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote catalog.npz: {os.path.getsize(path) // 1024} KiB; found o3 mq {out['o3_out/mq/data'].shape}, o4a mq {out['o4a_out/mq/data'].shape}")
+
+
 def load_gwtc3(n_samples=64):
     """The reference's own PE tensor (tests/data/..., NetCDF-3 classic): 69 events x 9 params x
     1000 samples, big-endian float32 -> float64; first n_samples per event."""
@@ -561,7 +628,9 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3", "catalog"]
+    if "catalog" in todo:
+        make_catalog_fixture()
     if "terms" in todo:
         make_terms()
     if "bases" in todo:

@@ -1,0 +1,89 @@
+"""CPU: catalog ingestion (gwinferno_amd/catalog.py) against the outputs of the UNMODIFIED reference
+functions (preprocess/selection.py:12-142, preprocess/data_collection.py:93-98) recorded in
+tests/golden/catalog.npz by tests/golden/make_golden.py (in-memory h5py/xarray stand-ins)."""
+import os
+
+import numpy as np
+import pytest
+
+from gwinferno_amd import catalog as cat
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "catalog.npz"))
+
+
+def _table(prefix):
+    return {k[len(prefix):]: GOLD[k] for k in GOLD.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("tag,names,kw", [
+    ("mq", ["mass_1", "mass_ratio", "redshift"], {}),
+    ("spins", ["mass_1", "mass_ratio", "redshift", "a_1", "a_2", "cos_tilt_1", "cos_tilt_2"], {"ifar": 2.0, "snr": 12.0}),
+    ("cuts", ["mass_1", "redshift"], {"additional_cuts": {"pastro_cwb": 0.9}}),
+])
+def test_o3_found_injections_match_reference(tag, names, kw):
+    injs, found = cat.o3_found_injections(_table("o3_in/"), names, **kw)
+    ref = GOLD[f"o3_out/{tag}/data"]
+    params = [str(p) for p in GOLD[f"o3_out/{tag}/params"]]
+    assert list(injs) == params
+    assert int(found.sum()) == ref.shape[1] and 0 < found.sum() < found.size
+    for i, p in enumerate(params):
+        assert np.array_equal(injs[p], ref[i]) or np.allclose(injs[p], ref[i], rtol=1e-15, atol=0), p
+    total, t_years = GOLD[f"o3_out/{tag}/attrs"]
+    assert cat.analysis_time_years({"analysis_time_s": GOLD["o3_attrs"][1]}) == t_years
+
+
+@pytest.mark.parametrize("tag,names,kw", [("mq", ["mass_1", "mass_ratio", "redshift"], {}), ("spins", ["mass_1", "mass_ratio", "redshift", "a_1"], {"ifar": 0.5, "snr": 11.0})])
+def test_o4a_found_injections_match_reference(tag, names, kw):
+    injs, found = cat.o4a_found_injections(_table("o4a_in/"), names, **kw)
+    ref = GOLD[f"o4a_out/{tag}/data"]
+    params = [str(p) for p in GOLD[f"o4a_out/{tag}/params"]]
+    assert list(injs) == params
+    assert int(found.sum()) == ref.shape[1] and 0 < found.sum() < found.size
+    for i, p in enumerate(params):
+        assert np.allclose(injs[p], ref[i], rtol=1e-15, atol=0), p
+
+
+def test_redshift_prior_tables_match_reference():
+    z = GOLD["pz/z"]
+    assert np.allclose(cat.dl_2_prior_on_z(z), GOLD["pz/comoving"], rtol=1e-12)
+    assert np.allclose(cat.dl_2_prior_on_z(z, euclidean=True), GOLD["pz/euclidean"], rtol=1e-12)
+
+
+def test_pe_sampling_prior_formula():
+    """data_collection.py:101-132 spelled out for a two-event tensor with mixed redshift priors."""
+    rng = np.random.default_rng(3)
+    pe = {"redshift": rng.uniform(0.05, 1.5, (2, 50)), "mass_1": rng.uniform(5, 80, (2, 50))}
+    got = cat.pe_sampling_prior(pe, ["mass_1", "mass_ratio", "redshift", "a_1"], redshift_prior=["euclidean", "comoving"])
+    zs = np.linspace(0, 1.9 * 1.01, 1000)
+    for i, eu in enumerate((True, False)):
+        p = cat.dl_2_prior_on_z(zs, euclidean=eu)
+        want = np.interp(pe["redshift"][i], zs, p / np.trapezoid(p, zs)) * (1 + pe["redshift"][i]) ** 2 * pe["mass_1"][i] / 4
+        assert np.allclose(got[i], want, rtol=1e-14)
+    with pytest.raises(AssertionError):
+        cat.pe_sampling_prior(pe, ["redshift"], redshift_prior="flat")
+
+
+def test_read_pe_netcdf3_roundtrip(tmp_path):
+    """The reference's PE tensor layout (NetCDF-3 classic: a char `param` coordinate + one (param, sample)
+    float32 variable per event), written here with scipy and read back."""
+    from scipy.io import netcdf_file
+
+    params = ["mass_1", "mass_ratio", "redshift", "prior"]
+    rng = np.random.default_rng(0)
+    events = {f"GW{150914 + i}": rng.uniform(0.1, 50.0, (len(params), 12)).astype(">f4") for i in range(3)}
+    path = str(tmp_path / "pe.h5")
+    with netcdf_file(path, "w") as f:
+        f.createDimension("param", len(params))
+        f.createDimension("sample", 12)
+        f.createDimension("string10", 10)
+        v = f.createVariable("param", "S1", ("param", "string10"))
+        for i, p in enumerate(params):
+            v[i] = np.array(list(p.ljust(10)), dtype="S1")
+        f.createVariable("sample", "i4", ("sample",))[:] = np.arange(12)
+        for name, arr in events.items():
+            f.createVariable(name, ">f4", ("param", "sample"))[:] = arr
+    pedict, names = cat.read_pe_netcdf3(path, n_samples=8)
+    assert names == list(events) and list(pedict) == params
+    for i, p in enumerate(params):
+        assert pedict[p].shape == (3, 8) and pedict[p].dtype == np.float64
+        assert np.array_equal(pedict[p], np.stack([events[n][i, :8].astype(np.float64) for n in names]))
