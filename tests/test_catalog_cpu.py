@@ -87,3 +87,19 @@ def test_read_pe_netcdf3_roundtrip(tmp_path):
     for i, p in enumerate(params):
         assert pedict[p].shape == (3, 8) and pedict[p].dtype == np.float64
         assert np.array_equal(pedict[p], np.stack([events[n][i, :8].astype(np.float64) for n in names]))
+
+
+_REF_PE = "/root/reference/tests/data/xarray_GWTC3_BBH_69evs_downsampled_1000samps_nospin.h5"
+
+
+@pytest.mark.skipif(not os.path.exists(_REF_PE), reason="reference tree only exists in the build container")
+def test_reader_on_the_reference_pe_file():
+    """The reference's own GWTC-3 PE tensor, read by the product reader, equals the PE arrays stored in the
+    committed GWTC-3 golden case (which the generator read independently)."""
+    from golden_util import GoldenCase
+
+    pe, events = cat.read_pe_netcdf3(_REF_PE, n_samples=64)
+    case = GoldenCase("gwtc3_pl_test")
+    assert len(events) == 69
+    for k, v in case.pe.items():
+        assert np.array_equal(pe[k], v), k
