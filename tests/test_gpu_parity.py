@@ -282,3 +282,49 @@ def test_gradient_with_marginalised_selection(comp_name):
         one = eng.evaluate(thetas[k], total, **flags)
         assert np.allclose(batch[k].grad, one.grad, rtol=1e-10, atol=1e-11)
     eng.close()
+
+
+@pytest.mark.parametrize("n_ev,n_pe,n_inj,env", [
+    (700, 40, 3000, {}),                                   # many short events: one partly filled wave per event
+    (3, 20000, 300000, {"GWI_SAMPLES_PER_BLOCK": "512"}),  # > 64 injection groups -> widened groups; 40 tiles per event
+    (6, 33, 40, {}),                                       # everything shorter than one wave
+    (64, 1, 65, {}),                                       # one posterior sample per event
+])
+def test_launch_geometry_extremes(n_ev, n_pe, n_inj, env, monkeypatch):
+    """Shapes that stress the tile / group bookkeeping (tiles per event, injection groups > 64 ->
+    regrouped, device-final vs host-final mode) against the NumPy oracle."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle import numpy_oracle as O
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=23)
+    comp = COMPOSITIONS["bspline_test"](pe, inj)
+    eng = comp.engine()
+    orc = O.COMPOSITIONS["bspline_test"](pe, inj)
+    p = draw_params("bspline_test", np.random.default_rng(4))
+    res = eng.evaluate(comp.theta(p), total, min_neff_cut=False)
+    ref = orc.evaluate(p, total, min_neff_cut=False)
+    ok = np.isfinite(ref["logBFs"])
+    assert np.array_equal(np.isfinite(res.log_bfs), ok)
+    assert rel_err(res.log_bfs[ok], ref["logBFs"][ok]) < VALUE_RTOL
+    assert rel_err(res.log_neffs[ok], ref["log_nEffs"][ok]) < VALUE_RTOL
+    assert rel_err(np.exp(res.summary.log_det_eff), ref["detection_efficiency"]) < VALUE_RTOL
+    if n_inj > 1:
+        assert rel_err(res.summary.log_nEff_inj, ref["log_nEff_inj"]) < 1e-8
+    if np.isfinite(float(ref["log_likelihood"])) and abs(float(ref["log_likelihood"])) < 1e300:
+        assert rel_err(res.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+    eng.close()
+
+
+def test_geometry_over_the_tile_limit_is_refused(monkeypatch):
+    """More than 64 tile records per event cannot be combined by one wave: gwi_create says so."""
+    from gwinferno_amd._native import NativeEngineError
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.synthetic import make_catalog
+
+    monkeypatch.setenv("GWI_SAMPLES_PER_BLOCK", "512")  # = one trip of the two-samples-per-lane kernel
+    pe, inj, _ = make_catalog(2, 512 * 70, 100, seed=1)
+    with pytest.raises(NativeEngineError, match="more than 64 tile records"):
+        COMPOSITIONS["pl_test"](pe, inj).engine()

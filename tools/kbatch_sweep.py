@@ -18,3 +18,10 @@ for rep in range(2):
         for _ in range(n): eng.evaluate_batch(ths[:K], total, min_neff_cut=False)
         dt = time.perf_counter() - t0
         print(cfg, "K", K, "us/batch %.1f  us/eval %.2f" % (1e6*dt/n, 1e6*dt/n/K), flush=True)
+# where a K = 16 batch spends its time: kernel durations (launch-attached events) vs the whole call
+eng.set_timing(True)
+ks = []
+for _ in range(50):
+    eng.evaluate_batch(ths, total, min_neff_cut=False)
+    ks.append(eng.last_kernel_ms())
+print(cfg, "K 16 kernel us [scan, combine, final] (median):", np.round(1e3 * np.median(np.array(ks), axis=0), 1), flush=True)
