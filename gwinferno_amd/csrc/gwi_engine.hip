@@ -88,6 +88,8 @@ const Variant kVariants[] = {
     // mass pair, and with BSplinePrimaryBSplineRatio
     GWI_VARIANT("pl+plq+spline", K_PL, K_PQ, K_SP),
     GWI_VARIANT("spline3", K_SP, K_SP, K_SP),
+    // BSplinePrimaryBSplineRatio alone: the (m1, q) mesh of the posterior-predictive curves (postprocess/calculations.py:20-60)
+    GWI_VARIANT("spline2", K_SP, K_SP),
     // single-term sequences (term-level parity tests)
     GWI_VARIANT("lspline", K_LS),
     GWI_VARIANT("tiltjoint", K_TJ),

@@ -615,6 +615,39 @@ def make_catalog_fixture():
     print(f"wrote catalog.npz: {os.path.getsize(path) // 1024} KiB; found o3 mq {out['o3_out/mq/data'].shape}, o4a mq {out['o4a_out/mq/data'].shape}")
 
 
+def make_ppd_fixture():
+    """Posterior-predictive curves (postprocess/calculations.py:20-242) from the unmodified reference for a
+    few seeded posterior draws; stored with their inputs."""
+    from ref_import import load_postprocess
+
+    calc = load_postprocess()
+    rng = np.random.default_rng(BASE_SEED + 31)
+    n = 3
+    out = {}
+    plp = dict(alpha=rng.normal(-2.5, 0.7, n), beta=rng.normal(1.0, 0.7, n), mu_peak=rng.uniform(25, 45, n), sig_peak=rng.uniform(2, 8, n), lamb=rng.uniform(0.02, 0.2, n))
+    rate, frac = rng.uniform(10, 40, n), rng.uniform(0.3, 1.0, n)
+    mp, ms, qp, qs = calc.calculate_powerlaw_peak_mass_ppds(plp["alpha"], plp["beta"], plp["mu_peak"], plp["sig_peak"], plp["lamb"], 5.0, 100.0, rate=rate, pop_frac=frac)
+    out.update({f"plpeak_in/{k}": v for k, v in plp.items()})
+    out.update({"rate": rate, "pop_frac": frac, "plpeak_out/mpdfs": np.asarray(mp), "plpeak_out/ms": np.asarray(ms), "plpeak_out/qpdfs": np.asarray(qp), "plpeak_out/qs": np.asarray(qs)})
+    nsp = {"m1": 14, "q": 8}
+    m_cs, q_cs = rng.normal(size=(n, nsp["m1"])), rng.normal(size=(n, nsp["q"]))
+    mp, ms, qp, qs = calc.calculate_bspline_mass_ppds(m_cs, q_cs, nsp, 5.0, 100.0)
+    out.update({"bspline_in/m_cs": m_cs, "bspline_in/q_cs": q_cs, "bspline_out/mpdfs": np.asarray(mp), "bspline_out/qpdfs": np.asarray(qp)})
+    a_a, b_a = rng.uniform(1.0, 4.0, n), rng.uniform(1.0, 6.0, n)
+    ap, aa = calc.calculate_beta_spin_mag(a_a, b_a, rate=rate, pop_frac=frac)
+    out.update({"beta_in/alpha": a_a, "beta_in/beta": b_a, "beta_out/apdfs": np.asarray(ap), "beta_out/aa": np.asarray(aa)})
+    s_ct, l_ct = rng.uniform(0.3, 3.0, n), rng.uniform(0.0, 1.0, n)
+    cp, ct = calc.calculate_mixture_iso_aligned_spin_tilt(s_ct, l_ct)
+    out.update({"tilt_in/sig": s_ct, "tilt_in/lam": l_ct, "tilt_out/ctpdfs": np.asarray(cp), "tilt_out/ct": np.asarray(ct)})
+    nss = {"a": 10, "tilt": 9}
+    a_cs, t_cs = rng.normal(size=(n, nss["a"])), rng.normal(size=(n, nss["tilt"]))
+    ap, aa, cp, cc = calc.calculate_bspline_spin_ppds(a_cs, t_cs, nss)
+    out.update({"spin_in/a_cs": a_cs, "spin_in/t_cs": t_cs, "spin_out/apdfs": np.asarray(ap), "spin_out/ctpdfs": np.asarray(cp)})
+    path = os.path.join(HERE, "ppd.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote ppd.npz: {os.path.getsize(path) // 1024} KiB")
+
+
 def load_gwtc3(n_samples=64):
     """The reference's own PE tensor (tests/data/..., NetCDF-3 classic): 69 events x 9 params x
     1000 samples, big-endian float32 -> float64; first n_samples per event."""
@@ -628,7 +661,9 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3", "catalog"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3", "catalog", "ppd"]
+    if "ppd" in todo:
+        make_ppd_fixture()
     if "catalog" in todo:
         make_catalog_fixture()
     if "terms" in todo:

@@ -47,6 +47,16 @@ def load_reference():
     return ns
 
 
+def load_postprocess():
+    """postprocess/calculations.py (posterior-predictive curves); pure jax.numpy + tqdm."""
+    load_reference()
+    if "gwinferno.postprocess" not in sys.modules:
+        mod = types.ModuleType("gwinferno.postprocess")
+        mod.__path__ = [os.path.join(REFERENCE_ROOT, "gwinferno/postprocess")]
+        sys.modules["gwinferno.postprocess"] = mod
+    return importlib.import_module("gwinferno.postprocess.calculations")
+
+
 def load_preprocess():
     """The reference's injection-selection and PE-prior helpers (preprocess/selection.py,
     preprocess/data_collection.py) under in-memory h5py / xarray / arviz stand-ins (refstub/)."""
