@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end sampling with NumPy only: BASELINE config-2 model (PL+Peak m1 x PL q x PL z) on a
-synthetic catalog, Normal priors, the built-in HMC driver.  Every leapfrog step is one engine
-evaluation (value + gradient), exactly what NUTS pays per step in the reference
-(examples/utils.py:63-85).   python examples/sample_plpeak_hmc.py [n_events n_pe n_inj]"""
+synthetic catalog, the priors of the reference's example, and the built-in NUTS driver (200 warm-up +
+200 samples, as examples/simple_powerlaw_peak_example.py runs numpyro's NUTS; `--hmc` selects the
+fixed-length HMC driver instead).  Every leapfrog step is one engine evaluation (value + gradient),
+exactly what NUTS pays per step in the reference (examples/utils.py:63-85).
+    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut]"""
 import os
 import sys
 import time
@@ -11,10 +13,12 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gwinferno_amd.compositions import COMPOSITIONS  # noqa: E402
-from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_target  # noqa: E402
+from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_target, nuts  # noqa: E402
 from gwinferno_amd.synthetic import make_catalog  # noqa: E402
 
-n_ev, n_pe, n_inj = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (69, 5000, 50_000)
+use_hmc = "--hmc" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_ev, n_pe, n_inj = (int(x) for x in argv[:3]) if len(argv) >= 3 else (69, 5000, 50_000)
 pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=2025)
 comp = COMPOSITIONS["plpeak"](pe, inj)
 eng = comp.engine()
@@ -29,11 +33,18 @@ for n in ("alpha", "beta", "lamb"):
     prior.sigmas[idx[n]] = 5.0
 prior.sigmas[idx["sigpp"]] = 10.0
 bij = Bijector(eng.n_theta).interval(idx["mpp"], 5.0, 100.0).interval(idx["lam"], 0.0, 1.0).positive(idx["sigpp"])
-target = make_target(eng, total, prior, bijector=bij, min_neff_cut=False)
+# min_neff_cut=False as in the reference's inference tests (tests/inference_test.py:185); `--neff-cut` applies the
+# default cuts of analysis.py:272-303 (on a small catalog the posterior then hugs the cut and most trajectories
+# end on it -- reported as divergences -- exactly as under numpyro)
+target = make_target(eng, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv)
 t0 = time.perf_counter()
-out = hmc(target, bij.inverse(theta0), n_warmup=150, n_samples=150, n_leapfrog=8, seed=1, progress=50)
+if use_hmc:
+    out = hmc(target, bij.inverse(theta0), n_warmup=150, n_samples=150, n_leapfrog=8, seed=1, progress=50)
+else:
+    out = nuts(target, bij.inverse(theta0), n_warmup=200, n_samples=200, seed=1, progress=50)
 out["samples"] = np.array([bij.forward(u)[0] for u in out["samples"]])
 dt = time.perf_counter() - t0
-print(f"{out['n_evals']} engine evaluations in {dt:.2f}s ({out['n_evals'] / dt:.0f} evals/s incl. Python HMC), accept {out['accept_rate']:.2f}, step {out['step_size']:.3g}")
+print(f"{out['n_evals']} engine evaluations in {dt:.2f}s ({out['n_evals'] / dt:.0f} evals/s incl. the Python sampler), accept {out['accept_rate']:.2f}, step {out['step_size']:.3g}"
+      + ("" if use_hmc else f", mean tree depth {out['tree_depth'].mean():.1f}, {out['n_divergent']} divergent"))
 for i, n in enumerate(names):
     print(f"  {n:8s} mean {out['samples'][:, i].mean():9.3f}  sd {out['samples'][:, i].std():8.3f}")

@@ -158,3 +158,139 @@ def hmc(target, theta0, n_warmup=200, n_samples=200, n_leapfrog=8, target_accept
         if progress and (it + 1) % progress == 0:
             print(f"[hmc] iter {it + 1}: log_prob {lp:.3f} step {eps:.4g}", flush=True)
     return {"samples": np.array(samples), "log_prob": np.array(lps), "accept_rate": float(np.mean(accepts)) if accepts else 0.0, "step_size": eps, "n_evals": n_evals}
+
+
+# ------------------------------------------------------------------------------------------------
+# No-U-Turn sampler (the reference's sampler is numpyro.infer.NUTS, examples/utils.py:63-85)
+# ------------------------------------------------------------------------------------------------
+def _leapfrog(target, th, p, g, eps, inv_mass):
+    p = p + 0.5 * eps * g
+    th = th + eps * inv_mass * p
+    lp, g = target(th)
+    p = p + 0.5 * eps * g
+    return th, p, g, lp
+
+
+def _find_step_size(target, th, lp, g, inv_mass, rng, eps=0.1):
+    """Heuristic of Hoffman & Gelman (2014), algorithm 4: double / halve until the one-step acceptance
+    probability crosses 1/2."""
+    p = rng.normal(size=th.size) / np.sqrt(inv_mass)
+    h0 = -lp + 0.5 * np.sum(inv_mass * p**2)
+
+    def log_ratio(e):
+        th1, p1, _, lp1 = _leapfrog(target, th, p, g, e, inv_mass)
+        h1 = -lp1 + 0.5 * np.sum(inv_mass * p1**2)
+        return h0 - h1 if np.isfinite(h1) and lp1 > -1e300 else -np.inf
+
+    a = 1.0 if log_ratio(eps) > np.log(0.5) else -1.0
+    for _ in range(50):
+        if not a * log_ratio(eps) > -a * np.log(2.0):
+            break
+        eps *= 2.0**a
+    return eps
+
+
+def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, progress=None):
+    """Multinomial NUTS with the generalised U-turn criterion (Betancourt 2017, as in Stan / NumPyro), dual-
+    averaging step size and one diagonal mass-matrix update during warm-up.  Every leapfrog step is one
+    engine evaluation (value + gradient).  Returns dict(samples, log_prob, accept_rate, step_size,
+    n_evals, tree_depth, n_divergent)."""
+    rng = np.random.default_rng(seed)
+    theta = np.array(theta0, dtype=np.float64)
+    dim = theta.size
+    n_evals = [0]
+    user_target = target
+
+    def target(x):  # every call is one engine evaluation
+        n_evals[0] += 1
+        return user_target(x)
+
+    lp, grad = target(theta)
+    inv_mass = np.ones(dim)
+    eps = _find_step_size(target, theta, lp, grad, inv_mass, rng)
+    mu, log_eps_bar, h_bar, gamma, t0, kappa = np.log(10 * eps), 0.0, 0.0, 0.05, 10.0, 0.75
+    da_count = 0
+
+    def build(th, p, g, lp_, direction, depth, eps_, h0):
+        """Subtree of 2^depth leapfrog states grown from (th, p, g) in `direction`.  Returns the outer edge,
+        a multinomially drawn proposal, log sum of weights, summed momentum, and termination flags."""
+        if depth == 0:
+            th1, p1, g1, lp1 = _leapfrog(target, th, p, g, direction * eps_, inv_mass)
+            h1 = -lp1 + 0.5 * np.sum(inv_mass * p1**2)
+            ok = np.isfinite(h1) and lp1 > -1e300 and np.all(np.isfinite(g1))
+            d = h0 - h1 if ok else -np.inf
+            return dict(edge=(th1, p1, g1, lp1), prop=(th1, lp1, g1), logw=d, rho=p1.copy(), p_first=p1, turning=False, diverging=(not ok) or d < -1000.0,
+                        sum_alpha=float(min(1.0, np.exp(min(0.0, d)))) if ok else 0.0, n_alpha=1)
+        a = build(th, p, g, lp_, direction, depth - 1, eps_, h0)
+        if a["diverging"] or a["turning"]:
+            return a
+        b = build(*a["edge"], direction, depth - 1, eps_, h0)
+        logw = np.logaddexp(a["logw"], b["logw"])
+        prop = a["prop"]
+        if not (b["diverging"] or b["turning"]) and np.log(rng.uniform()) < b["logw"] - logw:  # uniform over the subtree
+            prop = b["prop"]
+        rho = a["rho"] + b["rho"]
+        # generalised U-turn test on this subtree: summed momentum against the velocities at its two ends
+        p_first, p_last = a["p_first"], b["edge"][1]
+        turning = b["turning"] or (np.dot(rho, inv_mass * p_first) <= 0) or (np.dot(rho, inv_mass * p_last) <= 0)
+        return dict(edge=b["edge"], prop=prop, logw=logw, rho=rho, p_first=p_first, turning=turning, diverging=b["diverging"],
+                    sum_alpha=a["sum_alpha"] + b["sum_alpha"], n_alpha=a["n_alpha"] + b["n_alpha"])
+
+    samples, lps, accepts, depths = [], [], [], []
+    n_div = 0
+    warm = []
+    for it in range(n_warmup + n_samples):
+        p0 = rng.normal(size=dim) / np.sqrt(inv_mass)
+        h0 = -lp + 0.5 * np.sum(inv_mass * p0**2)
+        left = right = (theta, p0, grad, lp)
+        prop = (theta, lp, grad)
+        logw, rho = 0.0, p0.copy()
+        sum_alpha, n_alpha, depth, diverged = 0.0, 0, 0, False
+        while depth < max_tree_depth:
+            direction = 1 if rng.uniform() < 0.5 else -1
+            sub = build(*(right if direction == 1 else left), direction, depth, eps, h0)
+            sum_alpha += sub["sum_alpha"]
+            n_alpha += sub["n_alpha"]
+            if sub["diverging"]:
+                diverged = True
+                break
+            if sub["turning"]:
+                break
+            if np.log(rng.uniform()) < sub["logw"] - logw:  # biased progressive sampling across doublings
+                prop = sub["prop"]
+            logw = np.logaddexp(logw, sub["logw"])
+            rho = rho + sub["rho"]
+            if direction == 1:
+                right = sub["edge"]
+            else:
+                left = sub["edge"]
+            depth += 1
+            if (np.dot(rho, inv_mass * left[1]) <= 0) or (np.dot(rho, inv_mass * right[1]) <= 0):
+                break
+        theta, lp, grad = prop
+        acc = sum_alpha / max(n_alpha, 1)
+        n_div += int(diverged)
+        if it < n_warmup:
+            m = it + 1
+            da_count += 1
+            h_bar = (1 - 1 / (da_count + t0)) * h_bar + (target_accept - acc) / (da_count + t0)
+            log_eps = mu - np.sqrt(da_count) / gamma * h_bar
+            log_eps_bar = da_count**-kappa * log_eps + (1 - da_count**-kappa) * log_eps_bar
+            eps = float(np.exp(log_eps))
+            warm.append(theta.copy())
+            if m == (2 * n_warmup) // 3 and len(warm) > 20:  # one diagonal mass-matrix update, then re-tune the step
+                var = np.var(np.array(warm[len(warm) // 3 :]), axis=0)
+                inv_mass = np.where(var > 1e-12, var, 1.0)
+                eps = _find_step_size(target, theta, lp, grad, inv_mass, rng, eps=float(np.exp(log_eps_bar)))
+                mu, log_eps_bar, h_bar, da_count = np.log(10 * eps), 0.0, 0.0, 0
+            if m == n_warmup:
+                eps = float(np.exp(log_eps_bar)) if da_count > 0 else eps
+        else:
+            samples.append(theta.copy())
+            lps.append(lp)
+            accepts.append(acc)
+            depths.append(depth)
+        if progress and (it + 1) % progress == 0:
+            print(f"[nuts] iter {it + 1}: log_prob {lp:.3f} step {eps:.4g} depth {depth}", flush=True)
+    return {"samples": np.array(samples), "log_prob": np.array(lps), "accept_rate": float(np.mean(accepts)) if accepts else 0.0, "step_size": eps,
+            "n_evals": n_evals[0], "tree_depth": np.array(depths), "n_divergent": n_div}

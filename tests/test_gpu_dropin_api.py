@@ -160,3 +160,25 @@ def test_builtin_hmc_runs_end_to_end():
     assert 0.3 < out["accept_rate"] <= 1.0
     assert np.std(out["samples"], axis=0).min() > 0  # the chain moves
     eng.close()
+
+
+def test_builtin_nuts_runs_end_to_end():
+    """The reference's sampler flow (NUTS over the model, examples/utils.py:63-85) with the built-in driver:
+    engine likelihood + priors, a short run that moves, accepts and stays finite; every leapfrog step is one
+    engine evaluation (counted).  Same catalog and model as the HMC test above."""
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.sampling import GaussianSmoothingPrior, make_target, nuts
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(20, 400, 4000, seed=3)
+    comp = COMPOSITIONS["pl_test"](pe, inj)
+    eng = comp.engine()
+    theta0 = comp.theta({"alpha": -2.0, "beta": 1.0, "lamb": 2.0})
+    prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), 5.0)
+    out = nuts(make_target(eng, total, prior, min_neff_cut=False), theta0, n_warmup=80, n_samples=60, seed=4, max_tree_depth=6)
+    assert out["samples"].shape == (60, eng.n_theta)
+    assert np.all(np.isfinite(out["samples"])) and np.all(np.isfinite(out["log_prob"]))
+    assert 0.4 < out["accept_rate"] <= 1.0 and out["n_divergent"] < 10
+    assert np.std(out["samples"], axis=0).min() > 0
+    assert out["n_evals"] >= 140 and out["tree_depth"].max() <= 6
+    eng.close()
