@@ -272,12 +272,13 @@ def main():
             # which is one sequential chain)
             K = args.k_batch
             tb = np.stack(thetas[:K] if len(thetas) >= K else (thetas * K)[:K])
+            vgb = eng.configure_batch(K, total, min_neff_cut=False)  # values_and_grads(thetas[K]) -> (log_l[K], grad[K, n_theta])
             for _ in range(30):
-                eng.evaluate_batch(tb, total, min_neff_cut=False)
+                vgb(tb)
             n_b = max(20, args.steps // (4 * K))
             t0 = time.perf_counter()
             for _ in range(n_b):
-                eng.evaluate_batch(tb, total, min_neff_cut=False)
+                vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
         if not args.no_cpu_baseline:

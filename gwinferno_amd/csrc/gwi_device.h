@@ -1192,6 +1192,16 @@ __global__ __launch_bounds__(kFinalThreads) void final_kernel(const TailArgs a) 
   final_reduce<kFinalThreads>(a, blockIdx.y, threadIdx.x, s_tile);
 }
 
+// ---- batched launches: pull the K theta blocks from pinned host memory into device memory (one
+//      workgroup per block, 16-byte loads over PCIe), in stream order ahead of the scan.  A
+//      hipMemcpyAsync of the same 2 KiB x K costs more in copy-engine start-up than the whole scan. ----
+__global__ __launch_bounds__(kBlock) void stage_theta_kernel(const ThetaBlock* host_src, ThetaBlock* dst) {
+  static_assert(sizeof(ThetaBlock) % 16 == 0, "ThetaBlock is copied in 16-byte pieces");
+  const double2* s = reinterpret_cast<const double2*>(host_src + blockIdx.x);
+  double2* d = reinterpret_cast<double2*>(dst + blockIdx.x);
+  for (int i = threadIdx.x; i < (int)(sizeof(ThetaBlock) / 16); i += kBlock) d[i] = s[i];
+}
+
 // ---- after the all-gather: copy the gathered records to pinned host memory and stamp completion -----
 __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered, double* host, int n, unsigned long long seq) {
   for (int i = threadIdx.x + 1; i < n; i += kBlock) store_sys(host + i, gathered[i]);

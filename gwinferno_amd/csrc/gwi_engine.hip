@@ -234,7 +234,8 @@ struct gwi_engine {
   std::vector<double> host_consts = std::vector<double>(1, 0.0);
   // batched evaluation: up to max_batch hyper-parameter points per launch (blockIdx.y)
   int max_batch = 16;
-  ThetaBlock *d_tblocks = nullptr, *h_tblocks = nullptr;
+  ThetaBlock *d_tblocks = nullptr, *h_tblocks = nullptr, *h_tblocks_dev = nullptr;
+  bool stage_kernel = true;  // GWI_STAGE_KERNEL=0: upload theta blocks with hipMemcpyAsync instead
   // timing
   bool timing = false;
   bool spin_wait = true;
@@ -437,7 +438,12 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     h->kargs.tblocks = nullptr;
   } else {
     for (int k = 0; k < K; ++k) prelude(h, theta + (size_t)k * n_theta, h->h_tblocks[k].theta, h->h_tblocks[k].derived, &h->host_consts[k]);
-    GWI_HIP(hipMemcpyAsync(h->d_tblocks, h->h_tblocks, sizeof(ThetaBlock) * K, hipMemcpyHostToDevice, h->stream));
+    if (h->stage_kernel && K >= 10) {  // below ~20 KiB the runtime's small-copy path is quicker than a launch
+      hipLaunchKernelGGL(stage_theta_kernel, dim3(K), dim3(kBlock), 0, h->stream, (const ThetaBlock*)h->h_tblocks_dev, h->d_tblocks);
+      GWI_HIP(hipGetLastError());
+    } else {
+      GWI_HIP(hipMemcpyAsync(h->d_tblocks, h->h_tblocks, sizeof(ThetaBlock) * K, hipMemcpyHostToDevice, h->stream));
+    }
     GWI_HIP(hipEventRecord(h->ev_tblocks, h->stream));
     h->kargs.tblocks = h->d_tblocks;
   }
@@ -955,7 +961,9 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * KB * 4 * (size_t)h->n_inj_groups));
   GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * KB * (size_t)h->n_inj_groups * spec->n_theta));
   GWI_HIP(hipMalloc(&h->d_tblocks, sizeof(ThetaBlock) * KB));
-  GWI_HIP(hipHostMalloc((void**)&h->h_tblocks, sizeof(ThetaBlock) * KB, hipHostMallocDefault));
+  GWI_HIP(hipHostMalloc((void**)&h->h_tblocks, sizeof(ThetaBlock) * KB, hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_tblocks_dev, h->h_tblocks, 0));
+  if (const char* env = std::getenv("GWI_STAGE_KERNEL")) h->stage_kernel = std::atoi(env) != 0;
   GWI_HIP(hipHostMalloc((void**)&h->h_record, sizeof(double) * KB * record_len(h), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_record_dev, h->h_record, 0));
   GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * KB * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));

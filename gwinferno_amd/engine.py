@@ -376,6 +376,31 @@ class NativePopulationLikelihood:
         self.value_and_grad = value_and_grad
         return value_and_grad
 
+    def configure_batch(self, k_batch, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """The batched counterpart of :meth:`configure` for vectorised chains: returns
+        ``values_and_grads(thetas[K, n_theta]) -> (log_likelihood[K], grad[K, n_theta])`` writing into
+        buffers allocated once (valid until the next call)."""
+        K = int(k_batch)
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        summ = (N.GwiSummary * K)()
+        thetas_buf, grads = np.zeros((K, self.n_theta)), np.zeros((K, self.n_theta))
+        values = np.zeros(K)
+        args = (self.handle, N.as_dp(thetas_buf), K, C.byref(opt), summ, N.as_dp(grads), None, None, None, None)
+        fn = self.lib.gwi_eval_batch
+        # log_likelihood is the first double of each gwi_summary: view them without a Python loop
+        summ_view = np.frombuffer(summ, dtype=np.float64).reshape(K, -1)[:, 0]
+
+        def values_and_grads(thetas):
+            thetas_buf[:] = thetas
+            st = fn(*args)
+            if st != 0:
+                self._check(st)
+            values[:] = summ_view
+            return values, grads
+
+        self._batch_keepalive = (opt, summ)
+        return values_and_grads
+
     def value_and_grad(self, theta):  # replaced by configure()
         raise RuntimeError("call configure(total_inj, ...) first")
 

@@ -225,6 +225,14 @@ def test_batched_evaluation_matches_single(comp_name):
         assert np.allclose(b.grad, one.grad, rtol=1e-10, atol=1e-11)
         assert np.allclose(b.norms, one.norms, rtol=1e-13)
         assert rel_err(b.summary.log_nEff_inj, one.summary.log_nEff_inj) < 1e-10
+    # the lean entry for vectorised chains (preallocated buffers) and both theta-upload paths (K < 10: copy, K >= 10: stage kernel)
+    for K in (3, 12):
+        tk = np.stack([thetas[k % len(thetas)] for k in range(K)])
+        values, grads = eng.configure_batch(K, total, min_neff_cut=False)(tk)
+        for k in range(K):
+            one = eng.evaluate(tk[k], total, min_neff_cut=False)
+            assert rel_err(values[k], one.log_likelihood) < 1e-12
+            assert np.allclose(grads[k], one.grad, rtol=1e-10, atol=1e-11)
     eng.close()
 
 
