@@ -429,7 +429,28 @@ gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long se
 // it -- was measured and lost: every workgroup then has to drain agent-scope write-through stores and
 // wait for an atomic round trip across the XCDs' separate L2s, ~5 us of a resident slot each, more than
 // the two launch boundaries cost.  See DESIGN.md.)
+#ifdef GWI_HOST_PHASES
+// diagnostic build only: accumulated host time per phase of run_pipeline [prelude, scan launch, combine
+// launch, norm launch, wait] in seconds, and the call count
+double g_phase[5] = {0, 0, 0, 0, 0};
+long g_phase_calls = 0;
+#define GWI_PHASE(i)                                                                       \
+  do {                                                                                     \
+    const auto now_ = std::chrono::steady_clock::now();                                    \
+    g_phase[i] += std::chrono::duration<double>(now_ - phase_t_).count();                  \
+    phase_t_ = now_;                                                                       \
+  } while (0)
+#else
+#define GWI_PHASE(i) \
+  do {               \
+  } while (0)
+#endif
+
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+#ifdef GWI_HOST_PHASES
+  auto phase_t_ = std::chrono::steady_clock::now();
+  ++g_phase_calls;
+#endif
   const int n_theta = h->spec.n_theta;
   h->kargs.square = square ? 1 : 0;
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
@@ -469,16 +490,22 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   ta.n_norms = h->spec.n_norms;
   ta.record_len = record_len(h);
   ta.n_pe = (double)h->n_pe;
+  GWI_PHASE(0);
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
+  GWI_PHASE(1);
   launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(kBlock), 0, ta);
   GWI_HIP(hipGetLastError());
   ++h->seq;
   h->timed_final = false;
+  GWI_PHASE(2);
   if (ta.host_rows) {
     gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
     if (sn != GWI_OK) return sn;
-    return wait ? wait_for_rows(h, K) : GWI_OK;
+    GWI_PHASE(3);
+    const gwi_status sw = wait ? wait_for_rows(h, K) : GWI_OK;
+    GWI_PHASE(4);
+    return sw;
   }
   launch_timed(h, 2, final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, ta);
   GWI_HIP(hipGetLastError());
@@ -1234,6 +1261,15 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
   *seconds_per_eval = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n_iter;
   return GWI_OK;
 }
+
+#ifdef GWI_HOST_PHASES
+extern "C" void gwi_debug_host_phases(double* out6) {
+  for (int i = 0; i < 5; ++i) out6[i] = g_phase[i];
+  out6[5] = (double)g_phase_calls;
+  for (int i = 0; i < 5; ++i) g_phase[i] = 0;
+  g_phase_calls = 0;
+}
+#endif
 
 #ifdef GWI_STAMPS
 // diagnostic build only (not part of the ABI): fetch the per-wave phase stamps of the last scan launch
