@@ -802,6 +802,16 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   const double* mine = rec + (long long)(has ? lane : 0) * a.rec_stride;
   const double m_t = has ? mine[0] : GWI_NEG_INF;
   const double r1 = has ? mine[1] : 0.0, r2 = has ? mine[2] : 0.0;
+  // the first gradient slot of this thread: its tile values are requested NOW, together with the
+  // headers, so that one memory round trip (not two) precedes the arithmetic
+  constexpr int kEarly = 16;
+  double early[kEarly];
+  const bool early_on = tid < a.n_theta;
+  {
+    const double* col0 = rec + kRecHeader + (early_on ? tid : 0);
+#pragma unroll
+    for (int t = 0; t < kEarly; ++t) early[t] = (early_on && t < n_tiles) ? col0[(long long)t * a.rec_stride] : 0.0;
+  }
   const double M = wave_max(m_t);
   const double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
   const double S1 = wave_sum(f * r1);
@@ -811,8 +821,15 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double acc = 0.0;
     const double* col = rec + kRecHeader + p;
+    int t = 0;
+    if (p == tid) {
+#pragma unroll
+      for (; t < kEarly; ++t)
+        if (t < n_tiles) acc += lane_bcast(f, t) * early[t];
+      t = n_tiles < kEarly ? n_tiles : kEarly;
+    }
 #pragma unroll 4
-    for (int t = 0; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
+    for (; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
     if (host_rows)
       store_sys(host_rows + (long long)e * (4 + a.n_theta) + 4 + p, is_inj ? acc : acc * inv_s1);
     else if (is_inj)
