@@ -931,14 +931,21 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
       store_sys(r + 7, (double)a.n_ev);
     }
   }
-  // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups
+  // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups.  Everything this thread
+  // will need from memory is requested before the first dependent instruction (one round trip).
   const bool hasg = lane < a.n_inj_groups;
   const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
+  const double s1_j = hasg ? inj_out[lane * 4 + 1] : 0.0, s2_j = hasg ? inj_out[lane * 4 + 2] : 0.0;
+  constexpr int kEarly = 8;
+  double early[kEarly];
+  const bool early_on = tid < a.n_theta;
+#pragma unroll
+  for (int j = 0; j < kEarly; ++j) early[j] = (early_on && j < a.n_inj_groups) ? inj_grad[(long long)j * a.n_theta + tid] : 0.0;
   const double Minj = wave_max(m_j);
   const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
   if (wave == 1) {
-    const double S1 = wave_sum(fj * (hasg ? inj_out[lane * 4 + 1] : 0.0));
-    const double S2 = wave_sum(fj * fj * (hasg ? inj_out[lane * 4 + 2] : 0.0));
+    const double S1 = wave_sum(fj * s1_j);
+    const double S2 = wave_sum(fj * fj * s2_j);
     if (lane == 0) {
       store_sys(r + 4, Minj);
       store_sys(r + 5, S1);
@@ -948,7 +955,14 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
   for (int p = tid; p < a.n_theta; p += THREADS) {
     double g = 0.0;
-    for (int j = 0; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
+    int j = 0;
+    if (p == tid) {
+#pragma unroll
+      for (; j < kEarly; ++j)
+        if (j < a.n_inj_groups) g += lane_bcast(fj, j) * early[j];
+      j = a.n_inj_groups < kEarly ? a.n_inj_groups : kEarly;
+    }
+    for (; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
     store_sys(r + off_ginj + p, g);
   }
   __syncthreads();
