@@ -281,7 +281,7 @@ def main():
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
             out["cpu_baseline"] = cpu_baseline(comp, thetas, total)
     if dist is not None:
         dist.barrier()
