@@ -48,7 +48,7 @@ enum {
   GWI_ERR_INVALID = -1,     /* malformed spec / argument */
   GWI_ERR_NO_DEVICE = -2,   /* no usable gfx950 device: the engine never falls back to the CPU */
   GWI_ERR_HIP = -3,         /* a HIP runtime call failed; see gwi_last_error() */
-  GWI_ERR_UNSUPPORTED = -4, /* term sequence has no compiled kernel */
+  GWI_ERR_UNSUPPORTED = -4, /* term sequence has no compiled kernel; gradient of marginalize_selection via gwi_combine */
   GWI_ERR_TIMEOUT = -5
 };
 
@@ -191,7 +191,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
  * hierarchical_likelihood(...) (analysis.py:139-319) under jit(value_and_grad)
  * (tests/inference_test.py:320-326).  theta has spec.n_theta entries.  Nullable outputs:
  * grad[n_theta] = d log_likelihood / d theta; log_bfs / log_neffs / variances [n_ev] = sites
- * "logBFs", "log_nEffs", "variance_log_BFs"; norms[n_norms] = normaliser values Z. */
+ * "logBFs", "log_nEffs", "variance_log_BFs"; norms[n_norms] = normaliser values Z.
+ * A non-finite theta yields the reference's NaN branch: log_likelihood = nan_to_num(-inf), zero gradient
+ * (analysis.py:287-289).  With opt->marginalize_selection and a gradient requested, a second launch set
+ * with squared weights supplies sum_j w_j^2 dl_j/dtheta (analysis.py:270-271). */
 gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
                     double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
@@ -233,8 +236,9 @@ gwi_status gwi_comm_init(gwi_handle h, const char* rccl_path, const void* id128,
 gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
                             double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
-/* Timing of the most recent gwi_eval*: HIP-event milliseconds of each launch on the engine's
- * stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce). */
+/* Timing of the most recent gwi_eval*: milliseconds between the start/stop HIP events attached to each
+ * launch on the engine's stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce; 0 when the
+ * host does the final sum). */
 gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]);
 /* Enable/disable per-launch HIP-event timing (off by default: events add host overhead). */
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled);
