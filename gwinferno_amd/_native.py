@@ -154,6 +154,10 @@ def load_library():
     # system one).  If torch is importable, load it FIRST so that the engine binds to the runtime
     # torch.distributed / RCCL will use; otherwise a later `import torch` would bring in a second,
     # disjoint runtime and the in-engine RCCL exchange (gwi_comm_init) could not see our buffers.
+    # Kernel arguments in device memory: the scan kernel reads ~3 KB of them with scalar loads at wave start;
+    # with host-resident kernargs (HIP_FORCE_DEV_KERNARG=0) the config-2 scan takes 13-15 us instead of 8
+    # (measured).  Device placement is the runtime's default on this ROCm; make it explicit, before HIP starts.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     try:
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for single-GPU use
