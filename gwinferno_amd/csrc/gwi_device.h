@@ -68,8 +68,12 @@ struct TailArgs {
 };
 
 struct KArgs {
-  const double* pe_cols[GWI_MAX_COLS];   // column base pointers live in the kernel-argument block:
-  const double* inj_cols[GWI_MAX_COLS];  // one scalar load away, no pointer-table round trip
+  // column base pointers, already resolved per term by the host ([term][0|1]): ONE scalar load from the
+  // kernel-argument block per pointer, not term descriptor -> column index -> pointer table
+  const double* pe_tcols[GWI_MAX_TERMS][2];
+  const double* inj_tcols[GWI_MAX_TERMS][2];
+  const double* kappa_pe;
+  const double* kappa_inj;
   const NormD* norms;
   double* partials;   // [n_scan_blocks][rec_stride]
   double* logw_pe;    // only for the log-weight variant
@@ -231,7 +235,7 @@ struct Ctx {
   const double (*derived)[kMaxDerived];  // host-precomputed theta-only scalars per term
   const double* coefs;          // LDS copy of theta for the lane-varying spline coefficient reads
   double* gacc;                 // this wave's LDS gradient-numerator row [n_theta]
-  const double* const* cols;    // column table of the sample set this workgroup scans
+  const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
 };
 
 // ---- term library --------------------------------------------------------------------------
@@ -256,7 +260,7 @@ struct Term<GWI_TERM_POWERLAW> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double lx;
   };
@@ -284,9 +288,9 @@ struct Term<GWI_TERM_PLPEAK> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
-    in.x0 = gload(c.cols[t.col0], idx);
-    in.x1 = gload(c.cols[t.col1], idx);
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
   }
   struct State {
     double da, dmu, dsg, dlam;
@@ -342,9 +346,9 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
-    in.x0 = gload(c.cols[t.col0], idx);
-    in.x1 = gload(c.cols[t.col1], idx);
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
   }
   struct State {
     double db;
@@ -384,9 +388,9 @@ struct Term<GWI_TERM_BETA> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
-    in.x0 = gload(c.cols[t.col0], idx);
-    in.x1 = gload(c.cols[t.col1], idx);
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
   }
   struct State {
     double la, l1;
@@ -425,7 +429,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double dxi, dsg;
   };
@@ -470,7 +474,7 @@ struct Term<GWI_TERM_TRUNCNORM> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double dmu, dsg;
   };
@@ -510,7 +514,7 @@ struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double l1pz;
   };
@@ -538,7 +542,7 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double t;
     int k;  // -1: outside the domain of a zero-outside basis (factor 1, no gradient)
@@ -590,7 +594,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) { in.x0 = gload(c.cols[t.col0], idx); }
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double t, inv_f;
     int k;
@@ -636,9 +640,9 @@ struct Term<GWI_TERM_TILT_JOINT> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const TermD& t, const Ctx& c, long long idx, In& in) {
-    in.x0 = gload(c.cols[t.col0], idx);
-    in.x1 = gload(c.cols[t.col1], idx);
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
   }
   struct State {
     double dxi, dsg;
@@ -706,7 +710,7 @@ struct Chain<U, K, Rest...> {
     rest.init();
   }
   __device__ void load(int buf, int u, int ti, const Ctx& c, long long idx) {
-    Term<K>::load(c.a->terms[ti], c, idx, in[buf][u]);
+    Term<K>::load(c.tcols[ti], idx, in[buf][u]);
     rest.load(buf, u, ti + 1, c, idx);
   }
   __device__ void advance() {
@@ -1042,17 +1046,17 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     start = (long long)t * a.chunk_pe;
     end = start + a.chunk_pe < a.n_pe ? start + a.chunk_pe : a.n_pe;
     base = (long long)e * a.n_pe;
-    ctx.cols = a.pe_cols;
+    ctx.tcols = a.pe_tcols;
     logw = a.logw_pe;
   } else {
     const int t = b - n_pe_blocks;
     start = (long long)t * a.chunk_inj;
     end = start + a.chunk_inj < a.n_inj ? start + a.chunk_inj : a.n_inj;
     base = 0;
-    ctx.cols = a.inj_cols;
+    ctx.tcols = a.inj_tcols;
     logw = a.logw_inj;
   }
-  const double* kappa_col = ctx.cols[a.kappa_col];
+  const double* kappa_col = b < n_pe_blocks ? a.kappa_pe : a.kappa_inj;
 
   double m = GWI_NEG_INF, s1 = 0.0, s2 = 0.0;
   ChainT chain;

@@ -1025,10 +1025,14 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   // ---- constant part of the kernel-argument block
   KArgs& k = h->kargs;
   std::memset(&k, 0, sizeof(k));
-  for (int c = 0; c < spec->n_cols; ++c) {
-    k.pe_cols[c] = tab_pe[c];
-    k.inj_cols[c] = tab_inj[c];
-  }
+  for (int t = 0; t < spec->n_terms; ++t)
+    for (int j = 0; j < 2; ++j) {
+      const int c = spec->terms[t].cols[j] >= 0 && spec->terms[t].cols[j] < spec->n_cols ? spec->terms[t].cols[j] : spec->terms[t].cols[0];
+      k.pe_tcols[t][j] = tab_pe[c];
+      k.inj_tcols[t][j] = tab_inj[c];
+    }
+  k.kappa_pe = tab_pe[spec->kappa_col];
+  k.kappa_inj = tab_inj[spec->kappa_col];
   k.norms = h->d_norms;
   k.partials = h->d_partials;
   k.n_pe = n_pe;
