@@ -568,9 +568,6 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     return v;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-#ifdef GWI_ABLATE_ATOMICS
-    return;
-#endif
     if (s.k >= 0 && w != 0.0) {
       const Taps b = cubic_taps(s.t);
       double* g = c.gacc + t.th0 + s.k;
@@ -1078,22 +1075,15 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   };
   const long long i0 = start + tid;
   GWI_STAMP(1);
-#ifndef GWI_NO_PREFETCH
   if (i0 - lane < end) issue_loads(0, i0);
-#endif
 #ifdef GWI_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
   GWI_STAMP(2);
 #endif
   for (long long i = i0; i - lane < end; i += kU * kBlock) {
     const long long i_next = i + kU * kBlock;
-#ifdef GWI_NO_PREFETCH
-    const bool has_next = false;
-    issue_loads(0, i);
-#else
     const bool has_next = i_next - lane < end;  // wave-uniform
     if (has_next) issue_loads(1, i_next);
-#endif
     double ell[kU], lin[kU];
     bool live[kU];
     double mx_lane = GWI_NEG_INF;
