@@ -1,0 +1,72 @@
+"""GPU (-m gpu): randomised parity sweep -- every composition, many hyper-points drawn WIDER than the
+benchmark priors (steep slopes, narrow / wide peaks, mixing fractions near 0 and 1, large spline
+coefficients), HIP engine vs the C oracle (itself pinned to the reference's golden vectors, tests/test_c_oracle.py)
+on one seeded mid-size catalog.  Values to 1e-9, analytic gradients to 1e-8 of their scale."""
+import numpy as np
+import pytest
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+N_POINTS = 48
+
+
+def _wide(name, p, rng):
+    """Push a benchmark draw outwards (in place)."""
+    for k, v in p.items():
+        if np.ndim(v) > 0:
+            p[k] = np.asarray(v) * rng.uniform(0.5, 4.0)  # spline coefficients up to ~ +-10
+            if k == "z_coefs" and name != "bspline_redshift":
+                p[k][0] = 0.0
+        elif k in ("alpha", "beta", "lamb"):
+            p[k] = float(v) + rng.normal(0.0, 3.0)
+        elif k in ("sigpp",):
+            p[k] = float(rng.uniform(0.3, 25.0))
+        elif k in ("lam", "xi", "xi1", "xi2"):
+            p[k] = float(rng.choice([rng.uniform(0, 1), rng.uniform(0, 1e-3), 1 - rng.uniform(0, 1e-3)]))
+        elif k.startswith("sig_t"):
+            p[k] = float(rng.uniform(0.05, 6.0))
+    if name == "bspline_redshift":  # exponent coefficients are c / (c . I): keep the denominator away from 0
+        p["z_coefs"] = np.abs(p["z_coefs"]) + 0.05
+    if "e_coefs" in p:  # linear (density) splines need positive coefficients
+        p["e_coefs"], p["p_coefs"] = np.abs(p["e_coefs"]) + 0.01, np.abs(p["p_coefs"]) + 0.01
+    return p
+
+
+@pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_chieff",
+                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw"])
+def test_randomised_parity_against_c_oracle(name):
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(14, 600, 6000, seed=77)
+    comp = COMPOSITIONS[name](pe, inj)
+    eng = comp.engine()
+    orc = COracle(eng.bound)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    worst = 0.0
+    n_finite = 0
+    for i in range(N_POINTS):
+        p = draw_params(name, rng)
+        if i >= N_POINTS // 3:
+            p = _wide(name, p, rng)
+        th = comp.theta(p)
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = orc.evaluate(th, total, min_neff_cut=False)
+        rs = ref["summary"]
+        ok = np.isfinite(ref["logBFs"])
+        assert np.array_equal(np.isfinite(got.log_bfs), ok), (name, i)
+        assert rel_err(got.log_bfs[ok], ref["logBFs"][ok]) < 1e-9, (name, i, p)
+        assert rel_err(got.log_neffs[ok], ref["log_nEffs"][ok]) < 1e-8, (name, i)
+        if np.isfinite(rs.log_det_eff):
+            assert abs(got.summary.log_det_eff - rs.log_det_eff) < 1e-9 * max(1.0, abs(rs.log_det_eff)), (name, i)
+        assert got.log_likelihood == rs.log_likelihood or rel_err(got.log_likelihood, rs.log_likelihood) < 1e-9, (name, i, got.log_likelihood, rs.log_likelihood)
+        if abs(rs.log_likelihood) < 1e300:
+            n_finite += 1
+            scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+            err = float(np.max(np.abs(got.grad - ref["grad"]))) / scale
+            worst = max(worst, err)
+            assert err < 1e-8, (name, i, err)
+    assert n_finite >= N_POINTS // 2, (name, n_finite)  # the sweep must mostly land on live likelihoods
+    eng.close()
