@@ -26,6 +26,8 @@ TERM_EXP_SPLINE = 7
 TERM_TRUNCNORM = 8
 TERM_LINEAR_SPLINE = 9
 TERM_TILT_JOINT = 10
+TERM_SMOOTH = 11
+TERM_PLPEAK_SMOOTH = 12
 
 SPLINE_OUTSIDE_ZERO_EXPONENT = 1
 POWERLAW_UNNORMALISED = 2

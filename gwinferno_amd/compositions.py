@@ -108,6 +108,20 @@ class PLPeak(PLTest):
         return q
 
 
+class PLPeakSmooth(PLPeak):
+    """PL+Peak with the low-mass taper ``delta`` on both masses (parametric.py:39-53 with delta)."""
+
+    PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "delta": (), "lamb": ()}
+
+    def mass(self, p, d):
+        return M.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"], delta=p["delta"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q["delta"] = 4.0
+        return q
+
+
 class PLPeakFull(PLPeak):
     """BASELINE config 1 (examples/simple_powerlaw_peak_example.py:82-94)."""
 
@@ -317,6 +331,7 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
 
 
 COMPOSITIONS = {
+    "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,
     "pl_test": PLTest,
@@ -342,6 +357,10 @@ def draw_params(name, rng):
         if name == "plpeak_full":
             p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
                      xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
+        return {k: p[k] for k in cls.PARAMS}
+    if name == "plpeak_smooth":
+        p = draw_params("plpeak", rng)
+        p["delta"] = rng.uniform(1.0, 8.0)
         return {k: p[k] for k in cls.PARAMS}
     if name == "plpeak_default_tilt":
         p = draw_params("plpeak", rng)

@@ -26,7 +26,7 @@ constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerat
 struct TermD {
   int kind, col0, col1, n_basis;
   int th0, th1, th2, th3;  // EXP_SPLINE: th0 = coef_off
-  int flags, pad;
+  int flags, th4;     // th4: fifth hyper-parameter (PLPEAK_SMOOTH: delta)
   double p0, p1, p2;  // EXP_SPLINE: lo, hi, 1/dx of the spline coordinate
 };
 
@@ -308,7 +308,7 @@ struct Term<GWI_TERM_PLPEAK> {
     const double e_tn = fast_exp(-0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
-    const double ip = fast_rcp(p);
+    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
     s.da = P * (lx + d[1]) * ip;
     s.dmu = T * (dx * d[5] + d[3]) * ip;
     s.dsg = T * (dx2 * d[6] + d[4]) * ip;
@@ -443,7 +443,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
     const double dx2 = dx * dx;
     const double e_tn = fast_exp(-0.5 * dx2 * d[2] + d[0]);
     const double p = 0.5 * (1.0 - xi) + xi * e_tn;
-    const double ip = fast_rcp(p);
+    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
     s.dxi = (e_tn - 0.5) * ip;
     s.dsg = xi * e_tn * (dx2 * d[3] + d[1]) * ip;
     lin *= p;
@@ -653,7 +653,7 @@ struct Term<GWI_TERM_TILT_JOINT> {
     const double r2 = d1 * d1 + d2 * d2;
     const double A = fast_exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
     const double p = 0.25 * (1.0 - xi) + xi * A;
-    const double ip = fast_rcp(p);
+    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
     s.dxi = (A - 0.25) * ip;
     s.dsg = xi * A * (r2 * d[3] + 2.0 * d[1]) * ip;
     lin *= p;
@@ -674,6 +674,112 @@ struct Term<GWI_TERM_TILT_JOINT> {
     vals[1] = a.g[1];
     th[0] = t.th0;
     th[1] = t.th1;
+  }
+};
+
+// reference `smooth` (distributions.py:16-21), which is 1/(1 + exp(d/y + d/(y-d))) for every y = x - xmin.
+// Returns S and d log S / d delta = -(1 - S) (1/y + y/(y-d)^2).
+// fast_rcp has no IEEE special cases: 1/(+-0) and 1/inf are patched here, because an overflowing exponent
+// (x just above xmin + delta) must give S = 0 exactly -- in the PL+Peak mixture the Gaussian part survives it.
+__device__ __forceinline__ double taper(double y, double dl, double& dlog_ddelta) {
+  const double yd = y - dl;
+  const double iy = (y == 0.0) ? __builtin_copysign(GWI_POS_INF, y) : fast_rcp(y);
+  const double iyd = (yd == 0.0) ? __builtin_copysign(GWI_POS_INF, yd) : fast_rcp(yd);
+  const double E = fast_exp(dl * iy + dl * iyd);
+  const double S = (E < GWI_POS_INF) ? fast_rcp(1.0 + E) : 0.0;
+  dlog_ddelta = -(1.0 - S) * (iy + y * iyd * iyd);
+  return S;
+}
+
+template <>
+struct Term<GWI_TERM_SMOOTH> {
+  static constexpr bool kSpline = false;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  struct State {
+    double dd;
+  };
+  struct Acc {
+    double g0;
+  };
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double& lin) {
+    lin *= taper(in.x0, c.theta[t.th0], s.dd);
+    return 0.0;
+  }
+  __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.dd; }
+  GWI_ACC1(g0)
+  static constexpr int kNumAcc = 1;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g0;
+    th[0] = t.th0;
+  }
+};
+
+// (1-lam) A x^alpha S(x - lo; delta) + lam Cn exp(-(x-mu)^2/(2 sig^2))  (parametric.py:49-53 with delta)
+// derived as PLPEAK; th4 = delta
+template <>
+struct Term<GWI_TERM_PLPEAK_SMOOTH> {
+  static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
+  }
+  struct State {
+    double da, dmu, dsg, dlam, ddel;
+  };
+  struct Acc {
+    double g[5];
+  };
+  __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    const double x = in.x0;
+    const double lx = in.x1;
+    const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
+    const double dx = x - mu;
+    const double dx2 = dx * dx;
+    double dlogS;
+    const double S = taper(x - t.p0, c.theta[t.th4], dlogS);
+    const double e_pl = fast_exp(alpha * lx + d[0]) * S;
+    const double e_tn = fast_exp(-0.5 * dx2 * d[5] + d[2]);
+    const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
+    const double p = P + T;
+    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
+    s.da = P * (lx + d[1]) * ip;
+    s.dmu = T * (dx * d[5] + d[3]) * ip;
+    s.dsg = T * (dx2 * d[6] + d[4]) * ip;
+    s.dlam = (e_tn - e_pl) * ip;
+    s.ddel = (P > 0.0) ? P * dlogS * ip : 0.0;  // S = 0: the power-law part and its delta-derivative vanish
+    lin *= p;
+    return 0.0;
+  }
+  __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) {
+    a.g[0] += w * s.da;
+    a.g[1] += w * s.dmu;
+    a.g[2] += w * s.dsg;
+    a.g[3] += w * s.dlam;
+    a.g[4] += w * s.ddel;
+  }
+  __device__ static void init(Acc& a) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a.g[j] = 0;
+  }
+  __device__ static void rescale(Acc& a, double sc) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a.g[j] *= sc;
+  }
+  static constexpr int kNumAcc = 5;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) vals[j] = a.g[j];
+    th[0] = t.th0;
+    th[1] = t.th1;
+    th[2] = t.th2;
+    th[3] = t.th3;
+    th[4] = t.th4;
   }
 };
 

@@ -45,6 +45,8 @@ struct Variant {
 #define K_TN GWI_TERM_TRUNCNORM
 #define K_LS GWI_TERM_LINEAR_SPLINE
 #define K_TJ GWI_TERM_TILT_JOINT
+#define K_SM GWI_TERM_SMOOTH
+#define K_PS GWI_TERM_PLPEAK_SMOOTH
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
@@ -90,6 +92,10 @@ const Variant kVariants[] = {
     GWI_VARIANT("spline3", K_SP, K_SP, K_SP),
     // BSplinePrimaryBSplineRatio alone: the (m1, q) mesh of the posterior-predictive curves (postprocess/calculations.py:20-60)
     GWI_VARIANT("spline2", K_SP, K_SP),
+    // plpeak_primary_ratio_pdf with the low-mass taper `delta` (parametric.py:39-53) [x PL z]
+    GWI_VARIANT("plq+plz+smooth+plpeaksmooth", K_PQ, K_PZ, K_SM, K_PS),
+    GWI_VARIANT("plq+smooth+plpeaksmooth", K_PQ, K_SM, K_PS),
+    GWI_VARIANT("plz+plpeaksmooth", K_PZ, K_PS),
     // single-term sequences (term-level parity tests)
     GWI_VARIANT("lspline", K_LS),
     GWI_VARIANT("tiltjoint", K_TJ),
@@ -101,6 +107,8 @@ const Variant kVariants[] = {
     GWI_VARIANT("plz", K_PZ),
     GWI_VARIANT("spline", K_SP),
     GWI_VARIANT("truncnorm", K_TN),
+    GWI_VARIANT("smooth", K_SM),
+    GWI_VARIANT("plpeaksmooth", K_PS),
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -293,6 +301,12 @@ gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
       case GWI_TERM_POWERLAW_REDSHIFT: break;
       case GWI_TERM_TRUNCNORM: n_th = 2; break;
       case GWI_TERM_TILT_JOINT: n_cols = 2; n_th = 2; break;
+      case GWI_TERM_SMOOTH: break;
+      case GWI_TERM_PLPEAK_SMOOTH:
+        n_cols = 2;
+        n_th = 4;
+        if (!theta_ok(tm.coef_off)) return fail(h, GWI_ERR_INVALID, "PLPEAK_SMOOTH: coef_off must be the theta index of delta");
+        break;
       case GWI_TERM_LINEAR_SPLINE:
       case GWI_TERM_EXP_SPLINE:
         n_th = 0;
@@ -340,6 +354,7 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
         d[3] = d[2] / sg;
         break;
       }
+      case GWI_TERM_PLPEAK_SMOOTH:
       case GWI_TERM_PLPEAK: {
         powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &d[0], &d[1]);
         truncnorm_lognorm(theta[tm.theta[1]], theta[tm.theta[2]], tm.p[0], tm.p[1], &d[2], &d[3], &d[4]);
@@ -1068,6 +1083,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     d.p0 = tm.p[0];
     d.p1 = tm.p[1];
     d.p2 = tm.p[2];
+    d.th4 = tm.kind == GWI_TERM_PLPEAK_SMOOTH ? tm.coef_off : 0;
     if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)

@@ -173,6 +173,8 @@ def bind(pe, inj, hypervolume=None):
                 bm.norm_keys.append(nkey)
                 bm.norms.append((g, expo_theta, norm_coef_off if g.n_basis > 0 else 0))
                 norm_idx = len(bm.norms) - 1
+        if fp.kind == N.TERM_PLPEAK_SMOOTH:  # five scalars: gwi_term.theta holds four, coef_off carries the index of delta
+            coef_off = slots[4]
         bm.terms.append(dict(kind=fp.kind, cols=cols, theta=slots, n_basis=fp.n_basis, coef_off=max(coef_off, 0), flags=fp.flags, norm=norm_idx, p=fp.consts,
                              owner=fp.norm_owner))
     if len(bm.norms) > N.GWI_MAX_NORMS:

@@ -31,19 +31,28 @@ def side_of(arr):
 class Column:
     """One per-sample fp64 column for one side: a transform of a user array."""
 
-    __slots__ = ("transform", "source", "_cache")
+    __slots__ = ("transform", "source", "const", "_cache")
 
-    def __init__(self, transform, source):
-        self.transform, self.source, self._cache = transform, source, None
+    def __init__(self, transform, source, const=0.0):
+        """``source``: the user's array, or a tuple of two for the product transform; ``const``: the
+        subtrahend of "sub" / "prod_sub".  Identity of the SOURCE arrays keys the engine cache."""
+        self.transform, self.source, self.const, self._cache = transform, source, float(const), None
 
     def key(self):
-        return (self.transform, id(self.source))
+        ids = tuple(id(a) for a in self.source) if isinstance(self.source, tuple) else (id(self.source),)
+        return (self.transform, self.const) + ids
 
     def values(self):
         if self._cache is None:
+            if self.transform == "prod_sub":  # a * b - const  (e.g. m2 - mmin = q m1 - mmin)
+                a, b = (np.asarray(v, dtype=np.float64) for v in self.source)
+                self._cache = np.ascontiguousarray(a * b - self.const)
+                return self._cache
             x = np.asarray(self.source, dtype=np.float64)
             with np.errstate(all="ignore"):
-                if self.transform == "id":
+                if self.transform == "sub":
+                    v = x - self.const
+                elif self.transform == "id":
                     v = x
                 elif self.transform == "log":
                     v = np.log(x)

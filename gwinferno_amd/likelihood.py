@@ -252,7 +252,7 @@ def _mirror(density, side):
     other = INJ if side == PE else PE
     factors = []
     for f in density.factors:
-        factors.append(Factor(f.kind, other, [Column(c.transform, _cut(c.source, side)) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
+        factors.append(Factor(f.kind, other, [Column(c.transform, tuple(_cut(a, side) for a in c.source) if isinstance(c.source, tuple) else _cut(c.source, side), c.const) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
                               n_basis=f.n_basis, flags=f.flags, mask=None if f.mask is None else _cut(f.mask, side),
                               static_log=None if f.static_log is None else _cut(f.static_log, side), norm=f.norm, owner=f.owner, norm_owner=f.norm_owner, tag=f.tag))
     return Density(factors, other, [(sgn, _cut(a, side)) for sgn, a in density.log_static], density.log_const)

@@ -93,15 +93,25 @@ def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
 # ================================================================================================
 # parametric models (gwinferno/models/parametric/parametric.py)
 # ================================================================================================
+def smooth(dx, x, xmin):
+    """distributions.py:16-21.  As written there the second ``where`` holds for every ``x``
+    (``x < xmin + dx  |  x >= xmin``), so the function IS ``1 / (1 + exp(dx/(x-xmin) + dx/(x-xmin-dx)))``
+    everywhere -- it tends to 1/2, not 1, far above ``xmin + dx``.  Reproduced as is; ``dx`` (delta) is a
+    hyper-parameter with an analytic gradient."""
+    side = side_of(x)
+    return Density([Factor(N.TERM_SMOOTH, side, [Column("sub", x, xmin)], [dx])], side)
+
+
 def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
-    """parametric.py:49-53 (delta=None)."""
-    if delta is not None:
-        raise NotImplementedError("low-mass smoothing (delta) is not used by the BASELINE configurations")
+    """parametric.py:49-53; with ``delta`` the power-law component carries the taper ``smooth(delta, m1, mmin)``."""
     m1 = _f(m1)
     side = side_of(m1)
     with np.errstate(all="ignore"):
         mask = ~((m1 < mmin) | (m1 > mmax))
-    return Density([Factor(N.TERM_PLPEAK, side, [Column("id", m1), Column("log", m1)], [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
+    cols = [Column("id", m1), Column("log", m1)]
+    if delta is None:
+        return Density([Factor(N.TERM_PLPEAK, side, cols, [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
+    return Density([Factor(N.TERM_PLPEAK_SMOOTH, side, cols, [alpha, mpp, sigpp, lam, delta], consts=(mmin, mmax), mask=mask)], side)
 
 
 def powerlaw_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax):
@@ -110,8 +120,12 @@ def powerlaw_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax):
 
 
 def plpeak_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax, mpp, sigpp, lam, delta=None):
-    """parametric.py:39-46 (delta=None)."""
-    return _powerlaw_ratio(q, m1, beta, mmin) * plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=delta)
+    """parametric.py:39-46; with ``delta`` also ``smooth(delta, q m1, mmin)`` on the secondary mass."""
+    p = _powerlaw_ratio(q, m1, beta, mmin) * plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=delta)
+    if delta is None:
+        return p
+    side = side_of(q)  # smooth(delta, q * m1, mmin): the product is formed once, keyed by the identity of q and m1
+    return p * Density([Factor(N.TERM_SMOOTH, side, [Column("prod_sub", (q, m1), mmin)], [delta])], side)
 
 
 def beta_spin_magnitude(a, alpha, beta, amax=1):

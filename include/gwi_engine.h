@@ -88,7 +88,14 @@ enum {
   GWI_TERM_LINEAR_SPLINE = 9,
   /* (1-xi)/4 + xi TN(ct1;1,sigma,-1,1) TN(ct2;1,sigma,-1,1)   parametric.py:97-102 (default_spin_tilt)
    * cols = cos tilt 1, cos tilt 2; theta = xi, sigma */
-  GWI_TERM_TILT_JOINT = 10
+  GWI_TERM_TILT_JOINT = 10,
+  /* low-mass taper as the reference evaluates it: 1 / (1 + exp(d/(x-xmin) + d/(x-xmin-d))) for EVERY x
+   * (distributions.py:16-21: the second `where` condition holds for all x), e.g. smooth(delta, q m1, mmin)
+   * of plpeak_primary_ratio_pdf (parametric.py:39-46).  cols[0] = x - xmin; theta[0] = d (delta) */
+  GWI_TERM_SMOOTH = 11,
+  /* (1-lam) PL(x) smooth(delta, x, lo) + lam TN(x): plpeak_primary_pdf with delta (parametric.py:49-53).
+   * cols[0]=x, cols[1]=log x; theta = alpha, mpp, sigpp, lam; coef_off = theta index of delta; p[0]=lo, p[1]=hi */
+  GWI_TERM_PLPEAK_SMOOTH = 12
 };
 
 /* POWERLAW flag: bare x^alpha with no normaliser and no truncation (the (m2/m1)^beta pairing factor,

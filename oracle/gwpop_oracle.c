@@ -121,6 +121,28 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         d[tm->theta[3]] += (etn - epl) / p;
         break;
       }
+      case GWI_TERM_SMOOTH: { /* distributions.py:16-21: 1/(1+exp(d/y + d/(y-d))) for every y = x - xmin */
+        const double dl = th[tm->theta[0]], y = x0;
+        const double S = 1.0 / (1.0 + exp(dl / y + dl / (y - dl)));
+        ell += log(S);
+        d[tm->theta[0]] += -(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl)));
+        break;
+      }
+      case GWI_TERM_PLPEAK_SMOOTH: { /* parametric.py:49-53 with delta; coef_off = theta index of delta */
+        const double lx = cols[tm->cols[1]][idx];
+        const double al = th[tm->theta[0]], mu = th[tm->theta[1]], sg = th[tm->theta[2]], lam = th[tm->theta[3]], dl = th[tm->coef_off];
+        const double y = x0 - tm->p[0];
+        const double S = 1.0 / (1.0 + exp(dl / y + dl / (y - dl)));
+        const double epl = exp(al * lx + der[t][0]) * S, etn = exp(-0.5 * (x0 - mu) * (x0 - mu) / (sg * sg) + der[t][2]);
+        const double P = (1.0 - lam) * epl, T = lam * etn, p = P + T;
+        ell += log(p);
+        d[tm->theta[0]] += P * (lx + der[t][1]) / p;
+        d[tm->theta[1]] += T * ((x0 - mu) / (sg * sg) + der[t][3]) / p;
+        d[tm->theta[2]] += T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p;
+        d[tm->theta[3]] += (etn - epl) / p;
+        d[tm->coef_off] += P * (-(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl)))) / p;
+        break;
+      }
       case GWI_TERM_POWERLAW_RATIO: {
         const double lr = tm->p[0] - cols[tm->cols[1]][idx], beta = th[tm->theta[0]], b1 = 1.0 + beta;
         if (b1 == 0.0) {
@@ -257,6 +279,7 @@ int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int
           host_const += a;
         }
         break;
+      case GWI_TERM_PLPEAK_SMOOTH:
       case GWI_TERM_PLPEAK:
         pl_lognorm(th[tm->theta[0]], tm->p[0], tm->p[1], &der[t][0], &der[t][1]);
         tn_lognorm(th[tm->theta[1]], th[tm->theta[2]], tm->p[0], tm->p[1], &der[t][2], &der[t][3], &der[t][4]);

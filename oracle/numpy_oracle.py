@@ -198,9 +198,19 @@ def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
 # ==========================================================================================
 # 3. parametric population models  (gwinferno/models/parametric/parametric.py)
 # ==========================================================================================
-def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam):
-    """parametric.py:49-53 (delta=None)."""
-    return (1 - lam) * powerlaw_pdf(m1, alpha, mmin, mmax) + lam * truncnorm_pdf(m1, mpp, sigpp, mmin, mmax)
+def smooth(dx, x, xmin):
+    """distributions.py:16-21, literally: the second ``where`` is true for every x, so s2 = 1/(func+1) everywhere."""
+    with np.errstate(all="ignore"):
+        func = np.exp(dx / (x - xmin) + dx / (x - xmin - dx))
+        s1 = np.where(x < xmin, 0, 1)
+        return np.where((x < xmin + dx) | (x >= xmin), (func + 1) ** (-1), s1)
+
+
+def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
+    """parametric.py:49-53."""
+    if delta is None:
+        return (1 - lam) * powerlaw_pdf(m1, alpha, mmin, mmax) + lam * truncnorm_pdf(m1, mpp, sigpp, mmin, mmax)
+    return (1 - lam) * powerlaw_pdf(m1, alpha, mmin, mmax) * smooth(delta, m1, mmin) + lam * truncnorm_pdf(m1, mpp, sigpp, mmin, mmax)
 
 
 def powerlaw_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax):
@@ -208,9 +218,10 @@ def powerlaw_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax):
     return powerlaw_pdf(q, beta, mmin / m1, 1.0) * powerlaw_pdf(m1, alpha, mmin, mmax)
 
 
-def plpeak_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax, mpp, sigpp, lam):
-    """parametric.py:39-46 (delta=None)."""
-    return powerlaw_pdf(q, beta, mmin / m1, 1.0) * plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam)
+def plpeak_primary_ratio_pdf(m1, q, alpha, beta, mmin, mmax, mpp, sigpp, lam, delta=None):
+    """parametric.py:39-46."""
+    p = powerlaw_pdf(q, beta, mmin / m1, 1.0) * plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=delta)
+    return p if delta is None else p * smooth(delta, q * m1, mmin)
 
 
 def independent_spin_magnitude_beta_dist(a1, a2, alpha1, beta1, alpha2, beta2):
@@ -668,7 +679,20 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
     NORMALIZE = False
 
 
+class PLPeakSmooth(PLPeak):
+    """plpeak_primary_ratio_pdf with the low-mass taper delta (parametric.py:39-53) x PowerlawRedshiftModel."""
+
+    PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "delta": (), "lamb": ()}
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            dens = plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"], delta=p["delta"])
+            return _finite_or_zero(dens * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+
 COMPOSITIONS = {
+    "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,
     "plpeak_default_tilt": PLPeakDefaultTilt,

@@ -87,6 +87,15 @@ def log_weights(bm, theta, include_consts=True):
                     pl = np.exp(alpha * c[1] + _pl_lognorm(alpha, p[0], p[1]))
                     tn = np.exp(-0.5 * (c[0] - mu) ** 2 / sg**2 + _tn_lognorm(mu, sg, p[0], p[1]))
                     ell = ell + np.log((1 - lam) * pl + lam * tn)
+                elif k == N.TERM_PLPEAK_SMOOTH:
+                    alpha, mu, sg, lam, dl = th
+                    y = c[0] - p[0]
+                    taper = 1.0 / (1.0 + np.exp(dl / y + dl / (y - dl)))
+                    pl = np.exp(alpha * c[1] + _pl_lognorm(alpha, p[0], p[1])) * taper
+                    tn = np.exp(-0.5 * (c[0] - mu) ** 2 / sg**2 + _tn_lognorm(mu, sg, p[0], p[1]))
+                    ell = ell + np.log((1 - lam) * pl + lam * tn)
+                elif k == N.TERM_SMOOTH:
+                    ell = ell - np.log1p(np.exp(th[0] / c[0] + th[0] / (c[0] - th[0])))
                 elif k == N.TERM_POWERLAW_RATIO:
                     lr = p[0] - c[1]
                     b1 = 1 + th[0]

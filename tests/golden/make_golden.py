@@ -294,6 +294,24 @@ class BSplineComponentMasses(Composition):
         return {"m_coefs": rng.normal(size=cls.NM), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
 
 
+class PLPeakSmooth(PLPeak):
+    """plpeak_primary_ratio_pdf with the low-mass taper ``delta`` (parametric.py:39-53; distributions.py:16-21)
+    x PowerlawRedshiftModel."""
+
+    params = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "delta": (), "lamb": ()}
+    fd_rel = {"delta": 1e-6}
+
+    def weights(self, p, d, pe_samples):
+        pm = ref.parametric.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], MMIN, MMAX, p["mpp"], p["sigpp"], p["lam"], delta=p["delta"])
+        return _guard(pm * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    @staticmethod
+    def draw(rng):
+        q = PLPeak.draw(rng)
+        q["delta"] = rng.uniform(1.0, 8.0)
+        return {k: q[k] for k in PLPeakSmooth.params}
+
+
 class BSplineRedshiftCase(Composition):
     """powerlaw_primary_ratio_pdf x BSplineRedshift(8, z, z_inj, dVc/dz, dVc/dz_inj) (single.py:398-492) with
     the class defaults: LogXBSpline(normalize=True) on (1e-4, 2.3)."""
@@ -330,6 +348,7 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
 
 
 COMPOSITIONS = {
+    "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,
     "plpeak_default_tilt": PLPeakDefaultTilt,
@@ -381,7 +400,10 @@ def fd_gradient(comp, p, nobs, total_inj, flags, rel=1e-3):
         arr = np.atleast_1d(np.asarray(val, dtype=np.float64))
         g = np.zeros_like(arr)
         for i in range(arr.size):
-            h = rel * max(1.0, abs(arr[i]))
+            # per-parameter step override: the taper `delta` moves a singularity of the reference's `smooth`
+            # (x = xmin + delta) across samples, so log_l is only piecewise smooth in it; a step of 1e-6 keeps
+            # the stencil inside one piece (rounding error ~1e-9) where 1e-3 does not
+            h = getattr(comp, "fd_rel", {}).get(name, rel) * max(1.0, abs(arr[i]))
             vals = []
             for k in (-2, -1, 1, 2):
                 q = {n: (np.array(v, dtype=np.float64, copy=True) if np.ndim(v) else float(v)) for n, v in p.items()}
@@ -661,7 +683,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "gwtc3", "catalog", "ppd"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "gwtc3", "catalog", "ppd"]
     if "ppd" in todo:
         make_ppd_fixture()
     if "catalog" in todo:
@@ -688,6 +710,9 @@ def main(which):
         pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
         make_case("case_bspline_redshift.npz", "bspline_redshift", pe, inj, tot, seed=12, n_points=3, n_grad=1)
         make_case("case_bspline_redshift_raw.npz", "bspline_redshift_raw", pe, inj, tot, seed=13, n_points=3, n_grad=1)
+    if "cases4" in todo:
+        pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+        make_case("case_plpeak_smooth.npz", "plpeak_smooth", pe, inj, tot, seed=14, n_points=4, n_grad=2)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

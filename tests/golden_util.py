@@ -18,6 +18,7 @@ CASES = [
     "bspline_component_masses",
     "bspline_redshift",
     "bspline_redshift_raw",
+    "plpeak_smooth",
     "gwtc3_pl_test",
     "gwtc3_bspline_test",
 ]

@@ -26,6 +26,8 @@ def _wide(name, p, rng):
             p[k] = float(rng.choice([rng.uniform(0, 1), rng.uniform(0, 1e-3), 1 - rng.uniform(0, 1e-3)]))
         elif k.startswith("sig_t"):
             p[k] = float(rng.uniform(0.05, 6.0))
+        elif k == "delta":
+            p[k] = float(rng.uniform(0.1, 30.0))
     if name == "bspline_redshift":  # exponent coefficients are c / (c . I): keep the denominator away from 0
         p["z_coefs"] = np.abs(p["z_coefs"]) + 0.05
     if "e_coefs" in p:  # linear (density) splines need positive coefficients
@@ -34,7 +36,7 @@ def _wide(name, p, rng):
 
 
 @pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_chieff",
-                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw"])
+                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth"])
 def test_randomised_parity_against_c_oracle(name):
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
