@@ -367,7 +367,9 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
       return -lq;
     }
     const double em1 = fast_expm1(b1 * lr);   // r^(1+beta) - 1
-    const double inv_den = -fast_rcp(em1);  // 1/(1 - r^(1+beta))
+    // m1 == mmin exactly (lr = 0): the q interval is empty, the reference's weight is NaN -> 0; keep the
+    // gradient state finite so that the dead sample adds 0, not NaN
+    const double inv_den = (em1 != 0.0) ? -fast_rcp(em1) : 0.0;  // 1/(1 - r^(1+beta))
     s.db = lq + d[0] + (em1 + 1.0) * lr * inv_den;
     lin *= b1 * inv_den;
     return beta * lq;
@@ -687,7 +689,7 @@ __device__ __forceinline__ double taper(double y, double dl, double& dlog_ddelta
   const double iyd = (yd == 0.0) ? __builtin_copysign(GWI_POS_INF, yd) : fast_rcp(yd);
   const double E = fast_exp(dl * iy + dl * iyd);
   const double S = (E < GWI_POS_INF) ? fast_rcp(1.0 + E) : 0.0;
-  dlog_ddelta = -(1.0 - S) * (iy + y * iyd * iyd);
+  dlog_ddelta = (S > 0.0) ? -(1.0 - S) * (iy + y * iyd * iyd) : 0.0;  // S == 0: factor (and its derivative) vanish
   return S;
 }
 

@@ -179,6 +179,15 @@ def bind(pe, inj, hypervolume=None):
                              owner=fp.norm_owner))
     if len(bm.norms) > N.GWI_MAX_NORMS:
         raise ValueError(f"{len(bm.norms)} normalisers exceed GWI_MAX_NORMS={N.GWI_MAX_NORMS}")
+    # A non-finite column entry (log of a non-positive number, NaN in the data) can only produce a NaN / Inf
+    # weight, which counts as zero (tests/inference_test.py:172): exclude the sample and park a finite value
+    # in its place, so that the per-sample gradient state the kernel carries stays finite (0 x NaN = NaN).
+    for cols, kap in ((bm.pe_cols, kap_pe), (bm.inj_cols, kap_inj)):
+        for ci, col in enumerate(cols):
+            bad = ~np.isfinite(col)
+            if bad.any():
+                kap[bad] = -np.inf
+                cols[ci] = np.where(bad, 0.0, col)
     bm.kappa_col = len(bm.pe_cols)
     bm.pe_cols.append(kap_pe)
     bm.inj_cols.append(kap_inj)
