@@ -52,6 +52,10 @@ class Column:
             with np.errstate(all="ignore"):
                 if self.transform == "sub":
                     v = x - self.const
+                elif self.transform == "logdiv":    # log(x / const)
+                    v = np.log(x / self.const)
+                elif self.transform == "log1mdiv":  # log(1 - x / const)
+                    v = np.log(1.0 - x / self.const)
                 elif self.transform == "id":
                     v = x
                 elif self.transform == "log":

@@ -69,25 +69,29 @@ def _powerlaw_ratio(q, m1, beta, mmin):
 
 
 def truncnorm_pdf(xx, mu, sig, low, high, log=False):
-    """distributions.py:122-143 (log=False branch)."""
-    if log:
-        raise NotImplementedError("log-normal branch is not used by any reference model")
+    """distributions.py:122-143.  ``log=True`` is the log-normal: a truncated normal in log x on
+    [log low, log high] times the Jacobian 1/x (:129-134)."""
     xx = _f(xx)
     side = side_of(xx)
     with np.errstate(all="ignore"):
         mask = ~((xx > high) | (xx < low))
+        if log:
+            return Density([Factor(N.TERM_TRUNCNORM, side, [Column("log", xx)], [mu, sig], consts=(np.log(low), np.log(high)), mask=mask, static_log=-np.log(xx))], side)
     return Density([Factor(N.TERM_TRUNCNORM, side, [Column("id", xx)], [mu, sig], consts=(low, high), mask=mask)], side)
 
 
 def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
-    """distributions.py:146-162 (scale == 1)."""
-    if float(scale) != 1.0 or floor != 0.0:
-        raise NotImplementedError("scale != 1 / floor != 0 are not used by any reference model")
+    """distributions.py:146-162.  With ``scale`` = s: Beta in x/s divided by s."""
+    if floor != 0.0:
+        raise NotImplementedError("floor != 0 is not used by any reference model")
     xx = _f(xx)
     side = side_of(xx)
+    scale = float(scale)
     with np.errstate(all="ignore"):
         mask = (xx <= scale) & (xx >= 0)
-    return Density([Factor(N.TERM_BETA, side, [Column("log", xx), Column("log1m", xx)], [alpha, beta], mask=mask)], side)
+    if scale == 1.0:
+        return Density([Factor(N.TERM_BETA, side, [Column("log", xx), Column("log1m", xx)], [alpha, beta], mask=mask)], side)
+    return Density([Factor(N.TERM_BETA, side, [Column("logdiv", xx, scale), Column("log1mdiv", xx, scale)], [alpha, beta], mask=mask)], side, log_const=-np.log(scale))
 
 
 # ================================================================================================

@@ -491,6 +491,8 @@ def make_terms():
     out["powerlaw_alphas"] = np.array([-2.35, 1.3, -1.0, 0.0])
     out["truncnorm_pdf"] = np.asarray(D.truncnorm_pdf(jnp.asarray(x), 33.0, 4.5, MMIN, MMAX))
     out["truncnorm_params"] = np.array([33.0, 4.5, MMIN, MMAX])
+    out["truncnorm_pdf_lognormal"] = np.asarray(D.truncnorm_pdf(jnp.asarray(x), 3.4, 0.3, MMIN, MMAX, log=True))
+    out["lognormal_params"] = np.array([3.4, 0.3, MMIN, MMAX])
     out["plpeak_primary_pdf"] = np.asarray(P.plpeak_primary_pdf(jnp.asarray(x), -2.7, MMIN, MMAX, 33.0, 4.5, 0.08))
     out["plpeak_params"] = np.array([-2.7, MMIN, MMAX, 33.0, 4.5, 0.08])
     out["plpeak_primary_ratio_pdf"] = np.asarray(P.plpeak_primary_ratio_pdf(jnp.asarray(x), jnp.asarray(q), -2.7, 1.4, MMIN, MMAX, 33.0, 4.5, 0.08))
@@ -501,6 +503,9 @@ def make_terms():
     with np.errstate(all="ignore"):
         out["betadist"] = np.asarray(D.betadist(jnp.asarray(a), 2.2, 3.7))
     out["beta_params"] = np.array([2.2, 3.7])
+    with np.errstate(all="ignore"):
+        out["betadist_scaled"] = np.asarray(D.betadist(jnp.asarray(a), 1.6, 2.9, scale=0.8))
+    out["beta_scaled_params"] = np.array([1.6, 2.9, 0.8])
     ct = rng.uniform(-1.05, 1.05, n)
     ct[:4] = [-1.0, 1.0, np.nextafter(-1.0, -2), np.nextafter(1.0, 2)]
     out["ct"] = ct

@@ -77,6 +77,9 @@ def test_truncnorm_plpeak_and_ratio(terms):
     mu, sig, lo, hi = terms["truncnorm_params"]
     d_pe, d_inj = M.truncnorm_pdf(mp, mu, sig, lo, hi), M.truncnorm_pdf(mi, mu, sig, lo, hi)
     _check(_logw(d_pe, d_inj, d_pe)[1], terms["truncnorm_pdf"])
+    mu, sig, lo, hi = terms["lognormal_params"]  # log=True: the log-normal branch (distributions.py:129-134)
+    d_pe, d_inj = M.truncnorm_pdf(mp, mu, sig, lo, hi, log=True), M.truncnorm_pdf(mi, mu, sig, lo, hi, log=True)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["truncnorm_pdf_lognormal"])
     al, lo, hi, mpp, sigpp, lam = terms["plpeak_params"]
     d_pe, d_inj = M.plpeak_primary_pdf(mp, al, lo, hi, mpp, sigpp, lam), M.plpeak_primary_pdf(mi, al, lo, hi, mpp, sigpp, lam)
     _check(_logw(d_pe, d_inj, d_pe)[1], terms["plpeak_primary_pdf"])
@@ -93,6 +96,9 @@ def test_beta_and_tilt(terms):
     a, b = terms["beta_params"]
     d_pe, d_inj = M.betadist(ap, a, b), M.betadist(ai, a, b)
     _check(_logw(d_pe, d_inj, d_pe)[1], terms["betadist"])
+    a, b, scale = terms["beta_scaled_params"]  # Beta on [0, scale] (distributions.py:159-161)
+    d_pe, d_inj = M.betadist(ap, a, b, scale=scale), M.betadist(ai, a, b, scale=scale)
+    _check(_logw(d_pe, d_inj, d_pe)[1], terms["betadist_scaled"])
     cp, ci = _pair(terms["ct"])
     xi, sg = terms["tilt_params"]
     d_pe, d_inj = M.mixture_isoalign_spin_tilt(cp, xi, sg), M.mixture_isoalign_spin_tilt(ci, xi, sg)
