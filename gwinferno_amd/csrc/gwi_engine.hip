@@ -92,6 +92,8 @@ const Variant kVariants[] = {
     GWI_VARIANT("spline3", K_SP, K_SP, K_SP),
     // BSplinePrimaryBSplineRatio alone: the (m1, q) mesh of the posterior-predictive curves (postprocess/calculations.py:20-60)
     GWI_VARIANT("spline2", K_SP, K_SP),
+    // log-normal m1 peak x BSplineRatio (postprocess/calculations.py:94-130)
+    GWI_VARIANT("spline+truncnorm", K_SP, K_TN),
     // plpeak_primary_ratio_pdf with the low-mass taper `delta` (parametric.py:39-53) [x PL z]
     GWI_VARIANT("plq+plz+smooth+plpeaksmooth", K_PQ, K_PZ, K_SM, K_PS),
     GWI_VARIANT("plq+smooth+plpeaksmooth", K_PQ, K_SM, K_PS),

@@ -66,10 +66,11 @@ def _normalise(p, grid, rate, frac):
     return rate[:, None] * p * frac[:, None] / np.trapezoid(p, grid, axis=1)[:, None]
 
 
-def _mass_ppds(weights_fn, draws, placeholder, mmin, mmax, rate, pop_frac):
+def _mass_ppds(weights_fn, draws, placeholder, mmin, mmax, rate, pop_frac, keep=None):
     ms = np.linspace(mmin, mmax, GRID)
     qs = np.linspace(mmin / mmax, 1, GRID)
-    mesh = _MeshMarginals(ms, qs, weights_fn, placeholder, keep=lambda Mg, Qg: Qg > mmin / Mg)  # calculations.py:46, 80
+    keep = keep if keep is not None else (lambda Mg, Qg: Qg > mmin / Mg)  # calculations.py:46, 80
+    mesh = _MeshMarginals(ms, qs, weights_fn, placeholder, keep=keep)
     p_q, p_m = mesh(draws)  # integrate over m (axis=1 of the mesh) / over q (axis=0)
     mesh.close()
     n = len(draws)
@@ -104,6 +105,21 @@ def calculate_bspline_mass_ppds(m_cs, q_cs, nspline_dict, mmin, mmax, rate=None,
         return lambda d, pe_samples: model(d["m"], d["q"], pe_samples=pe_samples)
 
     return _mass_ppds(weights_fn, draws, dict(m=np.zeros(nspline_dict["m1"]), q=np.zeros(nspline_dict["q"])), mmin, mmax, rate, pop_frac)
+
+
+def calculate_peak_logm1_bspline_q_ppds(logmp, logsigp, q_cs, nspline_dict, mmin, mmax, rate=None, pop_frac=None):
+    """calculations.py:94-130: log-normal primary-mass peak x LogY B-spline mass ratio -> ``(mpdfs, ms, qpdfs, qs)``."""
+    logmp, logsigp = np.atleast_1d(np.asarray(logmp, dtype=np.float64)), np.atleast_1d(np.asarray(logsigp, dtype=np.float64))
+    q_cs = np.atleast_2d(np.asarray(q_cs, dtype=np.float64))
+    draws = [dict(mu=float(logmp[i]), sg=float(logsigp[i]), q=q_cs[i]) for i in range(q_cs.shape[0])]
+
+    def weights_fn(Mg, Qg, ms, qs):
+        q_model = M.BSplineRatio(nspline_dict["q"], Qg, qs, mmin / mmax, basis=LogYBSpline)
+        data = {True: Mg, False: ms}
+        return lambda d, pe_samples: q_model(d["q"], pe_samples=pe_samples) * M.truncnorm_pdf(data[pe_samples], d["mu"], d["sg"], mmin, mmax, log=True)
+
+    keep = lambda Mg, Qg: ~((Mg < mmin) | (Mg * Qg < mmin))  # noqa: E731  (calculations.py:118)
+    return _mass_ppds(weights_fn, draws, dict(mu=3.0, sg=0.5, q=np.zeros(nspline_dict["q"])), mmin, mmax, rate, pop_frac, keep=keep)
 
 
 # ---- 1-D curves: per-sample log-weights of an 800-point grid -------------------------------------------

@@ -661,6 +661,11 @@ def make_ppd_fixture():
     mp, ms, qp, qs = calc.calculate_bspline_mass_ppds(m_cs, q_cs, nsp, 5.0, 100.0)
     out.update({"bspline_in/m_cs": m_cs, "bspline_in/q_cs": q_cs, "bspline_out/mpdfs": np.asarray(mp), "bspline_out/qpdfs": np.asarray(qp)})
     a_a, b_a = rng.uniform(1.0, 4.0, n), rng.uniform(1.0, 6.0, n)
+    # (drawn from a generator of its own so that the fixtures above keep their values)
+    rng2 = np.random.default_rng(BASE_SEED + 32)
+    lmp, lsp, q2 = rng2.uniform(2.8, 3.8, n), rng2.uniform(0.1, 0.6, n), rng2.normal(size=(n, 8))
+    mp, ms, qp, qs = calc.calculate_peak_logm1_bspline_q_ppds(lmp, lsp, q2, {"q": 8}, 5.0, 100.0)
+    out.update({"peaklog_in/logmp": lmp, "peaklog_in/logsigp": lsp, "peaklog_in/q_cs": q2, "peaklog_out/mpdfs": np.asarray(mp), "peaklog_out/qpdfs": np.asarray(qp)})
     ap, aa = calc.calculate_beta_spin_mag(a_a, b_a, rate=rate, pop_frac=frac)
     out.update({"beta_in/alpha": a_a, "beta_in/beta": b_a, "beta_out/apdfs": np.asarray(ap), "beta_out/aa": np.asarray(aa)})
     s_ct, l_ct = rng.uniform(0.3, 3.0, n), rng.uniform(0.0, 1.0, n)

@@ -35,6 +35,13 @@ def test_bspline_mass_ppds():
     assert _close(mp, GOLD["bspline_out/mpdfs"]) and _close(qp, GOLD["bspline_out/qpdfs"])
 
 
+def test_peak_logm1_bspline_q_ppds():
+    from gwinferno_amd import postprocess as P
+
+    mp, ms, qp, qs = P.calculate_peak_logm1_bspline_q_ppds(GOLD["peaklog_in/logmp"], GOLD["peaklog_in/logsigp"], GOLD["peaklog_in/q_cs"], {"q": 8}, 5.0, 100.0)
+    assert _close(mp, GOLD["peaklog_out/mpdfs"]) and _close(qp, GOLD["peaklog_out/qpdfs"])
+
+
 def test_one_dimensional_spin_curves():
     from gwinferno_amd import postprocess as P
 
