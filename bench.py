@@ -183,6 +183,23 @@ def main():
         def step(i):
             return vg(thetas[i % len(thetas)])
 
+    # N > 1: before timing, rank 0 checks the sharded evaluation against an unsharded engine over the whole
+    # catalog on its own GPU (same theta): the multi-GPU path is otherwise only covered by world-2 gloo tests
+    sharded_check = None
+    if dist is not None:
+        r_sh = step(0)
+        ll_sh, g_sh = (r_sh[0], np.array(r_sh[1])) if isinstance(r_sh, tuple) else (r_sh.log_likelihood, np.array(r_sh.grad))
+        if rank == 0:
+            full = COMPOSITIONS[comp_name](pe, inj)
+            eng_full = full.engine(device=local_rank)
+            r_full = eng_full.evaluate(thetas[0], total, min_neff_cut=False)
+            scale = max(1.0, float(np.max(np.abs(r_full.grad))))
+            sharded_check = {"log_likelihood_rel_err": abs(ll_sh - r_full.log_likelihood) / max(1e-300, abs(r_full.log_likelihood)),
+                             "grad_max_err_over_scale": float(np.max(np.abs(g_sh - r_full.grad))) / scale}
+            eng_full.close()
+            if sharded_check["log_likelihood_rel_err"] > 1e-9 or sharded_check["grad_max_err_over_scale"] > 1e-8:
+                print(f"[bench] WARNING: sharded result differs from the single-GPU result: {sharded_check}", file=sys.stderr)
+
     for i in range(args.warmup):
         step(i)
 
@@ -265,6 +282,7 @@ def main():
                 },
             },
             "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
+            "sharded_vs_single_gpu": sharded_check,
             "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,
         }
         if dist is None and args.k_batch > 1:
