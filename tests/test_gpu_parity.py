@@ -197,10 +197,12 @@ def test_in_engine_rccl_exchange_world1():
         th = comp.theta(draw_params("bspline_test", rng))
         a = eng.evaluate(th, total, min_neff_cut=False)
         b = eng.evaluate_sharded(th, total, min_neff_cut=False)
-        assert a.log_likelihood == b.log_likelihood
+        # per-event values are the same arithmetic; the sums over events run on the host in one path and in
+        # final_kernel in the other (different association): last-bit differences only
         assert np.array_equal(a.log_bfs, b.log_bfs)
+        assert rel_err(a.log_likelihood, b.log_likelihood) < 1e-14
         assert np.allclose(a.grad, b.grad, rtol=1e-12, atol=1e-13)
-        assert a.summary.log_nEff_inj == b.summary.log_nEff_inj
+        assert rel_err(a.summary.log_nEff_inj, b.summary.log_nEff_inj) < 1e-13
     eng.close()
 
 
