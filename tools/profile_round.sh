@@ -16,5 +16,5 @@ for c in $CONFIGS; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --timing-every 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS --output-format csv -d $out/sq_a -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --timing-every 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $out/sq_b -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --timing-every 0 > /dev/null 2>&1
-  python3 $R/bench.py --config $c --steps 1000 --warmup 100 --no-cpu-baseline > $out/bench.json 2> /dev/null
+  python3 $R/bench.py --config $c --steps 2000 --warmup 200 > $out/bench.json 2> /dev/null
 done
