@@ -203,6 +203,12 @@ def test_in_engine_rccl_exchange_world1():
         assert rel_err(a.log_likelihood, b.log_likelihood) < 1e-14
         assert np.allclose(a.grad, b.grad, rtol=1e-12, atol=1e-13)
         assert rel_err(a.summary.log_nEff_inj, b.summary.log_nEff_inj) < 1e-13
+        # marginalised selection: the sharded path runs a second exchange for the squared-weight records
+        am = eng.evaluate(th, total, min_neff_cut=False, marginalize_selection=True)
+        bm_ = eng.evaluate_sharded(th, total, min_neff_cut=False, marginalize_selection=True)
+        assert rel_err(am.log_likelihood, bm_.log_likelihood) < 1e-14
+        assert np.allclose(am.grad, bm_.grad, rtol=1e-11, atol=1e-12)
+        assert np.max(np.abs(am.grad - a.grad)) > 0
     eng.close()
 
 
