@@ -4,7 +4,6 @@
 its engine is created.   python tools/ab_bench.py c2 "GWI_SAMPLES_PER_LANE=2" "GWI_SAMPLES_PER_LANE=1 GWI_SINGLE_ROUND=1" """
 import os
 import sys
-import time
 
 import numpy as np
 
