@@ -230,6 +230,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1, secondary figure: the other way N GPUs are used for this workload -- one independent chain per GPU,
+    # each over the WHOLE catalog (numpyro chain_method="parallel"); no collective, per-GPU work fixed (weak scaling)
+    replicas = None
+    if dist is not None:
+        rep = COMPOSITIONS[comp_name](pe, inj)
+        eng_rep = rep.engine(device=local_rank)
+        vg_rep = eng_rep.configure(total, min_neff_cut=False)
+        n_rep = max(200, args.steps // 2)
+        for i in range(50):
+            vg_rep(thetas[i % len(thetas)])
+        fence()
+        t0r = time.perf_counter()
+        for i in range(n_rep):
+            vg_rep(thetas[i % len(thetas)])
+        fence()
+        tr = torch.tensor([time.perf_counter() - t0r], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        replicas = {"evals_per_s": world * n_rep / float(tr.item()), "scaling": "weak", "what": "one independent chain per GPU over the whole catalog, no collective"}
+        eng_rep.close()
+
     out = None
     if rank == 0:
         evals_per_s = args.steps / elapsed
@@ -283,6 +303,7 @@ def main():
             },
             "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
             "sharded_vs_single_gpu": sharded_check,
+            "independent_chains": replicas,
             "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,
         }
         if dist is None and args.k_batch > 1:
