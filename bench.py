@@ -134,8 +134,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # GWI_BENCH_BACKEND=gloo + GWI_BENCH_DEVICE=0: several ranks sharing ONE GPU with a CPU-side exchange --
+        # a logic test of the multi-rank path on a single-GPU box (implies the torch collective)
+        backend = os.environ.get("GWI_BENCH_BACKEND", "nccl")
+        if "GWI_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["GWI_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            os.environ["GWI_TORCH_COLLECTIVE"] = "1"
 
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_config_catalog
@@ -168,7 +177,7 @@ def main():
             use_torch = int(flag.item()) == 0
         collective = "torch.distributed all_gather_into_tensor" if use_torch else "ncclAllGather inside the engine"
         if use_torch:
-            sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank))
+            sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None)
 
             def step(i):
                 return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
@@ -226,7 +235,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -245,7 +254,7 @@ def main():
         for i in range(n_rep):
             vg_rep(thetas[i % len(thetas)])
         fence()
-        tr = torch.tensor([time.perf_counter() - t0r], dtype=torch.float64, device="cuda")
+        tr = torch.tensor([time.perf_counter() - t0r], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         replicas = {"evals_per_s": world * n_rep / float(tr.item()), "scaling": "weak", "what": "one independent chain per GPU over the whole catalog, no collective"}
         eng_rep.close()
