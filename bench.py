@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
+    ap.add_argument("--chains", type=int, default=4, help="also time this many independent chains interleaved on one GPU (begin/end); <= 1 disables")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event kernel timing on every n-th timed step")
     args = ap.parse_args()
 
@@ -329,6 +330,27 @@ def main():
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
+        if dist is None and args.chains > 1:
+            # secondary number: C independent chains on this one GPU, each with its own engine, their evaluations in
+            # flight together (gwi_eval_begin / gwi_eval_end); no lock step, every chain follows its own theta sequence
+            C = args.chains
+            extra = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C - 1)]
+            pairs = [e.configure_async(total, min_neff_cut=False) for e in [eng] + [c.engine(device=local_rank) for c in extra]]
+            n_c = max(200, args.steps // 2)
+            for rep in range(2):
+                for b, _ in pairs:
+                    b(thetas[0])
+                t0 = time.perf_counter()
+                for i in range(n_c):
+                    for c, (b, e) in enumerate(pairs):
+                        e()
+                        b(thetas[(i + c) % len(thetas)])
+                for _, e in pairs:
+                    e()
+                dt = time.perf_counter() - t0
+            out["interleaved_chains"] = {"chains": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
+            for c in extra:
+                c.engine().close()
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
             out["cpu_baseline"] = cpu_baseline(comp, thetas, total)
     if dist is not None:

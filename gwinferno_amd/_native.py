@@ -125,6 +125,8 @@ LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.p
 EXPORTED_SYMBOLS = [
     "gwi_create",
     "gwi_eval",
+    "gwi_eval_begin",
+    "gwi_eval_end",
     "gwi_eval_batch",
     "gwi_log_weights",
     "gwi_partial_len",
@@ -178,6 +180,10 @@ def load_library():
     lib.gwi_create.argtypes = [C.POINTER(GwiSpec), C.POINTER(_DP), C.c_int64, C.c_int64, C.POINTER(_DP), C.c_int64, C.c_int32, C.POINTER(vp)]
     lib.gwi_eval.restype = C.c_int32
     lib.gwi_eval.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_eval_begin.restype = C.c_int32
+    lib.gwi_eval_begin.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.c_int32]
+    lib.gwi_eval_end.restype = C.c_int32
+    lib.gwi_eval_end.argtypes = [vp, C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_eval_batch.restype = C.c_int32
     lib.gwi_eval_batch.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_log_weights.restype = C.c_int32

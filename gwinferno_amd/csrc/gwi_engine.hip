@@ -259,6 +259,10 @@ struct gwi_engine {
   hipEvent_t ev_tblocks = nullptr;
   float last_ms[3] = {0, 0, 0};
   bool timed_final = false;
+  bool last_host_rows = false;   // how the most recent run_pipeline publishes (what its waiter must poll)
+  bool pending = false;          // gwi_eval_begin issued, gwi_eval_end not yet called
+  bool pending_sq = false;
+  gwi_options pending_opt{};
   std::string err;
   KArgs kargs;
 };
@@ -494,6 +498,7 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   ta.inj_grad = h->d_inj_grad;
   ta.ev_host = h->h_ev_dev;
   ta.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
+  h->last_host_rows = ta.host_rows != nullptr;
   ta.record = record_dev ? record_dev : h->h_record_dev;
   ta.seq = h->seq + 1;
   ta.n_ev = (int)h->n_ev;
@@ -1139,24 +1144,42 @@ gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, con
   return GWI_OK;
 }
 
-gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs,
-                    double* variances, double* norms) {
+gwi_status gwi_eval_begin(gwi_handle h, const double* theta, const gwi_options* opt, int32_t want_grad) {
   if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
+  if (h->pending) return fail(h, GWI_ERR_INVALID, "gwi_eval_begin: the previous evaluation of this handle has not been collected (gwi_eval_end)");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
   GWI_HIP(hipSetDevice(h->device));
   gwi_status st;
-  const bool need_sq = opt->marginalize_selection && grad;
-  if (need_sq) {  // squared-weight pass first: the regular pass then leaves its per-event arrays in place
+  h->pending_opt = *opt;
+  h->pending_sq = opt->marginalize_selection && want_grad;
+  if (h->pending_sq) {  // squared-weight pass first: the regular pass then leaves its per-event arrays in place
     st = run_pipeline(h, theta, nullptr, true, 1, false, /*square=*/true);
     if (st != GWI_OK) return st;
     h->sq_records.assign(h->h_record, h->h_record + record_len(h));
   }
-  st = run_pipeline(h, theta);
+  st = run_pipeline(h, theta, nullptr, /*wait=*/false);
+  if (st != GWI_OK) return st;
+  h->pending = true;
+  return GWI_OK;
+}
+
+gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms) {
+  if (!h) return GWI_ERR_INVALID;
+  if (!h->pending) return fail(h, GWI_ERR_INVALID, "gwi_eval_end without gwi_eval_begin");
+  h->pending = false;
+  GWI_HIP(hipSetDevice(h->device));
+  gwi_status st;
+  if (h->last_host_rows) {
+    st = wait_for_rows(h, 1);
+  } else {
+    st = wait_for_stamp(h, h->h_record, 1);
+    if (st == GWI_OK) st = wait_for_norms(h, h->h_record, 1);
+  }
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_record, 1, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);
+  assemble(h, h->h_record, 1, &h->pending_opt, &s, grad, norms, h->host_consts[0], (h->pending_sq && grad) ? h->sq_records.data() : nullptr);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1165,6 +1188,13 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
   if (log_neffs) std::memcpy(log_neffs, h->h_ev + n, sizeof(double) * n);
   if (variances) std::memcpy(variances, h->h_ev + 2 * n, sizeof(double) * n);
   return GWI_OK;
+}
+
+gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs,
+                    double* variances, double* norms) {
+  const gwi_status st = gwi_eval_begin(h, theta, opt, grad != nullptr);
+  if (st != GWI_OK) return st;
+  return gwi_eval_end(h, summary, grad, log_bfs, log_neffs, variances, norms);
 }
 
 gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries, double* grads,

@@ -387,6 +387,35 @@ class NativePopulationLikelihood:
         self.value_and_grad = value_and_grad
         return value_and_grad
 
+    def configure_async(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """``begin(theta)`` issues the launches of one evaluation and returns at once; ``end()`` waits for it and
+        returns ``(log_likelihood, grad)``.  For several engines (one per chain) in flight on one GPU: the
+        evaluations of desynchronised chains overlap instead of queueing behind each other's host latency."""
+        b = self._buffers()
+        o = b.opt
+        o.n_obs = float(self.n_ev_global if nobs is None else nobs)
+        o.total_inj = float(total_inj)
+        o.marginalize_selection = int(bool(marginalize_selection))
+        o.min_neff_cut = int(bool(min_neff_cut))
+        o.max_variance_cut = int(bool(max_variance_cut))
+        lib, handle, theta_buf, summ, grad = self.lib, self.handle, b.theta, b.summ, b.grad
+        begin_args = (handle, b.p_theta, b.r_opt, 1)
+        end_args = (handle, b.r_summ, b.p_grad, b.p_lb, b.p_ln, b.p_lv, b.p_norms)
+
+        def begin(theta):
+            theta_buf[:] = theta
+            st = lib.gwi_eval_begin(*begin_args)
+            if st != 0:
+                self._check(st)
+
+        def end():
+            st = lib.gwi_eval_end(*end_args)
+            if st != 0:
+                self._check(st)
+            return summ.log_likelihood, grad
+
+        return begin, end
+
     def configure_batch(self, k_batch, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
         """The batched counterpart of :meth:`configure` for vectorised chains: returns
         ``values_and_grads(thetas[K, n_theta]) -> (log_likelihood[K], grad[K, n_theta])`` writing into

@@ -205,6 +205,15 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
 gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
                     double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
+/* The same in two halves, for several handles in flight on one GPU (independent chains whose trajectory
+ * lengths differ cannot be batched in lock step, but their evaluations can overlap): gwi_eval_begin() does the
+ * host prelude and issues the launches of handle h, gwi_eval_end() waits for and assembles that evaluation.
+ * gwi_eval == begin + end.  One evaluation per handle may be pending; every handle has its own stream,
+ * buffers and copy of the catalog. */
+gwi_status gwi_eval_begin(gwi_handle h, const double* theta, const gwi_options* opt, int32_t want_grad);
+gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs,
+                        double* variances, double* norms);
+
 /* k_batch hyper-parameter points in ONE set of launches (blockIdx.y = point): what vectorised
  * multi-chain NUTS evaluates per step.  thetas[k_batch][n_theta] row-major; outputs are arrays of
  * k_batch entries (summaries[k], grads[k][n_theta], log_bfs[k][n_ev], ..., norms[k][n_norms]; any may

@@ -382,3 +382,32 @@ def test_degenerate_samples_do_not_poison_the_gradient():
         fd = (eng.evaluate(th + e, total, min_neff_cut=False, want_grad=False).log_likelihood - eng.evaluate(th - e, total, min_neff_cut=False, want_grad=False).log_likelihood) / (2 * h)
         assert abs(res.grad[k] - fd) < 1e-5 * max(1.0, abs(fd))
     eng.close()
+
+
+def test_begin_end_and_interleaved_engines():
+    """gwi_eval_begin / gwi_eval_end: the two halves give the bits of gwi_eval; two engines with evaluations in
+    flight together do not disturb each other; a second begin on a busy handle is refused."""
+    from gwinferno_amd._native import NativeEngineError
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 500, 3000, seed=19)
+    comps = [COMPOSITIONS["bspline_test"](pe, inj) for _ in range(2)]
+    engs = [c.engine() for c in comps]
+    rng = np.random.default_rng(3)
+    ths = [comps[0].theta(draw_params("bspline_test", rng)) for _ in range(6)]
+    refs = [engs[0].evaluate(t, total, min_neff_cut=False) for t in ths]
+    (b0, e0), (b1, e1) = (e.configure_async(total, min_neff_cut=False) for e in engs)
+    for i in range(0, 6, 2):
+        b0(ths[i])
+        b1(ths[i + 1])
+        with pytest.raises(NativeEngineError, match="has not been collected"):
+            b0(ths[i])
+        v1, g1 = e1()
+        assert v1 == refs[i + 1].log_likelihood and np.allclose(g1, refs[i + 1].grad, rtol=1e-12, atol=1e-13)
+        v0, g0 = e0()
+        assert v0 == refs[i].log_likelihood and np.allclose(g0, refs[i].grad, rtol=1e-12, atol=1e-13)
+    with pytest.raises(NativeEngineError, match="without gwi_eval_begin"):
+        e0()
+    for e in engs:
+        e.close()
