@@ -4,7 +4,11 @@ synthetic catalog, the priors of the reference's example, and the built-in NUTS 
 200 samples, as examples/simple_powerlaw_peak_example.py runs numpyro's NUTS; `--hmc` selects the
 fixed-length HMC driver instead).  Every leapfrog step is one engine evaluation (value + gradient),
 exactly what NUTS pays per step in the reference (examples/utils.py:63-85).
-    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut]"""
+(Without the n_eff cuts a chain can fall into the known failure of importance-sampled likelihoods -- a
+vanishing peak width with all weight on a few samples -- which is what `min_neff_cut` exists to forbid.)
+With `--chains C` (C > 1) C independent NUTS chains run on the one GPU, one engine each, their evaluations in
+flight together (gwi_eval_begin / gwi_eval_end): chains of different tree depths overlap instead of queueing.
+    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut] [--chains C]"""
 import os
 import sys
 import time
@@ -13,11 +17,12 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gwinferno_amd.compositions import COMPOSITIONS  # noqa: E402
-from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_target, nuts  # noqa: E402
+from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_async_target, make_target, nuts, nuts_chains  # noqa: E402
 from gwinferno_amd.synthetic import make_catalog  # noqa: E402
 
 use_hmc = "--hmc" in sys.argv
-argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_chains = int(sys.argv[sys.argv.index("--chains") + 1]) if "--chains" in sys.argv else 1
+argv = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--chains"]
 n_ev, n_pe, n_inj = (int(x) for x in argv[:3]) if len(argv) >= 3 else (69, 5000, 50_000)
 pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=2025)
 comp = COMPOSITIONS["plpeak"](pe, inj)
@@ -37,6 +42,23 @@ bij = Bijector(eng.n_theta).interval(idx["mpp"], 5.0, 100.0).interval(idx["lam"]
 # default cuts of analysis.py:272-303 (on a small catalog the posterior then hugs the cut and most trajectories
 # end on it -- reported as divergences -- exactly as under numpyro)
 target = make_target(eng, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv)
+if n_chains > 1:
+    engines = [eng] + [COMPOSITIONS["plpeak"](pe, inj).engine() for _ in range(n_chains - 1)]
+    pairs = [make_async_target(e, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv) for e in engines]
+    rng = np.random.default_rng(0)
+    starts = [bij.inverse(theta0) + 0.05 * rng.normal(size=eng.n_theta) for _ in range(n_chains)]
+    t0 = time.perf_counter()
+    res = nuts_chains(pairs, starts, n_warmup=200, n_samples=200, seed=1)
+    dt = time.perf_counter() - t0
+    n_ev_total = sum(r["n_evals"] for r in res)
+    print(f"{n_chains} chains: {n_ev_total} engine evaluations in {dt:.2f}s ({n_ev_total / dt:.0f} evals/s aggregate incl. the Python samplers)")
+    allth = np.concatenate([np.array([bij.forward(u)[0] for u in r["samples"]]) for r in res])
+    for c, r in enumerate(res):
+        print(f"  chain {c}: accept {r['accept_rate']:.2f}, step {r['step_size']:.3g}, mean tree depth {r['tree_depth'].mean():.1f}, {r['n_divergent']} divergent")
+    for i, n in enumerate(names):
+        per_chain = [np.array([bij.forward(u)[0][i] for u in r["samples"]]).mean() for r in res]
+        print(f"  {n:8s} mean {allth[:, i].mean():9.3f}  sd {allth[:, i].std():8.3f}   chain means {np.round(per_chain, 3)}")
+    sys.exit(0)
 t0 = time.perf_counter()
 if use_hmc:
     out = hmc(target, bij.inverse(theta0), n_warmup=150, n_samples=150, n_leapfrog=8, seed=1, progress=50)

@@ -162,52 +162,68 @@ def hmc(target, theta0, n_warmup=200, n_samples=200, n_leapfrog=8, target_accept
 
 # ------------------------------------------------------------------------------------------------
 # No-U-Turn sampler (the reference's sampler is numpyro.infer.NUTS, examples/utils.py:63-85)
+#
+# The sampler is written as a generator that YIELDS every point it needs evaluated and is SENT back
+# (log_prob, gradient): `nuts` drives one such generator synchronously; `nuts_chains` drives several at once
+# and keeps their engine evaluations in flight together (begin/end), which is how independent chains -- whose
+# trajectories have different lengths and cannot be batched in lock step -- share one GPU.
 # ------------------------------------------------------------------------------------------------
-def _leapfrog(target, th, p, g, eps, inv_mass):
+def _leapfrog(th, p, g, eps, inv_mass):
     p = p + 0.5 * eps * g
     th = th + eps * inv_mass * p
-    lp, g = target(th)
+    lp, g = yield th
     p = p + 0.5 * eps * g
     return th, p, g, lp
 
 
-def _find_step_size(target, th, lp, g, inv_mass, rng, eps=0.1):
+def _find_step_size(th, lp, g, inv_mass, rng, eps=0.1):
     """Heuristic of Hoffman & Gelman (2014), algorithm 4: double / halve until the one-step acceptance
     probability crosses 1/2."""
     p = rng.normal(size=th.size) / np.sqrt(inv_mass)
     h0 = -lp + 0.5 * np.sum(inv_mass * p**2)
 
     def log_ratio(e):
-        th1, p1, _, lp1 = _leapfrog(target, th, p, g, e, inv_mass)
+        th1, p1, _, lp1 = yield from _leapfrog(th, p, g, e, inv_mass)
         h1 = -lp1 + 0.5 * np.sum(inv_mass * p1**2)
         return h0 - h1 if np.isfinite(h1) and lp1 > -1e300 else -np.inf
 
-    a = 1.0 if log_ratio(eps) > np.log(0.5) else -1.0
+    a = 1.0 if (yield from log_ratio(eps)) > np.log(0.5) else -1.0
     for _ in range(50):
-        if not a * log_ratio(eps) > -a * np.log(2.0):
+        if not a * (yield from log_ratio(eps)) > -a * np.log(2.0):
             break
         eps *= 2.0**a
     return eps
 
 
-def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, progress=None):
-    """Multinomial NUTS with the generalised U-turn criterion (Betancourt 2017, as in Stan / NumPyro), dual-
-    averaging step size and one diagonal mass-matrix update during warm-up.  Every leapfrog step is one
-    engine evaluation (value + gradient).  Returns dict(samples, log_prob, accept_rate, step_size,
-    n_evals, tree_depth, n_divergent)."""
+def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, progress, tag=""):
+    """Generator: yields points to evaluate, receives (log_prob, grad); returns the result dict."""
     rng = np.random.default_rng(seed)
     theta = np.array(theta0, dtype=np.float64)
     dim = theta.size
     n_evals = [0]
-    user_target = target
 
-    def target(x):  # every call is one engine evaluation
+    def evaluate(x):
         n_evals[0] += 1
-        return user_target(x)
+        return (yield x)
 
-    lp, grad = target(theta)
+    def leap(th, p, g, eps_):
+        n_evals[0] += 1
+        return (yield from _leapfrog(th, p, g, eps_, inv_mass))
+
+    lp, grad = yield from evaluate(theta)
     inv_mass = np.ones(dim)
-    eps = _find_step_size(target, theta, lp, grad, inv_mass, rng)
+
+    def step_size(th, lp_, g_, eps0):
+        gen = _find_step_size(th, lp_, g_, inv_mass, rng, eps=eps0)
+        try:
+            x = next(gen)
+            while True:
+                n_evals[0] += 1
+                x = gen.send((yield x))
+        except StopIteration as stop:
+            return stop.value
+
+    eps = yield from step_size(theta, lp, grad, 0.1)
     mu, log_eps_bar, h_bar, gamma, t0, kappa = np.log(10 * eps), 0.0, 0.0, 0.05, 10.0, 0.75
     da_count = 0
 
@@ -215,16 +231,16 @@ def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_
         """Subtree of 2^depth leapfrog states grown from (th, p, g) in `direction`.  Returns the outer edge,
         a multinomially drawn proposal, log sum of weights, summed momentum, and termination flags."""
         if depth == 0:
-            th1, p1, g1, lp1 = _leapfrog(target, th, p, g, direction * eps_, inv_mass)
+            th1, p1, g1, lp1 = yield from leap(th, p, g, direction * eps_)
             h1 = -lp1 + 0.5 * np.sum(inv_mass * p1**2)
             ok = np.isfinite(h1) and lp1 > -1e300 and np.all(np.isfinite(g1))
             d = h0 - h1 if ok else -np.inf
             return dict(edge=(th1, p1, g1, lp1), prop=(th1, lp1, g1), logw=d, rho=p1.copy(), p_first=p1, turning=False, diverging=(not ok) or d < -1000.0,
                         sum_alpha=float(min(1.0, np.exp(min(0.0, d)))) if ok else 0.0, n_alpha=1)
-        a = build(th, p, g, lp_, direction, depth - 1, eps_, h0)
+        a = yield from build(th, p, g, lp_, direction, depth - 1, eps_, h0)
         if a["diverging"] or a["turning"]:
             return a
-        b = build(*a["edge"], direction, depth - 1, eps_, h0)
+        b = yield from build(*a["edge"], direction, depth - 1, eps_, h0)
         logw = np.logaddexp(a["logw"], b["logw"])
         prop = a["prop"]
         if not (b["diverging"] or b["turning"]) and np.log(rng.uniform()) < b["logw"] - logw:  # uniform over the subtree
@@ -248,7 +264,7 @@ def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_
         sum_alpha, n_alpha, depth, diverged = 0.0, 0, 0, False
         while depth < max_tree_depth:
             direction = 1 if rng.uniform() < 0.5 else -1
-            sub = build(*(right if direction == 1 else left), direction, depth, eps, h0)
+            sub = yield from build(*(right if direction == 1 else left), direction, depth, eps, h0)
             sum_alpha += sub["sum_alpha"]
             n_alpha += sub["n_alpha"]
             if sub["diverging"]:
@@ -281,7 +297,7 @@ def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_
             if m == (2 * n_warmup) // 3 and len(warm) > 20:  # one diagonal mass-matrix update, then re-tune the step
                 var = np.var(np.array(warm[len(warm) // 3 :]), axis=0)
                 inv_mass = np.where(var > 1e-12, var, 1.0)
-                eps = _find_step_size(target, theta, lp, grad, inv_mass, rng, eps=float(np.exp(log_eps_bar)))
+                eps = yield from step_size(theta, lp, grad, float(np.exp(log_eps_bar)))
                 mu, log_eps_bar, h_bar, da_count = np.log(10 * eps), 0.0, 0.0, 0
             if m == n_warmup:
                 eps = float(np.exp(log_eps_bar)) if da_count > 0 else eps
@@ -291,6 +307,73 @@ def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_
             accepts.append(acc)
             depths.append(depth)
         if progress and (it + 1) % progress == 0:
-            print(f"[nuts] iter {it + 1}: log_prob {lp:.3f} step {eps:.4g} depth {depth}", flush=True)
+            print(f"[nuts{tag}] iter {it + 1}: log_prob {lp:.3f} step {eps:.4g} depth {depth}", flush=True)
     return {"samples": np.array(samples), "log_prob": np.array(lps), "accept_rate": float(np.mean(accepts)) if accepts else 0.0, "step_size": eps,
             "n_evals": n_evals[0], "tree_depth": np.array(depths), "n_divergent": n_div}
+
+
+def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, progress=None):
+    """Multinomial NUTS with the generalised U-turn criterion (Betancourt 2017, as in Stan / NumPyro), dual-
+    averaging step size and one diagonal mass-matrix update during warm-up.  Every leapfrog step is one
+    engine evaluation (value + gradient).  Returns dict(samples, log_prob, accept_rate, step_size,
+    n_evals, tree_depth, n_divergent)."""
+    gen = _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, progress)
+    try:
+        x = next(gen)
+        while True:
+            x = gen.send(target(x))
+    except StopIteration as stop:
+        return stop.value
+
+
+def nuts_chains(begin_end, theta0s, post=None, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, progress=None):
+    """Independent NUTS chains with their evaluations in flight together.  ``begin_end[c] = (begin, end)`` of
+    chain c's own engine (``NativePopulationLikelihood.configure_async``): ``begin(x)`` issues the evaluation of
+    point x, ``end()`` returns ``(log_likelihood, grad)``.  ``post(x, ll, grad) -> (log_prob, grad)`` adds the
+    prior / change of variables (default: identity); with a bijector pass ``pre`` inside it -- see
+    :func:`make_async_target`.  Chains advance independently (different tree depths); while one chain's result is
+    being turned into its next request, the others' kernels are running.  Returns a list of result dicts."""
+    C = len(begin_end)
+    gens = [_nuts_gen(theta0s[c], n_warmup, n_samples, max_tree_depth, target_accept, seed + 1000 * c, progress, tag=f" chain {c}") for c in range(C)]
+    post = post or (lambda x, ll, g: (ll, g))
+    pending = [None] * C
+    results = [None] * C
+    for c in range(C):
+        pending[c] = next(gens[c])
+        begin_end[c][0](pending[c])
+    live = C
+    while live:
+        for c in range(C):
+            if results[c] is not None:
+                continue
+            ll, g = begin_end[c][1]()
+            try:
+                pending[c] = gens[c].send(post(pending[c], ll, np.array(g)))
+                begin_end[c][0](pending[c])
+            except StopIteration as stop:
+                results[c] = stop.value
+                live -= 1
+    return results
+
+
+def make_async_target(engine, total_inj, prior, bijector=None, **likelihood_flags):
+    """(begin, end) in the sampler's unconstrained coordinates for :func:`nuts_chains`: the counterpart of
+    :func:`make_target` on the engine's begin/end entry."""
+    eng_begin, eng_end = engine.configure_async(total_inj, **likelihood_flags)
+    state = {}
+
+    def begin(u):
+        if bijector is None:
+            theta, dth, dlogj, logj = u, 1.0, 0.0, 0.0
+        else:
+            theta, dth, dlogj, logj = bijector.forward(u)
+        state["t"] = (theta, dth, dlogj, logj)
+        eng_begin(theta)
+
+    def end():
+        ll, g = eng_end()
+        theta, dth, dlogj, logj = state["t"]
+        lp, gp = prior(theta)
+        return ll + lp + logj, (g + gp) * dth + dlogj
+
+    return begin, end
