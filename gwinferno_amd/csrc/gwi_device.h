@@ -86,6 +86,9 @@ struct KArgs {
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
   int gacc_rep, gacc_pad;  // spline-gradient LDS rows: replicas per wave (power of two), row stride (odd)
+  double* norm_out_host;               // pinned host: Z_j of hyper-parameter point k at [k * n_norms + j]
+  unsigned long long* norm_stamps_host;  // pinned host: completion stamp per (k, j)
+  unsigned long long norm_seq;
   int square, pad_;        // square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
@@ -855,20 +858,10 @@ struct Chain<U, K, Rest...> {
 
 // ---- grid normalisers (interpolation.py:280-291, parametric.py:123-124, spline_perturbation.py:323-336):
 //      Z_j = sum_g tw_g exp(lb_g + (theta+add) l1_g + spline(us_g)), one workgroup per normaliser.
-//      Only the HOST consumes Z (it rescales sites; Z cancels in log_l and its gradient), so this runs
-//      as its own small launch on a second stream, concurrently with the scan, and publishes straight to
-//      pinned host memory -- keeping its registers and LDS out of the scan kernel's budget.
-struct NormArgs {
-  const NormD* norms;
-  double* out_host;    // pinned host [n_norms + 1]: slot 0 = completion stamps counter base, Z_j at 1 + j
-  unsigned long long* stamps_host;  // pinned host [n_norms]
-  unsigned long long seq;
-  int n_theta, n_norms;
-  const ThetaBlock* tblocks;  // batched launches: theta of point blockIdx.y; nullptr: the embedded copy
-  double theta[GWI_MAX_THETA];
-};
-
-__global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a);
+//      Only the HOST consumes Z (it rescales sites; Z cancels in log_l and its gradient).  The integration is
+//      norm_block() below, run by the FIRST n_norms workgroups of the scan launch (they finish long before the
+//      scan does, and a launch of their own cost the host 4 us per evaluation); results go straight to pinned
+//      host memory with a stamp per normaliser.
 
 // ---- publishing to pinned host memory without a system-scope fence ---------------------------------
 // __threadfence_system() = write back the whole L2 + invalidate (several us).  Results bound for the
@@ -1095,6 +1088,47 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   publish_stamp(r, a.seq, tid);
 }
 
+// ---- one grid normaliser Z_j(theta), integrated by one workgroup (see the comment above NormD's users):
+//      Z = sum_g tw_g exp(lb_g + (theta + add) l1_g + spline(us_g)), published to pinned host memory with a stamp
+__device__ __forceinline__ void norm_block(const NormD* norms, const double* theta_src, int n_theta, int j, double* out_slot, unsigned long long* stamp_slot,
+                                           unsigned long long seq, double* s_theta, double* s_part /* [kWaves] */) {
+  const int tid = threadIdx.x;
+  for (int p = tid; p < n_theta; p += kBlock) s_theta[p] = theta_src[p];
+  __syncthreads();
+  const NormD nd = norms[j];
+  double acc = 0.0;
+  const double expo = nd.expo_theta >= 0 ? s_theta[nd.expo_theta] + nd.expo_add : 0.0;
+  const double inv_dx = nd.n_basis > 0 ? (double)(nd.n_basis - 3) / (nd.hi - nd.lo) : 0.0;
+  for (int g = tid; g < nd.n_pts; g += kBlock) {
+    const double tw = nd.tw[g];
+    double e = nd.lb ? nd.lb[g] : 0.0;
+    if (nd.expo_theta >= 0) e += expo * nd.l1[g];
+    if (nd.n_basis > 0) {
+      const double x = nd.us[g];
+      int k;
+      double tt;
+      spline_locate(x, nd.lo, inv_dx, nd.n_basis, k, tt);
+      const Taps b = cubic_taps(tt);
+      const double* cf = s_theta + nd.coef_off + k;
+      double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+      if ((nd.flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
+      if (nd.flags & GWI_NORM_LINEAR_SPLINE) {  // BSpline.norm: trapz of the spline itself
+        acc += tw * v;
+        continue;
+      }
+      e += v;
+    }
+    if (tw != 0.0) acc += tw * fast_exp(e);
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) store_sys(out_slot, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(stamp_slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- the scan kernel -----------------------------------------------------------------------------
 // grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
 // belongs to that event's logsumexp; an injection workgroup owns `chunk_inj` consecutive
@@ -1120,9 +1154,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   __shared__ double s_red[kRedChunk][kBlock];
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
 #ifdef GWI_STAMPS
-  unsigned long long* stamp_row = a.stamps + ((long long)b * kWaves + wave) * 8;
+  unsigned long long* stamp_row = a.stamps + ((long long)blockIdx.x * kWaves + wave) * 8;
 #define GWI_STAMP(k)                                                        \
   do {                                                                      \
     const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();         \
@@ -1134,12 +1167,19 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   } while (0)
 #endif
   GWI_STAMP(0);
-  const int n_pe_blocks = a.n_ev * a.tiles_per_event;
-
-  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
   // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
   const int kb = BATCH ? (int)blockIdx.y : 0;
   const double* theta_src = BATCH ? a.tblocks[kb].theta : a.theta;
+  const int n_norm_blocks = WRITE_LOGW ? 0 : a.n_norms;
+  if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
+    const int j = blockIdx.x;
+    norm_block(a.norms, theta_src, a.n_theta, j, a.norm_out_host + kb * a.n_norms + j, a.norm_stamps_host + kb * a.n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
+    return;
+  }
+  const int b = (int)blockIdx.x - n_norm_blocks;
+  const int n_pe_blocks = a.n_ev * a.tiles_per_event;
+
+  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
   if (ChainT::kSpline)
     for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
   const int wave_span = a.gacc_rep * a.gacc_pad;
@@ -1278,7 +1318,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   chain.collect(0, ctx, vals + 2, th + 2);
 #pragma unroll
   for (int v = 2; v < kNV; ++v) vals[v] *= f;
-  double* out = a.partials + ((long long)kb * gridDim.x + b) * a.rec_stride;
+  double* out = a.partials + ((long long)kb * (n_pe_blocks + a.n_inj_tiles) + b) * a.rec_stride;
 #pragma unroll
   for (int v0 = 0; v0 < kNV; v0 += kRedChunk) {
     if (v0 > 0) __syncthreads();
@@ -1351,47 +1391,6 @@ __global__ __launch_bounds__(kBlock) void stage_theta_kernel(const ThetaBlock* h
 __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered, double* host, int n, unsigned long long seq) {
   for (int i = threadIdx.x + 1; i < n; i += kBlock) store_sys(host + i, gathered[i]);
   publish_stamp(host, seq, threadIdx.x);
-}
-
-__global__ __launch_bounds__(kBlock) void norm_kernel(const NormArgs a) {
-  __shared__ double s_theta[GWI_MAX_THETA];
-  __shared__ double s_red[kWaves];
-  const int tid = threadIdx.x, j = blockIdx.x, kb = blockIdx.y;
-  const double* theta_src = a.tblocks ? a.tblocks[kb].theta : a.theta;
-  for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
-  __syncthreads();
-  const NormD nd = a.norms[j];
-  double acc = 0.0;
-  const double expo = nd.expo_theta >= 0 ? s_theta[nd.expo_theta] + nd.expo_add : 0.0;
-  const double inv_dx = nd.n_basis > 0 ? (double)(nd.n_basis - 3) / (nd.hi - nd.lo) : 0.0;
-  for (int g = tid; g < nd.n_pts; g += kBlock) {
-    const double tw = nd.tw[g];
-    double e = nd.lb ? nd.lb[g] : 0.0;
-    if (nd.expo_theta >= 0) e += expo * nd.l1[g];
-    if (nd.n_basis > 0) {
-      const double x = nd.us[g];
-      int k;
-      double tt;
-      spline_locate(x, nd.lo, inv_dx, nd.n_basis, k, tt);
-      const Taps b = cubic_taps(tt);
-      const double* cf = s_theta + nd.coef_off + k;
-      double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-      if ((nd.flags & (GWI_SPLINE_OUTSIDE_ZERO_EXPONENT | GWI_NORM_LINEAR_SPLINE)) && !((x >= nd.lo) && (x <= nd.hi))) v = 0.0;
-      if (nd.flags & GWI_NORM_LINEAR_SPLINE) {  // BSpline.norm: trapz of the spline itself
-        acc += tw * v;
-        continue;
-      }
-      e += v;
-    }
-    if (tw != 0.0) acc += tw * fast_exp(e);
-  }
-  acc = wave_sum(acc);
-  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
-  __syncthreads();
-  if (tid == 0) store_sys(a.out_host + kb * a.n_norms + j, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(a.stamps_host + kb * a.n_norms + j, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace gwi

@@ -216,7 +216,6 @@ struct gwi_engine {
   const Variant* variant = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t norm_stream = nullptr;  // normaliser grids run beside the scan
   long long n_ev = 0, n_pe = 0, n_inj = 0;
   // device memory
   std::vector<double*> d_cols_pe, d_cols_inj;
@@ -233,7 +232,6 @@ struct gwi_engine {
   double *h_rows = nullptr, *h_rows_dev = nullptr;
   double *h_norm = nullptr, *h_norm_dev = nullptr;                    // pinned: Z_j
   unsigned long long *h_norm_stamp = nullptr, *h_norm_stamp_dev = nullptr;  // pinned: per-normaliser stamps
-  NormArgs nargs;
   // launch geometry
   int tiles_per_event = 1, chunk_pe = 256, n_inj_tiles = 1, chunk_inj = 256, rec_stride = 0, n_scan_blocks = 0;
   int n_inj_groups = 1, tiles_per_inj_group = 1;
@@ -256,7 +254,6 @@ struct gwi_engine {
   double *d_send = nullptr, *d_recv = nullptr;
   double *h_gather = nullptr, *h_gather_dev = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/stop pairs: scan, combine, final
-  hipEvent_t ev_tblocks = nullptr;
   float last_ms[3] = {0, 0, 0};
   bool timed_final = false;
   bool last_host_rows = false;   // how the most recent run_pipeline publishes (what its waiter must poll)
@@ -420,7 +417,7 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
 }
 
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
-  const int grid = h->n_scan_blocks;
+  const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   ScanFn fn = logw ? h->variant->logw : (batch ? h->variant->scan_batch : h->variant->scan);
   launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs);
   GWI_HIP(hipGetLastError());
@@ -430,19 +427,6 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K = 1);
 gwi_status wait_for_rows(gwi_handle h, int K = 1);
 gwi_status wait_for_norms(gwi_handle h, double* record, int K = 1);
-
-// Normaliser grids: own stream, beside the scan; launched AFTER the main-stream kernels so that its
-// host-side launch cost is off the critical path.  `seq` is the stamp the waiters will look for.
-gwi_status launch_norms(gwi_handle h, const double* theta, unsigned long long seq, int K = 1, bool batch = false) {
-  if (h->spec.n_norms == 0) return GWI_OK;
-  if (!batch) std::memcpy(h->nargs.theta, theta, sizeof(double) * h->spec.n_theta);
-  h->nargs.tblocks = batch ? h->d_tblocks : nullptr;
-  h->nargs.seq = seq;
-  if (batch) GWI_HIP(hipStreamWaitEvent(h->norm_stream, h->ev_tblocks, 0));  // theta blocks are uploaded on the main stream
-  hipLaunchKernelGGL(norm_kernel, dim3(h->spec.n_norms, batch ? K : 1), dim3(kBlock), 0, h->norm_stream, h->nargs);
-  GWI_HIP(hipGetLastError());
-  return GWI_OK;
-}
 
 // launches scan -> combine -> final; `record_dev` is where final_kernel publishes (pinned host record
 // or, for the sharded path, the device send buffer); `wait` polls the pinned completion stamp.
@@ -486,7 +470,6 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     } else {
       GWI_HIP(hipMemcpyAsync(h->d_tblocks, h->h_tblocks, sizeof(ThetaBlock) * K, hipMemcpyHostToDevice, h->stream));
     }
-    GWI_HIP(hipEventRecord(h->ev_tblocks, h->stream));
     h->kargs.tblocks = h->d_tblocks;
   }
   const unsigned gy = batch ? (unsigned)K : 1u;
@@ -512,6 +495,7 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   ta.n_norms = h->spec.n_norms;
   ta.record_len = record_len(h);
   ta.n_pe = (double)h->n_pe;
+  h->kargs.norm_seq = h->seq + 1;  // the normaliser workgroups of this launch stamp their results with it
   GWI_PHASE(0);
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
@@ -522,8 +506,6 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   h->timed_final = false;
   GWI_PHASE(2);
   if (ta.host_rows) {
-    gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
-    if (sn != GWI_OK) return sn;
     GWI_PHASE(3);
     const gwi_status sw = wait ? wait_for_rows(h, K) : GWI_OK;
     GWI_PHASE(4);
@@ -532,10 +514,6 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   launch_timed(h, 2, final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, ta);
   GWI_HIP(hipGetLastError());
   h->timed_final = true;
-  {
-    gwi_status sn = launch_norms(h, theta, h->seq, K, batch);
-    if (sn != GWI_OK) return sn;
-  }
   if (!wait) return GWI_OK;
   gwi_status st_ = wait_for_stamp(h, h->h_record, K);
   if (st_ != GWI_OK) return st_;
@@ -554,7 +532,7 @@ gwi_status wait_for_norms(gwi_handle h, double* record, int K) {
     if (!done) __builtin_ia32_pause();
   }
   if (!done) {
-    GWI_HIP(hipStreamSynchronize(h->norm_stream));
+    GWI_HIP(hipStreamSynchronize(h->stream));
     for (int j = 0; j < total; ++j)
       if (h->h_norm_stamp[j] != h->seq) return fail(h, GWI_ERR_HIP, "normaliser stamp mismatch after stream synchronise");
   }
@@ -798,10 +776,8 @@ void destroy_impl(gwi_engine* h) {
   if (h->h_rows) (void)hipHostFree(h->h_rows);
   if (h->h_norm) (void)hipHostFree(h->h_norm);
   if (h->h_norm_stamp) (void)hipHostFree(h->h_norm_stamp);
-  if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  if (h->ev_tblocks) (void)hipEventDestroy(h->ev_tblocks);
   (void)hipFree(h->d_tblocks);
   if (h->h_tblocks) (void)hipHostFree(h->h_tblocks);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -877,10 +853,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
   GWI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  GWI_HIP(hipStreamCreateWithFlags(&h->norm_stream, hipStreamNonBlocking));
   if (const char* env = std::getenv("GWI_SPIN_WAIT")) h->spin_wait = std::atoi(env) != 0;
   for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
-  GWI_HIP(hipEventCreateWithFlags(&h->ev_tblocks, hipEventDisableTiming));
   if (const char* env = std::getenv("GWI_MAX_BATCH")) h->max_batch = std::atoi(env);
   if (h->max_batch < 1) h->max_batch = 1;
   if (h->max_batch > 64) h->max_batch = 64;
@@ -1036,12 +1010,6 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     GWI_HIP(hipHostMalloc((void**)&h->h_norm_stamp, sizeof(unsigned long long) * nn, hipHostMallocMapped));
     GWI_HIP(hipHostGetDevicePointer((void**)&h->h_norm_stamp_dev, h->h_norm_stamp, 0));
     std::memset(h->h_norm_stamp, 0, sizeof(unsigned long long) * nn);
-    std::memset(&h->nargs, 0, sizeof(h->nargs));
-    h->nargs.norms = h->d_norms;
-    h->nargs.out_host = h->h_norm_dev;
-    h->nargs.stamps_host = h->h_norm_stamp_dev;
-    h->nargs.n_theta = spec->n_theta;
-    h->nargs.n_norms = spec->n_norms;
   }
 
   // ---- constant part of the kernel-argument block
@@ -1056,6 +1024,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   k.kappa_pe = tab_pe[spec->kappa_col];
   k.kappa_inj = tab_inj[spec->kappa_col];
   k.norms = h->d_norms;
+  k.norm_out_host = h->h_norm_dev;
+  k.norm_stamps_host = h->h_norm_stamp_dev;
   k.partials = h->d_partials;
   k.n_pe = n_pe;
   k.n_inj = n_inj;
