@@ -3,7 +3,7 @@
 // One fused "scan" launch streams the catalog columns once and produces, per workgroup, a partial
 // record (running max m, S1 = sum e^{l-m}, S2 = sum e^{2(l-m)}, G[p] = sum e^{l-m} dl/dtheta_p).
 // A small launch then combines records per event (and, for large problems, a third sums over
-// events); the grid normalisers are integrated by norm_kernel on a side stream.  Everything is fp64.
+// events); the grid normalisers are integrated by the first workgroups of the scan launch.  Everything is fp64.
 //
 // Reference arithmetic being replaced (paths relative to the reference root):
 //   per-sample densities      gwinferno/distributions.py:100-162, models/parametric/parametric.py:27-145
