@@ -348,7 +348,30 @@ def main():
                 for _, e in pairs:
                     e()
                 dt = time.perf_counter() - t0
-            out["interleaved_chains"] = {"chains": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
+            out["interleaved_chains"] = {"chains": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c), "host_threads": 1}
+            # the same C engines, one HOST THREAD each running blocking evaluations in a C loop (the GIL is released inside
+            # the library): launch costs spread over cores, the GPU interleaves the chains' kernels
+            import threading
+
+            all_engines = [eng] + [c.engine() for c in extra]
+            gate = threading.Barrier(C + 1)
+
+            def chain(e, th):
+                e.selftime(th, total, n_iter=50, min_neff_cut=False)
+                gate.wait()
+                e.selftime(th, total, n_iter=n_c, min_neff_cut=False)
+                gate.wait()
+
+            workers = [threading.Thread(target=chain, args=(e, thetas[i])) for i, e in enumerate(all_engines)]
+            for w in workers:
+                w.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            gate.wait()
+            dt = time.perf_counter() - t0
+            for w in workers:
+                w.join()
+            out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
             for c in extra:
                 c.engine().close()
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
