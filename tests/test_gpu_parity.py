@@ -411,3 +411,39 @@ def test_begin_end_and_interleaved_engines():
         e0()
     for e in engs:
         e.close()
+
+
+def test_engines_in_concurrent_host_threads():
+    """One engine per host thread, evaluations running concurrently (handles are independent: own stream, buffers
+    and catalog copy; the library releases the GIL): every thread gets exactly the single-threaded results."""
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 500, 3000, seed=19)
+    n_threads = 4
+    comps = [COMPOSITIONS["bspline_test"](pe, inj) for _ in range(n_threads)]
+    engs = [c.engine() for c in comps]
+    rng = np.random.default_rng(8)
+    ths = [comps[0].theta(draw_params("bspline_test", rng)) for _ in range(8)]
+    refs = [engs[0].evaluate(t, total, min_neff_cut=False) for t in ths]
+    errors = []
+
+    def work(c):
+        vg = engs[c].configure(total, min_neff_cut=False)
+        for i in range(300):
+            k = (i + c) % len(ths)
+            v, g = vg(ths[k])
+            if v != refs[k].log_likelihood or not np.allclose(g, refs[k].grad, rtol=1e-12, atol=1e-13):
+                errors.append((c, i, v, refs[k].log_likelihood))
+                return
+
+    workers = [threading.Thread(target=work, args=(c,)) for c in range(n_threads)]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    assert not errors, errors[:3]
+    for e in engs:
+        e.close()
