@@ -130,3 +130,31 @@ def test_non_finite_hyper_parameter_takes_the_nan_branch(bad):
     again = eng.evaluate(th, total, min_neff_cut=False)
     assert again.log_likelihood == good.log_likelihood
     assert np.array_equal(again.grad, good.grad)
+
+
+@pytest.mark.parametrize("cfg,comp_name", [("c5", "bspline_full"), ("c3", "bspline_iid"), ("c2", "plpeak")])
+def test_full_size_against_c_oracle(cfg, comp_name):
+    """The BASELINE catalogs at FULL size (config 5: 2.5 M samples, 9 columns, 109 hyper-parameters) against the
+    C/OpenMP oracle on the host: value, every per-event site and the whole gradient."""
+    from golden_util import rel_err
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_config_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_config_catalog(cfg)
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    eng = comp.engine()
+    orc = COracle(eng.bound)
+    rng = np.random.default_rng(1)
+    for _ in range(2):
+        th = comp.theta(draw_params(comp_name, rng))
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = orc.evaluate(th, total, min_neff_cut=False)
+        assert rel_err(got.log_likelihood, ref["log_likelihood"]) < 1e-9
+        assert rel_err(got.log_bfs, ref["logBFs"]) < 1e-9
+        assert rel_err(got.log_neffs, ref["log_nEffs"]) < 1e-8
+        assert abs(got.summary.log_det_eff - ref["summary"].log_det_eff) < 1e-9 * abs(ref["summary"].log_det_eff)
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    eng.close()
