@@ -1018,22 +1018,43 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   const int row = tid / vp, col = tid - row * vp;
   double acc = 0.0;
   if (col < a.n_theta) {
-#pragma unroll 8
-    for (int e = row; e < a.n_ev; e += rows) acc += ev_grad[(long long)e * a.n_theta + col];
+    // chunks of 16 events: the 16 loads go out together (one memory round trip), then the ordered sum
+    for (int e0 = row; e0 < a.n_ev; e0 += 16 * rows) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = e0 + q * rows;
+        v[q] = e < a.n_ev ? ev_grad[(long long)e * a.n_theta + col] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += v[q];
+    }
   }
   s_tile[tid] = acc;
 
   // ---- meanwhile wave 0: scalar sums over events; wave 1: injection groups
   if (wave == 0) {
     double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
-    for (int e = lane; e < a.n_ev; e += 64) {
-      const double* o = ev_out + (long long)e * 4;
-      sum += o[0];
-      var += o[2];
-      double le = o[1];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
-      if (le != le) le = 0.0;
-      le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
-      mn = fmin(mn, le);
+    for (int e0 = lane; e0 < a.n_ev; e0 += 4 * 64) {  // four events per lane per round trip
+      double o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + 64 * q;
+        const double* o = ev_out + (long long)(e < a.n_ev ? e : 0) * 4;
+        o0[q] = o[0];
+        o1[q] = o[1];
+        o2[q] = o[2];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (e0 + 64 * q >= a.n_ev) continue;
+        sum += o0[q];
+        var += o2[q];
+        double le = o1[q];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+        if (le != le) le = 0.0;
+        le = fmin(fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
+        mn = fmin(mn, le);
+      }
     }
     sum = wave_sum(sum);
     var = wave_sum(var);
@@ -1050,7 +1071,7 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   const bool hasg = lane < a.n_inj_groups;
   const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
   const double s1_j = hasg ? inj_out[lane * 4 + 1] : 0.0, s2_j = hasg ? inj_out[lane * 4 + 2] : 0.0;
-  constexpr int kEarly = 8;
+  constexpr int kEarly = 32;
   double early[kEarly];
   const bool early_on = tid < a.n_theta;
 #pragma unroll
@@ -1076,7 +1097,14 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
         if (j < a.n_inj_groups) g += lane_bcast(fj, j) * early[j];
       j = a.n_inj_groups < kEarly ? a.n_inj_groups : kEarly;
     }
-    for (; j < a.n_inj_groups; ++j) g += lane_bcast(fj, j) * inj_grad[(long long)j * a.n_theta + p];
+    for (; j < a.n_inj_groups; j += 8) {  // eight independent loads per round trip, then the ordered sum
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (j + q < a.n_inj_groups) ? inj_grad[(long long)(j + q) * a.n_theta + p] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j + q < a.n_inj_groups) g += lane_bcast(fj, j + q) * v[q];
+    }
     store_sys(r + off_ginj + p, g);
   }
   __syncthreads();

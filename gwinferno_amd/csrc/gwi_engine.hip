@@ -954,8 +954,10 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
   h->rec_stride = kRecHeader + spec->n_theta;
-  // injection tiles are combined in groups of <= 32 records (one workgroup each)
-  h->tiles_per_inj_group = 32;  // <= 64: one tile per lane in combine_kernel
+  // injection tiles are combined in groups of <= 16 records (one workgroup each): a group's tile values are then
+  // all requested in the combine kernel's first memory round trip (kEarly there)
+  h->tiles_per_inj_group = 16;  // <= 64: one tile per lane in combine_kernel
+  if (const char* env = std::getenv("GWI_TILES_PER_INJ_GROUP")) h->tiles_per_inj_group = std::max(1, std::min(64, std::atoi(env)));
   h->n_inj_groups = (h->n_inj_tiles + h->tiles_per_inj_group - 1) / h->tiles_per_inj_group;
   if (h->n_inj_groups < 1) h->n_inj_groups = 1;
   if (h->n_inj_groups > 64) {  // final_kernel maps groups to the lanes of one wave
