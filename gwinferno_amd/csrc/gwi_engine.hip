@@ -999,7 +999,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   {
     const size_t n_groups = (size_t)n_ev + h->n_inj_groups;
     const size_t row_bytes = sizeof(double) * n_groups * (4 + spec->n_theta);
-    size_t host_final_limit = 32 * 1024;
+    size_t host_final_limit = 64 * 1024;  // measured: config 3 (41 KB of rows) gains 2 us from host-final, config 5 (195 KB) loses 5
     if (const char* env = std::getenv("GWI_HOST_FINAL_BYTES")) host_final_limit = (size_t)std::atoll(env);
     h->host_final = row_bytes <= host_final_limit;
     if (const char* env = std::getenv("GWI_HOST_FINAL")) h->host_final = h->host_final && std::atoi(env) != 0;
