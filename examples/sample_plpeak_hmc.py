@@ -8,7 +8,9 @@ exactly what NUTS pays per step in the reference (examples/utils.py:63-85).
 vanishing peak width with all weight on a few samples -- which is what `min_neff_cut` exists to forbid.)
 With `--chains C` (C > 1) C independent NUTS chains run on the one GPU, one engine each, their evaluations in
 flight together (gwi_eval_begin / gwi_eval_end): chains of different tree depths overlap instead of queueing.
-    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut] [--chains C]"""
+`--native` runs the library's C++ sampler instead (gwi_nuts_engine, include/gwi_sampler.h): the same algorithm,
+target and priors with no Python between two evaluations -- one host thread per chain, each on its own engine.
+    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut] [--chains C] [--native]"""
 import os
 import sys
 import time
@@ -17,7 +19,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gwinferno_amd.compositions import COMPOSITIONS  # noqa: E402
-from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_async_target, make_target, nuts, nuts_chains  # noqa: E402
+from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_async_target, make_target, nuts, nuts_chains, nuts_engine  # noqa: E402
 from gwinferno_amd.synthetic import make_catalog  # noqa: E402
 
 use_hmc = "--hmc" in sys.argv
@@ -42,6 +44,21 @@ bij = Bijector(eng.n_theta).interval(idx["mpp"], 5.0, 100.0).interval(idx["lam"]
 # default cuts of analysis.py:272-303 (on a small catalog the posterior then hugs the cut and most trajectories
 # end on it -- reported as divergences -- exactly as under numpyro)
 target = make_target(eng, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv)
+if "--native" in sys.argv:
+    engines = [eng] + [COMPOSITIONS["plpeak"](pe, inj).engine() for _ in range(n_chains - 1)]
+    rng = np.random.default_rng(0)
+    starts = np.stack([bij.forward(bij.inverse(theta0) + (0.05 * rng.normal(size=eng.n_theta) if c else 0.0))[0] for c in range(n_chains)])
+    t0 = time.perf_counter()
+    res = nuts_engine(engines, total, prior, bij, starts, n_warmup=200, n_samples=200, seed=1, min_neff_cut="--neff-cut" in sys.argv)
+    dt = time.perf_counter() - t0
+    n_ev_total = sum(r["n_evals"] for r in res)
+    print(f"native sampler, {n_chains} chain(s): {n_ev_total} engine evaluations in {dt:.2f}s ({n_ev_total / dt:.0f} evals/s aggregate)")
+    allth = np.concatenate([r["samples"] for r in res])
+    for c, r in enumerate(res):
+        print(f"  chain {c}: accept {r['accept_rate']:.2f}, step {r['step_size']:.3g}, mean tree depth {r['tree_depth'].mean():.1f}, {r['n_divergent']} divergent")
+    for i, n in enumerate(names):
+        print(f"  {n:8s} mean {allth[:, i].mean():9.3f}  sd {allth[:, i].std():8.3f}   chain means {np.round([r['samples'][:, i].mean() for r in res], 3)}")
+    sys.exit(0)
 if n_chains > 1:
     engines = [eng] + [COMPOSITIONS["plpeak"](pe, inj).engine() for _ in range(n_chains - 1)]
     pairs = [make_async_target(e, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv) for e in engines]

@@ -119,6 +119,38 @@ class GwiSummary(C.Structure):
     ]
 
 
+class GwiNutsOptions(C.Structure):
+    _fields_ = [
+        ("n_warmup", C.c_int32),
+        ("n_samples", C.c_int32),
+        ("max_tree_depth", C.c_int32),
+        ("reserved", C.c_int32),
+        ("target_accept", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
+class GwiNutsResult(C.Structure):
+    _fields_ = [
+        ("accept_rate", C.c_double),
+        ("step_size", C.c_double),
+        ("n_evals", C.c_int64),
+        ("n_divergent", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class GwiParamPrior(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("lo", C.c_double), ("hi", C.c_double), ("sigma", C.c_double)]
+
+
+class GwiSmoothingPenalty(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("count", C.c_int32), ("degree", C.c_int32), ("reserved", C.c_int32), ("tau", C.c_double)]
+
+
+# include/gwi_sampler.h: int32 (*)(void* user, const double* x, double* log_prob, double* grad)
+GWI_TARGET_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
 LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgwi_engine.so")
 
 # every symbol include/gwi_engine.h declares
@@ -145,6 +177,8 @@ EXPORTED_SYMBOLS = [
     "gwi_kernel_variants",
     "gwi_kernel_variant_name",
 ]
+# ... and include/gwi_sampler.h
+EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine"]
 
 _lib = None
 
@@ -216,6 +250,12 @@ def load_library():
     lib.gwi_kernel_variants.restype = C.c_int32
     lib.gwi_kernel_variant_name.restype = C.c_char_p
     lib.gwi_kernel_variant_name.argtypes = [C.c_int32]
+    _IP = C.POINTER(C.c_int32)
+    lib.gwi_nuts_run.restype = C.c_int32
+    lib.gwi_nuts_run.argtypes = [GWI_TARGET_FN, vp, C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
+    lib.gwi_nuts_engine.restype = C.c_int32
+    lib.gwi_nuts_engine.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiParamPrior), C.POINTER(GwiSmoothingPenalty), C.c_int32, _DP,
+                                    C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
     if lib.gwi_abi_version() != GWI_ABI_VERSION:
         raise NativeEngineError(f"ABI mismatch: library {lib.gwi_abi_version()} vs binding {GWI_ABI_VERSION}")
     _lib = lib

@@ -1,0 +1,383 @@
+// gwi_sampler.cpp -- host-side No-U-Turn sampler of the engine library (declared in include/gwi_sampler.h).
+//
+// The reference drives its model with numpyro.infer.NUTS (examples/utils.py:63-85): jit-compiled host code
+// around one value_and_grad per leapfrog step.  This is the native counterpart for environments without
+// JAX/NumPyro, so that sampling runs at the engine's evaluation rate instead of a Python interpreter's:
+// multinomial NUTS with the generalised U-turn criterion (Betancourt 2017; the scheme of Stan / NumPyro),
+// dual-averaging step size (Hoffman & Gelman 2014, alg. 5) and one diagonal mass-matrix update in warm-up.
+// gwinferno_amd/sampling.py holds the same algorithm in NumPy (the two are tested against the same targets).
+//
+//   gwi_nuts_run      any target given as a C callback (log-probability and gradient)
+//   gwi_nuts_engine   target = engine log-likelihood + Normal priors + P-spline difference penalties
+//                     (pipeline/utils.py:163-216) on constrained parameters mapped by interval / positive
+//                     bijectors; chains run in one host thread each, every chain on its own engine handle
+#include "gwi_sampler.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+using Vec = std::vector<double>;
+
+struct Target {
+  gwi_target_fn fn;
+  void* user;
+  int dim;
+  long long n_evals = 0;
+  bool failed = false;
+  // evaluates at x; returns log-probability, writes the gradient
+  double operator()(const Vec& x, Vec& grad) {
+    double lp = 0.0;
+    ++n_evals;
+    if (fn(user, x.data(), &lp, grad.data()) != 0) failed = true;
+    return lp;
+  }
+};
+
+struct State {
+  Vec th, p, g;
+  double lp = 0.0;
+};
+
+double dot_w(const Vec& a, const Vec& w, const Vec& b) {  // sum a_i w_i b_i
+  double s = 0.0;
+  for (size_t i = 0; i < a.size(); ++i) s += a[i] * w[i] * b[i];
+  return s;
+}
+double kinetic(const Vec& p, const Vec& inv_mass) { return 0.5 * dot_w(p, inv_mass, p); }
+
+void leapfrog(Target& t, const State& a, double eps, const Vec& inv_mass, State& b) {
+  const int d = t.dim;
+  b.th.resize(d);
+  b.p.resize(d);
+  b.g.resize(d);
+  for (int i = 0; i < d; ++i) {
+    b.p[i] = a.p[i] + 0.5 * eps * a.g[i];
+    b.th[i] = a.th[i] + eps * inv_mass[i] * b.p[i];
+  }
+  b.lp = t(b.th, b.g);
+  for (int i = 0; i < d; ++i) b.p[i] += 0.5 * eps * b.g[i];
+}
+
+bool usable(double lp, const Vec& g) {
+  if (!(std::isfinite(lp) && lp > -1e300)) return false;
+  for (double v : g)
+    if (!std::isfinite(v)) return false;
+  return true;
+}
+
+struct Tree {
+  State edge;      // outer end of the subtree
+  Vec p_first;     // momentum at its inner end
+  Vec prop_th, prop_g;
+  double prop_lp = 0.0;
+  double logw = -std::numeric_limits<double>::infinity();
+  Vec rho;
+  bool turning = false, diverging = false;
+  double sum_alpha = 0.0;
+  int n_alpha = 0;
+};
+
+struct Sampler {
+  Target& t;
+  std::mt19937_64 rng;
+  std::normal_distribution<double> normal{0.0, 1.0};
+  std::uniform_real_distribution<double> unif{0.0, 1.0};
+  Vec inv_mass;
+  Sampler(Target& t_, unsigned long long seed) : t(t_), rng(seed), inv_mass(t_.dim, 1.0) {}
+
+  double log_unif() { return std::log(unif(rng)); }
+
+  // Hoffman & Gelman (2014), algorithm 4
+  double find_step_size(const State& s, double eps) {
+    State a = s;
+    for (int i = 0; i < t.dim; ++i) a.p[i] = normal(rng) / std::sqrt(inv_mass[i]);
+    const double h0 = -a.lp + kinetic(a.p, inv_mass);
+    auto log_ratio = [&](double e) {
+      State b;
+      leapfrog(t, a, e, inv_mass, b);
+      const double h1 = -b.lp + kinetic(b.p, inv_mass);
+      return (std::isfinite(h1) && b.lp > -1e300) ? h0 - h1 : -std::numeric_limits<double>::infinity();
+    };
+    const double dir = log_ratio(eps) > std::log(0.5) ? 1.0 : -1.0;
+    for (int it = 0; it < 50; ++it) {
+      if (!(dir * log_ratio(eps) > -dir * std::log(2.0))) break;
+      eps *= std::pow(2.0, dir);
+    }
+    return eps;
+  }
+
+  void build(const State& from, int direction, int depth, double eps, double h0, Tree& out) {
+    const int d = t.dim;
+    if (depth == 0) {
+      leapfrog(t, from, direction * eps, inv_mass, out.edge);
+      const double h1 = -out.edge.lp + kinetic(out.edge.p, inv_mass);
+      const bool ok = std::isfinite(h1) && usable(out.edge.lp, out.edge.g);
+      const double dl = ok ? h0 - h1 : -std::numeric_limits<double>::infinity();
+      out.p_first = out.edge.p;
+      out.prop_th = out.edge.th;
+      out.prop_g = out.edge.g;
+      out.prop_lp = out.edge.lp;
+      out.logw = dl;
+      out.rho = out.edge.p;
+      out.turning = false;
+      out.diverging = !ok || dl < -1000.0;
+      out.sum_alpha = ok ? std::fmin(1.0, std::exp(std::fmin(0.0, dl))) : 0.0;
+      out.n_alpha = 1;
+      return;
+    }
+    Tree a;
+    build(from, direction, depth - 1, eps, h0, a);
+    if (a.diverging || a.turning) {
+      out = std::move(a);
+      return;
+    }
+    Tree b;
+    build(a.edge, direction, depth - 1, eps, h0, b);
+    const double m = std::fmax(a.logw, b.logw);
+    const double logw = std::isfinite(m) ? m + std::log(std::exp(a.logw - m) + std::exp(b.logw - m)) : m;
+    out.prop_th = a.prop_th;
+    out.prop_g = a.prop_g;
+    out.prop_lp = a.prop_lp;
+    if (!(b.diverging || b.turning) && log_unif() < b.logw - logw) {  // uniform over the subtree
+      out.prop_th = b.prop_th;
+      out.prop_g = b.prop_g;
+      out.prop_lp = b.prop_lp;
+    }
+    out.rho.resize(d);
+    for (int i = 0; i < d; ++i) out.rho[i] = a.rho[i] + b.rho[i];
+    out.p_first = a.p_first;
+    // generalised U-turn test: summed momentum against the velocities at the two ends of this subtree
+    out.turning = b.turning || dot_w(out.rho, inv_mass, out.p_first) <= 0.0 || dot_w(out.rho, inv_mass, b.edge.p) <= 0.0;
+    out.diverging = b.diverging;
+    out.sum_alpha = a.sum_alpha + b.sum_alpha;
+    out.n_alpha = a.n_alpha + b.n_alpha;
+    out.logw = logw;
+    out.edge = std::move(b.edge);
+  }
+};
+
+int run_nuts(Target& t, const double* x0, const gwi_nuts_options& o, double* samples, double* logp, int32_t* tree_depth, gwi_nuts_result* res) {
+  const int d = t.dim;
+  Sampler s(t, o.seed);
+  State cur;
+  cur.th.assign(x0, x0 + d);
+  cur.p.assign(d, 0.0);
+  cur.g.assign(d, 0.0);
+  cur.lp = t(cur.th, cur.g);
+  double eps = s.find_step_size(cur, 0.1);
+  double mu = std::log(10 * eps), log_eps_bar = 0.0, h_bar = 0.0;
+  const double gamma = 0.05, t0 = 10.0, kappa = 0.75;
+  int da_count = 0;
+  std::vector<Vec> warm;
+  double acc_sum = 0.0;
+  int n_div = 0;
+  const int max_depth = o.max_tree_depth > 0 ? o.max_tree_depth : 10;
+  for (int it = 0; it < o.n_warmup + o.n_samples && !t.failed; ++it) {
+    for (int i = 0; i < d; ++i) cur.p[i] = s.normal(s.rng) / std::sqrt(s.inv_mass[i]);
+    const double h0 = -cur.lp + kinetic(cur.p, s.inv_mass);
+    State left = cur, right = cur;
+    Vec prop_th = cur.th, prop_g = cur.g;
+    double prop_lp = cur.lp;
+    double logw = 0.0;
+    Vec rho = cur.p;
+    double sum_alpha = 0.0;
+    int n_alpha = 0, depth = 0;
+    bool diverged = false;
+    while (depth < max_depth) {
+      const int direction = s.unif(s.rng) < 0.5 ? 1 : -1;
+      Tree sub;
+      s.build(direction == 1 ? right : left, direction, depth, eps, h0, sub);
+      sum_alpha += sub.sum_alpha;
+      n_alpha += sub.n_alpha;
+      if (sub.diverging) {
+        diverged = true;
+        break;
+      }
+      if (sub.turning) break;
+      if (s.log_unif() < sub.logw - logw) {  // biased progressive sampling across doublings
+        prop_th = sub.prop_th;
+        prop_g = sub.prop_g;
+        prop_lp = sub.prop_lp;
+      }
+      const double m = std::fmax(logw, sub.logw);
+      logw = m + std::log(std::exp(logw - m) + std::exp(sub.logw - m));
+      for (int i = 0; i < d; ++i) rho[i] += sub.rho[i];
+      if (direction == 1)
+        right = std::move(sub.edge);
+      else
+        left = std::move(sub.edge);
+      ++depth;
+      if (dot_w(rho, s.inv_mass, left.p) <= 0.0 || dot_w(rho, s.inv_mass, right.p) <= 0.0) break;
+    }
+    cur.th = prop_th;
+    cur.g = prop_g;
+    cur.lp = prop_lp;
+    const double acc = sum_alpha / (n_alpha > 0 ? n_alpha : 1);
+    if (it < o.n_warmup) {
+      const int m = it + 1;
+      ++da_count;
+      h_bar = (1 - 1.0 / (da_count + t0)) * h_bar + (o.target_accept - acc) / (da_count + t0);
+      const double log_eps = mu - std::sqrt((double)da_count) / gamma * h_bar;
+      const double w = std::pow((double)da_count, -kappa);
+      log_eps_bar = w * log_eps + (1 - w) * log_eps_bar;
+      eps = std::exp(log_eps);
+      warm.push_back(cur.th);
+      if (m == (2 * o.n_warmup) / 3 && warm.size() > 20) {  // one diagonal mass-matrix update, then re-tune the step
+        const size_t first = warm.size() / 3, cnt = warm.size() - first;
+        for (int i = 0; i < d; ++i) {
+          double mean = 0.0, var = 0.0;
+          for (size_t k = first; k < warm.size(); ++k) mean += warm[k][i];
+          mean /= cnt;
+          for (size_t k = first; k < warm.size(); ++k) var += (warm[k][i] - mean) * (warm[k][i] - mean);
+          var /= cnt;
+          s.inv_mass[i] = var > 1e-12 ? var : 1.0;
+        }
+        eps = s.find_step_size(cur, std::exp(log_eps_bar));
+        mu = std::log(10 * eps);
+        log_eps_bar = 0.0;
+        h_bar = 0.0;
+        da_count = 0;
+      }
+      if (m == o.n_warmup && da_count > 0) eps = std::exp(log_eps_bar);
+    } else {
+      const int k = it - o.n_warmup;
+      std::memcpy(samples + (size_t)k * d, cur.th.data(), sizeof(double) * d);
+      if (logp) logp[k] = cur.lp;
+      if (tree_depth) tree_depth[k] = depth;
+      acc_sum += acc;
+      n_div += diverged ? 1 : 0;  // post-warm-up transitions only, as numpyro reports them
+    }
+  }
+  if (res) {
+    res->accept_rate = o.n_samples > 0 ? acc_sum / o.n_samples : 0.0;
+    res->step_size = eps;
+    res->n_evals = t.n_evals;
+    res->n_divergent = n_div;
+  }
+  return t.failed ? 1 : 0;
+}
+
+// ---- engine target: log-likelihood + priors in unconstrained coordinates (mirror of sampling.make_target) ----
+struct EngineTarget {
+  gwi_handle h;
+  gwi_options lopt;
+  const gwi_param_prior* priors;
+  const gwi_smoothing_penalty* pens;
+  int n_pens, n_theta;
+  Vec theta, dth, dlogj, grad_ll, d1, d2;
+};
+
+int engine_target(void* user, const double* u, double* logp, double* grad) {
+  EngineTarget& e = *static_cast<EngineTarget*>(user);
+  const int n = e.n_theta;
+  double logj = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const gwi_param_prior& pr = e.priors[i];
+    if (pr.kind == GWI_BIJECT_INTERVAL) {
+      const double sig = 1.0 / (1.0 + std::exp(-u[i])), width = pr.hi - pr.lo;
+      e.theta[i] = pr.lo + width * sig;
+      e.dth[i] = width * sig * (1 - sig);
+      e.dlogj[i] = 1 - 2 * sig;
+      logj += std::log(e.dth[i]);
+    } else if (pr.kind == GWI_BIJECT_POSITIVE) {
+      e.theta[i] = std::exp(u[i]);
+      e.dth[i] = e.theta[i];
+      e.dlogj[i] = 1.0;
+      logj += u[i];
+    } else {
+      e.theta[i] = u[i];
+      e.dth[i] = 1.0;
+      e.dlogj[i] = 0.0;
+    }
+  }
+  gwi_summary s;
+  if (gwi_eval(e.h, e.theta.data(), &e.lopt, &s, e.grad_ll.data(), nullptr, nullptr, nullptr, nullptr) != GWI_OK) return 1;
+  double lp = s.log_likelihood + logj;
+  for (int i = 0; i < n; ++i) {
+    double g = e.grad_ll[i];
+    const double sg = e.priors[i].sigma;
+    if (std::isfinite(sg) && sg > 0) {  // Normal(0, sigma) on the constrained value
+      lp += -0.5 * e.theta[i] * e.theta[i] / (sg * sg);
+      g += -e.theta[i] / (sg * sg);
+    }
+    grad[i] = g;
+  }
+  for (int k = 0; k < e.n_pens; ++k) {  // -0.5 tau ||D^deg c||^2 (models/bsplines/smoothing.py:8-28)
+    const gwi_smoothing_penalty& pn = e.pens[k];
+    e.d1.assign(e.theta.begin() + pn.offset, e.theta.begin() + pn.offset + pn.count);
+    for (int r = 0; r < pn.degree; ++r) {
+      for (size_t i = 0; i + 1 < e.d1.size(); ++i) e.d1[i] = e.d1[i + 1] - e.d1[i];
+      e.d1.pop_back();
+    }
+    double ss = 0.0;
+    for (double v : e.d1) ss += v * v;
+    lp += -0.5 * pn.tau * ss;
+    e.d2 = e.d1;  // (D^deg)^T d: apply the transposed difference `degree` times
+    for (int r = 0; r < pn.degree; ++r) {
+      Vec nx(e.d2.size() + 1);
+      nx[0] = -e.d2[0];
+      for (size_t i = 1; i < e.d2.size(); ++i) nx[i] = e.d2[i - 1] - e.d2[i];
+      nx[e.d2.size()] = e.d2.back();
+      e.d2.swap(nx);
+    }
+    for (int i = 0; i < pn.count; ++i) grad[pn.offset + i] -= pn.tau * e.d2[i];
+  }
+  for (int i = 0; i < n; ++i) grad[i] = grad[i] * e.dth[i] + e.dlogj[i];
+  *logp = lp;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+gwi_status gwi_nuts_run(gwi_target_fn fn, void* user, int32_t dim, const double* x0, const gwi_nuts_options* opt, double* samples, double* logp, int32_t* tree_depth,
+                        gwi_nuts_result* result) {
+  if (!fn || dim < 1 || !x0 || !opt || !samples || opt->n_warmup < 0 || opt->n_samples < 0) return GWI_ERR_INVALID;
+  Target t{fn, user, dim};
+  return run_nuts(t, x0, *opt, samples, logp, tree_depth, result) == 0 ? GWI_OK : GWI_ERR_HIP;
+}
+
+gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors, const gwi_smoothing_penalty* pens,
+                           int32_t n_pens, const double* u0, const gwi_nuts_options* opt, double* samples, double* logp, int32_t* tree_depth, gwi_nuts_result* results) {
+  if (!handles || n_chains < 1 || n_theta < 1 || !lopt || !priors || !u0 || !opt || !samples) return GWI_ERR_INVALID;
+  for (int k = 0; k < n_pens; ++k)
+    if (!pens || pens[k].offset < 0 || pens[k].count < 2 || pens[k].offset + pens[k].count > n_theta || pens[k].degree < 1 || pens[k].degree >= pens[k].count) return GWI_ERR_INVALID;
+  std::vector<int> rc(n_chains, 0);
+  auto chain = [&](int c) {
+    EngineTarget e{handles[c], *lopt, priors, pens, n_pens, n_theta, Vec(n_theta), Vec(n_theta), Vec(n_theta), Vec(n_theta), {}, {}};
+    Target t{engine_target, &e, n_theta};
+    gwi_nuts_options o = *opt;
+    o.seed = opt->seed + 1000ULL * (unsigned long long)c;
+    const size_t ns = (size_t)opt->n_samples;
+    double* out = samples + (size_t)c * ns * n_theta;
+    rc[c] = run_nuts(t, u0 + (size_t)c * n_theta, o, out, logp ? logp + (size_t)c * ns : nullptr, tree_depth ? tree_depth + (size_t)c * ns : nullptr, results ? results + c : nullptr);
+    for (size_t k = 0; k < ns; ++k)  // unconstrained draws -> constrained hyper-parameters
+      for (int i = 0; i < n_theta; ++i) {
+        double& v = out[k * n_theta + i];
+        if (priors[i].kind == GWI_BIJECT_INTERVAL)
+          v = priors[i].lo + (priors[i].hi - priors[i].lo) / (1.0 + std::exp(-v));
+        else if (priors[i].kind == GWI_BIJECT_POSITIVE)
+          v = std::exp(v);
+      }
+  };
+  if (n_chains == 1) {
+    chain(0);
+  } else {  // one host thread per chain: every chain has its own engine handle (stream, buffers, catalog copy)
+    std::vector<std::thread> workers;
+    for (int c = 0; c < n_chains; ++c) workers.emplace_back(chain, c);
+    for (auto& w : workers) w.join();
+  }
+  for (int c = 0; c < n_chains; ++c)
+    if (rc[c] != 0) return GWI_ERR_HIP;
+  return GWI_OK;
+}
+
+}  // extern "C"

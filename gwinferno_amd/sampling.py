@@ -377,3 +377,101 @@ def make_async_target(engine, total_inj, prior, bijector=None, **likelihood_flag
         return ll + lp + logj, (g + gp) * dth + dlogj
 
     return begin, end
+
+
+# ---- the library's native sampler (include/gwi_sampler.h) ----
+def _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed):
+    from . import _native as N
+
+    return N.GwiNutsOptions(int(n_warmup), int(n_samples), int(max_tree_depth), 0, float(target_accept), int(seed))
+
+
+def _result_dict(r):
+    return dict(accept_rate=r.accept_rate, step_size=r.step_size, n_evals=int(r.n_evals), n_divergent=int(r.n_divergent))
+
+
+def nuts_native(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0):
+    """:func:`nuts` run by the engine library's C++ sampler (``gwi_nuts_run``) on a Python ``target(x) ->
+    (log_prob, grad)``: the tree building happens natively, the target is called back per leapfrog step.
+    Same return value as :func:`nuts`."""
+    import ctypes as C
+
+    from . import _native as N
+
+    lib = N.load_library()
+    theta0 = N.f64(theta0)
+    d = theta0.size
+    err = []
+
+    def cb(_user, x, lp, grad):
+        try:
+            v, g = target(np.ctypeslib.as_array(x, (d,)).copy())
+            lp[0] = v
+            np.ctypeslib.as_array(grad, (d,))[:] = g
+            return 0
+        except Exception as exc:  # propagate through the C frames
+            err.append(exc)
+            return 1
+
+    samples, logp, depth = np.empty((n_samples, d)), np.empty(n_samples), np.empty(n_samples, dtype=np.int32)
+    res = N.GwiNutsResult()
+    opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
+    st = lib.gwi_nuts_run(N.GWI_TARGET_FN(cb), None, d, N.as_dp(theta0), C.byref(opt), N.as_dp(samples), N.as_dp(logp), depth.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res))
+    if err:
+        raise err[0]
+    if st != 0:
+        raise N.NativeEngineError(f"gwi_nuts_run: {N.STATUS_NAMES.get(st, st)}")
+    out = _result_dict(res)
+    out.update(samples=samples, log_prob=logp, tree_depth=depth)
+    return out
+
+
+def nuts_engine(engines, total_inj, prior, bijector, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, **likelihood_flags):
+    """NUTS on ``engine log-likelihood + prior`` entirely inside the library (``gwi_nuts_engine``): one host
+    thread and one engine per chain, no Python between two likelihood evaluations.
+
+    ``engines`` is one :class:`~gwinferno_amd.engine.BoundEngine` per chain (each holds its own copy of the
+    catalog and its own stream); ``prior`` a :class:`GaussianSmoothingPrior`, ``bijector`` a :class:`Bijector`
+    (or ``None``); ``theta0s[c]`` the constrained starting point of chain ``c``.  Returns one dict per chain,
+    as :func:`nuts` does, with ``samples`` in constrained coordinates."""
+    import ctypes as C
+
+    from . import _native as N
+
+    engines = list(engines)
+    theta0s = np.atleast_2d(N.f64(theta0s))
+    n_chains, n_theta = theta0s.shape
+    if len(engines) != n_chains:
+        raise ValueError("one engine per chain")
+    lib = engines[0].lib
+    bij = bijector if bijector is not None else Bijector(n_theta)
+    pri = (N.GwiParamPrior * n_theta)()
+    for i in range(n_theta):
+        pri[i] = N.GwiParamPrior(int(bij.kind[i]), 0, float(bij.lo[i]), float(bij.hi[i]), float(prior.sigmas[i]))
+    pens = (N.GwiSmoothingPenalty * max(1, len(prior.penalties)))()
+    for k, (sl, tau, deg) in enumerate(prior.penalties):
+        start, stop, step = sl.indices(n_theta)
+        if step != 1:
+            raise ValueError("smoothing penalties act on contiguous slices")
+        pens[k] = N.GwiSmoothingPenalty(start, stop - start, deg, 0, tau)
+    u0 = N.f64(np.stack([bij.inverse(t) for t in theta0s]))
+    if not np.all(np.isfinite(u0)):
+        raise ValueError("starting points must lie strictly inside the parameter supports")
+    lopt = engines[0]._options(total_inj, **likelihood_flags)
+    handles = (C.c_void_p * n_chains)(*[e.handle for e in engines])
+    samples = np.empty((n_chains, n_samples, n_theta))
+    logp = np.empty((n_chains, n_samples))
+    depth = np.empty((n_chains, n_samples), dtype=np.int32)
+    res = (N.GwiNutsResult * n_chains)()
+    opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
+    st = lib.gwi_nuts_engine(handles, n_chains, n_theta, C.byref(lopt), pri, pens, len(prior.penalties), N.as_dp(u0), C.byref(opt), N.as_dp(samples), N.as_dp(logp),
+                             depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    if st != 0:
+        msgs = "; ".join(lib.gwi_last_error(e.handle).decode() for e in engines)
+        raise N.NativeEngineError(f"gwi_nuts_engine: {N.STATUS_NAMES.get(st, st)}: {msgs}")
+    out = []
+    for c in range(n_chains):
+        r = _result_dict(res[c])
+        r.update(samples=samples[c], log_prob=logp[c], tree_depth=depth[c])
+        out.append(r)
+    return out

@@ -1,0 +1,66 @@
+/* gwi_sampler.h -- C ABI of the engine library's host-side No-U-Turn sampler.
+ *
+ * Stands in for the sampler the reference drives its model with, numpyro.infer.NUTS / MCMC
+ * (examples/utils.py:63-85; tests/inference_test.py:367-411), in environments without JAX/NumPyro: every
+ * leapfrog step is one gwi_eval (value + gradient), and nothing but C++ runs between two evaluations.
+ * Multinomial NUTS, generalised U-turn criterion, dual-averaging step size, one diagonal mass-matrix update
+ * during warm-up.  gwinferno_amd/sampling.py is the NumPy statement of the same algorithm. */
+#ifndef GWI_SAMPLER_H
+#define GWI_SAMPLER_H
+
+#include "gwi_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* log-probability and gradient of the target at x[dim]; returns 0, or non-zero to abort the run */
+typedef int32_t (*gwi_target_fn)(void* user, const double* x, double* log_prob, double* grad);
+
+typedef struct {
+  int32_t n_warmup, n_samples;
+  int32_t max_tree_depth; /* <= 0: 10 */
+  int32_t reserved;
+  double target_accept;   /* 0.8 is the usual choice */
+  uint64_t seed;
+} gwi_nuts_options;
+
+typedef struct {
+  double accept_rate, step_size;
+  int64_t n_evals;
+  int32_t n_divergent, reserved; /* divergent transitions after warm-up */
+} gwi_nuts_result;
+
+/* One chain on an arbitrary target.  samples[n_samples][dim], log_prob[n_samples] and tree_depth[n_samples]
+ * (the last two nullable) receive the post-warm-up draws. */
+gwi_status gwi_nuts_run(gwi_target_fn fn, void* user, int32_t dim, const double* x0, const gwi_nuts_options* opt, double* samples, double* log_prob,
+                        int32_t* tree_depth, gwi_nuts_result* result);
+
+/* Change of variables per hyper-parameter (what numpyro's biject_to(support) does for Uniform / HalfNormal sites,
+ * e.g. examples/simple_powerlaw_peak_example.py:52-77) and an optional Normal(0, sigma) prior on its constrained value. */
+enum { GWI_BIJECT_IDENTITY = 0, GWI_BIJECT_INTERVAL = 1 /* (lo, hi) via the logistic map */, GWI_BIJECT_POSITIVE = 2 /* exp */ };
+typedef struct {
+  int32_t kind, reserved;
+  double lo, hi;  /* GWI_BIJECT_INTERVAL */
+  double sigma;   /* Normal(0, sigma) prior; +inf (or <= 0): flat */
+} gwi_param_prior;
+
+/* P-spline penalty  -0.5 tau ||Delta^degree theta[offset .. offset+count)||^2  (models/bsplines/smoothing.py:8-28,
+ * callers pipeline/utils.py:163-216) */
+typedef struct {
+  int32_t offset, count, degree, reserved;
+  double tau;
+} gwi_smoothing_penalty;
+
+/* n_chains chains, chain c on engine handles[c] (its own stream, buffers and catalog copy) in a host thread of its
+ * own; target = log-likelihood (gwi_eval with *lopt) + priors + penalties + log-Jacobian, sampled in unconstrained
+ * coordinates from u0[c][n_theta].  samples[c][n_samples][n_theta] are returned in CONSTRAINED coordinates;
+ * log_prob / tree_depth [c][n_samples] and results[c] are nullable.  Chain c uses seed opt->seed + 1000 c. */
+gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors,
+                           const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt, double* samples, double* log_prob,
+                           int32_t* tree_depth, gwi_nuts_result* results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWI_SAMPLER_H */

@@ -204,3 +204,63 @@ def test_interleaved_nuts_chains_on_one_gpu():
         assert np.all(np.isfinite(r["log_prob"]))
     for e in engs:
         e.close()
+
+
+def _native_nuts_setup(n_engines):
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(20, 400, 4000, seed=3)
+    comps = [COMPOSITIONS["pl_test"](pe, inj) for _ in range(n_engines)]
+    engs = [c.engine() for c in comps]
+    n = engs[0].n_theta
+    theta0 = comps[0].theta({"alpha": -2.0, "beta": 1.0, "lamb": 2.0})
+    # every feature of the native target at once: a Normal prior, an interval and a positive bijector and a
+    # (physically meaningless here, arithmetically complete) first-difference penalty over all parameters
+    prior = GaussianSmoothingPrior(n).normal(slice(0, n), 5.0).smoothing(slice(0, n), 0.05, 1)
+    names = list(comps[0].names) if hasattr(comps[0], "names") else None
+    bij = Bijector(n)
+    order = np.argsort(theta0)  # most negative entry gets the interval, most positive the positive map
+    bij.interval(int(order[0]), theta0[order[0]] - 4.0, theta0[order[0]] + 3.0).positive(int(order[-1]))
+    return engs, total, prior, bij, theta0, names
+
+
+def test_native_nuts_on_the_engine_matches_the_callback_path():
+    """gwi_nuts_engine (target assembled in C++: likelihood + priors + penalties + Jacobian) against
+    gwi_nuts_run on the Python statement of the same target (sampling.make_target): same seed, same chain."""
+    from gwinferno_amd.sampling import make_target, nuts_engine, nuts_native
+
+    engs, total, prior, bij, theta0, _ = _native_nuts_setup(1)
+    kw = dict(n_warmup=40, n_samples=30, seed=11, max_tree_depth=5)
+    (a,) = nuts_engine(engs, total, prior, bij, [theta0], min_neff_cut=False, **kw)
+    b = nuts_native(make_target(engs[0], total, prior, bij, min_neff_cut=False), bij.inverse(theta0), **kw)
+    th_b = np.array([bij.forward(u)[0] for u in b["samples"]])
+    assert a["n_evals"] == b["n_evals"] and np.array_equal(a["tree_depth"], b["tree_depth"])
+    assert np.allclose(a["samples"], th_b, rtol=1e-8, atol=1e-10)
+    assert np.allclose(a["log_prob"], b["log_prob"], rtol=1e-9)
+    assert np.all(np.isfinite(a["samples"])) and 0.4 < a["accept_rate"] <= 1.0
+    k = int(np.argmax(bij.kind == 1))
+    assert np.all((a["samples"][:, k] > bij.lo[k]) & (a["samples"][:, k] < bij.hi[k]))
+    assert np.all(a["samples"][:, int(np.argmax(bij.kind == 2))] > 0)
+    engs[0].close()
+
+
+def test_native_nuts_chains_in_threads_equal_chains_run_alone():
+    """Four chains, one host thread and one engine each, concurrently on one GPU: every chain equals the chain
+    with the same seed run alone (no cross-talk between engines, streams or host buffers)."""
+    from gwinferno_amd.sampling import nuts_engine
+
+    engs, total, prior, bij, theta0, _ = _native_nuts_setup(4)
+    starts = np.stack([theta0 + 0.05 * c for c in range(4)])
+    kw = dict(n_warmup=40, n_samples=30, seed=5, max_tree_depth=5)
+    res = nuts_engine(engs, total, prior, bij, starts, min_neff_cut=False, **kw)
+    for c, r in enumerate(res):
+        kw1 = dict(kw, seed=5 + 1000 * c)
+        (alone,) = nuts_engine(engs[:1], total, prior, bij, starts[c : c + 1], min_neff_cut=False, **kw1)
+        assert np.array_equal(r["samples"], alone["samples"]) and r["n_evals"] == alone["n_evals"]
+        assert np.std(r["samples"], axis=0).min() > 0
+    with pytest.raises(ValueError):
+        nuts_engine(engs[:2], total, prior, bij, starts, min_neff_cut=False, **kw)
+    for e in engs:
+        e.close()

@@ -23,9 +23,8 @@ def lib():
 def test_header_symbols_are_exported(lib):
     from gwinferno_amd import _native
 
-    hdr = open(os.path.join(ROOT, "include", "gwi_engine.h")).read()
-    declared = set(re.findall(r"\b(gwi_[a-z_]+)\s*\(", hdr))
-    declared -= {"gwi_engine"}
+    hdr = open(os.path.join(ROOT, "include", "gwi_engine.h")).read() + open(os.path.join(ROOT, "include", "gwi_sampler.h")).read()
+    declared = set(re.findall(r"^(?:const )?[a-z_0-9]+\**\s+\**(gwi_[a-z_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
     raw = ctypes.CDLL(_native.LIB_PATH)
     for sym in declared:
@@ -41,6 +40,11 @@ def test_struct_sizes_match_header(lib):
     assert ctypes.sizeof(N.GwiSpec) == 4 * 8 + ctypes.sizeof(N.GwiTerm) * N.GWI_MAX_TERMS + ctypes.sizeof(N.GwiNorm) * N.GWI_MAX_NORMS
     assert ctypes.sizeof(N.GwiOptions) == 32
     assert ctypes.sizeof(N.GwiSummary) == 16 * 8
+    # include/gwi_sampler.h
+    assert ctypes.sizeof(N.GwiNutsOptions) == 4 * 4 + 8 + 8
+    assert ctypes.sizeof(N.GwiNutsResult) == 8 + 8 + 8 + 4 + 4
+    assert ctypes.sizeof(N.GwiParamPrior) == 4 * 2 + 8 * 3
+    assert ctypes.sizeof(N.GwiSmoothingPenalty) == 4 * 4 + 8
 
 
 def test_version_and_variants(lib):
