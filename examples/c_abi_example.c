@@ -1,7 +1,9 @@
 /* The C ABI on its own (no Python, no torch): a power-law population in one parameter x on [lo, hi],
  *     w(x; alpha) = x^alpha (1+alpha)/(hi^(1+alpha) - lo^(1+alpha)) / prior(x),
  * 4 "events" x 1000 posterior samples and 3000 found injections, evaluated by gwi_eval and checked against
- * a plain double loop in this file (value of log_l, per-event log Bayes factors, d log_l / d alpha).
+ * a plain double loop in this file (value of log_l, per-event log Bayes factors, d log_l / d alpha); then the
+ * library's NUTS (gwi_nuts_engine) samples alpha under a Normal(0, 5) prior and its posterior mean and width are
+ * checked against quadrature of the same posterior on a grid.
  *   gcc -O2 -Iinclude examples/c_abi_example.c -o c_abi_example -Lgwinferno_amd/_lib -lgwi_engine \
  *       -Wl,-rpath,$PWD/gwinferno_amd/_lib -lm && ./c_abi_example                                        */
 #include <math.h>
@@ -10,6 +12,7 @@
 #include <string.h>
 
 #include "gwi_engine.h"
+#include "gwi_sampler.h"
 
 #define N_EV 4
 #define N_PE 1000
@@ -101,8 +104,42 @@ int main(void) {
   const double e_val = fabs(s.log_likelihood - log_l) / fabs(log_l), e_grad = fabs(grad[0] - dlog_l) / fmax(1.0, fabs(dlog_l));
   printf("log_l engine %.12f  loop %.12f  rel.err %.2e | dlog_l/dalpha engine %.10f loop %.10f err %.2e | max |dlogBF| %.2e\n", s.log_likelihood, log_l, e_val, grad[0],
          dlog_l, e_grad, worst_bf);
+
+  /* posterior of alpha by quadrature (engine likelihood x Normal(0, 5) prior) ... */
+  double z0 = 0.0, z1 = 0.0, z2 = 0.0, top = -INFINITY;
+  static double lp_grid[2400];
+  for (int k = 0; k < 2400; ++k) {
+    const double a = -22.005 + 0.01 * k;
+    gwi_summary sk;
+    if (gwi_eval(h, &a, &opt, &sk, NULL, NULL, NULL, NULL, NULL) != GWI_OK) return 2;
+    lp_grid[k] = sk.log_likelihood - 0.5 * a * a / 25.0;
+    top = fmax(top, lp_grid[k]);
+  }
+  for (int k = 0; k < 2400; ++k) {
+    const double a = -22.005 + 0.01 * k, w = exp(lp_grid[k] - top);
+    z0 += w;
+    z1 += w * a;
+    z2 += w * a * a;
+  }
+  const double q_mean = z1 / z0, q_sd = sqrt(z2 / z0 - q_mean * q_mean);
+  /* ... and by the library's sampler: one chain, 300 warm-up + 2000 draws */
+  const gwi_param_prior prior = {GWI_BIJECT_IDENTITY, 0, 0.0, 0.0, 5.0};
+  const gwi_nuts_options nopt = {300, 2000, 8, 0, 0.8, 2025};
+  static double draws[2000];
+  gwi_nuts_result nres;
+  st = gwi_nuts_engine(&h, 1, 1, &opt, &prior, NULL, 0, &alpha, &nopt, draws, NULL, NULL, &nres);
+  if (st != GWI_OK) {
+    fprintf(stderr, "gwi_nuts_engine failed (%d): %s\n", (int)st, gwi_last_error(h));
+    return 2;
+  }
+  double m1 = 0.0, m2 = 0.0;
+  for (int k = 0; k < 2000; ++k) m1 += draws[k] / 2000.0;
+  for (int k = 0; k < 2000; ++k) m2 += (draws[k] - m1) * (draws[k] - m1) / 2000.0;
+  printf("alpha | data: quadrature %.4f +- %.4f, NUTS %.4f +- %.4f (%lld evaluations, accept %.2f, %d divergent)\n", q_mean, q_sd, m1, sqrt(m2), (long long)nres.n_evals,
+         nres.accept_rate, (int)nres.n_divergent);
+  const int nuts_ok = fabs(m1 - q_mean) < 0.2 * q_sd && fabs(sqrt(m2) / q_sd - 1.0) < 0.2;
   gwi_destroy(h);
-  if (e_val < 1e-11 && e_grad < 1e-10 && worst_bf < 1e-11) {
+  if (e_val < 1e-11 && e_grad < 1e-10 && worst_bf < 1e-11 && nuts_ok) {
     printf("OK\n");
     return 0;
   }
