@@ -28,6 +28,8 @@ TERM_LINEAR_SPLINE = 9
 TERM_TILT_JOINT = 10
 TERM_SMOOTH = 11
 TERM_PLPEAK_SMOOTH = 12
+TERM_POWERLAW_BOUNDS = 13
+TERM_EXP_SPLINE_LERP = 14
 
 SPLINE_OUTSIDE_ZERO_EXPONENT = 1
 POWERLAW_UNNORMALISED = 2

@@ -55,12 +55,13 @@ class Composition:
                 coded[name] = vals.reshape(shape) if shape else float(vals[0])
                 code += size
             th = eng.bound.theta_of(self.weights(coded, True))
-            self._slices = [lookup[v] for v in th]
+            # a slot fed by a fixed number (e.g. the constant bounds of a Powerlaw distribution) keeps that number
+            self._slices = [lookup.get(v, (None, float(v))) for v in th]
         return self._slices
 
     def theta(self, p):
         """Flat theta for parameter dict ``p`` (layout = order in which the factors consume parameters)."""
-        return np.array([np.asarray(p[name], dtype=np.float64).flat[i] for name, i in self._theta_map()])
+        return np.array([i if name is None else np.asarray(p[name], dtype=np.float64).flat[i] for name, i in self._theta_map()])
 
     def named_gradient(self, grad, p=None):
         """Scatter a flat gradient back onto parameter names (a parameter feeding several theta
@@ -68,7 +69,8 @@ class Composition:
         compositions whose theta is a non-trivial function of the parameters."""
         out = {name: np.zeros(int(np.prod(shape)) if shape else 1) for name, shape in self.PARAMS.items()}
         for g, (name, i) in zip(grad, self._theta_map()):
-            out[name][i] += g
+            if name is not None:
+                out[name][i] += g
         return {name: (v.reshape(self.PARAMS[name]) if self.PARAMS[name] else float(v[0])) for name, v in out.items()}
 
 
@@ -330,7 +332,69 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
     KW = {"normalize": False}
 
 
+class ChmPowerlaw(Composition):
+    """construct_hierarchical_model's weights (analysis.py:401-402) for the model of
+    examples/config_files/config.yml: Powerlaw mass_1 with sampled bounds, Powerlaw mass_ratio on [0.02, 1],
+    PowerlawRedshift -- written in log space with the distribution classes, as that function sums them."""
+
+    ZMAX, QMIN = 1.9, 0.02
+    PARAMS = {"alpha": (), "mmin": (), "mmax": (), "beta": (), "lamb": ()}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        from .cosmology import planck15_lvk
+
+        self.zgrid = np.linspace(1e-9, self.ZMAX, 1000)  # analysis.py:371-372
+        self.dV = planck15_lvk().dVc_dz(self.zgrid)
+
+    def populations(self, p):
+        from . import numpyro_distributions as D
+
+        return {"mass_1": D.Powerlaw(p["alpha"], p["mmin"], p["mmax"]), "mass_ratio": D.Powerlaw(p["beta"], self.QMIN, 1.0),
+                "redshift": D.PowerlawRedshift(p["lamb"], self.ZMAX, self.zgrid, self.dV)}
+
+    def weights(self, p, pe_samples):
+        from .lazy import log
+
+        d = self.data(pe_samples)
+        pops = self.populations(p)
+        return sum(pops[k].log_prob(d[k]) for k in pops) - log(d["prior"])
+
+    def hypervolume(self, p):
+        return self.populations(p)["redshift"].norm
+
+    def placeholder(self):
+        return {"alpha": -2.0, "mmin": 5.0, "mmax": 80.0, "beta": 1.0, "lamb": 2.0}
+
+
+class ChmBSpline(ChmPowerlaw):
+    """The same with BSplineDistribution populations (numpyro_distributions.py:266-303) for mass_1 (LogXLogYBSpline
+    design matrix on a 1000-point grid) and mass_ratio (LogYBSpline), as tests/numpyro_distributions_test.py:91-129."""
+
+    NM, NQ = 16, 10
+    PARAMS = {"m_coefs": (NM,), "q_coefs": (NQ,), "lamb": ()}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.m_grid = np.linspace(self.mmin, self.mmax, 1000)
+        self.m_dmat = LogXLogYBSpline(self.NM, xrange=(self.mmin, self.mmax), normalize=True).bases(self.m_grid)
+        self.q_grid = np.linspace(0.0, 1.0, 1000)
+        self.q_dmat = LogYBSpline(self.NQ, xrange=(0.0, 1.0), normalize=True).bases(self.q_grid)
+
+    def populations(self, p):
+        from . import numpyro_distributions as D
+
+        return {"mass_1": D.BSplineDistribution(self.mmin, self.mmax, p["m_coefs"], self.m_grid, self.m_dmat),
+                "mass_ratio": D.BSplineDistribution(0.0, 1.0, p["q_coefs"], self.q_grid, self.q_dmat),
+                "redshift": D.PowerlawRedshift(p["lamb"], self.ZMAX, self.zgrid, self.dV)}
+
+    def placeholder(self):
+        return Composition.placeholder(self)
+
+
 COMPOSITIONS = {
+    "chm_powerlaw": ChmPowerlaw,
+    "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,
@@ -358,6 +422,10 @@ def draw_params(name, rng):
             p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
                      xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
         return {k: p[k] for k in cls.PARAMS}
+    if name == "chm_powerlaw":
+        return {"alpha": rng.normal(-2.5, 1.0), "mmin": rng.uniform(3.0, 9.0), "mmax": rng.uniform(60.0, 100.0), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
+    if name == "chm_bspline":
+        return {"m_coefs": rng.normal(size=cls.NM), "q_coefs": rng.normal(size=cls.NQ), "lamb": rng.normal(2.7, 1.0)}
     if name == "plpeak_smooth":
         p = draw_params("plpeak", rng)
         p["delta"] = rng.uniform(1.0, 8.0)

@@ -800,6 +800,113 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
   }
 };
 
+// x^alpha on [lo, hi] with the bounds themselves hyper-parameters (numpyro_distributions.py:101-136: Powerlaw with
+// sampled minimum / maximum, examples/config_files/config.yml:8-25).  The truncation is a theta-dependent mask, so
+// it cannot live in kappa: the term reads x next to log x and applies the reference's own test, x < lo | x > hi
+// excluded (a sample exactly on a bound is inside).  The normaliser is sample-independent (host);
+// d log_l / d lo = d log_l / d hi = 0 wherever log_l is differentiable (the normaliser cancels).
+template <>
+struct Term<GWI_TERM_POWERLAW_BOUNDS> {
+  static constexpr bool kSpline = false;
+  struct In {
+    double x0, x1;
+  };
+  __device__ static void load(const double* const* tc, long long idx, In& in) {
+    in.x0 = gload(tc[0], idx);
+    in.x1 = gload(tc[1], idx);
+  }
+  struct State {
+    double lx;
+  };
+  struct Acc {
+    double g0;
+  };
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double& lin) {
+    s.lx = in.x0;
+    if ((in.x1 < c.theta[t.th1]) || (in.x1 > c.theta[t.th2])) {
+      lin = 0.0;   // dead sample
+      s.lx = 0.0;  // keep the gradient state finite whatever log x is out there
+    }
+    return c.theta[t.th0] * s.lx;
+  }
+  __device__ static void accumulate(const TermD&, const Ctx&, double w, const State& s, Acc& a) { a.g0 += w * s.lx; }
+  GWI_ACC1(g0)
+  static constexpr int kNumAcc = 1;
+  __device__ static void collect(const TermD& t, const Acc& a, double* vals, int* th) {
+    vals[0] = a.g0;
+    th[0] = t.th0;
+  }
+};
+
+// exp of a log-density tabulated on a grid and linearly interpolated between grid points
+// (BSplineDistribution, numpyro_distributions.py:266-293: lpdfs = cs . grid_dmat, log_prob = interp(value, grid, lpdfs)).
+// cols[0] = fractional grid index u = j + f of the sample (static; outside the grid np.interp holds the end value,
+// so u is clamped by the caller); th1 = index of the grid normaliser, whose `us` table holds the spline coordinate
+// of every grid point.  l = (1-f) L_j + f L_{j+1}, L_g = sum_k c_k B_k(us_g); d l / d c_k is the same blend of taps.
+template <>
+struct Term<GWI_TERM_EXP_SPLINE_LERP> {
+  static constexpr bool kSpline = true;
+  struct In {
+    double x0;
+  };
+  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  struct State {
+    double t0, t1, f;
+    int k0, k1;  // -1: node contributes nothing (outside a zero-outside basis, or zero blend weight)
+  };
+  struct Acc {};
+  __device__ static double node(const TermD& t, const Ctx& c, double sx, double wt, int& k, double& tt, double& lin) {
+    spline_locate(sx, t.p0, t.p2, t.n_basis, k, tt);
+    const double* cf = c.coefs + t.th0 + k;
+    const Taps b = cubic_taps(tt);
+    double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+    if (!((sx >= t.p0) && (sx <= t.p1))) {
+      k = -1;
+      v = 0.0;
+      // a log-Y basis is -inf out there (interpolation.py:407, :449): the interpolated log-density is -inf
+      if (!(t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) && wt != 0.0) lin = 0.0;
+    }
+    if (wt == 0.0) k = -1;
+    return v;
+  }
+  __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double& lin) {
+    const NormD& nd = c.a->norms[t.th1];
+    const double u = in.x0;
+    int j = (int)u;
+    j = max(0, min(j, nd.n_pts - 2));
+    const double f = u - (double)j;
+    const double s0 = gload(nd.us, j), s1 = gload(nd.us, j + 1);
+    const double l0 = node(t, c, s0, 1.0 - f, s.k0, s.t0, lin);
+    const double l1 = node(t, c, s1, f, s.k1, s.t1, lin);
+    s.f = f;
+    return fma(f, l1 - l0, l0);
+  }
+  __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
+    if (w != 0.0) {
+      if (s.k0 >= 0) {
+        const Taps b = cubic_taps_weighted(s.t0, w * (1.0 - s.f));
+        double* g = c.gacc + t.th0 + s.k0;
+        unsafeAtomicAdd(g + 0, b.b0);
+        unsafeAtomicAdd(g + 1, b.b1);
+        unsafeAtomicAdd(g + 2, b.b2);
+        unsafeAtomicAdd(g + 3, b.b3);
+      }
+      if (s.k1 >= 0) {
+        const Taps b = cubic_taps_weighted(s.t1, w * s.f);
+        double* g = c.gacc + t.th0 + s.k1;
+        unsafeAtomicAdd(g + 0, b.b0);
+        unsafeAtomicAdd(g + 1, b.b1);
+        unsafeAtomicAdd(g + 2, b.b2);
+        unsafeAtomicAdd(g + 3, b.b3);
+      }
+    }
+  }
+  __device__ static void init(Acc&) {}
+  __device__ static void rescale(Acc&, double) {}
+  static constexpr int kNumAcc = 0;
+  __device__ static void collect(const TermD&, const Acc&, double*, int*) {}
+};
+
 // ---- compile-time chain of terms.  U = samples per lane per trip; inputs are double-buffered in
 //      registers (in[0] = current trip, in[1] = next trip) so the column loads of trip k+1 are in
 //      flight while trip k is being evaluated. ----------------------------------------------------------

@@ -47,6 +47,8 @@ struct Variant {
 #define K_TJ GWI_TERM_TILT_JOINT
 #define K_SM GWI_TERM_SMOOTH
 #define K_PS GWI_TERM_PLPEAK_SMOOTH
+#define K_PB GWI_TERM_POWERLAW_BOUNDS
+#define K_SL GWI_TERM_EXP_SPLINE_LERP
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
@@ -98,6 +100,13 @@ const Variant kVariants[] = {
     GWI_VARIANT("plq+plz+smooth+plpeaksmooth", K_PQ, K_PZ, K_SM, K_PS),
     GWI_VARIANT("plq+smooth+plpeaksmooth", K_PQ, K_SM, K_PS),
     GWI_VARIANT("plz+plpeaksmooth", K_PZ, K_PS),
+    // construct_hierarchical_model (analysis.py:359-424) on the reference's own distributions
+    // (numpyro_distributions.py): Powerlaw m1 and q with sampled bounds x PowerlawRedshift
+    // (examples/config_files/config.yml), and BSplineDistribution m1, q x PowerlawRedshift
+    GWI_VARIANT("plz+plb2", K_PZ, K_PB, K_PB),
+    GWI_VARIANT("plz+lerp2", K_PZ, K_SL, K_SL),
+    GWI_VARIANT("plb", K_PB),
+    GWI_VARIANT("lerp", K_SL),
     // single-term sequences (term-level parity tests)
     GWI_VARIANT("lspline", K_LS),
     GWI_VARIANT("tiltjoint", K_TJ),
@@ -310,6 +319,11 @@ gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
         n_th = 4;
         if (!theta_ok(tm.coef_off)) return fail(h, GWI_ERR_INVALID, "PLPEAK_SMOOTH: coef_off must be the theta index of delta");
         break;
+      case GWI_TERM_POWERLAW_BOUNDS: n_cols = 2; n_th = 3; break;
+      case GWI_TERM_EXP_SPLINE_LERP:
+        if (tm.norm < 0 || tm.norm >= s->n_norms || !s->norms[tm.norm].us || s->norms[tm.norm].n_pts < 2)
+          return fail(h, GWI_ERR_INVALID, "EXP_SPLINE_LERP: norm must name the grid normaliser carrying the grid's spline coordinates (us)");
+        [[fallthrough]];
       case GWI_TERM_LINEAR_SPLINE:
       case GWI_TERM_EXP_SPLINE:
         n_th = 0;
@@ -346,6 +360,16 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
         if (tm.flags & GWI_POWERLAW_UNNORMALISED) break;  // bare x^alpha pairing factor
         double la, dla;
         powerlaw_lognorm(theta[tm.theta[0]], tm.p[0], tm.p[1], &la, &dla);
+        c += la;
+        break;
+      }
+      case GWI_TERM_POWERLAW_BOUNDS: {
+        const double lo = theta[tm.theta[1]], hi = theta[tm.theta[2]];
+        double la, dla;
+        powerlaw_lognorm(theta[tm.theta[0]], lo, hi, &la, &dla);
+        // at alpha == -1 exactly the reference's Powerlaw.log_prob subtracts log(max/min), not log(log(max/min))
+        // (numpyro_distributions.py:130); reproduced, since the per-event sites show it (it cancels in log_l)
+        if (theta[tm.theta[0]] == -1.0) la = -std::log(hi / lo);
         c += la;
         break;
       }
@@ -916,7 +940,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     if (rep0 > 16) rep0 = 16;
     while (rep0 & (rep0 - 1)) rep0 &= rep0 - 1;
     bool spl = false;
-    for (int t = 0; t < spec->n_terms; ++t) spl = spl || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE;
+    for (int t = 0; t < spec->n_terms; ++t) spl = spl || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
     scan_lds = spl ? sizeof(double) * (size_t)kWaves * rep0 * (spec->n_theta | 1) : 0;
   }
   // ---- launch geometry.  Default: ~2048 scan workgroups (8 per CU).  A step lasts only ~10 us, so a
@@ -975,7 +999,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   const int pad = spec->n_theta | 1;        // odd row stride: replicas land in different banks
   bool has_spline = false;
   for (int t = 0; t < spec->n_terms; ++t)
-    has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE;
+    has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
   if (!has_spline) rep = 1;
   h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
 
@@ -1063,7 +1087,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     d.p1 = tm.p[1];
     d.p2 = tm.p[2];
     d.th4 = tm.kind == GWI_TERM_PLPEAK_SMOOTH ? tm.coef_off : 0;
-    if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE) {
+    if (tm.kind == GWI_TERM_EXP_SPLINE_LERP) d.th1 = tm.norm;  // the grid's spline coordinates live in that normaliser's `us`
+    if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE || tm.kind == GWI_TERM_EXP_SPLINE_LERP) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
     }

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .lazy import INJ, PE, Density, LazyNorm
+from .lazy import INJ, PE, Density, LazyNorm, static_key, static_log_values
 
 NEG_BIG = float(np.nan_to_num(-np.inf))
 
@@ -58,7 +58,7 @@ def structure_key(pe, inj):
     parts = []
     for d in (pe, inj):
         parts.append(tuple(f.structure() + tuple(c.key() for c in f.columns) for f in d.factors))
-        parts.append(tuple((sgn, id(a)) for sgn, a in d.log_static))
+        parts.append(tuple((sgn, static_key(a)) for sgn, a in d.log_static))
     return tuple(parts)
 
 
@@ -134,7 +134,7 @@ def bind(pe, inj, hypervolume=None):
         for d, kap in ((pe, kap_pe), (inj, kap_inj)):
             kap += d.log_const  # plain scalar multipliers (e.g. the 0.5 of a symmetrised density)
             for sgn, arr in d.log_static:
-                kap += sgn * np.log(np.asarray(arr, dtype=np.float64))
+                kap += sgn * static_log_values(arr)
             for f in d.factors:
                 if f.static_log is not None:
                     kap += f.static_log

@@ -20,6 +20,25 @@ def trapezoid_weights(x):
     return w
 
 
+class DesignMatrix(np.ndarray):
+    """``basis.bases(xs)`` as a dense array that remembers which basis and which points produced it, so that
+    consumers which the reference hands a design matrix (BSplineDistribution's ``grid_dmat``,
+    numpyro_distributions.py:266-279) can recompute the taps on the device instead of reading the matrix."""
+
+    basis = None
+    xs = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None and obj.shape == self.shape:  # views / copies keep the tag; slices and reductions drop it
+            self.basis, self.xs = getattr(obj, "basis", None), getattr(obj, "xs", None)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):  # arithmetic yields plain arrays: no longer THE design matrix
+        plain = tuple(np.asarray(i) if isinstance(i, DesignMatrix) else i for i in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, DesignMatrix) else o for o in kwargs["out"])
+        return getattr(ufunc, method)(*plain, **kwargs)
+
+
 class _Basis:
     """Common descriptor: ``name``, log-X / log-Y flags, number of grid points."""
 
@@ -79,7 +98,8 @@ class _Basis:
         for j in range(4):
             np.add.at(out.reshape(self.N, -1), ((k + j).ravel(), flat_idx.ravel()), taps[j].ravel())
         bad = self.outside(coord)
-        out = np.where(bad, -np.inf if self.log_y else 0.0, out)
+        out = np.where(bad, -np.inf if self.log_y else 0.0, out).view(DesignMatrix)
+        out.basis, out.xs = self, np.asarray(xs, dtype=np.float64)
         return out
 
 

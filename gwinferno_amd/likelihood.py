@@ -19,7 +19,7 @@ posterior-predictive-check branch (:321-355) raise NotImplementedError.
 import numpy as np
 
 from .engine import NEG_BIG, NativePopulationLikelihood, structure_key
-from .lazy import INJ, PE, Column, Density, Factor, LazyNorm, side_of
+from .lazy import INJ, PE, Column, Density, Factor, LazyNorm, LogValues, side_of, static_key
 
 _ENGINES = {}
 _LAST_SITES = {}
@@ -233,6 +233,86 @@ def hierarchical_likelihood(
     return sites.get("rate")
 
 
+def construct_hierarchical_model(
+    model_dict,
+    prior_dict,
+    marginalize_selection=False,
+    min_neff_cut=True,
+    max_variance_cut=False,
+    posterior_predictive_check=True,
+):
+    """analysis.py:359-424: the model function ``model(samps, injs, Ninj, Nobs, Tobs)`` assembled from
+    ``model_dict[source parameter] -> PopModel`` (or the name of another parameter whose distribution it
+    shares, :394-399) and ``prior_dict[hyper-parameter] -> PopPrior | constant``.  Every population model's
+    ``log_prob`` is summed per sample, ``- log prior`` (:401-402), and handed to
+    :func:`hierarchical_likelihood` with ``log=True`` and the redshift model's ``norm`` as surveyed
+    hypervolume (:404-423).
+
+    The distribution classes are those of :mod:`gwinferno_amd.numpyro_distributions` (or anything whose
+    ``log_prob`` returns a lazy log-density).  Hyper-parameters with a ``PopPrior`` are drawn with
+    ``numpyro.sample`` where NumPyro is installed and read from ``SAMPLE_VALUES[name]`` where it is not.
+    Mixture models (``PopMixtureModel``, :383-389) are NumPyro mixture distributions, not part of the
+    accelerated path.  The reference's default ``posterior_predictive_check=True`` draws per-event samples
+    with ``jax.random`` (analysis.py:321-355) and is refused here as in :func:`hierarchical_likelihood`."""
+    from .lazy import log as lazy_log
+    from .parser import PopMixtureModel, PopModel
+
+    source_param_names = [k for k in model_dict.keys()]
+    hyper_params = {k: None for k in prior_dict.keys()}
+    pop_models = {k: None for k in model_dict.keys()}
+    z_grid = None
+    if "redshift" in pop_models.keys():
+        z_grid = np.linspace(1e-9, prior_dict["redshift_maximum"], 1000)  # :371-372
+
+    def model(samps, injs, Ninj, Nobs, Tobs):
+        npro = _numpyro()
+        for k, v in prior_dict.items():
+            if hasattr(v, "dist") and hasattr(v, "params"):  # :376-379
+                hyper_params[k] = npro.sample(k, v.dist(**v.params)) if npro is not None else SAMPLE_VALUES[k]
+            else:
+                hyper_params[k] = v
+        iid_mapping = {}
+        for k, v in model_dict.items():
+            if isinstance(v, PopMixtureModel):
+                raise NotImplementedError("mixture population models (analysis.py:383-389) are outside the accelerated path")
+            elif isinstance(v, PopModel):
+                hps = {p: hyper_params[f"{k}_{p}"] for p in v.params}
+                if k == "redshift":
+                    hps["grid"] = z_grid
+                pop_models[k] = v.model(**hps)
+            elif isinstance(v, str):
+                iid_mapping[v] = k
+            else:
+                raise ValueError(f"Unknown model type: {type(v)}:{v}")
+        for shared_param, param in iid_mapping.items():
+            pop_models[shared_param] = pop_models[param]
+
+        inj_weights = sum(pop_models[k].log_prob(injs[k]) for k in source_param_names) - lazy_log(injs["prior"])
+        pe_weights = sum(pop_models[k].log_prob(samps[k]) for k in source_param_names) - lazy_log(samps["prior"])
+
+        return hierarchical_likelihood(
+            pe_weights,
+            inj_weights,
+            total_inj=Ninj,
+            Nobs=Nobs,
+            Tobs=Tobs,
+            surveyed_hypervolume=pop_models["redshift"].norm,
+            marginalize_selection=marginalize_selection,
+            min_neff_cut=min_neff_cut,
+            max_variance_cut=max_variance_cut,
+            posterior_predictive_check=posterior_predictive_check,
+            pedata=samps,
+            injdata=injs,
+            param_names=source_param_names,
+            m1min=2.0,
+            m2min=2.0,
+            mmax=100.0,
+            log=True,
+        )
+
+    return model
+
+
 _ONE_SIDED = {}
 
 
@@ -252,17 +332,17 @@ def _mirror(density, side):
     other = INJ if side == PE else PE
     factors = []
     for f in density.factors:
-        factors.append(Factor(f.kind, other, [Column(c.transform, tuple(_cut(a, side) for a in c.source) if isinstance(c.source, tuple) else _cut(c.source, side), c.const) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
+        factors.append(Factor(f.kind, other, [Column(c.transform, tuple(_cut(a, side) for a in c.source) if isinstance(c.source, tuple) else _cut(c.source, side), c.const, c.aux) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
                               n_basis=f.n_basis, flags=f.flags, mask=None if f.mask is None else _cut(f.mask, side),
                               static_log=None if f.static_log is None else _cut(f.static_log, side), norm=f.norm, owner=f.owner, norm_owner=f.norm_owner, tag=f.tag))
-    return Density(factors, other, [(sgn, _cut(a, side)) for sgn, a in density.log_static], density.log_const)
+    return Density(factors, other, [(sgn, LogValues(_cut(a.values, side)) if isinstance(a, LogValues) else _cut(a, side)) for sgn, a in density.log_static], density.log_const)
 
 
 def _one_sided(weights):
     if not isinstance(weights, Density) or not weights.factors:
         raise TypeError("weights must be a lazy density from gwinferno_amd.models")
     side = weights.side if weights.side is not None else side_of(weights.factors[0].columns[0].source)
-    key = (side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in weights.factors), tuple((sgn, id(a)) for sgn, a in weights.log_static))
+    key = (side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in weights.factors), tuple((sgn, static_key(a)) for sgn, a in weights.log_static))
     hit = _ONE_SIDED.get(key)
     if hit is None:
         mirror = _mirror(weights, side)
@@ -297,4 +377,4 @@ def detection_efficiency(weights, Ninj, log=False):
     return s.log_det_eff, s.log_nEff_inj, s.variance_log_detection_efficiency
 
 
-__all__ = ["hierarchical_likelihood", "per_event_log_bayes_factors", "detection_efficiency", "last_sites", "engine_for", "clear_engine_cache", "SAMPLE_VALUES", "NEG_BIG"]
+__all__ = ["hierarchical_likelihood", "construct_hierarchical_model", "per_event_log_bayes_factors", "detection_efficiency", "last_sites", "engine_for", "clear_engine_cache", "SAMPLE_VALUES", "NEG_BIG"]

@@ -95,7 +95,18 @@ enum {
   GWI_TERM_SMOOTH = 11,
   /* (1-lam) PL(x) smooth(delta, x, lo) + lam TN(x): plpeak_primary_pdf with delta (parametric.py:49-53).
    * cols[0]=x, cols[1]=log x; theta = alpha, mpp, sigpp, lam; coef_off = theta index of delta; p[0]=lo, p[1]=hi */
-  GWI_TERM_PLPEAK_SMOOTH = 12
+  GWI_TERM_PLPEAK_SMOOTH = 12,
+  /* x^alpha on [lo,hi] with the BOUNDS hyper-parameters too: Powerlaw.log_prob with sampled minimum / maximum
+   * (numpyro_distributions.py:101-136; examples/config_files/config.yml:8-25).  cols[0]=log x, cols[1]=x; theta = alpha, lo, hi.
+   * x < lo | x > hi is excluded (a sample exactly on a bound is inside); the gradient w.r.t. lo / hi is 0 (the normaliser cancels in log_l and the
+   * truncation itself is piecewise constant), as reverse-mode differentiation of the reference gives. */
+  GWI_TERM_POWERLAW_BOUNDS = 13,
+  /* exp(interp(x, grid, lpdfs)) / Z, lpdfs_g = sum_k c_k B_k(us_g): BSplineDistribution.log_prob
+   * (numpyro_distributions.py:266-293).  cols[0] = fractional grid index of the sample (j + f, clamped to the grid as
+   * np.interp holds the end values); coef_off/n_basis; p[0]=lo, p[1]=hi of the spline coordinate; norm = the grid
+   * normaliser whose `us` table (spline coordinate per grid point) and trapezoid weights define grid and Z (required);
+   * flags: GWI_SPLINE_OUTSIDE_ZERO_EXPONENT as for EXP_SPLINE (otherwise a grid point outside [lo,hi] has lpdf -inf) */
+  GWI_TERM_EXP_SPLINE_LERP = 14
 };
 
 /* POWERLAW flag: bare x^alpha with no normaliser and no truncation (the (m2/m1)^beta pairing factor,

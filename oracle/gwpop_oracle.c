@@ -192,6 +192,42 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         ell += (th[tm->theta[0]] - 1.0) * x0;
         d[tm->theta[0]] += x0;
         break;
+      case GWI_TERM_POWERLAW_BOUNDS: { /* numpyro_distributions.py:127-136: -inf outside [minimum, maximum] (bounds included) */
+        const double xv = cols[tm->cols[1]][idx];
+        if ((xv < th[tm->theta[1]]) || (xv > th[tm->theta[2]])) {
+          ell = -INFINITY;
+          break;
+        }
+        ell += th[tm->theta[0]] * x0;
+        d[tm->theta[0]] += x0;
+        break;
+      }
+      case GWI_TERM_EXP_SPLINE_LERP: { /* numpyro_distributions.py:273, :296-301: interp(value, grid, cs . grid_dmat) */
+        const gwi_norm* nm = &sp->norms[tm->norm];
+        int j = (int)x0;
+        if (j < 0) j = 0;
+        if (j > nm->n_pts - 2) j = nm->n_pts - 2;
+        const double f = x0 - (double)j;
+        const double wts[2] = {1.0 - f, f};
+        double val = 0.0;
+        for (int e = 0; e < 2 && ell > -INFINITY; ++e) {
+          if (wts[e] == 0.0) continue;
+          const double sx = nm->us[j + e];
+          double tt, b[4];
+          const int inside = (sx >= tm->p[0]) && (sx <= tm->p[1]);
+          if (!inside) {
+            if (!(tm->flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT)) ell = -INFINITY; /* log-Y basis: lpdf = -inf at that grid point */
+            continue;
+          }
+          const int k = locate(sx, tm->p[0], tm->p[1], tm->n_basis, &tt);
+          taps(tt, b);
+          const double* c = th + tm->coef_off + k;
+          val += wts[e] * (c[0] * b[0] + c[1] * b[1] + c[2] * b[2] + c[3] * b[3]);
+          for (int q = 0; q < 4; ++q) d[tm->coef_off + k + q] += wts[e] * b[q];
+        }
+        if (ell > -INFINITY) ell += val;
+        break;
+      }
       case GWI_TERM_EXP_SPLINE:
       case GWI_TERM_LINEAR_SPLINE: {
         double tt, b[4];
@@ -278,6 +314,11 @@ int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int
           pl_lognorm(th[tm->theta[0]], tm->p[0], tm->p[1], &a, &b);
           host_const += a;
         }
+        break;
+      case GWI_TERM_POWERLAW_BOUNDS:
+        pl_lognorm(th[tm->theta[0]], th[tm->theta[1]], th[tm->theta[2]], &a, &b);
+        if (th[tm->theta[0]] == -1.0) a = -log(th[tm->theta[2]] / th[tm->theta[1]]); /* numpyro_distributions.py:130 as written */
+        host_const += a;
         break;
       case GWI_TERM_PLPEAK_SMOOTH:
       case GWI_TERM_PLPEAK:

@@ -691,7 +691,102 @@ class PLPeakSmooth(PLPeak):
             return _finite_or_zero(dens * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
 
 
+# ==========================================================================================
+# log-space distributions summed by construct_hierarchical_model  (gwinferno/numpyro_distributions.py)
+# ==========================================================================================
+def powerlaw_log_prob(value, alpha, minimum, maximum):
+    """Powerlaw.log_prob, numpyro_distributions.py:127-136."""
+    with np.errstate(all="ignore"):
+        logp = alpha * np.log(value) + np.log((1.0 + alpha) / (maximum ** (1.0 + alpha) - minimum ** (1.0 + alpha)))
+        logp_neg1 = -np.log(value) - np.log(maximum / minimum)
+        return np.where((value < minimum) | (value > maximum), NEG_BIG, np.where(alpha == -1.0, logp_neg1, logp))
+
+
+class PowerlawRedshiftDistribution:
+    """PowerlawRedshift, numpyro_distributions.py:156-201 (log_prob path only)."""
+
+    def __init__(self, lamb, maximum, zgrid, dVcdz):
+        self.lamb, self.maximum, self.zs, self.dVdc = lamb, maximum, np.asarray(zgrid), np.asarray(dVcdz)
+        self.norm = np.trapezoid(self.dVdc * (1 + self.zs) ** (lamb - 1), self.zs)  # (:174-175)
+
+    def log_prob(self, value):
+        with np.errstate(all="ignore"):
+            dV = np.interp(value, self.zs, self.dVdc)  # (:189-190)
+            return np.where(value <= self.maximum, np.log(dV) + (self.lamb - 1.0) * np.log(1.0 + value) - np.log(self.norm), NEG_BIG)  # (:191-195)
+
+
+class BSplineDistribution:
+    """numpyro_distributions.py:266-303 (log_prob path only): a gridded log-pdf, linearly interpolated."""
+
+    def __init__(self, cs, grid, grid_dmat):
+        self.grid = np.asarray(grid)
+        with np.errstate(all="ignore"):
+            self.lpdfs = np.nan_to_num(np.einsum("i,i...->...", np.asarray(cs, dtype=np.float64), grid_dmat), nan=-np.inf)  # (:273)
+            self.norm = np.trapezoid(np.exp(self.lpdfs), self.grid)  # (:274-275)
+
+    def log_prob(self, value):
+        return np.interp(value, self.grid, self.lpdfs) - np.log(self.norm)  # (:296-301)
+
+
+class ChmPowerlaw(Composition):
+    """construct_hierarchical_model (analysis.py:359-424) on Powerlaw mass_1 (sampled bounds) / Powerlaw mass_ratio /
+    PowerlawRedshift -- the model of examples/config_files/config.yml.  Always log-space (:422)."""
+
+    ZMAX, QMIN = 1.9, 0.02
+    PARAMS = {"alpha": (), "mmin": (), "mmax": (), "beta": (), "lamb": ()}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.zgrid = np.linspace(1e-9, self.ZMAX, 1000)  # (:371-372)
+        self.dV = planck15_lvk().dVc_dz(self.zgrid)
+
+    def log_probs(self, p, d):
+        z = PowerlawRedshiftDistribution(p["lamb"], self.ZMAX, self.zgrid, self.dV)
+        return [powerlaw_log_prob(d["mass_1"], p["alpha"], p["mmin"], p["mmax"]), powerlaw_log_prob(d["mass_ratio"], p["beta"], self.QMIN, 1.0), z.log_prob(d["redshift"])], z.norm
+
+    def log_weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            lps, _ = self.log_probs(p, d)
+            return np.sum(np.array(lps), axis=0) - np.log(d["prior"])  # (:401-402)
+
+    def weights(self, p, pe_samples):
+        with np.errstate(all="ignore"):
+            return np.exp(self.log_weights(p, pe_samples))
+
+    def hypervolume(self, p):
+        return self.log_probs(p, self.inj)[1]  # pop_models["redshift"].norm (:410)
+
+    def evaluate(self, params, total_inj, tobs=1.0, **flags):
+        flags = dict(flags, log=True)
+        w_pe, w_inj = self.log_weights(params, True), self.log_weights(params, False)
+        return hierarchical_likelihood(w_pe, w_inj, total_inj, w_pe.shape[0], tobs, self.hypervolume(params), **flags)
+
+
+class ChmBSpline(ChmPowerlaw):
+    """The same with BSplineDistribution populations for mass_1 (LogXLogYBSpline design matrix on its grid) and
+    mass_ratio (LogYBSpline), as tests/numpyro_distributions_test.py:91-129 build them."""
+
+    NM, NQ = 16, 10
+    PARAMS = {"m_coefs": (NM,), "q_coefs": (NQ,), "lamb": ()}
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.m_grid = np.linspace(self.mmin, self.mmax, 1000)
+        self.m_dmat = SplineBasis("logXlogY", self.NM, (self.mmin, self.mmax), True).design(self.m_grid)
+        self.q_grid = np.linspace(0.0, 1.0, 1000)
+        self.q_dmat = SplineBasis("logY", self.NQ, (0.0, 1.0), True).design(self.q_grid)
+
+    def log_probs(self, p, d):
+        z = PowerlawRedshiftDistribution(p["lamb"], self.ZMAX, self.zgrid, self.dV)
+        m = BSplineDistribution(p["m_coefs"], self.m_grid, self.m_dmat)
+        q = BSplineDistribution(p["q_coefs"], self.q_grid, self.q_dmat)
+        return [m.log_prob(d["mass_1"]), q.log_prob(d["mass_ratio"]), z.log_prob(d["redshift"])], z.norm
+
+
 COMPOSITIONS = {
+    "chm_powerlaw": ChmPowerlaw,
+    "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,

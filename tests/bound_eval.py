@@ -116,6 +116,21 @@ def log_weights(bm, theta, include_consts=True):
                 elif k == N.TERM_EXP_SPLINE:
                     co = t["coef_off"]
                     ell = ell + _spline(c[0], theta[co : co + t["n_basis"]], p[0], p[1], bool(t["flags"] & N.SPLINE_OUTSIDE_ZERO_EXPONENT))
+                elif k == N.TERM_POWERLAW_BOUNDS:
+                    alpha, lo, hi = th
+                    inside = ~((c[1] < lo) | (c[1] > hi))
+                    ln = -np.log(hi / lo) if alpha == -1.0 else _pl_lognorm(alpha, lo, hi)  # numpyro_distributions.py:130 as written
+                    ell = ell + np.where(inside, alpha * c[0] + k_const * ln, -np.inf)
+                elif k == N.TERM_EXP_SPLINE_LERP:
+                    co = t["coef_off"]
+                    g = bm.norms[t["norm"]][0]
+                    zero_out = bool(t["flags"] & N.SPLINE_OUTSIDE_ZERO_EXPONENT)
+                    lp = _spline(g.us, theta[co : co + t["n_basis"]], p[0], p[1], zero_out)
+                    if not zero_out:
+                        lp = np.where((g.us >= p[0]) & (g.us <= p[1]), lp, -np.inf)
+                    j = np.clip(np.floor(c[0]).astype(np.int64), 0, len(lp) - 2)
+                    f = c[0] - j
+                    ell = ell + np.where(f == 0, lp[j], np.where(f == 1, lp[j + 1], (1 - f) * lp[j] + f * lp[j + 1]))
                 else:
                     raise ValueError(k)
                 if t["norm"] >= 0 and include_consts:

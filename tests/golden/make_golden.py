@@ -347,7 +347,118 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
         return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.normal(size=cls.NZ)}
 
 
+class ChmPowerlaw(Composition):
+    """construct_hierarchical_model (pipeline/analysis.py:359-424) on the reference's own distributions:
+    mass_1 ~ Powerlaw(alpha, minimum, maximum) with the bounds hyper-parameters too, mass_ratio ~ Powerlaw(beta, 0.02, 1),
+    redshift ~ PowerlawRedshift(lamb, maximum=1.9) -- the model of examples/config_files/config.yml.  Hyper-parameters
+    with a PopPrior go through numpyro.sample, the others are prior_dict constants (analysis.py:376-379)."""
+
+    ZMAX, QMIN = 1.9, 0.02
+    params = {"alpha": (), "mmin": (), "mmax": (), "beta": (), "lamb": ()}
+    fd_skip = ("mmin", "mmax")  # log_l is piecewise constant in the truncation bounds: no finite-difference gradient
+    chm = True
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        self.cosmo = ref.cosmology.PLANCK_2015_LVK_Cosmology
+        D = ref.numpyro_distributions
+        cosmo = self.cosmo
+        # PowerlawRedshift takes (zgrid, dVcdz) while construct_hierarchical_model passes `grid` (analysis.py:391-393):
+        # the adapter a user of that function has to supply at the reference's HEAD
+        self.redshift_model = lambda lamb, maximum, grid: D.PowerlawRedshift(lamb, maximum, zgrid=grid, dVcdz=cosmo.dVcdz(grid))
+
+    def dicts(self, p):
+        from gwinferno.pipeline.parser import PopModel, PopPrior
+
+        D = ref.numpyro_distributions
+        model_dict = {
+            "mass_1": PopModel(D.Powerlaw, ["alpha", "minimum", "maximum"]),
+            "mass_ratio": PopModel(D.Powerlaw, ["alpha", "minimum", "maximum"]),
+            "redshift": PopModel(self.redshift_model, ["lamb", "maximum"]),
+        }
+        sampled = {"mass_1_alpha": p["alpha"], "mass_1_minimum": p["mmin"], "mass_1_maximum": p["mmax"], "mass_ratio_alpha": p["beta"], "redshift_lamb": p["lamb"]}
+        prior_dict = {k: PopPrior(lambda **kw: None, {}) for k in sampled}
+        prior_dict.update(mass_ratio_minimum=np.float64(self.QMIN), mass_ratio_maximum=np.float64(1.0), redshift_maximum=np.float64(self.ZMAX))
+        return model_dict, prior_dict, sampled
+
+    def populations(self, p):
+        D = ref.numpyro_distributions
+        zg = jnp.linspace(1e-9, self.ZMAX, 1000)
+        return {"mass_1": D.Powerlaw(p["alpha"], p["mmin"], p["mmax"]), "mass_ratio": D.Powerlaw(p["beta"], np.float64(self.QMIN), np.float64(1.0)),
+                "redshift": self.redshift_model(p["lamb"], np.float64(self.ZMAX), zg)}
+
+    def weights(self, p, d, pe_samples):
+        pops = self.populations(p)
+        with np.errstate(all="ignore"):
+            return jnp.exp(sum(pops[k].log_prob(d[k]) for k in pops) - jnp.log(d["prior"]))
+
+    def run(self, p, nobs, total_inj, flags):
+        """One execution of the model function construct_hierarchical_model returns."""
+        flags = {k: v for k, v in flags.items() if k != "log"}
+        model_dict, prior_dict, sampled = self.dicts(p)
+        numpyro.reset()
+        for k, v in sampled.items():
+            numpyro.SAMPLE_VALUES[k] = np.float64(v) if np.ndim(v) == 0 else jnp.asarray(v)
+        model = ref.analysis.construct_hierarchical_model(model_dict, prior_dict, posterior_predictive_check=False, **flags)
+        with np.errstate(all="ignore"):
+            model(self.pe, self.inj, total_inj, nobs, TOBS)
+        for k in sampled:
+            numpyro.SAMPLE_VALUES.pop(k)
+        return {k: np.asarray(v, dtype=np.float64) for k, v in numpyro.SITES.items()}
+
+    @classmethod
+    def draw(cls, rng):
+        return {"alpha": rng.normal(-2.5, 1.0), "mmin": rng.uniform(3.0, 9.0), "mmax": rng.uniform(60.0, 100.0), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
+
+
+class ChmBSpline(ChmPowerlaw):
+    """construct_hierarchical_model with BSplineDistribution populations (numpyro_distributions.py:266-303) as the
+    reference's tests build them (tests/numpyro_distributions_test.py:91-129): mass_1 on a LogXLogYBSpline design
+    matrix over a 1000-point grid, mass_ratio on a LogYBSpline one; redshift ~ PowerlawRedshift."""
+
+    NM, NQ = 16, 10
+    params = {"m_coefs": (NM,), "q_coefs": (NQ,), "lamb": ()}
+    fd_skip = ()
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        I = ref.interpolation
+        # the grid spans exactly the spline domain: samples beyond it get the end values (jnp.interp), and no grid
+        # cell straddles the edge of the log-Y basis (there the reference's lpdfs jump to nan_to_num(-inf) and the
+        # interpolation overflows to +inf)
+        self.m_grid = jnp.linspace(MMIN, MMAX, 1000)
+        self.m_dmat = I.LogXLogYBSpline(self.NM, xrange=(MMIN, MMAX), normalize=True).bases(self.m_grid)
+        self.q_grid = jnp.linspace(0.0, 1.0, 1000)
+        self.q_dmat = I.LogYBSpline(self.NQ, xrange=(0.0, 1.0), normalize=True).bases(self.q_grid)
+
+    def dicts(self, p):
+        from gwinferno.pipeline.parser import PopModel, PopPrior
+
+        D = ref.numpyro_distributions
+        names = ["minimum", "maximum", "cs", "grid", "grid_dmat"]
+        model_dict = {"mass_1": PopModel(D.BSplineDistribution, names), "mass_ratio": PopModel(D.BSplineDistribution, names), "redshift": PopModel(self.redshift_model, ["lamb", "maximum"])}
+        sampled = {"mass_1_cs": p["m_coefs"], "mass_ratio_cs": p["q_coefs"], "redshift_lamb": p["lamb"]}
+        prior_dict = {k: PopPrior(lambda **kw: None, {}) for k in sampled}
+        prior_dict.update(mass_1_minimum=MMIN, mass_1_maximum=MMAX, mass_1_grid=self.m_grid, mass_1_grid_dmat=self.m_dmat,
+                          mass_ratio_minimum=np.float64(0.0), mass_ratio_maximum=np.float64(1.0), mass_ratio_grid=self.q_grid, mass_ratio_grid_dmat=self.q_dmat,
+                          redshift_maximum=np.float64(self.ZMAX))
+        return model_dict, prior_dict, sampled
+
+    def populations(self, p):
+        D = ref.numpyro_distributions
+        zg = jnp.linspace(1e-9, self.ZMAX, 1000)
+        return {"mass_1": D.BSplineDistribution(MMIN, MMAX, jnp.asarray(p["m_coefs"]), self.m_grid, self.m_dmat),
+                "mass_ratio": D.BSplineDistribution(np.float64(0.0), np.float64(1.0), jnp.asarray(p["q_coefs"]), self.q_grid, self.q_dmat),
+                "redshift": self.redshift_model(p["lamb"], np.float64(self.ZMAX), zg)}
+
+    @classmethod
+    def draw(cls, rng):
+        return {"m_coefs": rng.normal(size=cls.NM), "q_coefs": rng.normal(size=cls.NQ), "lamb": rng.normal(2.7, 1.0)}
+
+
 COMPOSITIONS = {
+    "chm_powerlaw": ChmPowerlaw,
+    "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,
     "bspline_redshift": BSplineRedshiftCase,
     "bspline_redshift_raw": BSplineRedshiftRawCase,
@@ -369,6 +480,10 @@ FLAGSETS = {
     "lin_neff": dict(log=False, min_neff_cut=True),
     "lin_var": dict(log=False, min_neff_cut=False, max_variance_cut=True),
     "lin_marg": dict(log=False, min_neff_cut=False, marginalize_selection=True),
+    # construct_hierarchical_model always evaluates in the log domain (analysis.py:422)
+    "log_neff": dict(log=True, min_neff_cut=True),
+    "log_var": dict(log=True, min_neff_cut=False, max_variance_cut=True),
+    "log_marg": dict(log=True, min_neff_cut=False, marginalize_selection=True),
 }
 
 
@@ -378,6 +493,9 @@ def run_likelihood(comp, p, nobs, total_inj, flags):
     log = flags.pop("log")
     pe_w = comp.weights(p, comp.pe, True)
     inj_w = comp.weights(p, comp.inj, False)
+    if getattr(comp, "chm", False):  # through the reference's construct_hierarchical_model
+        assert log
+        return comp.run(p, nobs, total_inj, flags), np.asarray(pe_w), np.asarray(inj_w)
     numpyro.reset()
     with np.errstate(all="ignore"):
         a, b = (jnp.log(pe_w), jnp.log(inj_w)) if log else (pe_w, inj_w)
@@ -397,6 +515,8 @@ def fd_gradient(comp, p, nobs, total_inj, flags, rel=1e-3):
 
     grads = {}
     for name, val in p.items():
+        if name in getattr(comp, "fd_skip", ()):
+            continue
         arr = np.atleast_1d(np.asarray(val, dtype=np.float64))
         g = np.zeros_like(arr)
         for i in range(arr.size):
@@ -437,14 +557,14 @@ def make_case(fname, comp_name, pe, inj, total_inj, seed, n_points=4, n_grad=2, 
             sites, pe_w, inj_w = run_likelihood(comp, pt, nobs, total_inj, FLAGSETS[fs])
             for k, v in sites.items():
                 per_site.setdefault(k, []).append(v)
-            if fs == "lin" and i == 0:
+            if fs == flagsets[0] and i == 0:
                 out["weights/pe"] = pe_w
                 out["weights/inj"] = inj_w
         for k, v in per_site.items():
             out[f"sites/{fs}/{k}"] = np.stack(v)
         site_names = sorted(per_site)
     for i in range(n_grad):
-        g = fd_gradient(comp, points[i], nobs, total_inj, FLAGSETS["lin"])
+        g = fd_gradient(comp, points[i], nobs, total_inj, FLAGSETS[flagsets[0]])
         for name, arr in g.items():
             out[f"fdgrad/{i}/{name}"] = arr
     meta = {
@@ -465,8 +585,8 @@ def make_case(fname, comp_name, pe, inj, total_inj, seed, n_points=4, n_grad=2, 
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(HERE, fname)
     np.savez_compressed(path, **out)
-    ll = out["sites/lin/log_likelihood"]
-    print(f"wrote {fname}: {os.path.getsize(path) / 1024:.0f} KiB  log_l[lin]={ll}")
+    ll = out[f"sites/{flagsets[0]}/log_likelihood"]
+    print(f"wrote {fname}: {os.path.getsize(path) / 1024:.0f} KiB  log_l[{flagsets[0]}]={ll}")
 
 
 # ------------------------------------------------------------------------------------------
@@ -526,6 +646,32 @@ def make_terms():
     cs = rng.normal(size=12)
     out["smoothing/coefs"] = cs
     out["smoothing/values"] = np.array([float(ref.smoothing.apply_difference_prior(jnp.asarray(cs), tau, degree=deg)) for tau, deg in ((1.0, 1), (25.0, 2), (5.0, 3))])
+    # log_prob faces of the NumPyro distributions (numpyro_distributions.py:101-201, 266-303)
+    ND, I = ref.numpyro_distributions, ref.interpolation
+    with np.errstate(all="ignore"):
+        for tag, a in (("a", -2.35), ("b", 1.3), ("neg1", -1.0), ("zero", 0.0)):
+            out[f"dist/powerlaw/{tag}"] = np.asarray(ND.Powerlaw(np.float64(a), MMIN, MMAX).log_prob(jnp.asarray(x)))
+        zg = jnp.linspace(1e-9, 1.9, 1000)
+        dvg = ref.cosmology.PLANCK_2015_LVK_Cosmology.dVcdz(zg)
+        out["dist/z_grid"], out["dist/z_dVcdz"] = np.asarray(zg), np.asarray(dvg)
+        zd = [ND.PowerlawRedshift(np.float64(l), np.float64(1.4), zgrid=zg, dVcdz=dvg) for l in out["z_lamb"]]
+        out["dist/powerlaw_redshift/inj"] = np.stack([np.asarray(d.log_prob(jnp.asarray(zinj))) for d in zd])
+        out["dist/powerlaw_redshift/norm"] = np.array([float(d.norm) for d in zd])
+        out["dist/powerlaw_redshift/maximum"] = np.array(1.4)
+        # BSplineDistribution on the four bases, as tests/numpyro_distributions_test.py:91-129 builds them; the log-X
+        # basis keeps its default domain (0.01, 1) on a grid from 0.001 (zero-outside columns), the log-X log-Y one
+        # is given the grid's own range (its default would put -inf columns on the grid)
+        v = rng.uniform(-0.05, 1.05, 2048)
+        gr, grx = jnp.linspace(0, 1, 1000), jnp.linspace(0.001, 1, 1000)
+        v[:6] = [0.0, 1.0, gr[17], grx[500], 0.001, np.nextafter(1.0, 0)]
+        out["dist/bspline/value"] = v
+        cs = rng.normal(size=20)
+        out["dist/bspline/cs"] = cs
+        for tag, basis, g in (("bspline", I.BSpline(20, normalize=True), gr), ("logy", I.LogYBSpline(20, normalize=True), gr), ("logx", I.LogXBSpline(20, normalize=True), grx),
+                              ("logxy", I.LogXLogYBSpline(20, xrange=(0.001, 1), normalize=True), grx)):
+            d = ND.BSplineDistribution(minimum=g[0], maximum=g[-1], cs=jnp.asarray(cs), grid=g, grid_dmat=basis.bases(g))
+            out[f"dist/bspline/{tag}"] = np.asarray(d.log_prob(jnp.asarray(v)))
+            out[f"dist/bspline/{tag}_norm"] = np.array(float(d.norm))
     np.savez_compressed(os.path.join(HERE, "terms.npz"), **out)
     print("wrote terms.npz")
 
@@ -693,7 +839,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "gwtc3", "catalog", "ppd"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "gwtc3", "catalog", "ppd"]
     if "ppd" in todo:
         make_ppd_fixture()
     if "catalog" in todo:
@@ -723,6 +869,11 @@ def main(which):
     if "cases4" in todo:
         pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
         make_case("case_plpeak_smooth.npz", "plpeak_smooth", pe, inj, tot, seed=14, n_points=4, n_grad=2)
+    if "cases5" in todo:
+        pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+        chm_sets = ("log", "log_neff", "log_var", "log_marg")
+        make_case("case_chm_powerlaw.npz", "chm_powerlaw", pe, inj, tot, seed=15, n_points=4, n_grad=2, flagsets=chm_sets)
+        make_case("case_chm_bspline.npz", "chm_bspline", pe, inj, tot, seed=16, n_points=3, n_grad=1, flagsets=chm_sets)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

@@ -32,6 +32,22 @@ class Arr(_np.ndarray):
     def at(self):
         return _AtIndexer(self)
 
+    def __getitem__(self, idx):
+        # JAX clamps out-of-bounds integer indices on reads (the reference's cumtrapz,
+        # numpyro_distributions.py:20-24, relies on it: it reads y[len(y)])
+        if isinstance(idx, (int, _np.integer)) and self.ndim >= 1 and not isinstance(idx, bool):
+            n = self.shape[0]
+            if idx >= n:
+                idx = n - 1
+            elif idx < -n:
+                idx = 0
+        return _np.ndarray.__getitem__(self, idx)
+
+    def __iter__(self):  # ndarray iterates through the sequence protocol, which the clamp above would never end
+        if self.ndim == 0:
+            raise TypeError("iteration over a 0-d array")
+        return (_np.ndarray.__getitem__(self, i) for i in range(self.shape[0]))
+
     def __array_wrap__(self, obj, context=None, return_scalar=False):
         if obj.ndim == 0:
             return obj[()]

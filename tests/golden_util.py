@@ -19,6 +19,8 @@ CASES = [
     "bspline_redshift",
     "bspline_redshift_raw",
     "plpeak_smooth",
+    "chm_powerlaw",
+    "chm_bspline",
     "gwtc3_pl_test",
     "gwtc3_bspline_test",
 ]

@@ -264,3 +264,60 @@ def test_native_nuts_chains_in_threads_equal_chains_run_alone():
         nuts_engine(engs[:2], total, prior, bij, starts, min_neff_cut=False, **kw)
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("name", ["chm_powerlaw", "chm_bspline"])
+def test_construct_hierarchical_model_matches_the_reference(name):
+    """construct_hierarchical_model (analysis.py:359-424) with the distribution classes of this package, fed the way
+    the reference's function is (PopModel / PopPrior dictionaries; sampled hyper-parameters through the sample
+    sites): every site the reference's own function registered for the same dictionaries (golden case_chm_*)."""
+    from gwinferno_amd import interpolation as I
+    from gwinferno_amd import likelihood as L
+    from gwinferno_amd import numpyro_distributions as D
+    from gwinferno_amd.cosmology import planck15_lvk
+    from gwinferno_amd.parser import PopModel, PopPrior
+
+    case = GoldenCase(name)
+    cosmo = planck15_lvk()
+    tables = {}
+
+    def redshift(lamb, maximum, grid):  # the adapter PowerlawRedshift(zgrid=, dVcdz=) needs under this function (analysis.py:391-393)
+        dv = tables.setdefault(id(grid), (grid, cosmo.dVc_dz(grid)))[1]
+        return D.PowerlawRedshift(lamb, maximum, zgrid=grid, dVcdz=dv)
+
+    if name == "chm_powerlaw":
+        model_dict = {"mass_1": PopModel(D.Powerlaw, ["alpha", "minimum", "maximum"]), "mass_ratio": PopModel(D.Powerlaw, ["alpha", "minimum", "maximum"]),
+                      "redshift": PopModel(redshift, ["lamb", "maximum"])}
+        sampled = lambda p: {"mass_1_alpha": p["alpha"], "mass_1_minimum": p["mmin"], "mass_1_maximum": p["mmax"], "mass_ratio_alpha": p["beta"], "redshift_lamb": p["lamb"]}  # noqa: E731
+        consts = dict(mass_ratio_minimum=0.02, mass_ratio_maximum=1.0, redshift_maximum=1.9)
+    else:
+        m_grid, q_grid = np.linspace(case.meta["mmin"], case.meta["mmax"], 1000), np.linspace(0.0, 1.0, 1000)
+        m_dmat = I.LogXLogYBSpline(16, xrange=(case.meta["mmin"], case.meta["mmax"]), normalize=True).bases(m_grid)
+        q_dmat = I.LogYBSpline(10, xrange=(0.0, 1.0), normalize=True).bases(q_grid)
+        names = ["minimum", "maximum", "cs", "grid", "grid_dmat"]
+        model_dict = {"mass_1": PopModel(D.BSplineDistribution, names), "mass_ratio": PopModel(D.BSplineDistribution, names), "redshift": PopModel(redshift, ["lamb", "maximum"])}
+        sampled = lambda p: {"mass_1_cs": p["m_coefs"], "mass_ratio_cs": p["q_coefs"], "redshift_lamb": p["lamb"]}  # noqa: E731
+        consts = dict(mass_1_minimum=case.meta["mmin"], mass_1_maximum=case.meta["mmax"], mass_1_grid=m_grid, mass_1_grid_dmat=m_dmat, mass_ratio_minimum=0.0, mass_ratio_maximum=1.0,
+                      mass_ratio_grid=q_grid, mass_ratio_grid_dmat=q_dmat, redshift_maximum=1.9)
+    prior_dict = {k: PopPrior(None, {}) for k in sampled(case.point(0))}
+    prior_dict.update(consts)
+    L.SAMPLE_VALUES["unscaled_rate"] = case.meta["unscaled_rate"]
+    L.clear_engine_cache()
+    for fs, flags in case.flagsets.items():
+        flags = {k: v for k, v in flags.items() if k != "log"}
+        model = L.construct_hierarchical_model(model_dict, prior_dict, posterior_predictive_check=False, **flags)
+        for i in range(case.n_points):
+            L.SAMPLE_VALUES.update(sampled(case.point(i)))
+            model(case.pe, case.inj, case.total_inj, case.nobs, case.tobs)
+            sites = L.last_sites()
+            for site, ref in case.sites[fs].items():
+                if site.startswith("variance"):
+                    assert np.allclose(sites[site], ref[i], rtol=1e-8, atol=1e-12), (fs, i, site)
+                else:
+                    assert rel_err(sites[site], ref[i]) < 1e-9, (fs, i, site, sites[site], ref[i])
+            if not flags.get("marginalize_selection"):
+                assert np.all(np.isfinite(sites["grad_log_likelihood"]))
+    assert len(L._ENGINES) == 1  # every call and every flag set served by ONE engine: nothing keyed on per-call objects
+    with pytest.raises(NotImplementedError):
+        L.construct_hierarchical_model(model_dict, prior_dict)(case.pe, case.inj, case.total_inj, case.nobs, case.tobs)  # the reference's default asks for the PPC draws
+    L.clear_engine_cache()

@@ -28,6 +28,10 @@ def _wide(name, p, rng):
             p[k] = float(rng.uniform(0.05, 6.0))
         elif k == "delta":
             p[k] = float(rng.uniform(0.1, 30.0))
+        elif k == "mmin":  # truncation bounds as hyper-parameters: anywhere in the data, also excluding most of it
+            p[k] = float(rng.uniform(1.0, 30.0))
+        elif k == "mmax":
+            p[k] = float(rng.uniform(35.0, 130.0))
     if name == "bspline_redshift":  # exponent coefficients are c / (c . I): keep the denominator away from 0
         p["z_coefs"] = np.abs(p["z_coefs"]) + 0.05
     if "e_coefs" in p:  # linear (density) splines need positive coefficients
@@ -36,7 +40,7 @@ def _wide(name, p, rng):
 
 
 @pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_chieff",
-                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth"])
+                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth", "chm_powerlaw", "chm_bspline"])
 def test_randomised_parity_against_c_oracle(name):
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog

@@ -140,3 +140,75 @@ def test_spline_projection_against_design_matrix():
         _check(linj, z[f"{i}/project"], tol=1e-10)
         n_checked += 1
     assert n_checked == 6
+
+
+def test_numpyro_distribution_log_probs(terms):
+    """Powerlaw (bounds as hyper-parameters: samples ON the bounds and their nextafter neighbours, alpha = -1),
+    PowerlawRedshift and BSplineDistribution on the four bases, each evaluated ALONE by the engine, against the
+    reference's own log_prob arrays (tests/golden/terms.npz dist/*; numpyro_distributions.py:127-136, 186-195, 296-301)."""
+    from gwinferno_amd import interpolation as I
+    from gwinferno_amd import numpyro_distributions as D
+
+    def check(got, ref, tol=1e-11):
+        dead = ref < -1e300  # nan_to_num(-inf)
+        assert np.array_equal(np.isneginf(got), dead)
+        assert np.max(np.abs(got[~dead] - ref[~dead])) < tol
+
+    x = terms["m1"]
+    pe, inj = _pair(x)
+    for tag, a in zip(("a", "b", "neg1", "zero"), terms["powerlaw_alphas"]):
+        d_pe, d_inj = D.Powerlaw(a, 5.0, 100.0).log_prob(pe), D.Powerlaw(a, 5.0, 100.0).log_prob(inj)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        check(linj, terms[f"dist/powerlaw/{tag}"])
+        check(lpe.ravel(), terms[f"dist/powerlaw/{tag}"])
+    zg, dv = terms["dist/z_grid"], terms["dist/z_dVcdz"]
+    zpe, zinj = _pair(terms["z_inj"])
+    for i, lamb in enumerate(terms["z_lamb"]):
+        mk = lambda: D.PowerlawRedshift(lamb, float(terms["dist/powerlaw_redshift/maximum"]), zg, dv)  # noqa: E731
+        d_pe, d_inj = mk().log_prob(zpe), mk().log_prob(zinj)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        check(linj, terms["dist/powerlaw_redshift/inj"][i])
+        check(lpe.ravel(), terms["dist/powerlaw_redshift/inj"][i])
+    v, cs = terms["dist/bspline/value"], terms["dist/bspline/cs"]
+    vpe, vinj = _pair(v)
+    gr, grx = np.linspace(0, 1, 1000), np.linspace(0.001, 1, 1000)
+    for tag, basis, g in (("bspline", I.BSpline(20, normalize=True), gr), ("logy", I.LogYBSpline(20, normalize=True), gr), ("logx", I.LogXBSpline(20, normalize=True), grx),
+                          ("logxy", I.LogXLogYBSpline(20, xrange=(0.001, 1), normalize=True), grx)):
+        dm = basis.bases(g)
+        mk = lambda: D.BSplineDistribution(g[0], g[-1], cs, g, dm)  # noqa: E731
+        d_pe, d_inj = mk().log_prob(vpe), mk().log_prob(vinj)
+        lpe, linj = _logw(d_pe, d_inj, d_pe)
+        check(linj, terms[f"dist/bspline/{tag}"])
+        check(lpe.ravel(), terms[f"dist/bspline/{tag}"])
+
+
+def test_bspline_distribution_grid_reaching_outside_a_log_y_basis():
+    """A grid that starts below the domain of a log-Y basis (the default LogXLogYBSpline(20) on a grid from 0.001,
+    tests/numpyro_distributions_test.py:126-129): those grid points carry lpdf = -inf, so samples interpolating
+    into them have zero weight, the others follow the NumPy statement of the same table (tests/bound_eval.py)."""
+    from bound_eval import log_weights
+
+    from gwinferno_amd import interpolation as I
+    from gwinferno_amd import numpyro_distributions as D
+    from gwinferno_amd.engine import NativePopulationLikelihood
+
+    rng = np.random.default_rng(5)
+    g = np.linspace(0.001, 1, 1000)
+    dm = I.LogXLogYBSpline(20, normalize=True).bases(g)  # domain (0.1, 1)
+    cs = rng.normal(size=20)
+    v = rng.uniform(0.0, 1.05, 4096)
+    vpe, vinj = _pair(v)
+    mk = lambda: D.BSplineDistribution(0.001, 1.0, cs, g, dm)  # noqa: E731
+    d_pe, d_inj = mk().log_prob(vpe), mk().log_prob(vinj)
+    eng = NativePopulationLikelihood(d_pe, d_inj)
+    th = eng.bound.theta_of(d_pe)
+    lpe, linj = eng.log_weights(th)
+    rpe, rinj, _ = log_weights(eng.bound, th)
+    eng.close()
+    assert np.isneginf(linj).sum() > 300 and np.isfinite(linj).sum() > 3000
+    for got, ref in ((lpe, rpe), (linj, rinj)):
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+        ok = np.isfinite(ref)
+        assert np.max(np.abs(got[ok] - ref[ok])) < 1e-11
+    below = vinj < 0.1 - (g[1] - g[0])
+    assert np.all(np.isneginf(linj[below]))

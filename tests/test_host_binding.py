@@ -35,7 +35,7 @@ def test_bound_model_reproduces_reference_weights(name):
     ok = np.isfinite(ref_inj)
     assert np.max(np.abs(linj[ok] - ref_inj[ok])) < 2e-12
     # surveyed hypervolume = Z of the designated normaliser / 1e9 * Tobs (analysis.py:267)
-    assert rel_err(norms[bm.vt_norm] / 1e9 * case.tobs, case.sites["lin"]["surveyed_hypervolume"][0]) < 1e-12
+    assert rel_err(norms[bm.vt_norm] / 1e9 * case.tobs, case.sites[next(iter(case.flagsets))]["surveyed_hypervolume"][0]) < 1e-12
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -102,3 +102,53 @@ def test_named_theta_roundtrip():
     assert np.array_equal(th, bm.theta_of(comp.weights(case.point(1), True)))
     g = comp.named_gradient(np.arange(len(th), dtype=float))
     assert set(g) == set(comp.PARAMS) and g["m1_coefs"].shape == (30,)
+
+
+def test_distribution_log_prob_faces_bind_to_the_reference_values():
+    """gwinferno_amd.numpyro_distributions: what the host hands to the engine for Powerlaw (bounds as
+    hyper-parameters), PowerlawRedshift and BSplineDistribution reproduces the reference's log_prob arrays
+    (tests/golden/terms.npz, dist/*) -- static fractional grid indices, grid tables, normalisers."""
+    import os
+
+    from bound_eval import log_weights
+    from golden_util import GOLDEN_DIR
+
+    from gwinferno_amd import interpolation as I
+    from gwinferno_amd import numpyro_distributions as D
+    from gwinferno_amd.engine import bind
+
+    z = np.load(os.path.join(GOLDEN_DIR, "terms.npz"))
+
+    def both(make, pe_x, inj_x):
+        wp, wi = make().log_prob(pe_x), make().log_prob(inj_x)  # a new distribution object per call, as analysis.py:381-399
+        bm = bind(wp, wi)
+        return log_weights(bm, bm.theta_of(wp))
+
+    def check(got, ref):
+        dead = ref < -1e300  # nan_to_num(-inf)
+        assert np.array_equal(np.isneginf(got), dead)
+        assert np.max(np.abs(got[~dead] - ref[~dead])) < 1e-11
+
+    x = z["m1"]
+    for tag, a in zip(("a", "b", "neg1", "zero"), z["powerlaw_alphas"]):
+        lpe, linj, _ = both(lambda: D.Powerlaw(a, 5.0, 100.0), x.reshape(4, -1), x)
+        check(linj, z[f"dist/powerlaw/{tag}"])
+        check(lpe.ravel(), z[f"dist/powerlaw/{tag}"])
+    zg, dv, zinj = z["dist/z_grid"], z["dist/z_dVcdz"], z["z_inj"]
+    for i, lamb in enumerate(z["z_lamb"]):
+        lpe, linj, norms = both(lambda: D.PowerlawRedshift(lamb, float(z["dist/powerlaw_redshift/maximum"]), zg, dv), zinj.reshape(4, -1), zinj)
+        check(linj, z["dist/powerlaw_redshift/inj"][i])
+        assert abs(norms[0] / z["dist/powerlaw_redshift/norm"][i] - 1) < 1e-13
+    v, cs = z["dist/bspline/value"], z["dist/bspline/cs"]
+    gr, grx = np.linspace(0, 1, 1000), np.linspace(0.001, 1, 1000)
+    for tag, basis, g in (("bspline", I.BSpline(20, normalize=True), gr), ("logy", I.LogYBSpline(20, normalize=True), gr), ("logx", I.LogXBSpline(20, normalize=True), grx),
+                          ("logxy", I.LogXLogYBSpline(20, xrange=(0.001, 1), normalize=True), grx)):
+        dm = basis.bases(g)
+        lpe, linj, norms = both(lambda: D.BSplineDistribution(g[0], g[-1], cs, g, dm), v.reshape(4, -1), v)
+        check(linj, z[f"dist/bspline/{tag}"])
+        check(lpe.ravel(), z[f"dist/bspline/{tag}"])
+        assert abs(norms[0] / z[f"dist/bspline/{tag}_norm"] - 1) < 1e-13
+    with pytest.raises(TypeError):
+        D.BSplineDistribution(0.0, 1.0, cs, gr, np.asarray(I.BSpline(20).bases(gr)))  # a bare matrix: origin unknown
+    with pytest.raises(ValueError):
+        D.BSplineDistribution(0.0, 1.0, cs, grx, I.BSpline(20).bases(gr))

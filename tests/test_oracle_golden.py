@@ -149,3 +149,21 @@ def test_fd_gradient_reproduces(name):
     g = O.fd_gradient(comp, case.point(0), case.total_inj, log=False, min_neff_cut=False)
     for k, ref in case.fdgrad[0].items():
         assert np.allclose(g[k], ref, rtol=1e-7, atol=1e-8), k
+
+
+def test_numpyro_distribution_log_probs():
+    """Powerlaw / PowerlawRedshift / BSplineDistribution .log_prob (numpyro_distributions.py:127-136, 186-195,
+    296-301) against the reference's own outputs, boundary values and the alpha = -1 branch included."""
+    z = _load("terms.npz")
+    x = z["m1"]
+    for tag, a in zip(("a", "b", "neg1", "zero"), z["powerlaw_alphas"]):
+        assert rel_err(O.powerlaw_log_prob(x, a, 5.0, 100.0), z[f"dist/powerlaw/{tag}"]) < 1e-12
+    for i, lamb in enumerate(z["z_lamb"]):
+        d = O.PowerlawRedshiftDistribution(lamb, float(z["dist/powerlaw_redshift/maximum"]), z["dist/z_grid"], z["dist/z_dVcdz"])
+        assert rel_err(d.norm, z["dist/powerlaw_redshift/norm"][i]) < 1e-13
+        assert rel_err(d.log_prob(z["z_inj"]), z["dist/powerlaw_redshift/inj"][i]) < 1e-11
+    gr, grx = np.linspace(0, 1, 1000), np.linspace(0.001, 1, 1000)
+    for tag, kind, xr, g in (("bspline", "B", (0, 1), gr), ("logy", "logY", (0, 1), gr), ("logx", "logX", (0.01, 1), grx), ("logxy", "logXlogY", (0.001, 1), grx)):
+        d = O.BSplineDistribution(z["dist/bspline/cs"], g, O.SplineBasis(kind, 20, xr, True).design(g))
+        assert rel_err(d.norm, z[f"dist/bspline/{tag}_norm"]) < 1e-13
+        assert np.max(np.abs(d.log_prob(z["dist/bspline/value"]) - z[f"dist/bspline/{tag}"])) < 1e-12
