@@ -45,7 +45,7 @@ class Composition:
         uniquely coded parameter values through the model function."""
         if self._slices is None:
             eng = self.engine()
-            coded, code = {}, 1.0
+            coded, code = {}, 1048576.015625  # codes no fixed model constant (0.02, 1.0, ...) can collide with; exact in binary
             lookup = {}
             for name, shape in self.PARAMS.items():
                 size = int(np.prod(shape)) if shape else 1

@@ -28,10 +28,10 @@ def _wide(name, p, rng):
             p[k] = float(rng.uniform(0.05, 6.0))
         elif k == "delta":
             p[k] = float(rng.uniform(0.1, 30.0))
-        elif k == "mmin":  # truncation bounds as hyper-parameters: anywhere in the data, also excluding most of it
-            p[k] = float(rng.uniform(1.0, 30.0))
+        elif k == "mmin":  # truncation bounds as hyper-parameters: cutting into the data from both ends
+            p[k] = float(rng.uniform(1.0, 12.0))
         elif k == "mmax":
-            p[k] = float(rng.uniform(35.0, 130.0))
+            p[k] = float(rng.uniform(60.0, 130.0))
     if name == "bspline_redshift":  # exponent coefficients are c / (c . I): keep the denominator away from 0
         p["z_coefs"] = np.abs(p["z_coefs"]) + 0.05
     if "e_coefs" in p:  # linear (density) splines need positive coefficients
@@ -55,8 +55,12 @@ def test_randomised_parity_against_c_oracle(name):
     n_finite = 0
     for i in range(N_POINTS):
         p = draw_params(name, rng)
+        if name == "chm_powerlaw":  # bounds that cut samples off but leave every event some: the catalog's events span m1 ~ 8 .. 80
+            p["mmin"], p["mmax"] = float(rng.uniform(1.0, 6.5)), float(rng.uniform(88.0, 130.0))
         if i >= N_POINTS // 3:
             p = _wide(name, p, rng)
+        if name == "chm_powerlaw" and i % 2:
+            p["mmin"], p["mmax"] = float(rng.uniform(1.0, 6.5)), float(rng.uniform(88.0, 130.0))
         th = comp.theta(p)
         got = eng.evaluate(th, total, min_neff_cut=False)
         ref = orc.evaluate(th, total, min_neff_cut=False)
