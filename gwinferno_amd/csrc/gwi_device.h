@@ -1294,7 +1294,11 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   extern __shared__ double s_gacc[];
   __shared__ double s_theta[GWI_MAX_THETA];
   __shared__ double s_out[GWI_MAX_THETA];
-  __shared__ double s_red[kRedChunk][kBlock];
+  // spline models carry few scalar sums (their gradient lives in the s_gacc rows): a narrower staging
+  // area leaves the LDS to those rows (3 workgroups per CU still fit with 16 replicas per wave)
+  constexpr int kNVals = 2 + ChainT::kNumAcc;
+  constexpr int kChunk = ChainT::kSpline ? (kNVals < 4 ? kNVals : 4) : kRedChunk;
+  __shared__ double s_red[kChunk][kBlock];
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef GWI_STAMPS
@@ -1463,14 +1467,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   for (int v = 2; v < kNV; ++v) vals[v] *= f;
   double* out = a.partials + ((long long)kb * (n_pe_blocks + a.n_inj_tiles) + b) * a.rec_stride;
 #pragma unroll
-  for (int v0 = 0; v0 < kNV; v0 += kRedChunk) {
+  for (int v0 = 0; v0 < kNV; v0 += kChunk) {
     if (v0 > 0) __syncthreads();
 #pragma unroll
-    for (int v = v0; v < kNV && v < v0 + kRedChunk; ++v) s_red[v - v0][tid] = vals[v];
+    for (int v = v0; v < kNV && v < v0 + kChunk; ++v) s_red[v - v0][tid] = vals[v];
     __syncthreads();
     // wave w reduces values v0 + w, v0 + w + 4, ...: 4 strided reads (fixed order) + one DPP sum
 #pragma unroll
-    for (int v = v0; v < kNV && v < v0 + kRedChunk; ++v) {
+    for (int v = v0; v < kNV && v < v0 + kChunk; ++v) {
       if (((v - v0) & (kWaves - 1)) != wave) continue;  // wave-uniform
       const double* row = s_red[v - v0];
       const double r = wave_sum((row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]));

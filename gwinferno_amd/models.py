@@ -247,9 +247,9 @@ class Base1DBSplineModel(object):
     def __init__(self, n_splines, xx, xx_inj, xrange=(0.0, 1.0), degree=3, basis=BSpline, **kwargs):
         if degree != 3:
             raise NotImplementedError("only cubic splines are implemented")
-        if basis not in (LogYBSpline, LogXLogYBSpline, BSpline):
-            raise NotImplementedError(f"basis {getattr(basis, '__name__', basis)} is not implemented for 1-D density models (BSpline / LogYBSpline / LogXLogYBSpline are)")
-        self._linear = basis is BSpline
+        if basis not in (LogYBSpline, LogXLogYBSpline, BSpline, LogXBSpline):
+            raise NotImplementedError(f"basis {getattr(basis, '__name__', basis)} is not implemented for 1-D density models (the four cubic B-spline bases of interpolation.py are)")
+        self._linear = basis in (BSpline, LogXBSpline)  # linear-Y: the density is the spline itself
         self.n_splines = int(n_splines)
         self.xmin, self.xmax = xrange
         self.degree = degree

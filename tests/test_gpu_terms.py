@@ -119,14 +119,15 @@ def test_redshift_model(terms):
 
 
 def test_spline_projection_against_design_matrix():
-    """exp-spline density at the golden sample points == the reference's dense projection
-    (interpolation.py:306-317) for the LogY / LogXLogY bases, incl. domain ends and nextafter points."""
+    """Spline density at the golden sample points == the reference's dense projection (interpolation.py:306-317)
+    for all four bases -- exp-splines (LogY / LogXLogY) and linear ones (BSpline / LogXBSpline, where a
+    non-positive spline value counts as zero density) -- incl. domain ends and nextafter points."""
     from gwinferno_amd import models as M
-    from gwinferno_amd.interpolation import LogXLogYBSpline, LogYBSpline
+    from gwinferno_amd.interpolation import BSpline, LogXBSpline, LogXLogYBSpline, LogYBSpline
 
     z = np.load(os.path.join(GOLDEN_DIR, "bases.npz"))
     meta = json.loads(str(z["meta"]))
-    cls = {"LogYBSpline": LogYBSpline, "LogXLogYBSpline": LogXLogYBSpline}
+    cls = {"LogYBSpline": LogYBSpline, "LogXLogYBSpline": LogXLogYBSpline, "BSpline": BSpline, "LogXBSpline": LogXBSpline}
     n_checked = 0
     for i, m in enumerate(meta):
         if m["cls"] not in cls:
@@ -135,11 +136,16 @@ def test_spline_projection_against_design_matrix():
         xp, xi = _pair(xs)
         model = M.Base1DBSplineModel(m["n"], xp, xi, xrange=tuple(m["xrange"]), basis=cls[m["cls"]], normalize=True)
         cs = z[f"{i}/coefs"]
+        if not cls[m["cls"]].log_y and z[f"{i}/norm"] < 0:
+            # random coefficients of either sign can make the integral of a LINEAR spline negative; the reference's
+            # f / Z is then positive where f < 0.  -c describes the same normalised density with f, Z > 0, the
+            # only case the engine defines (a non-positive spline value is zero density)
+            cs = -cs
         d_pe, d_inj = model(cs, pe_samples=True), model(cs, pe_samples=False)
         lpe, linj = _logw(d_pe, d_inj, d_pe)
         _check(linj, z[f"{i}/project"], tol=1e-10)
         n_checked += 1
-    assert n_checked == 6
+    assert n_checked == 9
 
 
 def test_numpyro_distribution_log_probs(terms):
