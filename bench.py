@@ -372,6 +372,21 @@ def main():
             for w in workers:
                 w.join()
             out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
+            # the same engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain
+            # per engine and host thread, flat priors wide enough not to matter; trees capped at 2^6 leapfrogs so that the
+            # line stays within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second
+            # as a sampler sees them (every leapfrog = one value + gradient)
+            from gwinferno_amd.sampling import GaussianSmoothingPrior, nuts_engine
+
+            prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), 10.0)
+            starts = np.stack(thetas[:C])
+            kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
+            nuts_engine(all_engines, total, prior, None, starts, n_warmup=5, n_samples=5, **kw)
+            t0 = time.perf_counter()
+            res = nuts_engine(all_engines, total, prior, None, starts, n_warmup=60, n_samples=60, **kw)
+            dt = time.perf_counter() - t0
+            n_lf = sum(r["n_evals"] for r in res)
+            out["native_nuts"] = {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf}
             for c in extra:
                 c.engine().close()
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
