@@ -1311,6 +1311,33 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
   return GWI_OK;
 }
 
+// A given trajectory of hyper-parameter points, one blocking evaluation after the other (what a sampler's
+// leapfrog loop does between two of its own few flops), without a host-language binding in the loop.
+gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* log_likelihoods, double* grads, int32_t timing_every,
+                             float* kernel_ms) {
+  if (!h || !thetas || !opt || n < 1 || !log_likelihoods) return GWI_ERR_INVALID;
+  const int nt = h->spec.n_theta;
+  std::vector<double> scratch(grads ? 0 : nt);
+  const bool was_timing = h->timing;
+  gwi_summary s;
+  for (int i = 0; i < n; ++i) {
+    const bool timed = kernel_ms && timing_every > 0 && (i % timing_every == 0);
+    h->timing = timed;
+    double* g = grads ? grads + (size_t)i * nt : scratch.data();
+    const double* th = thetas + (size_t)i * nt;
+    const gwi_status st = h->nccl_comm ? gwi_eval_sharded(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr) : gwi_eval(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr);
+    if (st != GWI_OK) {
+      h->timing = was_timing;
+      return st;
+    }
+    log_likelihoods[i] = s.log_likelihood;
+    if (kernel_ms)
+      for (int k = 0; k < 3; ++k) kernel_ms[(size_t)i * 3 + k] = timed ? h->last_ms[k] : -1.0f;
+  }
+  h->timing = was_timing;
+  return GWI_OK;
+}
+
 #ifdef GWI_HOST_PHASES
 extern "C" void gwi_debug_host_phases(double* out6) {
   for (int i = 0; i < 5; ++i) out6[i] = g_phase[i];

@@ -363,6 +363,20 @@ class NativePopulationLikelihood:
         return [EvalResult(log_likelihood=summ[k].log_likelihood, grad=grads[k] if want_grad else None, summary=summ[k], log_bfs=lb[k], log_neffs=ln[k], variances=lv[k],
                            norms=norms[k, :n_norms]) for k in range(K)]
 
+    def evaluate_sequence(self, thetas, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, timing_every=0):
+        """``len(thetas)`` sequential blocking evaluations in one library call (``gwi_eval_sequence``): the loop a
+        sampler runs, without Python between two evaluations.  Returns ``(log_likelihoods, grads[, kernel_ms])``."""
+        thetas = N.f64(np.atleast_2d(thetas))
+        n = thetas.shape[0]
+        if thetas.shape[1] != self.n_theta:
+            raise ValueError(f"thetas must be (n, {self.n_theta})")
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        ll, grads = np.empty(n), np.empty((n, self.n_theta))
+        kms = np.empty((n, 3), dtype=np.float32) if timing_every > 0 else None
+        self._check(self.lib.gwi_eval_sequence(self.handle, N.as_dp(thetas), n, C.byref(opt), N.as_dp(ll), N.as_dp(grads), int(timing_every),
+                                               kms.ctypes.data_as(C.POINTER(C.c_float)) if kms is not None else None))
+        return (ll, grads, kms) if kms is not None else (ll, grads)
+
     def configure(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
         """Fix the likelihood options once; :meth:`value_and_grad` then has the smallest possible
         per-call overhead (what a sampler's inner loop wants)."""

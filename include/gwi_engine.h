@@ -274,6 +274,14 @@ gwi_status gwi_set_timing(gwi_handle h, int32_t enabled);
  * mean seconds per evaluation; separates host-language overhead from launch + device time. */
 gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* opt, int32_t n_iter, double* seconds_per_eval);
 
+/* n sequential, blocking evaluations (value + gradient) at the given points thetas[n][n_theta] -- the inner loop of
+ * a sampler (examples/utils.py:63-85 runs it inside one XLA program) with no host-language binding between two
+ * evaluations; uses gwi_eval_sharded when gwi_comm_init has been called on the handle.  log_likelihoods[n];
+ * grads[n][n_theta] nullable.  kernel_ms[n][3] (nullable): launch durations [scan, combine, final] of every
+ * `timing_every`-th evaluation (event timing switched on for those only), -1 for the others. */
+gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* log_likelihoods, double* grads, int32_t timing_every,
+                             float* kernel_ms);
+
 const char* gwi_last_error(gwi_handle h);
 void gwi_destroy(gwi_handle h);
 

@@ -209,6 +209,12 @@ def test_in_engine_rccl_exchange_world1():
         assert rel_err(am.log_likelihood, bm_.log_likelihood) < 1e-14
         assert np.allclose(am.grad, bm_.grad, rtol=1e-11, atol=1e-12)
         assert np.max(np.abs(am.grad - a.grad)) > 0
+    # the in-library loop switches to the sharded entry once a communicator is attached (bench.py at N > 1)
+    ths = np.stack([comp.theta(draw_params("bspline_test", rng)) for _ in range(4)])
+    ll, grads = eng.evaluate_sequence(ths, total, min_neff_cut=False)
+    for i, th in enumerate(ths):
+        b = eng.evaluate_sharded(th, total, min_neff_cut=False)
+        assert b.log_likelihood == ll[i] and np.array_equal(b.grad, grads[i])
     eng.close()
 
 
@@ -447,3 +453,26 @@ def test_engines_in_concurrent_host_threads():
     assert not errors, errors[:3]
     for e in engs:
         e.close()
+
+
+def test_eval_sequence_equals_one_by_one():
+    """gwi_eval_sequence (the sampler's loop inside the library) returns, point by point, exactly what gwi_eval
+    returns; kernel timings come back for every `timing_every`-th point only."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 300, 3000, seed=21)
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = comp.engine()
+    rng = np.random.default_rng(2)
+    thetas = np.stack([comp.theta(draw_params("plpeak", rng)) for _ in range(12)])
+    ll, grads, kms = eng.evaluate_sequence(thetas, total, min_neff_cut=False, timing_every=5)
+    for i, th in enumerate(thetas):
+        r = eng.evaluate(th, total, min_neff_cut=False)
+        assert r.log_likelihood == ll[i] and np.array_equal(r.grad, grads[i])
+    assert np.all(kms[[0, 5, 10], 0] > 0) and np.all(kms[[1, 2, 3, 4, 6, 11]] == -1)
+    ll2, grads2 = eng.evaluate_sequence(thetas, total, min_neff_cut=False)
+    assert np.array_equal(ll, ll2) and np.array_equal(grads, grads2)
+    with pytest.raises(ValueError):
+        eng.evaluate_sequence(thetas[:, :-1], total)
+    eng.close()
