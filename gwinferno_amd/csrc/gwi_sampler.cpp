@@ -297,9 +297,11 @@ int engine_target(void* user, const double* u, double* logp, double* grad) {
       e.dlogj[i] = 0.0;
     }
   }
-  gwi_summary s;
-  if (gwi_eval(e.h, e.theta.data(), &e.lopt, &s, e.grad_ll.data(), nullptr, nullptr, nullptr, nullptr) != GWI_OK) return 1;
-  double lp = s.log_likelihood + logj;
+  // one blocking evaluation; the sequence entry picks gwi_eval_sharded when the handle carries a communicator
+  // (every rank then runs the same chain from the same seed: the exchanged records make the bits identical)
+  double ll = 0.0;
+  if (gwi_eval_sequence(e.h, e.theta.data(), 1, &e.lopt, &ll, e.grad_ll.data(), 0, nullptr) != GWI_OK) return 1;
+  double lp = ll + logj;
   for (int i = 0; i < n; ++i) {
     double g = e.grad_ll[i];
     const double sg = e.priors[i].sigma;

@@ -55,7 +55,9 @@ typedef struct {
 /* n_chains chains, chain c on engine handles[c] (its own stream, buffers and catalog copy) in a host thread of its
  * own; target = log-likelihood (gwi_eval with *lopt) + priors + penalties + log-Jacobian, sampled in unconstrained
  * coordinates from u0[c][n_theta].  samples[c][n_samples][n_theta] are returned in CONSTRAINED coordinates;
- * log_prob / tree_depth [c][n_samples] and results[c] are nullable.  Chain c uses seed opt->seed + 1000 c. */
+ * log_prob / tree_depth [c][n_samples] and results[c] are nullable.  Chain c uses seed opt->seed + 1000 c.
+ * A handle with a communicator (gwi_comm_init) is evaluated with gwi_eval_sharded: call this on every rank with
+ * the same arguments (one chain per process) -- all ranks then walk the same trajectory, bit for bit. */
 gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors,
                            const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt, double* samples, double* log_prob,
                            int32_t* tree_depth, gwi_nuts_result* results);

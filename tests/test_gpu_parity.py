@@ -215,6 +215,12 @@ def test_in_engine_rccl_exchange_world1():
     for i, th in enumerate(ths):
         b = eng.evaluate_sharded(th, total, min_neff_cut=False)
         assert b.log_likelihood == ll[i] and np.array_equal(b.grad, grads[i])
+    # ... and so does the library's sampler: a short chain on the sharded handle moves and stays finite
+    from gwinferno_amd.sampling import GaussianSmoothingPrior, nuts_engine
+
+    prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), 3.0)
+    (out,) = nuts_engine([eng], total, prior, None, [ths[0]], n_warmup=15, n_samples=10, max_tree_depth=4, seed=3, min_neff_cut=False)
+    assert np.all(np.isfinite(out["samples"])) and np.std(out["samples"], axis=0).min() > 0 and out["n_evals"] > 25
     eng.close()
 
 
