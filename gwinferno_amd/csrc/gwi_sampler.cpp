@@ -171,6 +171,8 @@ int run_nuts(Target& t, const double* x0, const gwi_nuts_options& o, double* sam
   cur.p.assign(d, 0.0);
   cur.g.assign(d, 0.0);
   cur.lp = t(cur.th, cur.g);
+  if (t.failed) return 1;
+  if (!usable(cur.lp, cur.g)) return 2;  // zero likelihood (a cut, or outside the support) or a non-finite gradient at the start
   double eps = s.find_step_size(cur, 0.1);
   double mu = std::log(10 * eps), log_eps_bar = 0.0, h_bar = 0.0;
   const double gamma = 0.05, t0 = 10.0, kappa = 0.75;
@@ -344,7 +346,8 @@ gwi_status gwi_nuts_run(gwi_target_fn fn, void* user, int32_t dim, const double*
                         gwi_nuts_result* result) {
   if (!fn || dim < 1 || !x0 || !opt || !samples || opt->n_warmup < 0 || opt->n_samples < 0) return GWI_ERR_INVALID;
   Target t{fn, user, dim};
-  return run_nuts(t, x0, *opt, samples, logp, tree_depth, result) == 0 ? GWI_OK : GWI_ERR_HIP;
+  const int rc = run_nuts(t, x0, *opt, samples, logp, tree_depth, result);
+  return rc == 0 ? GWI_OK : (rc == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP);
 }
 
 gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors, const gwi_smoothing_penalty* pens,
@@ -361,7 +364,7 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
     const size_t ns = (size_t)opt->n_samples;
     double* out = samples + (size_t)c * ns * n_theta;
     rc[c] = run_nuts(t, u0 + (size_t)c * n_theta, o, out, logp ? logp + (size_t)c * ns : nullptr, tree_depth ? tree_depth + (size_t)c * ns : nullptr, results ? results + c : nullptr);
-    for (size_t k = 0; k < ns; ++k)  // unconstrained draws -> constrained hyper-parameters
+    for (size_t k = 0; k < ns && rc[c] == 0; ++k)  // unconstrained draws -> constrained hyper-parameters
       for (int i = 0; i < n_theta; ++i) {
         double& v = out[k * n_theta + i];
         if (priors[i].kind == GWI_BIJECT_INTERVAL)
@@ -378,7 +381,7 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
     for (auto& w : workers) w.join();
   }
   for (int c = 0; c < n_chains; ++c)
-    if (rc[c] != 0) return GWI_ERR_HIP;
+    if (rc[c] != 0) return rc[c] == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;
   return GWI_OK;
 }
 

@@ -419,6 +419,8 @@ def nuts_native(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, 
     st = lib.gwi_nuts_run(N.GWI_TARGET_FN(cb), None, d, N.as_dp(theta0), C.byref(opt), N.as_dp(samples), N.as_dp(logp), depth.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res))
     if err:
         raise err[0]
+    if st == -1:
+        raise ValueError("gwi_nuts_run: the starting point has zero probability or a non-finite gradient")
     if st != 0:
         raise N.NativeEngineError(f"gwi_nuts_run: {N.STATUS_NAMES.get(st, st)}")
     out = _result_dict(res)
@@ -466,6 +468,8 @@ def nuts_engine(engines, total_inj, prior, bijector, theta0s, n_warmup=200, n_sa
     opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
     st = lib.gwi_nuts_engine(handles, n_chains, n_theta, C.byref(lopt), pri, pens, len(prior.penalties), N.as_dp(u0), C.byref(opt), N.as_dp(samples), N.as_dp(logp),
                              depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    if st == -1:
+        raise ValueError("gwi_nuts_engine: a chain's starting point has zero likelihood (a cut, or outside the model's support) or a non-finite gradient")
     if st != 0:
         msgs = "; ".join(lib.gwi_last_error(e.handle).decode() for e in engines)
         raise N.NativeEngineError(f"gwi_nuts_engine: {N.STATUS_NAMES.get(st, st)}: {msgs}")

@@ -31,7 +31,10 @@ typedef struct {
   int32_t n_divergent, reserved; /* divergent transitions after warm-up */
 } gwi_nuts_result;
 
-/* One chain on an arbitrary target.  samples[n_samples][dim], log_prob[n_samples] and tree_depth[n_samples]
+/* Status: GWI_ERR_INVALID also when a chain's starting point has zero probability (log-probability -inf, NaN or the
+ * nan_to_num(-inf) value a likelihood cut returns) or a non-finite gradient; GWI_ERR_HIP when the target failed.
+ *
+ * One chain on an arbitrary target.  samples[n_samples][dim], log_prob[n_samples] and tree_depth[n_samples]
  * (the last two nullable) receive the post-warm-up draws. */
 gwi_status gwi_nuts_run(gwi_target_fn fn, void* user, int32_t dim, const double* x0, const gwi_nuts_options* opt, double* samples, double* log_prob,
                         int32_t* tree_depth, gwi_nuts_result* result);

@@ -143,3 +143,16 @@ def test_native_nuts_survives_a_wall_and_matches_the_numpy_sampler_statistically
     assert np.all(np.abs(out["samples"].mean(0)) < 0.2)
     # same target, independent streams: second moments agree within Monte-Carlo error
     assert np.all(np.abs(out["samples"].var(0) - ref["samples"].var(0)) < 0.2)
+
+
+def test_native_nuts_refuses_a_dead_starting_point():
+    from gwinferno_amd.sampling import nuts_native
+
+    def target(x):
+        if x[0] > 1.0:
+            return -1.7976931348623157e308, np.zeros_like(x)
+        return -0.5 * float(x @ x), -x
+
+    with pytest.raises(ValueError):
+        nuts_native(target, np.array([2.0, 0.0]), n_warmup=5, n_samples=5)
+    assert nuts_native(target, np.array([0.5, 0.0]), n_warmup=20, n_samples=20)["samples"].shape == (20, 2)
