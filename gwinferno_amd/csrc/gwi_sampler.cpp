@@ -293,6 +293,11 @@ int engine_target(void* user, const double* u, double* logp, double* grad) {
       e.dth[i] = e.theta[i];
       e.dlogj[i] = 1.0;
       logj += u[i];
+    } else if (pr.kind == GWI_BIJECT_FIXED) {  // pinned parameter; its coordinate is an independent N(0,1) dummy
+      e.theta[i] = pr.lo;
+      e.dth[i] = 0.0;
+      e.dlogj[i] = -u[i];
+      logj += -0.5 * u[i] * u[i];
     } else {
       e.theta[i] = u[i];
       e.dth[i] = 1.0;
@@ -371,6 +376,8 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
           v = priors[i].lo + (priors[i].hi - priors[i].lo) / (1.0 + std::exp(-v));
         else if (priors[i].kind == GWI_BIJECT_POSITIVE)
           v = std::exp(v);
+        else if (priors[i].kind == GWI_BIJECT_FIXED)
+          v = priors[i].lo;
       }
   };
   if (n_chains == 1) {

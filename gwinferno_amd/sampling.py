@@ -70,21 +70,28 @@ class Bijector:
         self.kind[idx] = 2
         return self
 
+    def fixed(self, idx, value):
+        """theta[idx] is pinned to ``value`` (e.g. the first redshift-spline coefficient, pipeline/utils.py:213-214).
+        The sampler's coordinate for it is an independent standard-normal dummy: log|J| stands in for its density."""
+        self.kind[idx], self.lo[idx] = 3, value
+        return self
+
     def forward(self, u):
         """theta, d theta/d u, d log|J| / d u, log|J|"""
         sig = 1.0 / (1.0 + np.exp(-u))
         width = self.hi - self.lo
-        theta = np.where(self.kind == 1, self.lo + width * sig, np.where(self.kind == 2, np.exp(u), u))
-        dth = np.where(self.kind == 1, width * sig * (1 - sig), np.where(self.kind == 2, np.exp(u), 1.0))
+        k = self.kind
+        theta = np.where(k == 1, self.lo + width * sig, np.where(k == 2, np.exp(u), np.where(k == 3, self.lo, u)))
+        dth = np.where(k == 1, width * sig * (1 - sig), np.where(k == 2, np.exp(u), np.where(k == 3, 0.0, 1.0)))
         with np.errstate(divide="ignore"):
-            logj = np.where(self.kind == 1, np.log(width * sig * (1 - sig)), np.where(self.kind == 2, u, 0.0))
-        dlogj = np.where(self.kind == 1, 1 - 2 * sig, np.where(self.kind == 2, 1.0, 0.0))
+            logj = np.where(k == 1, np.log(width * sig * (1 - sig)), np.where(k == 2, u, np.where(k == 3, -0.5 * u * u, 0.0)))
+        dlogj = np.where(k == 1, 1 - 2 * sig, np.where(k == 2, 1.0, np.where(k == 3, -u, 0.0)))
         return theta, dth, dlogj, float(np.sum(logj))
 
     def inverse(self, theta):
         with np.errstate(all="ignore"):
             x = (theta - self.lo) / (self.hi - self.lo)
-            return np.where(self.kind == 1, np.log(x / (1 - x)), np.where(self.kind == 2, np.log(theta), theta))
+            return np.where(self.kind == 1, np.log(x / (1 - x)), np.where(self.kind == 2, np.log(theta), np.where(self.kind == 3, 0.0, theta)))
 
 
 def make_target(engine, total_inj, prior, bijector=None, **likelihood_flags):

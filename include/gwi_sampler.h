@@ -41,7 +41,12 @@ gwi_status gwi_nuts_run(gwi_target_fn fn, void* user, int32_t dim, const double*
 
 /* Change of variables per hyper-parameter (what numpyro's biject_to(support) does for Uniform / HalfNormal sites,
  * e.g. examples/simple_powerlaw_peak_example.py:52-77) and an optional Normal(0, sigma) prior on its constrained value. */
-enum { GWI_BIJECT_IDENTITY = 0, GWI_BIJECT_INTERVAL = 1 /* (lo, hi) via the logistic map */, GWI_BIJECT_POSITIVE = 2 /* exp */ };
+enum {
+  GWI_BIJECT_IDENTITY = 0,
+  GWI_BIJECT_INTERVAL = 1, /* (lo, hi) via the logistic map */
+  GWI_BIJECT_POSITIVE = 2, /* exp */
+  GWI_BIJECT_FIXED = 3     /* theta pinned to `lo` (pipeline/utils.py:213-214: z_cs[0] = 0); the coordinate is a N(0,1) dummy */
+};
 typedef struct {
   int32_t kind, reserved;
   double lo, hi;  /* GWI_BIJECT_INTERVAL */

@@ -826,6 +826,52 @@ def make_ppd_fixture():
     print(f"wrote ppd.npz: {os.path.getsize(path) // 1024} KiB")
 
 
+def make_pipeline_fixture():
+    """pipeline/utils.py:104-216 run as they are: the three prior helpers (sample sites injected, factor sites read
+    back) and the three model factories (per-sample weights of the product the reference's example forms,
+    examples/simple_bspline_example.py:60-71)."""
+    import importlib
+
+    U = importlib.import_module("gwinferno.pipeline.utils")
+    rng = np.random.default_rng(BASE_SEED + 300)
+    out = {}
+    ns = {"m1": 14, "q": 9, "a": 8, "ct": 7, "z": 6}
+    vals = {"mass_cs": rng.normal(size=ns["m1"]), "q_cs": rng.normal(size=ns["q"]), "a1_cs": rng.normal(size=ns["a"]), "a2_cs": rng.normal(size=ns["a"]),
+            "tilt1_cs": rng.normal(size=ns["ct"]), "tilt2_cs": rng.normal(size=ns["ct"]), "z_cs": rng.normal(size=ns["z"] - 1), "a_cs_tag": rng.normal(size=ns["a"]),
+            "tilt_cs_tag": rng.normal(size=ns["ct"])}
+    for k, v in vals.items():
+        numpyro.SAMPLE_VALUES[k] = jnp.asarray(v)
+        out[f"sample/{k}"] = v
+    numpyro.reset()
+    mass_cs, q_cs = U.bspline_mass_prior(m_nsplines=ns["m1"], q_nsplines=ns["q"], m_tau=1, q_tau=1)
+    a1_cs, t1_cs, a2_cs, t2_cs = U.bspline_spin_prior(a_nsplines=ns["a"], ct_nsplines=ns["ct"], a_tau=25, ct_tau=25, IID=False)
+    z_cs = U.bspline_redshift_prior(z_nsplines=ns["z"], z_tau=1)
+    U.bspline_spin_prior(a_nsplines=ns["a"], ct_nsplines=ns["ct"], a_tau=3.0, ct_tau=0.5, IID=True, name="tag", a_deg=1, ct_deg=3)
+    only_q = U.bspline_mass_prior(q_nsplines=ns["q"], q_tau=7.0, q_deg=2)
+    for k, v in numpyro.SITES.items():
+        out[f"factor/{k}"] = np.asarray(v, dtype=np.float64)
+    out["returned/z_cs"] = np.asarray(z_cs)
+    out["returned/only_q"] = np.asarray(only_q)
+    pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+    pej, injj = {k: jnp.asarray(v) for k, v in pe.items()}, {k: jnp.asarray(v) for k, v in inj.items()}
+    mass_models = U.setup_bspline_mass_models(pej, injj, ns["m1"], ns["q"], MMIN, MMAX)
+    mag_model, tilt_model = U.setup_bspline_spin_models(pej, injj, ns["a"], ns["ct"], IID=False, a2_nsplines=ns["a"], ct2_nsplines=ns["ct"])
+    z_model = U.setup_powerlaw_spline_redshift_model(pej, injj, ns["z"])
+    lamb = np.float64(2.2)
+    out["lamb"] = np.array(lamb)
+    for tag, d, flag in (("pe", pej, True), ("inj", injj, False)):
+        with np.errstate(all="ignore"):
+            w = (mass_models(mass_cs, q_cs, pe_samples=flag) * mag_model(a1_cs, a2_cs, pe_samples=flag) * tilt_model(t1_cs, t2_cs, pe_samples=flag)
+                 * z_model(d["redshift"], lamb, z_cs) / d["prior"])
+        out[f"factory/{tag}"] = np.asarray(w)
+    out["factory/hypervolume"] = np.array(float(z_model.normalization(lamb, z_cs)))
+    for k in vals:
+        numpyro.SAMPLE_VALUES.pop(k)
+    out["meta"] = np.array(json.dumps({"nsplines": ns, "catalog": [8, 64, 512, BASE_SEED + 11], "mmin": float(MMIN), "mmax": float(MMAX)}))
+    np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **out)
+    print("wrote pipeline.npz", {k: float(v) for k, v in out.items() if k.startswith("factor/")})
+
+
 def load_gwtc3(n_samples=64):
     """The reference's own PE tensor (tests/data/..., NetCDF-3 classic): 69 events x 9 params x
     1000 samples, big-endian float32 -> float64; first n_samples per event."""
@@ -839,9 +885,11 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "gwtc3", "catalog", "ppd"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "gwtc3", "catalog", "ppd", "pipeline"]
     if "ppd" in todo:
         make_ppd_fixture()
+    if "pipeline" in todo:
+        make_pipeline_fixture()
     if "catalog" in todo:
         make_catalog_fixture()
     if "terms" in todo:

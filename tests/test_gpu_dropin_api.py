@@ -323,3 +323,53 @@ def test_construct_hierarchical_model_matches_the_reference(name):
     with pytest.raises(NotImplementedError):
         L.construct_hierarchical_model(model_dict, prior_dict)(case.pe, case.inj, case.total_inj, case.nobs, case.tobs)  # the reference's default asks for the PPC draws
     L.clear_engine_cache()
+
+
+def test_pipeline_factories_and_example_priors_end_to_end():
+    """The reference's B-spline example (examples/simple_bspline_example.py:26-94) through this package: models from
+    the pipeline_utils factories (weights == the reference's, tests/golden/pipeline.npz), its priors handed to the
+    library's sampler (bspline_example_prior), the first redshift coefficient pinned to 0 through a FIXED slot."""
+    import json
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from test_pipeline_utils_cpu import _example_product
+
+    from gwinferno_amd import pipeline_utils as U
+    from gwinferno_amd.engine import NativePopulationLikelihood
+    from gwinferno_amd.sampling import make_target, nuts_engine, nuts_native
+
+    fx = np.load(os.path.join(GOLDEN_DIR, "pipeline.npz"))
+    wp, wi, hv = _example_product(fx)
+    eng = NativePopulationLikelihood(wp, wi, hv)
+    theta = eng.bound.theta_of(wp)
+    lpe, linj = eng.log_weights(theta)
+    for got, ref in ((lpe, fx["factory/pe"]), (linj, fx["factory/inj"])):
+        with np.errstate(all="ignore"):
+            rl = np.log(ref)
+        dead = ~(ref > 0)
+        assert np.array_equal(np.isneginf(got), dead) and np.max(np.abs(got[~dead] - rl[~dead])) < 1e-10
+    # theta layout: find each coefficient block by value
+    cs = {k[7:]: fx[k] for k in fx.files if k.startswith("sample/")}
+    z_full = np.concatenate([np.zeros(1), cs["z_cs"]])
+
+    def where(block):
+        for off in range(eng.n_theta - len(block) + 1):
+            if np.array_equal(theta[off : off + len(block)], block):
+                return slice(off, off + len(block))
+        raise AssertionError("block not found")
+
+    slices = {"m1": where(cs["mass_cs"]), "q": where(cs["q_cs"]), "a1": where(cs["a1_cs"]), "a2": where(cs["a2_cs"]), "tilt1": where(cs["tilt1_cs"]), "tilt2": where(cs["tilt2_cs"]),
+              "redshift": where(z_full), "lamb": where(np.array([float(fx["lamb"])]))}
+    assert sum(s.stop - s.start for s in slices.values()) == eng.n_theta
+    prior, bij = U.bspline_example_prior(slices)
+    total = 20.0 * json.loads(str(fx["meta"]))["catalog"][2]
+    start = theta * 0.2  # a mild point: short trees
+    kw = dict(n_warmup=25, n_samples=15, seed=2, max_tree_depth=4)
+    (a,) = nuts_engine([eng], total, prior, bij, [start], min_neff_cut=False, **kw)
+    zi = slices["redshift"].start
+    assert np.all(a["samples"][:, zi] == 0.0) and np.std(np.delete(a["samples"], zi, axis=1), axis=0).min() > 0
+    b = nuts_native(make_target(eng, total, prior, bij, min_neff_cut=False), bij.inverse(start), **kw)
+    th_b = np.array([bij.forward(u)[0] for u in b["samples"]])
+    assert a["n_evals"] == b["n_evals"] and np.allclose(a["samples"], th_b, rtol=1e-8, atol=1e-10)
+    eng.close()
