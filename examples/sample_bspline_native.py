@@ -4,7 +4,10 @@ and mass ratio, independent B-spline spin magnitudes and tilts, power law x B-sp
 JAX / NumPyro: models from the reference's factories (gwinferno_amd.pipeline_utils = gwinferno/pipeline/utils.py:104-160),
 its priors (Normal + P-spline smoothing, z_cs[0] pinned to 0: pipeline/utils.py:163-216) handed to the library's C++
 NUTS, one chain per engine and host thread.
-    python examples/sample_bspline_native.py [n_events n_pe n_inj] [--chains C] [--warmup W] [--samples S]"""
+The likelihood keeps the reference's default cuts (min_neff_cut=True, analysis.py:272-303): on a small synthetic catalog
+the flexible model runs into the n_eff wall on most trajectories, which the sampler reports as divergences (as NumPyro
+does); `--no-neff-cut` lifts the cut (the setting of the reference's own inference tests, tests/inference_test.py:185).
+    python examples/sample_bspline_native.py [n_events n_pe n_inj] [--chains C] [--warmup W] [--samples S] [--no-neff-cut]"""
 import os
 import sys
 import time
@@ -64,7 +67,7 @@ prior, bij = U.bspline_example_prior(slices)  # m_tau = q_tau = z_tau = 1, a_tau
 starts = np.stack([theta0 + (0.02 * rng.normal(size=eng.n_theta) if c else 0.0) for c in range(n_chains)])
 starts[:, slices["redshift"].start] = 0.0
 t0 = time.perf_counter()
-res = nuts_engine(engines, total, prior, bij, starts, n_warmup=n_warm, n_samples=n_samp, seed=1, max_tree_depth=8)
+res = nuts_engine(engines, total, prior, bij, starts, n_warmup=n_warm, n_samples=n_samp, seed=1, max_tree_depth=8, min_neff_cut="--no-neff-cut" not in sys.argv)
 dt = time.perf_counter() - t0
 n_lf = sum(r["n_evals"] for r in res)
 print(f"{n_ev} events x {n_pe} PE samples, {n_inj} injections, {eng.n_theta} hyper-parameters; {n_chains} chain(s), {n_warm}+{n_samp} iterations: "
