@@ -973,8 +973,11 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (spb < gran) spb = gran;
   const long long n_pe_pad = ((n_pe + gran - 1) / gran) * gran;
   h->chunk_pe = (int)(spb < n_pe_pad ? spb : n_pe_pad);
-  h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
   h->chunk_inj = (int)spb;
+  // experiment knobs: exact tile sizes (the kernel takes any size; a trip covers samples_per_lane * 256 samples)
+  if (const char* env = std::getenv("GWI_PE_CHUNK")) h->chunk_pe = std::max(1, std::atoi(env));
+  if (const char* env = std::getenv("GWI_INJ_CHUNK")) h->chunk_inj = std::max(1, std::atoi(env));
+  h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
   h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
   h->rec_stride = kRecHeader + spec->n_theta;
