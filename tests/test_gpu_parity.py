@@ -151,7 +151,8 @@ def test_run_to_run_bit_stability():
     eng.close()
 
 
-def test_partial_records_combine_like_single_device():
+@pytest.mark.parametrize("comp_name", ["bspline_test", "chm_powerlaw", "chm_bspline"])
+def test_partial_records_combine_like_single_device(comp_name):
     """Two shards evaluated on the same GPU and combined == the unsharded evaluation (the
     multi-GPU path minus the RCCL exchange)."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
@@ -159,8 +160,10 @@ def test_partial_records_combine_like_single_device():
     from gwinferno_amd.synthetic import make_catalog
 
     pe, inj, total = make_catalog(9, 500, 3001, seed=21)
-    comp = COMPOSITIONS["bspline_test"](pe, inj)
-    p = draw_params("bspline_test", np.random.default_rng(4))
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    p = draw_params(comp_name, np.random.default_rng(4))
+    if comp_name == "chm_powerlaw":
+        p["mmin"], p["mmax"] = 4.0, 110.0  # truncation bounds that leave every event some samples
     full = comp.engine()
     th = comp.theta(p)
     ref = full.evaluate(th, total, min_neff_cut=False)
@@ -224,7 +227,7 @@ def test_in_engine_rccl_exchange_world1():
     eng.close()
 
 
-@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_test", "bspline_iid"])
+@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_test", "bspline_iid", "chm_powerlaw", "chm_bspline"])
 def test_batched_evaluation_matches_single(comp_name):
     """gwi_eval_batch (K points per launch, blockIdx.y = point) == K separate gwi_eval calls."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
