@@ -67,57 +67,52 @@ def _factor(site, value):
         PRIOR_FACTORS[site] = float(value)
 
 
+def _coefficient_block(site, n, sigma, tau, degree, factor_site, prepend_zero=False):
+    """One coefficient vector ~ Normal(0, sigma)^n with its difference penalty registered as a factor site."""
+    cs = _sample_normal(site, sigma, n)
+    if prepend_zero:  # the first redshift coefficient is not sampled (pipeline/utils.py:213-214)
+        if L._numpyro() is not None:
+            import jax.numpy as jnp
+
+            cs = jnp.concatenate([jnp.zeros(1), cs])
+        else:
+            cs = np.concatenate([np.zeros(1), cs])
+    _factor(factor_site, apply_difference_prior(cs, tau, degree=degree))
+    return cs
+
+
+def _suffix(name):
+    return "" if name is None else "_" + name
+
+
 def bspline_mass_prior(m_nsplines=None, q_nsplines=None, m_tau=1, q_tau=1, name=None, m_cs_sig=15, q_cs_sig=5, m_deg=1, q_deg=1):
-    """pipeline/utils.py:163-182."""
-    name = "_" + name if name is not None else ""
-    if m_nsplines is not None:
-        mass_cs = _sample_normal("mass_cs" + name, m_cs_sig, m_nsplines)
-        _factor("mass_smoothing_prior" + name, apply_difference_prior(mass_cs, m_tau, degree=m_deg))
-    if q_nsplines is not None:
-        q_cs = _sample_normal("q_cs" + name, q_cs_sig, q_nsplines)
-        _factor("q_smoothing_prior" + name, apply_difference_prior(q_cs, q_tau, degree=q_deg))
-    if m_nsplines is not None and q_nsplines is None:
-        return mass_cs
-    if m_nsplines is None and q_nsplines is not None:
-        return q_cs
+    """pipeline/utils.py:163-182: ``mass_cs`` and/or ``q_cs`` (sites ``mass_cs``, ``mass_smoothing_prior``, ``q_cs``,
+    ``q_smoothing_prior`` [+ ``_name``])."""
     if m_nsplines is None and q_nsplines is None:
         raise AssertionError("number of mass splines or q splines must be specified.")
-    return mass_cs, q_cs
+    sfx, out = _suffix(name), []
+    if m_nsplines is not None:
+        out.append(_coefficient_block("mass_cs" + sfx, m_nsplines, m_cs_sig, m_tau, m_deg, "mass_smoothing_prior" + sfx))
+    if q_nsplines is not None:
+        out.append(_coefficient_block("q_cs" + sfx, q_nsplines, q_cs_sig, q_tau, q_deg, "q_smoothing_prior" + sfx))
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def bspline_spin_prior(a_nsplines=None, ct_nsplines=None, a_tau=None, ct_tau=None, name=None, IID=False, a_cs_sig=5, ct_cs_sig=5, a_deg=2, ct_deg=2):
-    """pipeline/utils.py:185-208."""
-    name = "_" + name if name is not None else ""
-    if IID:
-        a_cs = _sample_normal("a_cs" + name, a_cs_sig, a_nsplines)
-        _factor("a_smoothing_prior" + name, apply_difference_prior(a_cs, a_tau, degree=a_deg))
-        ct_cs = _sample_normal("tilt_cs" + name, ct_cs_sig, ct_nsplines)
-        _factor("ct_smoothing_prior" + name, apply_difference_prior(ct_cs, ct_tau, degree=ct_deg))
-        return a_cs, ct_cs
-    a1_cs = _sample_normal("a1_cs" + name, a_cs_sig, a_nsplines)
-    _factor("a1_smoothing_prior" + name, apply_difference_prior(a1_cs, a_tau, degree=a_deg))
-    a2_cs = _sample_normal("a2_cs" + name, a_cs_sig, a_nsplines)
-    _factor("a2_smoothing_prior" + name, apply_difference_prior(a2_cs, a_tau, degree=a_deg))
-    ct1_cs = _sample_normal("tilt1_cs" + name, ct_cs_sig, ct_nsplines)
-    _factor("ct1_smoothing_prior" + name, apply_difference_prior(ct1_cs, ct_tau, degree=ct_deg))
-    ct2_cs = _sample_normal("tilt2_cs" + name, ct_cs_sig, ct_nsplines)
-    _factor("ct2_smoothing_prior" + name, apply_difference_prior(ct2_cs, ct_tau, degree=ct_deg))
-    return a1_cs, ct1_cs, a2_cs, ct2_cs
+    """pipeline/utils.py:185-208: ``(a_cs, tilt_cs)`` when IID, else ``(a1_cs, tilt1_cs, a2_cs, tilt2_cs)``; the sample
+    sites are visited in the reference's order (magnitudes first), which is what a seeded NumPyro run depends on."""
+    sfx = _suffix(name)
+    mags = [("a", "a")] if IID else [("a1", "a1"), ("a2", "a2")]
+    tilts = [("tilt", "ct")] if IID else [("tilt1", "ct1"), ("tilt2", "ct2")]
+    a = [_coefficient_block(f"{site}_cs{sfx}", a_nsplines, a_cs_sig, a_tau, a_deg, f"{fac}_smoothing_prior{sfx}") for site, fac in mags]
+    t = [_coefficient_block(f"{site}_cs{sfx}", ct_nsplines, ct_cs_sig, ct_tau, ct_deg, f"{fac}_smoothing_prior{sfx}") for site, fac in tilts]
+    return (a[0], t[0]) if IID else (a[0], t[0], a[1], t[1])
 
 
 def bspline_redshift_prior(z_nsplines=None, z_tau=None, name=None, z_cs_sig=1, z_deg=2):
-    """pipeline/utils.py:211-216: the first coefficient is pinned to 0."""
-    name = "_" + name if name is not None else ""
-    z_cs = _sample_normal("z_cs" + name, z_cs_sig, z_nsplines - 1)
-    npro = L._numpyro()
-    if npro is not None:
-        import jax.numpy as jnp
-
-        z_cs = jnp.concatenate([jnp.zeros(1), z_cs])
-    else:
-        z_cs = np.concatenate([np.zeros(1), z_cs])
-    _factor("z_smoothing_prior" + name, apply_difference_prior(z_cs, z_tau, degree=z_deg))
-    return z_cs
+    """pipeline/utils.py:211-216: ``z_nsplines - 1`` sampled coefficients behind a leading 0."""
+    sfx = _suffix(name)
+    return _coefficient_block("z_cs" + sfx, z_nsplines - 1, z_cs_sig, z_tau, z_deg, "z_smoothing_prior" + sfx, prepend_zero=True)
 
 
 def bspline_example_prior(slices, m_tau=1, q_tau=1, a_tau=25, ct_tau=25, z_tau=1, lamb_sigma=3.0):
