@@ -8,7 +8,7 @@ import numpy as np
 
 from gwinferno_amd import _native as N
 
-LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgwpop_oracle.so")
+LIB = os.environ.get("GWPOP_ORACLE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgwpop_oracle.so")  # the override: sanitizer builds
 
 
 def build():

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE (CPU): drives gwinferno_amd/csrc/gwi_sampler.cpp on its own under AddressSanitizer /
-// UndefinedBehaviorSanitizer / ThreadSanitizer builds (tests/test_sampler_sanitizers.py).  The engine entry the
+// UndefinedBehaviorSanitizer / ThreadSanitizer builds (tests/test_sanitizers_cpu.py).  The engine entry the
 // sampler calls, gwi_eval_sequence, is replaced here by a correlated-Gaussian log-likelihood so that no GPU and no
 // HIP runtime is involved: what is exercised is the sampler's own memory and thread behaviour -- tree building,
 // adaptation, bijectors, penalties, one host thread per chain.
