@@ -38,3 +38,30 @@ for i in range(n // 32):
     badb += int(np.sum(v != refb))
 dt = time.perf_counter() - t0
 print(f"{cfg}: {n // 32} batches of 16 in {dt:.1f} s ({(n // 32) * 16 / dt:.0f} evals/s), value mismatches: {badb}; single vs batched max rel diff {np.max(np.abs(refb - np.array(ref)) / np.abs(np.array(ref))):.2e}")
+
+# threaded: one engine per host thread, every thread its own in-library sequence; all results against the single-thread ones
+import threading  # noqa: E402
+
+C_THREADS = int(os.environ.get("SOAK_THREADS", "6"))
+comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C_THREADS)]
+engines = [c.engine() for c in comps]
+seq = np.concatenate([ths] * 64)  # 1024 points per call
+want = np.array(ref * 64)
+bad_t = [0] * C_THREADS
+calls = max(1, n // (1024 * 4))
+
+
+def work(k):
+    for _ in range(calls):
+        ll, g = engines[k].evaluate_sequence(seq, total, min_neff_cut=False)
+        bad_t[k] += int(np.sum(ll != want))
+
+
+t0 = time.perf_counter()
+workers = [threading.Thread(target=work, args=(k,)) for k in range(C_THREADS)]
+for w in workers:
+    w.start()
+for w in workers:
+    w.join()
+dt = time.perf_counter() - t0
+print(f"{cfg}: {C_THREADS} threads x {calls * 1024} evaluations in {dt:.1f} s ({C_THREADS * calls * 1024 / dt:.0f} evals/s aggregate), value mismatches per thread: {bad_t}")
