@@ -386,6 +386,37 @@ def make_async_target(engine, total_inj, prior, bijector=None, **likelihood_flag
     return begin, end
 
 
+def find_map(target, theta0, Niter=100, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
+    """MAP point of ``target(x) -> (log_prob, grad)`` by Adam ascent: what the reference's ``find_map``
+    (analysis.py:24-47: SVI with an AutoDelta guide, ``numpyro.optim.Adam(lr)``, ``Niter`` steps) does in the
+    sampler's unconstrained coordinates, started from ``theta0`` instead of the guide's random initial location.
+    Steps that land on a cut (the ``nan_to_num(-inf)`` value, zero gradient) or on a non-finite value are undone
+    and the step length halved.  Returns ``{"x", "log_prob", "trace"}`` with the best point visited."""
+    x = np.array(theta0, dtype=np.float64)
+    m, v = np.zeros_like(x), np.zeros_like(x)
+    lp, g = target(x)
+    if not (np.isfinite(lp) and lp > -1e300 and np.all(np.isfinite(g))):
+        raise ValueError("find_map: the starting point has zero probability or a non-finite gradient")
+    best = (float(lp), x.copy())
+    trace = [float(lp)]
+    for t in range(1, int(Niter) + 1):
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        step = lr * (m / (1 - b1**t)) / (np.sqrt(v / (1 - b2**t)) + eps)
+        for _ in range(30):
+            lp_new, g_new = target(x + step)
+            if np.isfinite(lp_new) and lp_new > -1e300 and np.all(np.isfinite(g_new)):
+                break
+            step = 0.5 * step
+        else:
+            break
+        x, lp, g = x + step, lp_new, g_new
+        trace.append(float(lp))
+        if lp > best[0]:
+            best = (float(lp), x.copy())
+    return {"x": best[1], "log_prob": best[0], "trace": np.array(trace)}
+
+
 # ---- the library's native sampler (include/gwi_sampler.h) ----
 def _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed):
     from . import _native as N

@@ -156,3 +156,22 @@ def test_native_nuts_refuses_a_dead_starting_point():
     with pytest.raises(ValueError):
         nuts_native(target, np.array([2.0, 0.0]), n_warmup=5, n_samples=5)
     assert nuts_native(target, np.array([0.5, 0.0]), n_warmup=20, n_samples=20)["samples"].shape == (20, 2)
+
+
+def test_find_map_climbs_to_the_mode_and_backs_off_a_wall():
+    from gwinferno_amd.sampling import find_map
+
+    target, mean, cov = _gaussian()
+    out = find_map(target, np.zeros(5), Niter=4000, lr=0.05)
+    sd = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(out["x"] - mean) < 0.05 * sd) and out["log_prob"] > -1e-2 and out["trace"][-1] > out["trace"][0]
+
+    def walled(x):  # the mode sits just inside a cut
+        if x[0] > 1.0:
+            return -1.7976931348623157e308, np.zeros_like(x)
+        return -0.5 * float((x[0] - 1.5) ** 2 + x[1] ** 2), np.array([-(x[0] - 1.5), -x[1]])
+
+    out = find_map(walled, np.array([0.0, 1.0]), Niter=600, lr=0.05)
+    assert 0.9 < out["x"][0] <= 1.0 and abs(out["x"][1]) < 0.1 and out["log_prob"] > -0.14  # stops at the wall, short of the (excluded) mode
+    with pytest.raises(ValueError):
+        find_map(walled, np.array([2.0, 0.0]))
