@@ -174,6 +174,7 @@ EXPORTED_SYMBOLS = [
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
+    "gwi_dispatch_info",
     "gwi_last_error",
     "gwi_destroy",
     "gwi_abi_version",
@@ -247,6 +248,8 @@ def load_library():
     lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.gwi_set_timing.restype = C.c_int32
     lib.gwi_set_timing.argtypes = [vp, C.c_int32]
+    lib.gwi_dispatch_info.restype = C.c_char_p
+    lib.gwi_dispatch_info.argtypes = [vp]
     lib.gwi_last_error.restype = C.c_char_p
     lib.gwi_last_error.argtypes = [vp]
     lib.gwi_destroy.restype = None

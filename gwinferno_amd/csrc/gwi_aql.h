@@ -1,0 +1,365 @@
+// gwi_aql.h -- the engine's own AQL dispatch path (host side).
+//
+// One likelihood evaluation is 2-3 kernel launches whose combined host cost (hipLaunchKernelGGL: 3.2-3.8 us per call on the
+// MI355X boxes, and 6.9 us from the call to the first result of a one-workgroup kernel) is a third of the step.  The
+// same kernels dispatched as AQL packets written straight into a user-mode HSA queue that belongs to the engine cost
+// 0.4 us of host time and 4.3 us to the first result (tools/microbench/aql_dispatch.cpp).  So the plain evaluation path
+// -- scan, combine[, final] of ONE hyper-parameter point, no event timing, nothing else ordered behind it on the HIP
+// stream -- goes this way; everything else (batched launches, the sharded path with its RCCL exchange on the HIP stream,
+// timed launches, gwi_log_weights) keeps the HIP stream.  An evaluation is fully drained before its entry point
+// returns, so the two queues never hold work of the same engine at the same time.
+//
+//  * code: the device code compiled a second time into a raw code object (gwi_kernels.hsaco next to the library; the
+//    HIP fat binary inside the .so is a bundle the HSA loader does not read), loaded into an HSA executable of ours;
+//    kernel symbols are found by the names HIP reports for the host-side function pointers.
+//  * kernel arguments: a ring of 4 KiB slots in DEVICE memory that the host writes through the PCIe BAR (arguments in
+//    host memory cost the scan 5-7 us of scalar loads over PCIe); an sfence orders those write-combined stores before
+//    the doorbell.  The engine's kernels take no implicit arguments (llvm-readelf --notes: by_value only).
+//  * queues: a small process-wide pool (four by default) shared by all engines on the device, see pool_size().
+//  * ordering: every packet carries the barrier bit and agent-scope acquire/release fences, i.e. what a HIP stream gives
+//    consecutive kernels.  Results reach the host through the kernels' own write-through stores and stamps, as before.
+//  * the HSA runtime is bound with dlopen to the instance HIP already loaded (no link-time dependency); any failure while
+//    setting up (no host window into device memory, symbol not found, ...) leaves the engine on the HIP path.
+//    GWI_AQL=0 disables it.
+#ifndef GWI_AQL_H
+#define GWI_AQL_H
+
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <immintrin.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace gwi {
+namespace aql {
+
+struct Api {
+  decltype(&hsa_init) init = nullptr;
+  decltype(&hsa_status_string) status_string = nullptr;
+  decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+  decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+  decltype(&hsa_queue_create) queue_create = nullptr;
+  decltype(&hsa_queue_destroy) queue_destroy = nullptr;
+  decltype(&hsa_queue_add_write_index_relaxed) add_write_index = nullptr;
+  decltype(&hsa_queue_load_read_index_scacquire) load_read_index = nullptr;
+  decltype(&hsa_signal_store_screlease) signal_store = nullptr;
+  decltype(&hsa_code_object_reader_create_from_memory) reader_create = nullptr;
+  decltype(&hsa_executable_create_alt) executable_create = nullptr;
+  decltype(&hsa_executable_load_agent_code_object) load_code_object = nullptr;
+  decltype(&hsa_executable_freeze) freeze = nullptr;
+  decltype(&hsa_executable_get_symbol_by_name) get_symbol = nullptr;
+  decltype(&hsa_executable_symbol_get_info) symbol_info = nullptr;
+  decltype(&hsa_amd_agent_iterate_memory_pools) iterate_pools = nullptr;
+  decltype(&hsa_amd_memory_pool_get_info) pool_info = nullptr;
+  decltype(&hsa_amd_memory_pool_allocate) pool_allocate = nullptr;
+  decltype(&hsa_amd_memory_pool_free) pool_free = nullptr;
+  decltype(&hsa_amd_agents_allow_access) allow_access = nullptr;
+};
+
+struct Kernel {
+  uint64_t object = 0;
+  uint32_t kernarg_bytes = 0, group_bytes = 0, private_bytes = 0;
+};
+
+// A user-mode queue shared by the engines assigned to it (multi-producer; the barrier bit orders ALL its packets, so
+// engines on one queue take turns -- exactly what HIP streams that share a hardware queue do).
+struct SharedQueue {
+  hsa_queue_t* q = nullptr;
+  volatile bool failed = false;
+  std::string why;
+};
+
+// one per (process, device): agents, the device-memory pool, the loaded executable, the queue pool
+struct Device {
+  bool ok = false;
+  std::string why;
+  hsa_agent_t gpu{}, cpu{};
+  hsa_amd_memory_pool_t pool{};
+  hsa_executable_t exe{};
+  std::vector<char> blob;  // the code object must outlive the executable
+  std::mutex mu;
+  std::vector<SharedQueue*> queues;  // created together on first use, never destroyed (process lifetime)
+  unsigned next_engine = 0;
+};
+
+// one per engine: its queue (shared) and its own ring of kernel-argument slots
+struct Queue {
+  Device* dev = nullptr;
+  SharedQueue* sq = nullptr;
+  char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable
+  unsigned next_slot = 0;
+  bool failed() const { return sq && sq->failed; }
+  const std::string& why() const { return sq->why; }
+};
+constexpr unsigned kSlots = 16, kSlotBytes = 4096;
+
+inline Api& api() {
+  static Api a;
+  return a;
+}
+
+inline bool bind_api(std::string& why) {
+  static std::once_flag once;
+  static bool ok = false;
+  static std::string err;
+  std::call_once(once, [] {
+    void* lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);  // the instance HIP runs on
+    if (!lib) lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW);
+    if (!lib) {
+      err = "libhsa-runtime64.so.1 not loadable";
+      return;
+    }
+    Api& a = api();
+    bool all = true;
+#define GWI_AQL_SYM(member, name)                                   \
+  a.member = reinterpret_cast<decltype(a.member)>(dlsym(lib, name)); \
+  all = all && a.member != nullptr;
+    GWI_AQL_SYM(init, "hsa_init")
+    GWI_AQL_SYM(status_string, "hsa_status_string")
+    GWI_AQL_SYM(iterate_agents, "hsa_iterate_agents")
+    GWI_AQL_SYM(agent_get_info, "hsa_agent_get_info")
+    GWI_AQL_SYM(queue_create, "hsa_queue_create")
+    GWI_AQL_SYM(queue_destroy, "hsa_queue_destroy")
+    GWI_AQL_SYM(add_write_index, "hsa_queue_add_write_index_relaxed")
+    GWI_AQL_SYM(load_read_index, "hsa_queue_load_read_index_scacquire")
+    GWI_AQL_SYM(signal_store, "hsa_signal_store_screlease")
+    GWI_AQL_SYM(reader_create, "hsa_code_object_reader_create_from_memory")
+    GWI_AQL_SYM(executable_create, "hsa_executable_create_alt")
+    GWI_AQL_SYM(load_code_object, "hsa_executable_load_agent_code_object")
+    GWI_AQL_SYM(freeze, "hsa_executable_freeze")
+    GWI_AQL_SYM(get_symbol, "hsa_executable_get_symbol_by_name")
+    GWI_AQL_SYM(symbol_info, "hsa_executable_symbol_get_info")
+    GWI_AQL_SYM(iterate_pools, "hsa_amd_agent_iterate_memory_pools")
+    GWI_AQL_SYM(pool_info, "hsa_amd_memory_pool_get_info")
+    GWI_AQL_SYM(pool_allocate, "hsa_amd_memory_pool_allocate")
+    GWI_AQL_SYM(pool_free, "hsa_amd_memory_pool_free")
+    GWI_AQL_SYM(allow_access, "hsa_amd_agents_allow_access")
+#undef GWI_AQL_SYM
+    if (!all) {
+      err = "HSA runtime lacks an entry point";
+      return;
+    }
+    if (a.init() != HSA_STATUS_SUCCESS) {
+      err = "hsa_init failed";
+      return;
+    }
+    ok = true;
+  });
+  if (!ok) why = err;
+  return ok;
+}
+
+inline std::string status_text(hsa_status_t s) {
+  const char* m = nullptr;
+  if (api().status_string && api().status_string(s, &m) == HSA_STATUS_SUCCESS && m) return m;
+  return "HSA status " + std::to_string((int)s);
+}
+
+struct AgentSearch {
+  uint32_t want_bdf, want_domain;
+  hsa_agent_t gpu{}, cpu{};
+  bool have_gpu = false, have_cpu = false;
+};
+inline hsa_status_t visit_agent(hsa_agent_t a, void* data) {
+  auto* s = static_cast<AgentSearch*>(data);
+  hsa_device_type_t t;
+  if (api().agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  if (t == HSA_DEVICE_TYPE_CPU && !s->have_cpu) s->cpu = a, s->have_cpu = true;
+  if (t == HSA_DEVICE_TYPE_GPU && !s->have_gpu) {
+    uint32_t bdf = 0, domain = 0;
+    api().agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    api().agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    if (bdf == s->want_bdf && domain == s->want_domain) s->gpu = a, s->have_gpu = true;
+  }
+  return HSA_STATUS_SUCCESS;
+}
+struct PoolSearch {
+  hsa_amd_memory_pool_t pool{};
+  bool have = false;
+};
+inline hsa_status_t visit_pool(hsa_amd_memory_pool_t p, void* data) {
+  auto* s = static_cast<PoolSearch*>(data);
+  hsa_amd_segment_t seg;
+  uint32_t flags = 0;
+  bool alloc = false;
+  api().pool_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+  api().pool_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  api().pool_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+  if (!s->have && seg == HSA_AMD_SEGMENT_GLOBAL && alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED)) s->pool = p, s->have = true;
+  return HSA_STATUS_SUCCESS;
+}
+
+// Agents and executable for the GPU at PCI (domain, bus, device, function); `code_path` = the raw code object.
+inline Device* open_device(uint32_t domain, uint32_t bus, uint32_t device, uint32_t function, const std::string& code_path) {
+  static std::mutex mu;
+  static std::vector<std::pair<uint64_t, Device*>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  const uint32_t bdf = (bus << 8) | (device << 3) | function;
+  const uint64_t key = ((uint64_t)domain << 32) | bdf;
+  for (auto& kv : cache)
+    if (kv.first == key) return kv.second;
+  Device* d = new Device;
+  cache.emplace_back(key, d);
+  if (!bind_api(d->why)) return d;
+  Api& a = api();
+  AgentSearch as{bdf, domain};
+  a.iterate_agents(visit_agent, &as);
+  if (!as.have_gpu || !as.have_cpu) {
+    d->why = "no HSA agent at the PCI address of the HIP device";
+    return d;
+  }
+  d->gpu = as.gpu, d->cpu = as.cpu;
+  PoolSearch ps;
+  a.iterate_pools(d->gpu, visit_pool, &ps);
+  if (!ps.have) {
+    d->why = "no coarse-grained device memory pool";
+    return d;
+  }
+  d->pool = ps.pool;
+  FILE* f = std::fopen(code_path.c_str(), "rb");
+  if (!f) {
+    d->why = code_path + " not found (built by __graft_entry__.build())";
+    return d;
+  }
+  std::fseek(f, 0, SEEK_END);
+  d->blob.resize((size_t)std::ftell(f));
+  std::fseek(f, 0, SEEK_SET);
+  const bool read_ok = std::fread(d->blob.data(), 1, d->blob.size(), f) == d->blob.size();
+  std::fclose(f);
+  if (!read_ok || d->blob.size() < 64 || std::memcmp(d->blob.data(), "\177ELF", 4) != 0) {
+    d->why = code_path + " is not a raw code object";
+    return d;
+  }
+  hsa_code_object_reader_t reader;
+  hsa_status_t st = a.reader_create(d->blob.data(), d->blob.size(), &reader);
+  if (st == HSA_STATUS_SUCCESS) st = a.executable_create(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &d->exe);
+  if (st == HSA_STATUS_SUCCESS) st = a.load_code_object(d->exe, d->gpu, reader, nullptr, nullptr);
+  if (st == HSA_STATUS_SUCCESS) st = a.freeze(d->exe, nullptr);
+  if (st != HSA_STATUS_SUCCESS) {
+    d->why = "loading " + code_path + ": " + status_text(st);
+    return d;
+  }
+  d->ok = true;
+  return d;
+}
+
+inline bool find_kernel(Device* d, const char* mangled_name, Kernel& out, std::string& why) {
+  if (!mangled_name) {
+    why = "HIP did not report a kernel name";
+    return false;
+  }
+  Api& a = api();
+  const std::string sym_name = std::string(mangled_name) + ".kd";
+  hsa_executable_symbol_t sym;
+  hsa_status_t st = a.get_symbol(d->exe, sym_name.c_str(), &d->gpu, &sym);
+  if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &out.object);
+  if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &out.kernarg_bytes);
+  if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &out.group_bytes);
+  if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &out.private_bytes);
+  if (st != HSA_STATUS_SUCCESS) {
+    why = sym_name + ": " + status_text(st);
+    return false;
+  }
+  if (out.private_bytes != 0) {  // the engine's kernels use no scratch; a build that does stays on the HIP path
+    why = sym_name + " needs scratch memory";
+    return false;
+  }
+  return true;
+}
+
+inline void queue_error(hsa_status_t status, hsa_queue_t*, void* data) {
+  auto* q = static_cast<SharedQueue*>(data);
+  q->why = "HSA queue error: " + status_text(status);
+  q->failed = true;
+}
+
+// Queue pool.  One queue per engine loses badly as soon as three or more are ACTIVE at once (config 2, blocking chains in
+// host threads: 1 chain 63 k evals/s, 2 chains 120 k, 3 chains 52 k, 8 chains 64 k): queues created at different times
+// end up sharing hardware pipes and keep evicting each other.  So the engines of a process share a small pool created in
+// one go -- as HIP shares its (default four) hardware queues among streams.  Measured with the pool (1 / 2 / 3 / 4 / 6 / 8
+// chains, k evals/s): pool of 1: 62 81 77 75 76 76; 2: 61 108 112 105 146 146; 3: 55 116 153 134 207 189;
+// 4: 61 103 154 138 188 203; HIP streams: 49 80 118 122 185 173.  GWI_AQL_QUEUES overrides the default of 4.
+inline unsigned pool_size() {
+  unsigned n = 4;
+  if (const char* env = std::getenv("GWI_AQL_QUEUES")) n = (unsigned)std::atoi(env);
+  return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
+
+inline bool open_queue(Device* d, Queue& out, std::string& why) {
+  Api& a = api();
+  out.dev = d;
+  {
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (d->queues.empty()) {
+      const unsigned n = pool_size();
+      for (unsigned i = 0; i < n; ++i) {
+        auto* sq = new SharedQueue;
+        const hsa_status_t st = a.queue_create(d->gpu, 1024, HSA_QUEUE_TYPE_MULTI, queue_error, sq, UINT32_MAX, UINT32_MAX, &sq->q);
+        if (st != HSA_STATUS_SUCCESS) {
+          why = "hsa_queue_create: " + status_text(st);
+          delete sq;
+          break;
+        }
+        d->queues.push_back(sq);
+      }
+    }
+    if (d->queues.empty()) return false;
+    out.sq = d->queues[d->next_engine++ % d->queues.size()];
+  }
+  hsa_status_t st = a.pool_allocate(d->pool, (size_t)kSlots * kSlotBytes, 0, reinterpret_cast<void**>(&out.kernarg));
+  if (st == HSA_STATUS_SUCCESS) st = a.allow_access(1, &d->cpu, nullptr, out.kernarg);  // needs a host window into device memory (large BAR)
+  if (st != HSA_STATUS_SUCCESS) {
+    why = "kernel-argument ring in device memory: " + status_text(st);
+    if (out.kernarg) a.pool_free(out.kernarg);
+    out.kernarg = nullptr;
+    out.sq = nullptr;
+    return false;
+  }
+  std::memset(out.kernarg, 0, (size_t)kSlots * kSlotBytes);
+  return true;
+}
+
+inline void close_queue(Queue& q) {
+  if (q.kernarg) api().pool_free(q.kernarg);
+  q.kernarg = nullptr;
+  q.sq = nullptr;  // the shared queues live as long as the process
+}
+
+// One kernel dispatch: arguments -> next ring slot, packet -> queue, doorbell.  Returns false (nothing submitted) when the
+// queue has reported an error.
+inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds) {
+  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u) return false;
+  Api& a = api();
+  hsa_queue_t* hq = q.sq->q;
+  char* ka = q.kernarg + (size_t)(q.next_slot++ % kSlots) * kSlotBytes;
+  std::memcpy(ka, args, arg_bytes);
+  const uint64_t idx = a.add_write_index(hq, 1);  // atomic: several engines (host threads) may produce into one queue
+  while (idx - a.load_read_index(hq) >= hq->size) _mm_pause();
+  auto* p = static_cast<hsa_kernel_dispatch_packet_t*>(hq->base_address) + (idx & (hq->size - 1));
+  const uint16_t setup = (uint16_t)((grid_y_blocks > 1 ? 2 : 1) << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+  p->workgroup_size_x = (uint16_t)block_threads, p->workgroup_size_y = 1, p->workgroup_size_z = 1;
+  p->reserved0 = 0;
+  p->grid_size_x = grid_x_blocks * block_threads, p->grid_size_y = grid_y_blocks, p->grid_size_z = 1;
+  p->private_segment_size = 0;
+  p->group_segment_size = k.group_bytes + dynamic_lds;
+  p->kernel_object = k.object;
+  p->kernarg_address = ka;
+  p->reserved2 = 0;
+  p->completion_signal.handle = 0;
+  constexpr uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+  __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+  _mm_sfence();  // the arguments went out as write-combined stores through the BAR: drain them before the doorbell
+  a.signal_store(hq->doorbell_signal, (hsa_signal_value_t)idx);
+  return true;
+}
+
+}  // namespace aql
+}  // namespace gwi
+#endif  // GWI_AQL_H

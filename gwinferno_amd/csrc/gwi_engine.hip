@@ -1,6 +1,7 @@
 // gwi_engine.hip -- host side + C ABI of the population-likelihood engine (see include/gwi_engine.h).
 // gfx950 only; no CPU fallback: every entry point that computes needs a live HIP device.
 #include "gwi_device.h"
+#include "gwi_aql.h"
 
 #include <hip/hip_ext.h>
 
@@ -270,6 +271,12 @@ struct gwi_engine {
   bool pending_sq = false;
   gwi_options pending_opt{};
   std::string err;
+  // the engine's own AQL queue (gwi_aql.h): plain single-point evaluations are dispatched through it
+  aql::Queue aq;
+  aql::Kernel aq_scan, aq_combine, aq_final;
+  bool aql_active = false;  // queue, argument ring and the three kernels are ready
+  bool aql_now = false;     // the pipeline being issued / awaited went through the AQL queue
+  std::string aql_note;     // why not, when not
   KArgs kargs;
 };
 
@@ -434,6 +441,12 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
 // trace shows -- instead of stream positions around it, which add 1-3 us of launch gap per bracket.
 template <typename F, typename A>
 void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args) {
+  if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
+    const aql::Kernel& k = slot == 0 ? h->aq_scan : (slot == 1 ? h->aq_combine : h->aq_final);
+    if (aql::dispatch(h->aq, k, &args, sizeof(A), grid.x, grid.y, block.x, (uint32_t)lds)) return;
+    // the queue reported an error: nothing was submitted; the waiters surface it
+    return;
+  }
   if (h->timing)
     hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, args);
   else
@@ -441,6 +454,7 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
 }
 
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
+  if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   ScanFn fn = logw ? h->variant->logw : (batch ? h->variant->scan_batch : h->variant->scan);
   launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs);
@@ -482,6 +496,9 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
 #endif
   const int n_theta = h->spec.n_theta;
   h->kargs.square = square ? 1 : 0;
+  // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
+  // (batched theta uploads, the sharded path's exchange behind record_dev) or timed with HIP events stays on the stream
+  h->aql_now = h->aql_active && !h->aq.failed() && !h->timing && !batch && K == 1 && record_dev == nullptr;
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
   if (!batch) {
     prelude(h, theta, h->kargs.theta, h->kargs.derived, &h->host_consts[0]);
@@ -544,6 +561,20 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   return wait_for_norms(h, h->h_record, K);
 }
 
+// The AQL path has no HIP stream behind it: when the quick poll gives up, keep polling (with the queue's error flag in
+// view) for up to 10 s, then report.  `ready` re-evaluates the completion condition.
+template <typename Ready>
+gwi_status aql_wait_slow(gwi_handle h, Ready ready, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spin = 1;; ++spin) {
+    if (ready()) return GWI_OK;
+    if (h->aq.failed()) return fail(h, GWI_ERR_HIP, h->aq.why());
+    __builtin_ia32_pause();
+    if ((spin & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+      return fail(h, GWI_ERR_TIMEOUT, std::string(what) + " did not arrive from the AQL queue within 10 s");
+  }
+}
+
 // the normaliser launch publishes Z_j + a stamp per normaliser; copy them into rank 0's record slots
 gwi_status wait_for_norms(gwi_handle h, double* record, int K) {
   const int n = h->spec.n_norms;
@@ -555,7 +586,14 @@ gwi_status wait_for_norms(gwi_handle h, double* record, int K) {
     for (int j = 0; j < total; ++j) done = done && *reinterpret_cast<volatile unsigned long long*>(h->h_norm_stamp + j) == h->seq;
     if (!done) __builtin_ia32_pause();
   }
-  if (!done) {
+  if (!done && h->aql_now) {
+    const gwi_status sw = aql_wait_slow(h, [&] {
+      for (int j = 0; j < total; ++j)
+        if (*reinterpret_cast<volatile unsigned long long*>(h->h_norm_stamp + j) != h->seq) return false;
+      return true;
+    }, "normaliser stamps");
+    if (sw != GWI_OK) return sw;
+  } else if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
     for (int j = 0; j < total; ++j)
       if (h->h_norm_stamp[j] != h->seq) return fail(h, GWI_ERR_HIP, "normaliser stamp mismatch after stream synchronise");
@@ -583,7 +621,15 @@ gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  if (!done) {
+  if (!done && h->aql_now) {
+    const gwi_status sw = aql_wait_slow(h, [&] {
+      for (int k = 0; k < K; ++k)
+        if (stamp_of(k) != h->seq) return false;
+      return true;
+    }, "the completion stamp");
+    if (sw != GWI_OK) return sw;
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
     for (int k = 0; k < K; ++k)
       if (stamp_of(k) != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
@@ -719,7 +765,15 @@ gwi_status wait_for_rows(gwi_handle h, int K) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  if (!done) {
+  if (!done && h->aql_now) {
+    const gwi_status sw = aql_wait_slow(h, [&] {
+      for (int g = 0; g < total; ++g)
+        if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq) return false;
+      return true;
+    }, "group result rows");
+    if (sw != GWI_OK) return sw;
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
     for (int g = 0; g < total; ++g)
       if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq)
@@ -780,6 +834,7 @@ void destroy_impl(gwi_engine* h) {
     return;
   }
   (void)hipSetDevice(h->device);
+  aql::close_queue(h->aq);
   for (double* p : h->d_cols_pe) (void)hipFree(p);
   for (double* p : h->d_cols_inj) (void)hipFree(p);
   for (double* p : h->d_norm_arrays) (void)hipFree(p);
@@ -836,6 +891,43 @@ const char* gwi_last_error(gwi_handle h) {
 }
 
 void gwi_destroy(gwi_handle h) { destroy_impl(h); }
+
+// The engine's AQL queue (gwi_aql.h).  Never fatal: on any failure the note says why and the HIP stream is used.
+static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
+  h->aql_active = false;
+  if (const char* env = std::getenv("GWI_AQL"))
+    if (std::atoi(env) == 0) {
+      h->aql_note = "disabled by GWI_AQL=0";
+      return;
+    }
+  std::string code = "gwi_kernels.hsaco";
+  if (const char* env = std::getenv("GWI_AQL_CODE")) {
+    code = env;
+  } else {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&gwi_abi_version), &info) && info.dli_fname) {
+      const std::string so = info.dli_fname;
+      const size_t cut = so.find_last_of('/');
+      code = (cut == std::string::npos ? std::string(".") : so.substr(0, cut)) + "/gwi_kernels.hsaco";
+    }
+  }
+  aql::Device* dev = aql::open_device((uint32_t)prop.pciDomainID, (uint32_t)prop.pciBusID, (uint32_t)prop.pciDeviceID, 0u, code);
+  if (!dev->ok) {
+    h->aql_note = dev->why;
+    return;
+  }
+  const void* fns[3] = {reinterpret_cast<const void*>(h->variant->scan), reinterpret_cast<const void*>(&combine_kernel), reinterpret_cast<const void*>(&final_kernel)};
+  aql::Kernel* out[3] = {&h->aq_scan, &h->aq_combine, &h->aq_final};
+  for (int i = 0; i < 3; ++i)
+    if (!aql::find_kernel(dev, hipKernelNameRefByPtr(fns[i], h->stream), *out[i], h->aql_note)) return;
+  if (h->aq_scan.kernarg_bytes != sizeof(KArgs) || h->aq_combine.kernarg_bytes != sizeof(TailArgs) || h->aq_final.kernarg_bytes != sizeof(TailArgs)) {
+    h->aql_note = "kernel argument sizes of the code object differ from this build (stale gwi_kernels.hsaco?)";
+    return;
+  }
+  if (!aql::open_queue(dev, h->aq, h->aql_note)) return;
+  h->aql_active = true;
+  h->aql_note = "active";
+}
 
 gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
                       int32_t device, gwi_handle* out) {
@@ -1096,7 +1188,13 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
     }
   }
+  setup_aql(h, prop);
   return GWI_OK;
+}
+
+const char* gwi_dispatch_info(gwi_handle h) {
+  if (!h) return "no engine";
+  return h->aql_active ? (h->aq.failed() ? h->aq.why().c_str() : "aql: active") : h->aql_note.c_str();
 }
 
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled) {

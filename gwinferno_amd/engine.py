@@ -363,6 +363,10 @@ class NativePopulationLikelihood:
         return [EvalResult(log_likelihood=summ[k].log_likelihood, grad=grads[k] if want_grad else None, summary=summ[k], log_bfs=lb[k], log_neffs=ln[k], variances=lv[k],
                            norms=norms[k, :n_norms]) for k in range(K)]
 
+    def dispatch_info(self):
+        """"aql: active" when plain evaluations go through the engine's own AQL queue, else why they use the HIP stream."""
+        return self.lib.gwi_dispatch_info(self.handle).decode()
+
     def evaluate_sequence(self, thetas, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, timing_every=0):
         """``len(thetas)`` sequential blocking evaluations in one library call (``gwi_eval_sequence``): the loop a
         sampler runs, without Python between two evaluations.  Returns ``(log_likelihoods, grads[, kernel_ms])``."""

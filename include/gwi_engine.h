@@ -282,6 +282,10 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
 gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* log_likelihoods, double* grads, int32_t timing_every,
                              float* kernel_ms);
 
+/* How plain evaluations are dispatched: "aql: active" (AQL packets into a user-mode queue of the engine's own,
+ * gwinferno_amd/csrc/gwi_aql.h: 0.4 us of host time per launch instead of 3.5) or the reason the HIP stream is used. */
+const char* gwi_dispatch_info(gwi_handle h);
+
 const char* gwi_last_error(gwi_handle h);
 void gwi_destroy(gwi_handle h);
 

@@ -485,3 +485,49 @@ def test_eval_sequence_equals_one_by_one():
     with pytest.raises(ValueError):
         eng.evaluate_sequence(thetas[:, :-1], total)
     eng.close()
+
+
+def test_aql_dispatch_path_equals_the_hip_stream_path():
+    """Plain evaluations go through the engine's own AQL queue (gwinferno_amd/csrc/gwi_aql.h); timed ones, log-weights
+    and batches through the HIP stream -- same kernels, other queue: identical bits, in any interleaving, also from
+    several engines (= several producers into the shared queue pool) at once."""
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 300, 3000, seed=21)
+    comps = [COMPOSITIONS["bspline_test"](pe, inj) for _ in range(6)]
+    engs = [c.engine() for c in comps]
+    eng = engs[0]
+    assert eng.dispatch_info() == "aql: active", eng.dispatch_info()
+    rng = np.random.default_rng(8)
+    thetas = np.stack([comps[0].theta(draw_params("bspline_test", rng)) for _ in range(10)])
+    aql = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    lpe, linj = eng.log_weights(thetas[0])  # HIP stream (runs one evaluation through the AQL queue first)
+    eng.set_timing(True)
+    hip = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    eng.set_timing(False)
+    for a, b in zip(aql, hip):
+        assert a.log_likelihood == b.log_likelihood and np.array_equal(a.grad, b.grad) and np.array_equal(a.log_bfs, b.log_bfs) and np.array_equal(a.norms, b.norms)
+    batch = eng.evaluate_batch(thetas[:5], total, min_neff_cut=False)  # HIP stream again
+    again = eng.evaluate(thetas[3], total, min_neff_cut=False)          # and back
+    assert again.log_likelihood == aql[3].log_likelihood and rel_err(batch[3].log_likelihood, aql[3].log_likelihood) < 1e-12
+    assert np.isfinite(lpe).any() and np.isfinite(linj).any()
+    # six engines hammering the pool from six threads
+    want = np.array([r.log_likelihood for r in aql] * 40)
+    seq = np.concatenate([thetas] * 40)
+    bad = [None] * len(engs)
+
+    def work(k):
+        ll, _ = engs[k].evaluate_sequence(seq, total, min_neff_cut=False)
+        bad[k] = int(np.sum(ll != want))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(engs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert bad == [0] * len(engs)
+    for e in engs:
+        e.close()
