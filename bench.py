@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
     ap.add_argument("--chains", type=int, default=4, help="also time this many independent chains interleaved on one GPU (begin/end); <= 1 disables")
-    ap.add_argument("--timing-every", type=int, default=50, help="HIP-event kernel timing on every n-th timed step (those steps go through the HIP stream, the others through the engine's AQL queue)")
+    ap.add_argument("--timing-every", type=int, default=50, help="kernel begin/end timing on every n-th timed step")
     args = ap.parse_args()
 
     import torch
@@ -331,8 +331,9 @@ def main():
                 "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
                 "median_scan_us": 1e3 * float(np.median(scan_ms)) if scan_ms else None,
-                "timing": f"HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's HIP stream, every {args.timing_every}th timed step "
-                          "(the other steps are dispatched through the engine's AQL queue: same kernels)",
+                "timing": (f"kernel begin/end of every {args.timing_every}th timed step: dispatch timestamps of the engine's AQL queue "
+                           "(hsa_amd_profiling_get_dispatch_time, what rocprofv3's kernel trace reports)" if eng.dispatch_info() == "aql: active" else
+                           f"HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's stream, every {args.timing_every}th timed step"),
                 "dispatch": eng.dispatch_info(),
                 "timed_launches": len(scan_ms),
                 # second view: the scan is fp64-issue/latency bound, not HBM bound

@@ -60,6 +60,14 @@ struct Api {
   decltype(&hsa_amd_memory_pool_allocate) pool_allocate = nullptr;
   decltype(&hsa_amd_memory_pool_free) pool_free = nullptr;
   decltype(&hsa_amd_agents_allow_access) allow_access = nullptr;
+  // kernel begin/end timestamps of a dispatch (timing mode only)
+  decltype(&hsa_signal_create) signal_create = nullptr;
+  decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+  decltype(&hsa_signal_store_relaxed) signal_set = nullptr;
+  decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
+  decltype(&hsa_amd_profiling_set_profiler_enabled) profiling_enable = nullptr;
+  decltype(&hsa_amd_profiling_get_dispatch_time) dispatch_time = nullptr;
+  decltype(&hsa_system_get_info) system_info = nullptr;
 };
 
 struct Kernel {
@@ -72,6 +80,7 @@ struct Kernel {
 struct SharedQueue {
   hsa_queue_t* q = nullptr;
   volatile bool failed = false;
+  bool profiling = false;  // dispatch timestamps are on (set when the queue is created)
   std::string why;
 };
 
@@ -94,6 +103,8 @@ struct Queue {
   SharedQueue* sq = nullptr;
   char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable
   unsigned next_slot = 0;
+  hsa_signal_t done[3] = {{0}, {0}, {0}};  // completion signals of the scan / combine / final packets of a TIMED evaluation
+  bool have_signals = false;
   bool failed() const { return sq && sq->failed; }
   const std::string& why() const { return sq->why; }
 };
@@ -140,6 +151,13 @@ inline bool bind_api(std::string& why) {
     GWI_AQL_SYM(pool_allocate, "hsa_amd_memory_pool_allocate")
     GWI_AQL_SYM(pool_free, "hsa_amd_memory_pool_free")
     GWI_AQL_SYM(allow_access, "hsa_amd_agents_allow_access")
+    GWI_AQL_SYM(signal_create, "hsa_signal_create")
+    GWI_AQL_SYM(signal_destroy, "hsa_signal_destroy")
+    GWI_AQL_SYM(signal_set, "hsa_signal_store_relaxed")
+    GWI_AQL_SYM(signal_wait, "hsa_signal_wait_scacquire")
+    GWI_AQL_SYM(profiling_enable, "hsa_amd_profiling_set_profiler_enabled")
+    GWI_AQL_SYM(dispatch_time, "hsa_amd_profiling_get_dispatch_time")
+    GWI_AQL_SYM(system_info, "hsa_system_get_info")
 #undef GWI_AQL_SYM
     if (!all) {
       err = "HSA runtime lacks an entry point";
@@ -306,6 +324,11 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
           delete sq;
           break;
         }
+        // Dispatch timestamps on from the start: the packet processor picks the property up when the queue is first
+        // mapped; switched on later it was honoured in some processes and not in others (timestamps never written).
+        // It costs nothing for packets without a completion signal, which is all of them outside timing mode.
+        const char* ts = std::getenv("GWI_AQL_TIMESTAMPS");  // 0: leave them off (timed evaluations then use HIP events on the HIP stream)
+        sq->profiling = !(ts && std::atoi(ts) == 0) && a.profiling_enable(sq->q, 1) == HSA_STATUS_SUCCESS;
         d->queues.push_back(sq);
       }
     }
@@ -322,10 +345,40 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
     return false;
   }
   std::memset(out.kernarg, 0, (size_t)kSlots * kSlotBytes);
+  out.have_signals = true;
+  for (auto& sg : out.done)
+    if (a.signal_create(1, 0, nullptr, &sg) != HSA_STATUS_SUCCESS) out.have_signals = false;
+  return true;
+}
+
+// Timing mode: kernel begin / end of the three dispatches as the packet processor stamps them (the quantity rocprofv3's
+// kernel trace reports), in milliseconds.  `n` = 2 or 3 packets carried signals.
+inline bool timed_prepare(Queue& q) {
+  if (!q.have_signals || !q.sq) return false;
+  Api& a = api();
+  if (!q.sq->profiling) return false;
+  for (auto& sg : q.done) a.signal_set(sg, 1);
+  return true;
+}
+inline bool timed_collect(Queue& q, int n, float* ms) {
+  Api& a = api();
+  uint64_t hz = 0;
+  if (a.system_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) != HSA_STATUS_SUCCESS || hz == 0) return false;
+  for (int i = 0; i < n; ++i) {
+    if (a.signal_wait(q.done[i], HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) return false;
+    hsa_amd_profiling_dispatch_time_t t{};
+    if (a.dispatch_time(q.dev->gpu, q.done[i], &t) != HSA_STATUS_SUCCESS) return false;
+    if (t.end <= t.start) return false;  // never stamped
+    ms[i] = (float)(1e3 * (double)(t.end - t.start) / (double)hz);
+  }
   return true;
 }
 
 inline void close_queue(Queue& q) {
+  if (q.have_signals)
+    for (auto& sg : q.done)
+      if (sg.handle) api().signal_destroy(sg);
+  q.have_signals = false;
   if (q.kernarg) api().pool_free(q.kernarg);
   q.kernarg = nullptr;
   q.sq = nullptr;  // the shared queues live as long as the process
@@ -333,7 +386,8 @@ inline void close_queue(Queue& q) {
 
 // One kernel dispatch: arguments -> next ring slot, packet -> queue, doorbell.  Returns false (nothing submitted) when the
 // queue has reported an error.
-inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds) {
+inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
+                     hsa_signal_t completion = hsa_signal_t{0}) {
   if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u) return false;
   Api& a = api();
   hsa_queue_t* hq = q.sq->q;
@@ -351,7 +405,7 @@ inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_byt
   p->kernel_object = k.object;
   p->kernarg_address = ka;
   p->reserved2 = 0;
-  p->completion_signal.handle = 0;
+  p->completion_signal = completion;
   constexpr uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                               (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);

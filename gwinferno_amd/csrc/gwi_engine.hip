@@ -276,6 +276,7 @@ struct gwi_engine {
   aql::Kernel aq_scan, aq_combine, aq_final;
   bool aql_active = false;  // queue, argument ring and the three kernels are ready
   bool aql_now = false;     // the pipeline being issued / awaited went through the AQL queue
+  bool force_hip_stream = false;  // gwi_set_timing(h, 2): time with HIP events on the HIP stream (A/B against the AQL path)
   std::string aql_note;     // why not, when not
   KArgs kargs;
 };
@@ -443,7 +444,7 @@ template <typename F, typename A>
 void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args) {
   if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
     const aql::Kernel& k = slot == 0 ? h->aq_scan : (slot == 1 ? h->aq_combine : h->aq_final);
-    if (aql::dispatch(h->aq, k, &args, sizeof(A), grid.x, grid.y, block.x, (uint32_t)lds)) return;
+    if (aql::dispatch(h->aq, k, &args, sizeof(A), grid.x, grid.y, block.x, (uint32_t)lds, h->timing ? h->aq.done[slot] : hsa_signal_t{0})) return;
     // the queue reported an error: nothing was submitted; the waiters surface it
     return;
   }
@@ -498,7 +499,8 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   h->kargs.square = square ? 1 : 0;
   // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
   // (batched theta uploads, the sharded path's exchange behind record_dev) or timed with HIP events stays on the stream
-  h->aql_now = h->aql_active && !h->aq.failed() && !h->timing && !batch && K == 1 && record_dev == nullptr;
+  h->aql_now = h->aql_active && !h->aq.failed() && !h->force_hip_stream && !batch && K == 1 && record_dev == nullptr;
+  if (h->aql_now && h->timing && !aql::timed_prepare(h->aq)) h->aql_now = false;  // no dispatch timestamps: time this one with HIP events
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
   if (!batch) {
     prelude(h, theta, h->kargs.theta, h->kargs.derived, &h->host_consts[0]);
@@ -634,7 +636,10 @@ gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K) {
     for (int k = 0; k < K; ++k)
       if (stamp_of(k) != h->seq) return fail(h, GWI_ERR_HIP, "completion stamp mismatch after stream synchronise");
   }
-  if (h->timing) {
+  if (h->timing && h->aql_now) {
+    h->last_ms[2] = 0.0f;
+    if (!aql::timed_collect(h->aq, h->timed_final ? 3 : 2, h->last_ms)) return fail(h, GWI_ERR_HIP, "dispatch timestamps of the AQL queue are not available");
+  } else if (h->timing) {
     GWI_HIP(hipStreamSynchronize(h->stream));
     h->last_ms[2] = 0.0f;  // host-final mode has no third launch
     for (int i = 0; i < (h->timed_final ? 3 : 2); ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
@@ -779,7 +784,10 @@ gwi_status wait_for_rows(gwi_handle h, int K) {
       if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq)
         return fail(h, GWI_ERR_HIP, "group stamp mismatch after stream synchronise");
   }
-  if (h->timing) {
+  if (h->timing && h->aql_now) {
+    h->last_ms[2] = 0.0f;
+    if (!aql::timed_collect(h->aq, h->timed_final ? 3 : 2, h->last_ms)) return fail(h, GWI_ERR_HIP, "dispatch timestamps of the AQL queue are not available");
+  } else if (h->timing) {
     GWI_HIP(hipStreamSynchronize(h->stream));
     h->last_ms[2] = 0.0f;  // host-final mode has no third launch
     for (int i = 0; i < (h->timed_final ? 3 : 2); ++i) GWI_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
@@ -1200,6 +1208,7 @@ const char* gwi_dispatch_info(gwi_handle h) {
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled) {
   if (!h) return GWI_ERR_INVALID;
   h->timing = enabled != 0;
+  h->force_hip_stream = enabled == 2;
   return GWI_OK;
 }
 

@@ -267,7 +267,9 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
  * launch on the engine's stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce; 0 when the
  * host does the final sum). */
 gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]);
-/* Enable/disable per-launch HIP-event timing (off by default: events add host overhead). */
+/* Per-launch kernel timing (off by default: it adds host overhead).  1: kernel begin/end of every launch of an
+ * evaluation -- dispatch timestamps of the engine's AQL queue where that is active, HIP events attached to the launches
+ * otherwise; 2: the same, forced through the HIP stream (A/B against the AQL path); 0: off. */
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled);
 
 /* Diagnostic: run `n_iter` sequential gwi_eval calls from C (no binding overhead) and return the

@@ -505,11 +505,18 @@ def test_aql_dispatch_path_equals_the_hip_stream_path():
     thetas = np.stack([comps[0].theta(draw_params("bspline_test", rng)) for _ in range(10)])
     aql = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
     lpe, linj = eng.log_weights(thetas[0])  # HIP stream (runs one evaluation through the AQL queue first)
-    eng.set_timing(True)
+    eng.set_timing(2)  # timed through the HIP stream
     hip = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
-    eng.set_timing(False)
-    for a, b in zip(aql, hip):
+    ms_hip = eng.last_kernel_ms()
+    eng.set_timing(1)  # timed on the AQL queue (dispatch timestamps)
+    aql_timed = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    ms_aql = eng.last_kernel_ms()
+    eng.set_timing(0)
+    for a, b, c in zip(aql, hip, aql_timed):
         assert a.log_likelihood == b.log_likelihood and np.array_equal(a.grad, b.grad) and np.array_equal(a.log_bfs, b.log_bfs) and np.array_equal(a.norms, b.norms)
+        assert a.log_likelihood == c.log_likelihood and np.array_equal(a.grad, c.grad)
+    # the two clocks bracket the same kernels: a few microseconds each, within a factor of two of one another
+    assert 1e-3 < ms_hip[0] < 0.1 and 1e-3 < ms_aql[0] < 0.1 and 0.5 < ms_aql[0] / ms_hip[0] < 2.0 and ms_aql[1] > 1e-3
     batch = eng.evaluate_batch(thetas[:5], total, min_neff_cut=False)  # HIP stream again
     again = eng.evaluate(thetas[3], total, min_neff_cut=False)          # and back
     assert again.log_likelihood == aql[3].log_likelihood and rel_err(batch[3].log_likelihood, aql[3].log_likelihood) < 1e-12

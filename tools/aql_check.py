@@ -22,11 +22,17 @@ rng = np.random.default_rng(0)
 ths = np.stack([comp.theta(draw_params(comp_name, rng)) for _ in range(8)])
 r = [eng.evaluate(t, total, min_neff_cut=False) for t in ths]
 print("log_l:", [f"{x.log_likelihood:.9f}" for x in r[:3]], flush=True)
-eng.set_timing(True)  # timed launches always use the HIP stream: same kernels, other queue
+eng.set_timing(2)  # mode 2: timed through the HIP stream -- same kernels, other queue
 r2 = [eng.evaluate(t, total, min_neff_cut=False) for t in ths]
 eng.set_timing(False)
 same = all(a.log_likelihood == b.log_likelihood and np.array_equal(a.grad, b.grad) and np.array_equal(a.log_bfs, b.log_bfs) for a, b in zip(r, r2))
-print("AQL path == HIP-stream path, bit for bit:", same, flush=True)
+ms_hip = np.array(eng.last_kernel_ms())
+eng.set_timing(1)
+for t in ths:
+    eng.evaluate(t, total, min_neff_cut=False)
+ms_aql = np.array(eng.last_kernel_ms())
+eng.set_timing(0)
+print("AQL path == HIP-stream path, bit for bit:", same, "| last kernel us [scan, combine, final]: HIP events", np.round(1e3 * ms_hip, 2), " AQL dispatch timestamps", np.round(1e3 * ms_aql, 2), flush=True)
 seq = np.concatenate([ths] * 250)
 eng.evaluate_sequence(seq[:200], total, min_neff_cut=False)
 t0 = time.perf_counter()
