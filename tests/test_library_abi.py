@@ -75,3 +75,39 @@ def test_no_silent_cpu_fallback(lib):
     comp = COMPOSITIONS["plpeak"](pe, inj)
     with pytest.raises(N.NativeEngineError):
         comp.engine()
+
+
+def test_raw_code_object_for_the_aql_path(lib):
+    """build() also produces the device code as a RAW gfx950 code object (what the engine's own AQL queue loads through
+    the HSA runtime, gwinferno_amd/csrc/gwi_aql.h): an ELF holding a kernel descriptor for every scan variant and the
+    two tail kernels, none of them with scratch or implicit arguments (the AQL path supplies neither)."""
+    import shutil
+    import subprocess
+
+    from gwinferno_amd import _native
+
+    path = os.path.join(os.path.dirname(_native.LIB_PATH), "gwi_kernels.hsaco")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+
+        g.build()
+    blob = open(path, "rb").read(4)
+    assert blob == b"\x7fELF"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        readelf = shutil.which("llvm-readelf")
+    if not readelf:
+        pytest.skip("llvm-readelf not available")
+    notes = subprocess.run([readelf, "--notes", path], capture_output=True, text=True).stdout
+    names = re.findall(r"\.name:\s+(\S+)", notes)
+    n_variants = lib.gwi_kernel_variants()
+    scans = [n for n in names if "scan_kernel" in n]
+    assert len(scans) == 3 * n_variants  # value / log-weight / batched instantiation per variant
+    assert any("combine_kernel" in n for n in names) and any("final_kernel" in n for n in names)
+    assert "hidden_" not in notes  # no implicit kernel arguments anywhere
+    # no scratch in anything the AQL path dispatches: the value-and-gradient scan of every variant and the tail kernels
+    per_kernel = dict(zip(names, re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)))
+    assert len(per_kernel) == len(names)
+    for n, scratch in per_kernel.items():
+        if "scan_kernelILb0ELb0E" in n or "combine_kernel" in n or "final_kernel" in n:
+            assert scratch == "0", (n, scratch)
