@@ -155,6 +155,10 @@ def main():
     n_ev, n_pe = pe["mass_1"].shape
     n_inj = inj["mass_1"].shape[0]
     comp = COMPOSITIONS[comp_name](pe, inj)
+    # the driving thread next to its GPU (numactl-style host placement), before anything pinned is allocated
+    from gwinferno_amd.engine import pin_thread_to_device
+
+    pinned = pin_thread_to_device(local_rank) if os.environ.get("GWI_BENCH_PIN", "1") != "0" and torch.cuda.is_available() else False
     eng = comp.engine(device=local_rank, rank=rank, world=world)
     rng = np.random.default_rng(1234)
     pool = [draw_params(comp_name, rng) for _ in range(64)]
@@ -335,6 +339,7 @@ def main():
                            "(hsa_amd_profiling_get_dispatch_time, what rocprofv3's kernel trace reports)" if eng.dispatch_info() == "aql: active" else
                            f"HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's stream, every {args.timing_every}th timed step"),
                 "dispatch": eng.dispatch_info(),
+                "host_thread_pinned_to_gpu_numa_node": bool(pinned),
                 "timed_launches": len(scan_ms),
                 # second view: the scan is fp64-issue/latency bound, not HBM bound
                 "fp64_vector": {

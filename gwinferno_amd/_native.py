@@ -175,6 +175,8 @@ EXPORTED_SYMBOLS = [
     "gwi_last_kernel_ms",
     "gwi_set_timing",
     "gwi_dispatch_info",
+    "gwi_pin_thread_to_engine",
+    "gwi_pin_thread_to_device",
     "gwi_last_error",
     "gwi_destroy",
     "gwi_abi_version",
@@ -248,6 +250,10 @@ def load_library():
     lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.gwi_set_timing.restype = C.c_int32
     lib.gwi_set_timing.argtypes = [vp, C.c_int32]
+    lib.gwi_pin_thread_to_engine.restype = C.c_int32
+    lib.gwi_pin_thread_to_engine.argtypes = [vp]
+    lib.gwi_pin_thread_to_device.restype = C.c_int32
+    lib.gwi_pin_thread_to_device.argtypes = [C.c_int32]
     lib.gwi_dispatch_info.restype = C.c_char_p
     lib.gwi_dispatch_info.argtypes = [vp]
     lib.gwi_last_error.restype = C.c_char_p

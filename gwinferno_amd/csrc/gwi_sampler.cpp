@@ -362,6 +362,7 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
     if (!pens || pens[k].offset < 0 || pens[k].count < 2 || pens[k].offset + pens[k].count > n_theta || pens[k].degree < 1 || pens[k].degree >= pens[k].count) return GWI_ERR_INVALID;
   std::vector<int> rc(n_chains, 0);
   auto chain = [&](int c) {
+    if (n_chains > 1) (void)gwi_pin_thread_to_engine(handles[c]);  // worker threads: stay on the GPU's side of the machine
     EngineTarget e{handles[c], *lopt, priors, pens, n_pens, n_theta, Vec(n_theta), Vec(n_theta), Vec(n_theta), Vec(n_theta), {}, {}};
     Target t{engine_target, &e, n_theta};
     gwi_nuts_options o = *opt;

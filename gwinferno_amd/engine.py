@@ -206,6 +206,13 @@ def bind(pe, inj, hypervolume=None):
     return bm
 
 
+def pin_thread_to_device(device=-1):
+    """Restrict the calling thread (and the threads it starts later) to the CPUs next to GPU ``device``
+    (``gwi_pin_thread_to_device``; numactl-style host placement, best done before engines are created).  Returns
+    whether the affinity was changed."""
+    return N.load_library().gwi_pin_thread_to_device(int(device)) == 0
+
+
 def shard_bounds(n, rank, world):
     """Contiguous, balanced blocks: the first ``n % world`` ranks get one extra item."""
     base, extra = divmod(n, world)
@@ -362,6 +369,11 @@ class NativePopulationLikelihood:
         self._check(self.lib.gwi_eval_batch(self.handle, N.as_dp(thetas), K, C.byref(opt), summ, N.as_dp(grads), N.as_dp(lb), N.as_dp(ln), N.as_dp(lv), N.as_dp(norms)))
         return [EvalResult(log_likelihood=summ[k].log_likelihood, grad=grads[k] if want_grad else None, summary=summ[k], log_bfs=lb[k], log_neffs=ln[k], variances=lv[k],
                            norms=norms[k, :n_norms]) for k in range(K)]
+
+    def pin_thread(self):
+        """Restrict the calling thread to the CPUs next to this engine's GPU (``gwi_pin_thread_to_engine``); returns
+        whether the affinity was changed (False when sysfs does not describe the device's locality)."""
+        return self.lib.gwi_pin_thread_to_engine(self.handle) == 0
 
     def dispatch_info(self):
         """"aql: active" when plain evaluations go through the engine's own AQL queue, else why they use the HIP stream."""

@@ -284,6 +284,14 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
 gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* log_likelihoods, double* grads, int32_t timing_every,
                              float* kernel_ms);
 
+/* Host tuning: restrict the CALLING thread to the CPUs next to the engine's GPU (the local_cpulist of its PCI function,
+ * intersected with the thread's current affinity).  Every evaluation is a few PCIe round trips driven by that thread.
+ * GWI_ERR_UNSUPPORTED (and no change) when sysfs does not say. */
+gwi_status gwi_pin_thread_to_engine(gwi_handle h);
+/* the same by device index (GWI_DEVICE_CURRENT = the current HIP device), e.g. BEFORE engines are created, so that their
+ * pinned host buffers are first touched on that side too */
+gwi_status gwi_pin_thread_to_device(int32_t device);
+
 /* How plain evaluations are dispatched: "aql: active" (AQL packets into a user-mode queue of the engine's own,
  * gwinferno_amd/csrc/gwi_aql.h: 0.4 us of host time per launch instead of 3.5) or the reason the HIP stream is used. */
 const char* gwi_dispatch_info(gwi_handle h);

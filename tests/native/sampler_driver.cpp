@@ -35,6 +35,8 @@ extern "C" gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int3
   return GWI_OK;
 }
 
+extern "C" gwi_status gwi_pin_thread_to_engine(gwi_handle) { return GWI_ERR_UNSUPPORTED; }
+
 static int32_t banana(void*, const double* x, double* lp, double* g) {  // a curved 2-d target for the callback entry
   const double a = x[1] - x[0] * x[0];
   *lp = -0.5 * x[0] * x[0] - 2.0 * a * a;
