@@ -540,3 +540,38 @@ def test_aql_dispatch_path_equals_the_hip_stream_path():
     assert bad == [0] * len(engs)
     for e in engs:
         e.close()
+
+
+def test_pinning_a_thread_next_to_the_gpu():
+    """gwi_pin_thread_to_engine / _to_device: the calling thread's affinity shrinks to (a subset of) what it had, and
+    evaluations from the pinned thread return the same bits.  Done in a worker thread: the test runner's own affinity
+    stays as it was."""
+    import os
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import pin_thread_to_device
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(5, 200, 2000, seed=3)
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = comp.engine()
+    th = comp.theta(draw_params("plpeak", np.random.default_rng(1)))
+    ref = eng.evaluate(th, total, min_neff_cut=False)
+    out = {}
+
+    def work():
+        before = os.sched_getaffinity(0)
+        out["changed"] = eng.pin_thread()
+        out["device"] = pin_thread_to_device(0)
+        after = os.sched_getaffinity(0)
+        out["subset"] = after <= before and len(after) >= 1
+        out["ll"] = eng.evaluate(th, total, min_neff_cut=False).log_likelihood
+
+    before_main = os.sched_getaffinity(0)
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert out["subset"] and out["ll"] == ref.log_likelihood and out["changed"] == out["device"]
+    assert os.sched_getaffinity(0) == before_main
+    eng.close()
