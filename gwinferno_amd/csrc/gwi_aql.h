@@ -60,6 +60,7 @@ struct Api {
   decltype(&hsa_amd_memory_pool_allocate) pool_allocate = nullptr;
   decltype(&hsa_amd_memory_pool_free) pool_free = nullptr;
   decltype(&hsa_amd_agents_allow_access) allow_access = nullptr;
+  decltype(&hsa_amd_agent_memory_pool_get_info) agent_pool_info = nullptr;
   // kernel begin/end timestamps of a dispatch (timing mode only)
   decltype(&hsa_signal_create) signal_create = nullptr;
   decltype(&hsa_signal_destroy) signal_destroy = nullptr;
@@ -151,6 +152,7 @@ inline bool bind_api(std::string& why) {
     GWI_AQL_SYM(pool_allocate, "hsa_amd_memory_pool_allocate")
     GWI_AQL_SYM(pool_free, "hsa_amd_memory_pool_free")
     GWI_AQL_SYM(allow_access, "hsa_amd_agents_allow_access")
+    GWI_AQL_SYM(agent_pool_info, "hsa_amd_agent_memory_pool_get_info")
     GWI_AQL_SYM(signal_create, "hsa_signal_create")
     GWI_AQL_SYM(signal_destroy, "hsa_signal_destroy")
     GWI_AQL_SYM(signal_set, "hsa_signal_store_relaxed")
@@ -240,6 +242,12 @@ inline Device* open_device(uint32_t domain, uint32_t bus, uint32_t device, uint3
     return d;
   }
   d->pool = ps.pool;
+  // the host must be able to map that pool (a PCIe BAR covering device memory): ask before ever touching such a pointer
+  hsa_amd_memory_pool_access_t access = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+  if (a.agent_pool_info(d->cpu, d->pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &access) != HSA_STATUS_SUCCESS || access == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED) {
+    d->why = "device memory is not host-accessible on this system (no large BAR): kernel arguments cannot live there";
+    return d;
+  }
   FILE* f = std::fopen(code_path.c_str(), "rb");
   if (!f) {
     d->why = code_path + " not found (built by __graft_entry__.build())";
