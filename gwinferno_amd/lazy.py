@@ -103,27 +103,39 @@ class GridNorm:
 class LogValues:
     """A theta-independent per-sample array that is ALREADY a logarithm (``jnp.log(samps["prior"])`` in the
     log-space model functions, examples/config_files/model.py:21-22; analysis.py:401-402).  ``key`` identifies it
-    for the engine cache: the identity of the array the logarithm was taken of (:func:`log`), or a content
-    fingerprint for an anonymous array (a model function recomputes ``log(prior)`` on every call)."""
+    for the engine cache: the identity of the array the logarithm was taken of (:func:`log`; the logarithm itself is
+    then only computed when an engine is bound), or a content fingerprint for an anonymous array (a model function
+    recomputes ``log(prior)`` on every call)."""
 
-    __slots__ = ("values", "key", "_keep")
+    __slots__ = ("_values", "key", "_source")
 
-    def __init__(self, values, source=None):
-        self.values = np.asarray(values, dtype=np.float64)
+    def __init__(self, values=None, source=None):
+        self._values, self._source = values, source
         if source is not None:
-            self.key, self._keep = ("log-of", id(source)), source
+            self.key = ("log-of", id(source))
         else:
-            v = self.values
+            v = self._values = np.asarray(values, dtype=np.float64)
             with np.errstate(all="ignore"):
                 self.key = ("log-values", v.shape, float(v.flat[0]) if v.size else 0.0, float(v.flat[-1]) if v.size else 0.0, float(np.sum(v[np.isfinite(v)])))
-            self._keep = None
+
+    @property
+    def values(self):
+        if self._values is None:
+            with np.errstate(all="ignore"):
+                self._values = np.log(np.asarray(self._source, dtype=np.float64))
+        return self._values
+
+    @property
+    def shape_source(self):
+        """An array with the shape of the values, without computing them."""
+        return self._source if self._values is None else self._values
 
 
 def log(x):
     """``jnp.log`` for per-sample data inside a log-space model function: a :class:`LogValues` remembering
-    which array it came from, so that repeated model calls hit the same cached engine."""
-    with np.errstate(all="ignore"):
-        return LogValues(np.log(np.asarray(x, dtype=np.float64)), source=x)
+    which array it came from, so that repeated model calls hit the same cached engine and never recompute the
+    logarithm."""
+    return LogValues(source=x)
 
 
 def static_key(a):
@@ -152,12 +164,29 @@ class Factor:
         self.consts = tuple(float(c) for c in consts)  # p[] of gwi_term
         self.n_basis = int(n_basis)
         self.flags = int(flags)
-        self.mask = mask                      # bool array: False -> sample excluded (weight 0)
-        self.static_log = static_log          # theta-independent per-sample log factor (e.g. log dVc/dz)
+        # bool array (False -> sample excluded, weight 0) and theta-independent per-sample log factor (e.g. log dVc/dz):
+        # either the arrays or zero-argument callables producing them.  Only bind() reads them, once per engine, while
+        # a model function builds its factors on EVERY call: comparisons over the whole catalog must not run per call.
+        self._mask = mask
+        self._static_log = static_log
         self.norm = norm                      # GridNorm dividing this factor, or None
         self.owner = owner                    # model object (pairs PE and injection sides)
         self.norm_owner = norm_owner if norm_owner is not None else owner  # normalisers are shared per owner
         self.tag = tag
+
+    @property
+    def mask(self):
+        if callable(self._mask):
+            with np.errstate(all="ignore"):
+                self._mask = self._mask()
+        return self._mask
+
+    @property
+    def static_log(self):
+        if callable(self._static_log):
+            with np.errstate(all="ignore"):
+                self._static_log = self._static_log()
+        return self._static_log
 
     def structure(self):
         return (self.kind, self.consts, self.n_basis, self.flags, id(self.owner) if self.owner is not None else None, self.tag)
@@ -213,7 +242,7 @@ class LogDensity(Density):
     def _shift(self, other, sgn):
         if isinstance(other, LogValues) or np.ndim(other) > 0:
             lv = other if isinstance(other, LogValues) else LogValues(other)
-            return LogDensity(self.factors, self._merge_side(side_of(lv.values)), self.log_static + [(sgn, lv)], self.log_const)
+            return LogDensity(self.factors, self._merge_side(side_of(lv.shape_source)), self.log_static + [(sgn, lv)], self.log_const)
         return LogDensity(self.factors, self.side, self.log_static, self.log_const + sgn * float(other))
 
     def __add__(self, other):

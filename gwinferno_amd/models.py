@@ -48,12 +48,12 @@ def powerlaw_pdf(xx, alpha, low, high, floor=0.0):
     side = side_of(xx)
     with np.errstate(all="ignore"):
         if np.ndim(low) == 0:
-            mask = ~((xx < low) | (xx > high))
+            mask = lambda: ~((xx < low) | (xx > high))  # noqa: E731 -- evaluated at bind time only
             return Density([Factor(N.TERM_POWERLAW, side, [Column("log", xx)], [alpha], consts=(low, high), mask=mask)], side)
         if float(high) != 1.0:
             raise NotImplementedError("per-sample lower bound is implemented for high == 1 (the reference's only use)")
         low = _f(low)
-        mask = ~((xx < low) | (xx > high))
+        mask = lambda: ~((xx < low) | (xx > high))  # noqa: E731
         # log r = 0 - (-log low)
         return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", xx), Column("neglog", low)], [alpha], consts=(0.0,), mask=mask)], side)
 
@@ -63,8 +63,7 @@ def _powerlaw_ratio(q, m1, beta, mmin):
     q, m1 = _f(q), _f(m1)
     side = side_of(q)
     with np.errstate(all="ignore"):
-        low = mmin / m1
-        mask = ~((q < low) | (q > 1))
+        mask = lambda: ~((q < mmin / m1) | (q > 1))  # noqa: E731 -- evaluated at bind time only
     return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", q), Column("log", m1)], [beta], consts=(np.log(mmin),), mask=mask)], side)
 
 
@@ -74,9 +73,9 @@ def truncnorm_pdf(xx, mu, sig, low, high, log=False):
     xx = _f(xx)
     side = side_of(xx)
     with np.errstate(all="ignore"):
-        mask = ~((xx > high) | (xx < low))
+        mask = lambda: ~((xx > high) | (xx < low))  # noqa: E731
         if log:
-            return Density([Factor(N.TERM_TRUNCNORM, side, [Column("log", xx)], [mu, sig], consts=(np.log(low), np.log(high)), mask=mask, static_log=-np.log(xx))], side)
+            return Density([Factor(N.TERM_TRUNCNORM, side, [Column("log", xx)], [mu, sig], consts=(np.log(low), np.log(high)), mask=mask, static_log=lambda: -np.log(xx))], side)
     return Density([Factor(N.TERM_TRUNCNORM, side, [Column("id", xx)], [mu, sig], consts=(low, high), mask=mask)], side)
 
 
@@ -88,7 +87,7 @@ def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
     side = side_of(xx)
     scale = float(scale)
     with np.errstate(all="ignore"):
-        mask = (xx <= scale) & (xx >= 0)
+        mask = lambda: (xx <= scale) & (xx >= 0)  # noqa: E731
     if scale == 1.0:
         return Density([Factor(N.TERM_BETA, side, [Column("log", xx), Column("log1m", xx)], [alpha, beta], mask=mask)], side)
     return Density([Factor(N.TERM_BETA, side, [Column("logdiv", xx, scale), Column("log1mdiv", xx, scale)], [alpha, beta], mask=mask)], side, log_const=-np.log(scale))
@@ -111,7 +110,7 @@ def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
     m1 = _f(m1)
     side = side_of(m1)
     with np.errstate(all="ignore"):
-        mask = ~((m1 < mmin) | (m1 > mmax))
+        mask = lambda: ~((m1 < mmin) | (m1 > mmax))  # noqa: E731 -- evaluated at bind time only
     cols = [Column("id", m1), Column("log", m1)]
     if delta is None:
         return Density([Factor(N.TERM_PLPEAK, side, cols, [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
@@ -149,7 +148,7 @@ def mixture_isoalign_spin_tilt(ct, xi_tilt, sigma_tilt):
     ct = _f(ct)
     side = side_of(ct)
     with np.errstate(all="ignore"):
-        mask = ~((ct > 1) | (ct < -1))
+        mask = lambda: ~((ct > 1) | (ct < -1))  # noqa: E731
     return Density([Factor(N.TERM_TILT_MIXTURE, side, [Column("id", ct)], [xi_tilt, sigma_tilt], mask=mask)], side)
 
 
@@ -166,7 +165,7 @@ def default_spin_tilt(ct1, ct2, xi_tilt, sigma_tilt):
     ct1, ct2 = _f(ct1), _f(ct2)
     side = side_of(ct1)
     with np.errstate(all="ignore"):
-        mask = ~((ct1 > 1) | (ct1 < -1)) & ~((ct2 > 1) | (ct2 < -1))
+        mask = lambda: ~((ct1 > 1) | (ct1 < -1)) & ~((ct2 > 1) | (ct2 < -1))  # noqa: E731
     return Density([Factor(N.TERM_TILT_JOINT, side, [Column("id", ct1), Column("id", ct2)], [xi_tilt, sigma_tilt], mask=mask)], side)
 
 
@@ -199,7 +198,7 @@ class PowerlawRedshiftModel(object):
     def _powerlaw_factor(self, z, lamb):
         side, zz = self._side_data(z)
         with np.errstate(all="ignore"):
-            mask = zz <= self.zmax
+            mask = lambda: zz <= self.zmax  # noqa: E731
         return Factor(N.TERM_POWERLAW_REDSHIFT, side, [Column("log1p", zz)], [lamb], mask=mask, static_log=self._log_dVdz[side], owner=self, tag="plz")
 
     def normalization(self, lamb):
@@ -453,7 +452,7 @@ class _ComponentMasses(object):
         mask = None
         if self.mask_ratio:
             with np.errstate(all="ignore"):
-                mask = ~((q < 0) | (q > 1))  # :609-613
+                mask = lambda: ~((q < 0) | (q > 1))  # noqa: E731  (:609-613)
         return Density([Factor(N.TERM_POWERLAW, side, [Column("log", q)], [beta], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, mask=mask, owner=self, tag="pairing")], side)
 
 

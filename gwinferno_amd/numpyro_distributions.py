@@ -105,13 +105,15 @@ class BSplineDistribution:
             raise TypeError("grid_dmat must be basis.bases(grid) from gwinferno_amd.interpolation (a dense matrix of unknown origin cannot be evaluated on the device)")
         basis = grid_dmat.basis
         g = np.asarray(grid, dtype=np.float64)
-        if g.ndim != 1 or g.shape != np.shape(grid_dmat.xs) or not np.array_equal(g, grid_dmat.xs):
-            raise ValueError("grid is not the grid the design matrix was evaluated on")
-        if g.size < 2 or np.any(np.diff(g) <= 0):
-            raise ValueError("grid must be strictly increasing")
         self.minimum, self.maximum, self.cs, self.grid, self.basis = minimum, maximum, cs, g, basis
         self._owner = _token("BSplineDistribution", (grid, grid_dmat))
-        if not isinstance(self._owner.keep, dict):
+        if not isinstance(self._owner.keep, dict):  # first time these two arrays are seen: check them, build the tables
+            if g.ndim != 1 or g.shape != np.shape(grid_dmat.xs) or not np.array_equal(g, grid_dmat.xs):
+                _TOKENS.pop(self._owner.key, None)
+                raise ValueError("grid is not the grid the design matrix was evaluated on")
+            if g.size < 2 or np.any(np.diff(g) <= 0):
+                _TOKENS.pop(self._owner.key, None)
+                raise ValueError("grid must be strictly increasing")
             us = basis.coordinate(g)
             with np.errstate(all="ignore"):
                 outside = ~np.isfinite(us) | basis.outside(us)
