@@ -26,13 +26,18 @@ _LAST_SITES = {}
 SAMPLE_VALUES = {}  # values for numpyro.sample sites when numpyro is absent (e.g. {"unscaled_rate": 30.0})
 
 
-def _numpyro():
-    try:
-        import numpyro  # noqa: F401
+_NUMPYRO = []  # [module | None] once probed: a failing import walks sys.path every time (76 us per model call, measured)
 
-        return numpyro
-    except Exception:
-        return None
+
+def _numpyro():
+    if not _NUMPYRO:
+        try:
+            import numpyro  # noqa: F401
+
+            _NUMPYRO.append(numpyro)
+        except Exception:
+            _NUMPYRO.append(None)
+    return _NUMPYRO[0]
 
 
 def last_sites():
