@@ -268,6 +268,52 @@ class BSplineComponentMasses(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class BSplineMisc(Composition):
+    """PLPeakPrimaryBSplineRatio (separable.py:368-443) x BSplineSymmetricChiEffective (single.py:233-284) x PL z."""
+
+    NQ, NE = 10, 9
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"alpha": (), "mpp": (), "sigpp": (), "lam": (), "q_coefs": (self.NQ,), "e_coefs": (self.NE,), "lamb": ()}
+        self.mass_model = M.PLPeakPrimaryBSplineRatio(self.NQ, self.pe["mass_ratio"], self.inj["mass_ratio"])
+        self.chi_model = M.BSplineSymmetricChiEffective(self.NE, self.pe["chi_eff"], self.inj["chi_eff"], normalize=True)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q.update(mpp=30.0, sigpp=5.0, lam=0.1, e_coefs=np.ones(self.NE))
+        return q
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        mass = self.mass_model(d["mass_1"], p["alpha"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"], p["q_coefs"], pe_samples=pe_samples)
+        return where_finite(mass * self.chi_model(p["e_coefs"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+class BSplineIndependentMasses(Composition):
+    """BSplineIndependentComponentMasses (separable.py:616-703) x PL z."""
+
+    N1, N2 = 14, 11
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.N1,), "m2_coefs": (self.N2,), "beta": (), "lamb": ()}
+        self.mass_model = M.BSplineIndependentComponentMasses(self.N1, self.N2, self.pe["mass_1"], self.pe["mass_2"], self.inj["mass_1"], self.inj["mass_2"], mmin1=3.0, mmax1=self.mmax,
+                                                              mmin2=3.0, mmax2=self.mmax)
+        self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        return where_finite(self.mass_model(p["m1_coefs"], p["m2_coefs"], beta=p["beta"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
 class BSplineRedshiftCase(Composition):
     """powerlaw_primary_ratio_pdf x BSplineRedshift(8) with the class defaults (single.py:398-492: LogXBSpline,
     ``normalize=True``).  The engine's theta holds the SCALED exponent coefficients c / (c . I) and, for the
@@ -393,6 +439,8 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "bspline_misc": BSplineMisc,
+    "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,
     "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,
@@ -422,6 +470,11 @@ def draw_params(name, rng):
             p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
                      xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
         return {k: p[k] for k in cls.PARAMS}
+    if name == "bspline_misc":
+        return {"alpha": rng.normal(-2.5, 1.0), "mpp": rng.uniform(20.0, 50.0), "sigpp": rng.uniform(1.0, 10.0), "lam": rng.uniform(0.0, 0.2),
+                "q_coefs": rng.normal(size=cls.NQ), "e_coefs": rng.uniform(0.1, 1.0, size=cls.NE), "lamb": rng.normal(2.7, 1.0)}
+    if name == "bspline_independent_masses":
+        return {"m1_coefs": rng.normal(size=cls.N1), "m2_coefs": rng.normal(size=cls.N2), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
     if name == "chm_powerlaw":
         return {"alpha": rng.normal(-2.5, 1.0), "mmin": rng.uniform(3.0, 9.0), "mmax": rng.uniform(60.0, 100.0), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
     if name == "chm_bspline":

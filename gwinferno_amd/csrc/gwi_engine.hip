@@ -103,6 +103,8 @@ const Variant kVariants[] = {
     GWI_VARIANT("plq+plz+smooth+plpeaksmooth", K_PQ, K_PZ, K_SM, K_PS),
     GWI_VARIANT("plq+smooth+plpeaksmooth", K_PQ, K_SM, K_PS),
     GWI_VARIANT("plz+plpeaksmooth", K_PZ, K_PS),
+    // PLPeakPrimaryBSplineRatio (separable.py:368-443) x BSplineSymmetricChiEffective (single.py:233-284) x PL z
+    GWI_VARIANT("plpeak+plz+spline+lspline", K_PP, K_PZ, K_SP, K_LS),
     // construct_hierarchical_model (analysis.py:359-424) on the reference's own distributions
     // (numpyro_distributions.py): Powerlaw m1 and q with sampled bounds x PowerlawRedshift
     // (examples/config_files/config.yml), and BSplineDistribution m1, q x PowerlawRedshift

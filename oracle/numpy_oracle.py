@@ -653,6 +653,53 @@ class BSplineComponentMasses(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class BSplineMisc(Composition):
+    """PLPeakPrimaryBSplineRatio (separable.py:368-443) x BSplineSymmetricChiEffective (single.py:233-284) x PL z."""
+
+    NQ, NE = 10, 9
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"alpha": (), "mpp": (), "sigpp": (), "lam": (), "q_coefs": (self.NQ,), "e_coefs": (self.NE,), "lamb": ()}
+        self.q_model = spline_ratio(self.NQ, pedict["mass_ratio"], injdict["mass_ratio"], 0.0)  # BSplineRatio default qmin = 0 (single.py:321-355)
+        self.e_model = Spline1D(self.NE, np.abs(pedict["chi_eff"]), np.abs(injdict["chi_eff"]), (0.0, 1.0), "B", normalize=True)  # :257-265
+        self.z_model = PowerlawRedshift(pedict["redshift"], injdict["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            mass = plpeak_primary_pdf(d["mass_1"], p["alpha"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"]) * self.q_model(p["q_coefs"], pe_samples)
+            chi = 0.5 * self.e_model(p["e_coefs"], pe_samples)  # :284
+            return _finite_or_zero(mass * chi * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
+class BSplineIndependentMasses(Composition):
+    """BSplineIndependentComponentMasses (separable.py:616-703: no mask on q) x PL z."""
+
+    N1, N2 = 14, 11
+
+    def __init__(self, pedict, injdict, **kw):
+        super().__init__(pedict, injdict, **kw)
+        self.PARAMS = {"m1_coefs": (self.N1,), "m2_coefs": (self.N2,), "beta": (), "lamb": ()}
+        self.m1_model = spline_mass(self.N1, pedict["mass_1"], injdict["mass_1"], 3.0, self.mmax)
+        self.m2_model = spline_mass(self.N2, pedict["mass_2"], injdict["mass_2"], 3.0, self.mmax)
+        with np.errstate(all="ignore"):
+            self.q = {True: pedict["mass_2"] / pedict["mass_1"], False: injdict["mass_2"] / injdict["mass_1"]}  # :679
+        self.z_model = PowerlawRedshift(pedict["redshift"], injdict["redshift"])
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            mass = self.m1_model(p["m1_coefs"], pe_samples) * self.m2_model(p["m2_coefs"], pe_samples) * np.power(self.q[pe_samples], p["beta"])  # :703
+            return _finite_or_zero(mass * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(p["lamb"])
+
+
 class BSplineRedshiftCase(Composition):
     """powerlaw_primary_ratio_pdf x BSplineRedshift(8) with the class defaults (single.py:398-492)."""
 
@@ -785,6 +832,8 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "bspline_misc": BSplineMisc,
+    "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,
     "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,

@@ -347,6 +347,55 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
         return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.normal(size=cls.NZ)}
 
 
+class BSplineMisc(Composition):
+    """PLPeakPrimaryBSplineRatio(10, q, q_inj) (separable.py:368-443) x BSplineSymmetricChiEffective(9) (single.py:233-284:
+    evaluated on |chi_eff|, halved) x PowerlawRedshiftModel."""
+
+    NQ, NE = 10, 9
+    params = {"alpha": (), "mpp": (), "sigpp": (), "lam": (), "q_coefs": (NQ,), "e_coefs": (NE,), "lamb": ()}
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        self.mass_model = ref.separable.PLPeakPrimaryBSplineRatio(self.NQ, pe["mass_ratio"], inj["mass_ratio"])
+        self.chi_model = ref.single.BSplineSymmetricChiEffective(self.NE, pe["chi_eff"], inj["chi_eff"], normalize=True)
+        self.z_model = ref.parametric.PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+
+    def weights(self, p, d, pe_samples):
+        mass = self.mass_model(d["mass_1"], p["alpha"], MMIN, MMAX, p["mpp"], p["sigpp"], p["lam"], p["q_coefs"], pe_samples=pe_samples)
+        return _guard(mass * self.chi_model(p["e_coefs"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(lamb=p["lamb"])
+
+    @classmethod
+    def draw(cls, rng):
+        return {"alpha": rng.normal(-2.5, 1.0), "mpp": rng.uniform(20.0, 50.0), "sigpp": rng.uniform(1.0, 10.0), "lam": rng.uniform(0.0, 0.2),
+                "q_coefs": rng.normal(size=cls.NQ), "e_coefs": rng.uniform(0.1, 1.0, size=cls.NE), "lamb": rng.normal(2.7, 1.0)}
+
+
+class BSplineIndependentMasses(Composition):
+    """BSplineIndependentComponentMasses(14, 11, mmin=3) (separable.py:616-703; no q mask, :703) x PowerlawRedshiftModel."""
+
+    N1, N2 = 14, 11
+    params = {"m1_coefs": (N1,), "m2_coefs": (N2,), "beta": (), "lamb": ()}
+
+    def __init__(self, pe, inj):
+        super().__init__(pe, inj)
+        self.mass_model = ref.separable.BSplineIndependentComponentMasses(self.N1, self.N2, pe["mass_1"], pe["mass_2"], inj["mass_1"], inj["mass_2"], mmin1=3.0, mmax1=MMAX,
+                                                                          mmin2=3.0, mmax2=MMAX)
+        self.z_model = ref.parametric.PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+
+    def weights(self, p, d, pe_samples):
+        return _guard(self.mass_model(p["m1_coefs"], p["m2_coefs"], beta=p["beta"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def hypervolume(self, p):
+        return self.z_model.normalization(lamb=p["lamb"])
+
+    @classmethod
+    def draw(cls, rng):
+        return {"m1_coefs": rng.normal(size=cls.N1), "m2_coefs": rng.normal(size=cls.N2), "beta": rng.normal(1.0, 1.0), "lamb": rng.normal(2.7, 1.0)}
+
+
 class ChmPowerlaw(Composition):
     """construct_hierarchical_model (pipeline/analysis.py:359-424) on the reference's own distributions:
     mass_1 ~ Powerlaw(alpha, minimum, maximum) with the bounds hyper-parameters too, mass_ratio ~ Powerlaw(beta, 0.02, 1),
@@ -457,6 +506,8 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "bspline_misc": BSplineMisc,
+    "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,
     "chm_bspline": ChmBSpline,
     "plpeak_smooth": PLPeakSmooth,
@@ -885,7 +936,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "gwtc3", "catalog", "ppd", "pipeline"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "gwtc3", "catalog", "ppd", "pipeline"]
     if "ppd" in todo:
         make_ppd_fixture()
     if "pipeline" in todo:
@@ -922,6 +973,10 @@ def main(which):
         chm_sets = ("log", "log_neff", "log_var", "log_marg")
         make_case("case_chm_powerlaw.npz", "chm_powerlaw", pe, inj, tot, seed=15, n_points=4, n_grad=2, flagsets=chm_sets)
         make_case("case_chm_bspline.npz", "chm_bspline", pe, inj, tot, seed=16, n_points=3, n_grad=1, flagsets=chm_sets)
+    if "cases6" in todo:
+        pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
+        make_case("case_bspline_misc.npz", "bspline_misc", pe, inj, tot, seed=17, n_points=3, n_grad=1)
+        make_case("case_bspline_independent_masses.npz", "bspline_independent_masses", pe, inj, tot, seed=18, n_points=3, n_grad=1)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

@@ -19,6 +19,8 @@ CASES = [
     "bspline_redshift",
     "bspline_redshift_raw",
     "plpeak_smooth",
+    "bspline_misc",
+    "bspline_independent_masses",
     "chm_powerlaw",
     "chm_bspline",
     "gwtc3_pl_test",
