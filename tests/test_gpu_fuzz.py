@@ -34,13 +34,14 @@ def _wide(name, p, rng):
             p[k] = float(rng.uniform(60.0, 130.0))
     if name == "bspline_redshift":  # exponent coefficients are c / (c . I): keep the denominator away from 0
         p["z_coefs"] = np.abs(p["z_coefs"]) + 0.05
-    if "e_coefs" in p:  # linear (density) splines need positive coefficients
-        p["e_coefs"], p["p_coefs"] = np.abs(p["e_coefs"]) + 0.01, np.abs(p["p_coefs"]) + 0.01
+    for k in ("e_coefs", "p_coefs"):  # linear (density) splines need positive coefficients
+        if k in p:
+            p[k] = np.abs(p[k]) + 0.01
     return p
 
 
 @pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_chieff",
-                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth", "chm_powerlaw", "chm_bspline"])
+                                  "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth", "chm_powerlaw", "chm_bspline", "bspline_misc", "bspline_independent_masses"])
 def test_randomised_parity_against_c_oracle(name):
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
