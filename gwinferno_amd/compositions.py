@@ -268,6 +268,25 @@ class BSplineComponentMasses(Composition):
         return self.z_model.normalization(p["lamb"])
 
 
+class PLPeakIIDSpins(PLPeak):
+    """PL+Peak x iid_spin_magnitude (parametric.py:67-68, amax = 0.9) x iid_spin_tilt (:89-90) x PL z: one set of spin
+    hyper-parameters feeds both components (two theta slots each; the named gradient is their sum)."""
+
+    PARAMS = {k: () for k in ("alpha", "beta", "mpp", "sigpp", "lam", "alpha_a", "beta_a", "xi", "sig_t", "lamb")}
+    AMAX = 0.9
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        p_a = M.iid_spin_magnitude(d["a_1"], d["a_2"], p["alpha_a"], p["beta_a"], amax=self.AMAX)
+        p_ct = M.iid_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+        return where_finite(self.mass(p, d) * p_a * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def placeholder(self):
+        q = super().placeholder()
+        q.update(alpha_a=2.0, beta_a=3.0, xi=0.5, sig_t=1.0)
+        return q
+
+
 class BSplineMisc(Composition):
     """PLPeakPrimaryBSplineRatio (separable.py:368-443) x BSplineSymmetricChiEffective (single.py:233-284) x PL z."""
 
@@ -439,6 +458,7 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "plpeak_iid_spins": PLPeakIIDSpins,
     "bspline_misc": BSplineMisc,
     "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,
@@ -469,6 +489,10 @@ def draw_params(name, rng):
         if name == "plpeak_full":
             p.update(alpha_a1=rng.uniform(1.0, 3.0), beta_a1=rng.uniform(1.0, 5.0), alpha_a2=rng.uniform(1.0, 3.0), beta_a2=rng.uniform(1.0, 5.0), xi1=rng.uniform(0.0, 1.0),
                      xi2=rng.uniform(0.0, 1.0), sig_t1=rng.uniform(0.3, 4.0), sig_t2=rng.uniform(0.3, 4.0))
+        return {k: p[k] for k in cls.PARAMS}
+    if name == "plpeak_iid_spins":
+        p = draw_params("plpeak", rng)
+        p.update(alpha_a=rng.uniform(1.0, 3.0), beta_a=rng.uniform(1.0, 5.0), xi=rng.uniform(0.0, 1.0), sig_t=rng.uniform(0.3, 4.0))
         return {k: p[k] for k in cls.PARAMS}
     if name == "bspline_misc":
         return {"alpha": rng.normal(-2.5, 1.0), "mpp": rng.uniform(20.0, 50.0), "sigpp": rng.uniform(1.0, 10.0), "lam": rng.uniform(0.0, 0.2),

@@ -517,6 +517,20 @@ class PLPeakFull(PLPeak):
             return _finite_or_zero(self.mass_density(p, d) * spins * tilts * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
 
 
+class PLPeakIIDSpins(PLPeak):
+    """PL+Peak x iid_spin_magnitude (parametric.py:67-68, amax = 0.9) x iid_spin_tilt (:89-90) x PL z."""
+
+    PARAMS = {k: () for k in ("alpha", "beta", "mpp", "sigpp", "lam", "alpha_a", "beta_a", "xi", "sig_t", "lamb")}
+    AMAX = 0.9
+
+    def weights(self, p, pe_samples):
+        d = self.data(pe_samples)
+        with np.errstate(all="ignore"):
+            spins = betadist(d["a_1"], p["alpha_a"], p["beta_a"], scale=self.AMAX) * betadist(d["a_2"], p["alpha_a"], p["beta_a"], scale=self.AMAX)
+            tilts = mixture_isoalign_spin_tilt(d["cos_tilt_1"], p["xi"], p["sig_t"]) * mixture_isoalign_spin_tilt(d["cos_tilt_2"], p["xi"], p["sig_t"])
+            return _finite_or_zero(self.mass_density(p, d) * spins * tilts * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+
 class BSplineTest(Composition):
     """tests/inference_test.py:124-143, 244-285 (BSplinePrimaryBSplineRatio, separable.py:446-530:
     q domain (m2min/mmax, 1) :508)."""
@@ -832,6 +846,7 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "plpeak_iid_spins": PLPeakIIDSpins,
     "bspline_misc": BSplineMisc,
     "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,

@@ -347,6 +347,27 @@ class BSplineRedshiftRawCase(BSplineRedshiftCase):
         return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "z_coefs": rng.normal(size=cls.NZ)}
 
 
+class PLPeakIIDSpins(PLPeakFull):
+    """PL+Peak x iid_spin_magnitude (parametric.py:67-68, amax = 0.9: the scaled Beta of distributions.py:146-162) x
+    iid_spin_tilt (:89-90) x power-law redshift: both components share one set of spin hyper-parameters."""
+
+    params = {k: () for k in ("alpha", "beta", "mpp", "sigpp", "lam", "alpha_a", "beta_a", "xi", "sig_t", "lamb")}
+    AMAX = np.float64(0.9)
+
+    def weights(self, p, d, pe_samples):
+        P = ref.parametric
+        p_m1q = P.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], MMIN, MMAX, p["mpp"], p["sigpp"], p["lam"])
+        p_a = P.iid_spin_magnitude(d["a_1"], d["a_2"], p["alpha_a"], p["beta_a"], amax=self.AMAX)
+        p_ct = P.iid_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+        return _guard(p_m1q * p_a * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    @staticmethod
+    def draw(rng):
+        out = PLPeak.draw(rng)
+        out.update(alpha_a=rng.uniform(1.0, 3.0), beta_a=rng.uniform(1.0, 5.0), xi=rng.uniform(0.0, 1.0), sig_t=rng.uniform(0.3, 4.0))
+        return {k: out[k] for k in PLPeakIIDSpins.params}
+
+
 class BSplineMisc(Composition):
     """PLPeakPrimaryBSplineRatio(10, q, q_inj) (separable.py:368-443) x BSplineSymmetricChiEffective(9) (single.py:233-284:
     evaluated on |chi_eff|, halved) x PowerlawRedshiftModel."""
@@ -506,6 +527,7 @@ class ChmBSpline(ChmPowerlaw):
 
 
 COMPOSITIONS = {
+    "plpeak_iid_spins": PLPeakIIDSpins,
     "bspline_misc": BSplineMisc,
     "bspline_independent_masses": BSplineIndependentMasses,
     "chm_powerlaw": ChmPowerlaw,
@@ -976,6 +998,7 @@ def main(which):
     if "cases6" in todo:
         pe, inj, tot = make_catalog(8, 64, 512, seed=BASE_SEED + 11)
         make_case("case_bspline_misc.npz", "bspline_misc", pe, inj, tot, seed=17, n_points=3, n_grad=1)
+        make_case("case_plpeak_iid_spins.npz", "plpeak_iid_spins", pe, inj, tot, seed=19, n_points=3, n_grad=1)
         make_case("case_bspline_independent_masses.npz", "bspline_independent_masses", pe, inj, tot, seed=18, n_points=3, n_grad=1)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)

@@ -19,6 +19,7 @@ CASES = [
     "bspline_redshift",
     "bspline_redshift_raw",
     "plpeak_smooth",
+    "plpeak_iid_spins",
     "bspline_misc",
     "bspline_independent_masses",
     "chm_powerlaw",
