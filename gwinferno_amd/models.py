@@ -32,8 +32,26 @@ __all__ = [
 ]
 
 
+_CONVERTED = {}  # id(original) -> (original, float64 ndarray)
+
+
 def _f(x):
-    return np.asarray(x, dtype=np.float64)
+    """The caller's array as a float64 ndarray WITHOUT losing its identity across calls: engines are cached on the
+    identity of the data arrays, and a model function hands the same objects in on every evaluation.  A plain float64
+    ndarray is returned as is; anything else (float32 catalogs, memmaps and other ndarray subclasses, lists) is converted
+    once and the conversion remembered for as long as the original lives here."""
+    if type(x) is np.ndarray and x.dtype == np.float64:
+        return x
+    if np.ndim(x) == 0:
+        return np.asarray(x, dtype=np.float64)
+    hit = _CONVERTED.get(id(x))
+    if hit is not None and hit[0] is x:
+        return hit[1]
+    if len(_CONVERTED) > 512:
+        _CONVERTED.clear()
+    y = np.asarray(x, dtype=np.float64)
+    _CONVERTED[id(x)] = (x, y)
+    return y
 
 
 # ================================================================================================

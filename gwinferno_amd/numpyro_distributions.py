@@ -15,6 +15,7 @@ import numpy as np
 from . import _native as N
 from .interpolation import DesignMatrix, trapezoid_weights
 from .lazy import Column, Factor, GridNorm, LazyNorm, LogDensity, side_of
+from .models import _f
 
 
 class _Token:
@@ -47,7 +48,7 @@ class Powerlaw:
         self.alpha, self.minimum, self.maximum = alpha, minimum, maximum
 
     def log_prob(self, value):
-        value = np.asarray(value, dtype=np.float64)
+        value = _f(value)
         side = side_of(value)
         # :131-136: -inf (as nan_to_num) outside [minimum, maximum], the alpha = -1 limit handled by the engine
         return LogDensity([Factor(N.TERM_POWERLAW_BOUNDS, side, [Column("log", value), Column("id", value)], [self.alpha, self.minimum, self.maximum])], side)
@@ -73,8 +74,7 @@ class PowerlawRedshift:
         return LazyNorm(self._owner, [self.lamb])
 
     def log_prob(self, value, dVdc=None):
-        src = value
-        value = np.asarray(value, dtype=np.float64)
+        value = src = _f(value)
         side = side_of(value)
         t = self._owner.keep
         if dVdc is None:
@@ -125,7 +125,7 @@ class BSplineDistribution:
 
     def _factor(self, src):
         basis, t = self.basis, self._owner.keep
-        value = np.asarray(src, dtype=np.float64)
+        value = src = _f(src)
         side = side_of(value)
         flags = 0 if basis.log_y else N.SPLINE_OUTSIDE_ZERO_EXPONENT
         f = Factor(N.TERM_EXP_SPLINE_LERP, side, [Column("gridindex", src if isinstance(src, np.ndarray) else value, aux=t["grid"])], coefs=self.cs, consts=(basis.lo, basis.hi), n_basis=basis.N,

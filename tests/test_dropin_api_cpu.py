@@ -134,3 +134,45 @@ def test_bijector_roundtrip_and_jacobian():
         assert abs(fd - dth[i]) < 1e-6
         fdj = (b.forward(u + e)[3] - b.forward(u - e)[3]) / 2e-6
         assert abs(fdj - dlogj[i]) < 1e-6
+
+
+def test_lazy_products_do_no_array_work_until_bound():
+    """A model function runs on every evaluation: building its lazy products must not touch the catalog (masks, static
+    logs and log(prior) stay unevaluated until an engine is bound), engines are found again by the identity of the
+    caller's arrays -- also when those are float32 or ndarray subclasses (memmaps) that have to be converted -- and the
+    log-space algebra maps onto the same products."""
+    from gwinferno_amd import lazy
+    from gwinferno_amd import models as M
+    from gwinferno_amd import numpyro_distributions as D
+    from gwinferno_amd.engine import bind, structure_key
+
+    class Sub(np.ndarray):  # stands for np.memmap and friends
+        pass
+
+    pe, inj, total = make_catalog(3, 16, 40, seed=2)
+    pe = {k: np.ascontiguousarray(v, dtype=np.float64).view(Sub) for k, v in pe.items()}
+    inj = {k: np.asarray(v, dtype=np.float32) if k == "mass_ratio" else v for k, v in inj.items()}  # one float32 column
+    z_model = M.PowerlawRedshiftModel(z_pe=pe["redshift"], z_inj=inj["redshift"])
+
+    def linear(d):
+        return M.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], -2.3, 1.1, 5.0, 100.0, 33.0, 4.0, 0.1) * z_model(d["redshift"], 2.5) / d["prior"]
+
+    def log_space(d):
+        return D.Powerlaw(-2.3, 5.0, 100.0).log_prob(d["mass_1"]) + D.Powerlaw(1.1, 0.02, 1.0).log_prob(d["mass_ratio"]) - lazy.log(d["prior"])
+
+    for build in (linear, log_space):
+        wp, wi = build(pe), build(inj)
+        for w in (wp, wi):
+            assert all(f._mask is None or callable(f._mask) for f in w.factors)            # no comparison has run
+            assert all(f._static_log is None or callable(f._static_log) or f.owner is not None for f in w.factors)
+            assert all(c._cache is None for f in w.factors for c in f.columns)             # no transform has run
+            assert all(a._values is None for _, a in w.log_static if isinstance(a, lazy.LogValues))
+        assert structure_key(wp, wi) == structure_key(build(pe), build(inj))  # stable across calls: ONE cached engine serves them all
+        bm = bind(wp, wi)  # ... and only now masks, transforms and logs are computed
+        assert bm.n_theta > 0 and all(c.dtype == np.float64 and type(c) is np.ndarray for c in bm.pe_cols + bm.inj_cols)
+    # log-space algebra: sum([...]) and scalar shifts
+    a = D.Powerlaw(-2.0, 5.0, 100.0).log_prob(np.asarray(inj["mass_1"]))
+    total_ld = sum([a, D.Powerlaw(1.0, 0.02, 1.0).log_prob(np.asarray(inj["mass_ratio"]))]) + 0.5
+    assert isinstance(total_ld, lazy.LogDensity) and len(total_ld.factors) == 2 and abs(total_ld.log_const - 0.5) < 1e-15
+    with pytest.raises(TypeError):
+        a - a
