@@ -16,6 +16,8 @@ Three ways to drive it
 Out of scope: the categorical / mixture branch (analysis.py:246-254) and the
 posterior-predictive-check branch (:321-355) raise NotImplementedError.
 """
+import os
+
 import numpy as np
 
 from .engine import NEG_BIG, NativePopulationLikelihood, structure_key
@@ -46,7 +48,7 @@ def last_sites():
 
 
 def clear_engine_cache():
-    for eng in _ENGINES.values():
+    for eng, *_ in _ENGINES.values():
         eng.close()
     _ENGINES.clear()
     for _, eng, _ in _ONE_SIDED.values():
@@ -74,11 +76,21 @@ def _collect_params(bound, density):
 def engine_for(pe_weights, inj_weights, surveyed_hypervolume=None, device=-1):
     """The cached engine for this model structure + catalog (built, i.e. uploaded, on first use)."""
     key = (structure_key(pe_weights, inj_weights), id(surveyed_hypervolume.owner) if isinstance(surveyed_hypervolume, LazyNorm) else None, device)
-    eng = _ENGINES.get(key)
-    if eng is None:
+    hit = _ENGINES.get(key)
+    if hit is None:
         eng = NativePopulationLikelihood(pe_weights, inj_weights, surveyed_hypervolume, device=device)
-        _ENGINES[key] = eng
-    return eng
+        # The key is made of object identities: the entry keeps the keyed objects (the data arrays through the factors'
+        # columns, the model objects through their owners) alive, so that an id can never come to mean other data.  A
+        # model function that hands in NEW arrays on every call gets a new engine every call: the cache is bounded
+        # (least recently used out first, GWI_ENGINE_CACHE entries, default 8) so that this costs time, not HBM.
+        _ENGINES[key] = hit = (eng, pe_weights, inj_weights, surveyed_hypervolume)
+        limit = max(1, int(os.environ.get("GWI_ENGINE_CACHE", "8")))
+        while len(_ENGINES) > limit:
+            old_key = next(iter(_ENGINES))
+            _ENGINES.pop(old_key)[0].close()
+    else:
+        _ENGINES[key] = _ENGINES.pop(key)  # most recently used last
+    return hit[0]
 
 
 def _sites_from_result(res, Nobs, Tobs, unscaled_rate, flags, xp=np):
@@ -353,6 +365,8 @@ def _one_sided(weights):
         mirror = _mirror(weights, side)
         eng = NativePopulationLikelihood(weights, mirror) if side == PE else NativePopulationLikelihood(mirror, weights)
         hit = _ONE_SIDED[key] = (mirror, eng, weights)  # the originals stay referenced: keys are object ids
+        while len(_ONE_SIDED) > max(1, int(os.environ.get("GWI_ENGINE_CACHE", "8"))):  # bounded like the two-sided cache
+            _ONE_SIDED.pop(next(iter(_ONE_SIDED)))[1].close()
     eng = hit[1]
     theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in _collect_params(eng.bound, weights)])
     return side, eng, theta

@@ -413,3 +413,32 @@ def test_torch_autograd_adapter():
     with pytest.raises(ValueError):
         log_likelihood(eng, torch.zeros(2, dtype=torch.float64), total)
     eng.close()
+
+
+def test_engine_cache_is_bounded_and_keyed_on_live_objects():
+    """A model function that hands in NEW arrays on every call gets a new engine every call (the key is the identity of
+    the data): the cache evicts (and closes) the least recently used engine instead of filling the HBM, and keeps the
+    keyed arrays alive so that a recycled id can never select an engine holding other data."""
+    import gc
+
+    from gwinferno_amd import likelihood as L
+    from gwinferno_amd.lazy import where_finite
+    from gwinferno_amd.models import PowerlawRedshiftModel, powerlaw_primary_ratio_pdf
+    from gwinferno_amd.synthetic import make_catalog
+
+    L.clear_engine_cache()
+    L.SAMPLE_VALUES["unscaled_rate"] = 30.0
+    values = {}
+    for rep in range(2):
+        for seed in range(11):
+            pe, inj, total = make_catalog(4, 64, 600, seed=100 + seed)  # fresh arrays every time
+            z_model = PowerlawRedshiftModel(z_pe=pe["redshift"], z_inj=inj["redshift"])
+            w = lambda d: where_finite(powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=-2.2, beta=1.0, mmin=5.0, mmax=100.0) * z_model(d["redshift"], 2.0) / d["prior"])  # noqa: E731
+            L.hierarchical_likelihood(w(pe), w(inj), total_inj=total, Nobs=4, Tobs=1.0, surveyed_hypervolume=z_model.normalization(2.0), min_neff_cut=False)
+            ll = L.last_sites()["log_likelihood"]
+            assert values.setdefault(seed, ll) == ll  # same data -> same value, whichever engine served it
+            del pe, inj, z_model, w
+            gc.collect()
+            assert len(L._ENGINES) <= 8
+    assert len(set(values.values())) == 11
+    L.clear_engine_cache()
