@@ -71,7 +71,7 @@ def main(round_name):
         sq_lines.append(f"| {cfg} | {w:.0f} | {valu / w:.0f} | {salu / w:.0f} | {lds / w:.0f} | {flop / 1e9:.2f} | {flop / (t_us * 1e-6) / 1e12:.2f} | {wa / wc:.0%} | {ai / wc:.0%} | {(bc / ia if ia else 0):.0%} |")
     lines += ["", "Scan-kernel SQ counters (separate `--pmc` passes; fp64 FLOP = 64 x (ADD + MUL + 2 FMA + TRANS) wave-instructions):", ""] + sq_lines
     with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
-        fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).\n\n")
+        fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  The traced launches are AQL dispatches from the engine's own queues (gwinferno_amd/csrc/gwi_aql.h); `<config>_bench.json` holds the untraced run of the same command, whose live kernel durations come from the same dispatch timestamps.\n\n")
         fh.write("\n".join(lines) + "\n")
     with open(os.path.join(dst, "traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
