@@ -4,9 +4,9 @@
 // MI355X boxes, and 6.9 us from the call to the first result of a one-workgroup kernel) is a third of the step.  The
 // same kernels dispatched as AQL packets written straight into a user-mode HSA queue that belongs to the engine cost
 // 0.4 us of host time and 4.3 us to the first result (tools/microbench/aql_dispatch.cpp).  So the plain evaluation path
-// -- scan, combine[, final] of ONE hyper-parameter point, no event timing, nothing else ordered behind it on the HIP
-// stream -- goes this way; everything else (batched launches, the sharded path with its RCCL exchange on the HIP stream,
-// timed launches, gwi_log_weights) keeps the HIP stream.  An evaluation is fully drained before its entry point
+// -- scan, combine[, final] of ONE hyper-parameter point, nothing else ordered behind it on the HIP stream -- goes this
+// way (timed or not: timing mode reads the queue's dispatch timestamps); everything else (batched launches, the sharded
+// path with its RCCL exchange on the HIP stream, gwi_log_weights) keeps the HIP stream.  An evaluation is fully drained before its entry point
 // returns, so the two queues never hold work of the same engine at the same time.
 //
 //  * code: the device code compiled a second time into a raw code object (gwi_kernels.hsaco next to the library; the

@@ -502,7 +502,8 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   const int n_theta = h->spec.n_theta;
   h->kargs.square = square ? 1 : 0;
   // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
-  // (batched theta uploads, the sharded path's exchange behind record_dev) or timed with HIP events stays on the stream
+  // (batched theta uploads, the sharded path's exchange behind record_dev) stays on the stream, and so does everything
+  // after gwi_set_timing(h, 2)
   h->aql_now = h->aql_active && !h->aq.failed() && !h->force_hip_stream && !batch && K == 1 && record_dev == nullptr;
   if (h->aql_now && h->timing && !aql::timed_prepare(h->aq)) h->aql_now = false;  // no dispatch timestamps: time this one with HIP events
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
