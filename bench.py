@@ -7,14 +7,21 @@ results, with the catalog already resident in HBM -- what one NUTS leapfrog cost
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5]
 
-N = 1: a single engine.  N > 1 (launched by torch.distributed.run, one rank per GPU): events and
-injections are sharded across ranks, each rank scans its shard, ONE RCCL all-gather of the small
-partial records is the only exchange, and every rank assembles the same result ("strong" scaling:
-the BASELINE catalog size is fixed).  Prints ONE JSON line on rank 0.
+N = 1: a single engine.  N > 1: one rank per GPU (events and injections sharded across ranks, each rank scans
+its shard, ONE exchange of the ~1 KiB partial records, every rank assembles the same result; "strong" scaling:
+the BASELINE catalog size is fixed).  Launched plainly (`python bench.py --gpus N`) the script starts its own
+ranks -- a fresh `python -m torch.distributed.run` child, before this process has touched a GPU -- and relays
+the child's JSON line; under torch.distributed.run it is a rank.  Prints ONE JSON line on rank 0.
+
+The headline block (`value`, `ms_per_step`, `roofline`, `cpu_baseline`) is BASELINE config 2, the configuration
+the metric is quoted on; `configs` carries the same measurements for the B-spline configs 3 and 5.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,42 +38,83 @@ CONFIGS = {
     "c5": ("bspline_full", "c5", 9, "C5: B-spline m1(30) q(14) a1,a2(12) ct1,ct2(12) x PL z x spline z(12), 200 ev x 10000 PE x 500k inj"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
+# ----------------------------------------------------------------------------------------------------
+# --gpus N launched plainly: start the ranks ourselves
+# ----------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Spawn `python -m torch.distributed.run --nproc-per-node n bench.py ...` as a CHILD (never exec: this process may
+    not replace itself once anything has initialised the GPU, and a child keeps that rule trivially true) and relay its
+    JSON line.  With fewer than n GPUs visible the ranks share what there is (round robin) and exchange over gloo --
+    a logic run of the multi-rank path, flagged in the output."""
+    import torch  # counting devices does not initialise the GPU
+
+    n_vis = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_vis < n:
+        env["GWI_BENCH_BACKEND"] = "gloo"
+        env["GWI_BENCH_SHARE_DEVICES"] = str(max(n_vis, 1))
+        print(f"[bench] {n_vis} GPU(s) visible for --gpus {n}: ranks share them (gloo rendezvous)", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + argv
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode if lines or child.returncode else 1
+
+
+# ----------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------
 def pmc_table(config):
-    """Row of profiles/<latest round>/traffic.json for this config (or {})."""
-    import glob
-
+    """Row of profiles/<latest round>/traffic.json for this config (or {}): HBM bytes and fp64 flops per scan launch from
+    separate rocprofv3 --pmc passes (tools/profile_round.sh + tools/summarize_profiles.py; FETCH_SIZE doubled per the
+    gfx950 correction of MI355X_MICROARCH.md)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")))
-    try:
-        return json.load(open(files[-1])).get(config, {}) if files else {}
-    except Exception:
-        return {}
+    for f in reversed(files):
+        try:
+            row = json.load(open(f)).get(config)
+            if row:
+                return dict(row, source=os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return {}
 
 
-def pmc_traffic(config):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of the latest round
-    (profiles/<round>/traffic.json, produced by tools/profile_round.sh + tools/summarize_profiles.py:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction)."""
-    import glob
+def read_clocks():
+    """Current shader / memory clock of every amdgpu card from sysfs (the `*` line of pp_dpm_sclk / pp_dpm_mclk)."""
+    out = []
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        row = {}
+        for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+            try:
+                for ln in open(os.path.join(d, fn)):
+                    if "*" in ln:
+                        row[key] = ln.split(":")[1].replace("*", "").strip()
+            except Exception:
+                pass
+        if row:
+            row["card"] = os.path.basename(os.path.dirname(d))
+            out.append(row)
+    return out or None
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")))
-    if not files:
-        return None, None
-    try:
-        table = json.load(open(files[-1]))
-        return table[config]["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
 
-
-def cpu_baseline(comp, thetas, total, budget_s=10.0):
-    """The C/OpenMP restatement (oracle/gwpop_oracle.c: value + gradient + sites, same flat model
-    description as the GPU engine receives) timed on all host cores, plus the NumPy restatement of the
-    reference formulation (value only, 1 core) for scale.  Checker code, never the product path."""
-    from oracle.c_oracle import COracle
-
-    orc = COracle(comp.engine().bound)
+def host_cores():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota of the container, if any
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -74,8 +122,18 @@ def cpu_baseline(comp, thetas, total, budget_s=10.0):
             avail = max(1, min(avail, int(float(quota) / float(period))))
     except Exception:
         pass
-    # the visible CPU count can exceed what the container may really use: probe a few thread counts
-    # (one evaluation each) and keep the fastest
+    return avail
+
+
+def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, numpy_reference=True):
+    """The C/OpenMP restatement (oracle/gwpop_oracle.c: value + gradient + sites, same flat model description as the GPU
+    engine receives) timed on the host cores, plus the NumPy restatement of the REFERENCE formulation (dense Cox-de Boor
+    design matrices contracted per evaluation, value only, one core).  Checker code, never the product path."""
+    from oracle.c_oracle import COracle
+
+    orc = COracle(comp.engine().bound)
+    avail = host_cores()
+    # the visible CPU count can exceed what the container may really use: probe a few thread counts and keep the fastest
     best, cores = None, 1
     for nt in sorted({1, 2, 4, 8, 16, 32, 64, 128, avail}):
         if nt > avail:
@@ -95,7 +153,7 @@ def cpu_baseline(comp, thetas, total, budget_s=10.0):
     t0 = time.perf_counter()
     orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=1)
     t_single = time.perf_counter() - t0
-    return {
+    out = {
         "value": n / t_used,
         "unit": "evals/s",
         "cores": cores,
@@ -103,109 +161,171 @@ def cpu_baseline(comp, thetas, total, budget_s=10.0):
         "sample": f"{n} value+gradient evals of the full catalog by the C/OpenMP oracle on {cores} threads ({t_used:.1f}s)",
         "single_thread_evals_per_s": 1.0 / t_single,
     }
+    if numpy_reference:
+        # reference formulation (interpolation.py:304 einsum over a dense (N_basis, N) matrix), NumPy, one core, value only
+        try:
+            from oracle import numpy_oracle as O
+
+            t0 = time.perf_counter()
+            ref = O.COMPOSITIONS[comp_name](pe, inj)  # builds the dense design matrices once (setup, not timed per eval)
+            t_setup = time.perf_counter() - t0
+            ref.evaluate(pool[0], total, min_neff_cut=False)
+            k, t_np = 0, 0.0
+            while t_np < 3.0 and k < 50:
+                t0 = time.perf_counter()
+                ref.evaluate(pool[k % len(pool)], total, min_neff_cut=False)
+                t_np += time.perf_counter() - t0
+                k += 1
+            out["numpy_reference_formulation"] = {"evals_per_s": k / t_np, "cores": 1, "value_only": True, "setup_s": t_setup,
+                                                 "sample": f"{k} evals by oracle/numpy_oracle.py (dense design matrices, einsum per eval)"}
+        except Exception as exc:  # the dense matrices of config 5 need ~2 GB
+            out["numpy_reference_formulation"] = {"error": repr(exc)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
-    ap.add_argument("--chains", type=int, default=4, help="also time this many independent chains interleaved on one GPU (begin/end); <= 1 disables")
-    ap.add_argument("--timing-every", type=int, default=50, help="kernel begin/end timing on every n-th timed step")
-    args = ap.parse_args()
+def percentiles(seconds):
+    ms = 1e3 * np.asarray(seconds)
+    return {"median_ms_per_step": float(np.median(ms)), "p5_ms": float(np.percentile(ms, 5)), "p95_ms": float(np.percentile(ms, 95)), "n_evals": int(ms.size)}
 
-    import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    dist = None
-    collective = None
-    force_sharded = os.environ.get("GWI_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
-    if world > 1 or force_sharded:
-        import torch.distributed as dist
+class Run:
+    """Process-wide context: rank, world, device and the torch.distributed group (if any)."""
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # GWI_BENCH_BACKEND=gloo + GWI_BENCH_DEVICE=0: several ranks sharing ONE GPU with a CPU-side exchange --
-        # a logic test of the multi-rank path on a single-GPU box (implies the torch collective)
-        backend = os.environ.get("GWI_BENCH_BACKEND", "nccl")
-        if "GWI_BENCH_DEVICE" in os.environ:
-            local_rank = int(os.environ["GWI_BENCH_DEVICE"])
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-            os.environ["GWI_TORCH_COLLECTIVE"] = "1"
+    def __init__(self, args):
+        import torch
 
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.shared_devices = None
+        force_sharded = os.environ.get("GWI_FORCE_SHARDED") == "1"  # exercise the N>1 code path in one process
+        if self.world > 1 or force_sharded:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            # GWI_BENCH_BACKEND=gloo with GWI_BENCH_DEVICE=d (all ranks on device d) or GWI_BENCH_SHARE_DEVICES=n (round
+            # robin over n devices): several ranks on fewer GPUs with a CPU-side rendezvous -- a logic run of the multi-rank
+            # path on a small box
+            backend = os.environ.get("GWI_BENCH_BACKEND", "nccl")
+            if "GWI_BENCH_DEVICE" in os.environ:
+                self.local_rank = int(os.environ["GWI_BENCH_DEVICE"])
+                self.shared_devices = 1
+            elif "GWI_BENCH_SHARE_DEVICES" in os.environ:
+                self.shared_devices = int(os.environ["GWI_BENCH_SHARE_DEVICES"])
+                self.local_rank = self.local_rank % self.shared_devices
+            torch.cuda.set_device(self.local_rank)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
+            self.dist = dist
+            self.backend = backend
+
+    def fence(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_agree(self, ok):
+        if self.dist is None:
+            return bool(ok)
+        t = self.torch.tensor([1 if ok else 0], device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def gather_rows(self, row):
+        """Every rank's small list of floats -> list over ranks (rank 0's view is what gets printed)."""
+        if self.dist is None:
+            return [row]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, row)
+        return box
+
+
+def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4):
+    """One configuration: W warm-up + exactly K timed steps (barrier + synchronise on both sides, max over ranks), then
+    the latency distribution of >= 1000 further evaluations, kernel durations of >= 20 timed launches, and the secondary
+    throughput figures.  Returns the dict that goes into the JSON line (rank 0) or None."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import pin_thread_to_device
     from gwinferno_amd.synthetic import make_config_catalog
 
-    comp_name, cat_name, c_alg, desc = CONFIGS[args.config]
+    torch, dist, rank, world, dev = run.torch, run.dist, run.rank, run.world, run.local_rank
+    comp_name, cat_name, c_alg, desc = CONFIGS[cfg]
     pe, inj, total = make_config_catalog(cat_name)
     n_ev, n_pe = pe["mass_1"].shape
     n_inj = inj["mass_1"].shape[0]
     comp = COMPOSITIONS[comp_name](pe, inj)
     # the driving thread next to its GPU (numactl-style host placement), before anything pinned is allocated
-    from gwinferno_amd.engine import pin_thread_to_device
-
-    pinned = pin_thread_to_device(local_rank) if os.environ.get("GWI_BENCH_PIN", "1") != "0" and torch.cuda.is_available() else False
-    eng = comp.engine(device=local_rank, rank=rank, world=world)
+    pinned = pin_thread_to_device(dev) if os.environ.get("GWI_BENCH_PIN", "1") != "0" and torch.cuda.is_available() else False
+    eng = comp.engine(device=dev, rank=rank, world=world)
     rng = np.random.default_rng(1234)
     pool = [draw_params(comp_name, rng) for _ in range(64)]
     thetas = [comp.theta(p) for p in pool]
 
+    exchange, sharded = None, None
     if dist is not None:
-        # hot loop: scan + ncclAllGather + assembly inside the engine (no Python/torch in the data path);
-        # GWI_TORCH_COLLECTIVE=1 selects the torch.distributed all_gather_into_tensor variant instead
-        from gwinferno_amd.distributed import ShardedLikelihood, init_engine_communicator
+        # hot loop inside the engine (no Python/torch in the data path).  Preferred exchange: the node's shared memory
+        # (publish + poll of the ~1 KiB records between host cores, no collective launch); GWI_BENCH_EXCHANGE=rccl selects
+        # the in-engine ncclAllGather over xGMI, =torch the torch.distributed all_gather_into_tensor variant
+        from gwinferno_amd.distributed import ShardedLikelihood, init_engine_communicator, init_shared_memory_exchange
 
-        use_torch = os.environ.get("GWI_TORCH_COLLECTIVE") == "1"
-        if not use_torch:
+        want = os.environ.get("GWI_BENCH_EXCHANGE", "shm")
+        if want == "shm":
+            try:
+                init_shared_memory_exchange(eng)
+                ok = True
+            except Exception as exc:
+                print(f"[rank {rank}] shared-memory exchange unavailable ({exc})", file=sys.stderr)
+                ok = False
+            if run.all_agree(ok):
+                exchange = "host shared-memory segment: every rank publishes its record and polls the others' stamps (no collective launch)"
+            else:
+                want = "rccl"
+        if exchange is None and want == "rccl" and run.backend == "nccl":
             try:
                 init_engine_communicator(eng)
-                ok = 1
-            except Exception as exc:  # keep the run alive on the torch path; say so
-                print(f"[rank {rank}] in-engine RCCL communicator unavailable ({exc}); using torch.distributed all_gather", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must agree on the path
-            use_torch = int(flag.item()) == 0
-        collective = "torch.distributed all_gather_into_tensor" if use_torch else "ncclAllGather inside the engine"
-        if use_torch:
-            sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None)
+                ok = True
+            except Exception as exc:
+                print(f"[rank {rank}] in-engine RCCL communicator unavailable ({exc})", file=sys.stderr)
+                ok = False
+            if run.all_agree(ok):
+                exchange = "ncclAllGather (RCCL over xGMI) on the engine's own stream"
+        if exchange is None:
+            exchange = "torch.distributed all_gather_into_tensor"
+            sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", dev) if run.backend == "nccl" else None)
 
-            def step(i):
-                return sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
-        else:
-            vg = eng.configure(total, min_neff_cut=False)
-
-            def step(i):
-                return vg(thetas[i % len(thetas)])
+    if sharded is not None:
+        def step(i):
+            r = sharded.evaluate(thetas[i % len(thetas)], min_neff_cut=False)
+            return r.log_likelihood, r.grad
     else:
-        vg = eng.configure(total, min_neff_cut=False)  # value_and_grad(theta) -> (log_likelihood, grad buffer)
+        vg = eng.configure(total, min_neff_cut=False)  # value_and_grad(theta) -> (log_likelihood, grad buffer); sharded when a communicator is attached
 
         def step(i):
             return vg(thetas[i % len(thetas)])
 
-    # N > 1: before timing, rank 0 checks the sharded evaluation against an unsharded engine over the whole
-    # catalog on its own GPU (same theta): the multi-GPU path is otherwise only covered by world-2 gloo tests
+    # N > 1: before timing, rank 0 checks the sharded evaluation against an unsharded engine over the whole catalog on
+    # its own GPU (same theta)
     sharded_check = None
     if dist is not None:
-        r_sh = step(0)
-        ll_sh, g_sh = (r_sh[0], np.array(r_sh[1])) if isinstance(r_sh, tuple) else (r_sh.log_likelihood, np.array(r_sh.grad))
+        ll_sh, g_sh = step(0)
+        g_sh = np.array(g_sh)
         if rank == 0:
             full = COMPOSITIONS[comp_name](pe, inj)
-            eng_full = full.engine(device=local_rank)
+            eng_full = full.engine(device=dev)
             r_full = eng_full.evaluate(thetas[0], total, min_neff_cut=False)
             scale = max(1.0, float(np.max(np.abs(r_full.grad))))
             sharded_check = {"log_likelihood_rel_err": abs(ll_sh - r_full.log_likelihood) / max(1e-300, abs(r_full.log_likelihood)),
@@ -214,104 +334,151 @@ def main():
             if sharded_check["log_likelihood_rel_err"] > 1e-9 or sharded_check["grad_max_err_over_scale"] > 1e-8:
                 print(f"[bench] WARNING: sharded result differs from the single-GPU result: {sharded_check}", file=sys.stderr)
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    in_library = sharded is None and os.environ.get("GWI_BENCH_PYTHON_LOOP") != "1"
+    seq = np.stack([thetas[i % len(thetas)] for i in range(max(steps, warmup, 64))])
+    clocks_before = read_clocks() if rank == 0 else None
 
-    # The K steps are K sequential, blocking evaluations at K given points.  The reference runs that loop inside one
-    # XLA program (NUTS under jit, examples/utils.py:63-85): no host-language binding between two evaluations.  So does
-    # the timed region here: one gwi_eval_sequence call (a C loop of gwi_eval / gwi_eval_sharded, every result back on
-    # the host before the next point starts).  The same loop driven from Python is reported beside it.
-    in_library = not (dist is not None and use_torch) and os.environ.get("GWI_BENCH_PYTHON_LOOP") != "1"
-    seq = np.stack([thetas[i % len(thetas)] for i in range(max(args.steps, args.warmup, 1))])
+    # ---- clocks up: >= spin_s seconds of evaluations whatever --steps / --warmup say (a 20-step run lasts 0.4 ms, during
+    # which the GPU would still be at its idle clocks).  Rank 0 decides the count so that all ranks issue the same number.
+    n_spin = 0
+    if spin_s > 0:
+        t0 = time.perf_counter()
+        for i in range(32):
+            step(i)
+        per = (time.perf_counter() - t0) / 32
+        n_spin = int(run.max_over_ranks(spin_s / max(per, 1e-7)))
+        n_spin = max(0, min(n_spin, 200000))
+        if in_library:
+            for i in range(0, n_spin, len(seq)):
+                eng.evaluate_sequence(seq[: min(len(seq), n_spin - i)], total, min_neff_cut=False)
+        else:
+            for i in range(n_spin):
+                step(i)
+
+    # ---- W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronise -----------------------
+    # The K steps are K sequential, blocking evaluations at K given points.  The reference runs that loop inside one XLA
+    # program (NUTS under jit, examples/utils.py:63-85): no host-language binding between two evaluations.  So does the
+    # timed region here: one gwi_eval_sequence call (a C loop of gwi_eval / gwi_eval_sharded, every result back on the
+    # host before the next point starts).
     scan_ms, comb_ms, fin_ms = [], [], []
     if in_library:
-        if args.warmup:
-            eng.evaluate_sequence(seq[: args.warmup], total, min_neff_cut=False)
-        fence()
+        if warmup:
+            eng.evaluate_sequence(seq[:warmup], total, min_neff_cut=False)
+        run.fence()
         t0 = time.perf_counter()
-        # ---- timed region: exactly K steps -------------------------------------------------------
-        ll_seq, g_seq, kms = eng.evaluate_sequence(seq[: args.steps], total, min_neff_cut=False, timing_every=max(args.timing_every, 0) or args.steps + 1)
-        fence()
+        ll_seq, _ = eng.evaluate_sequence(seq[:steps], total, min_neff_cut=False)
+        run.fence()
         elapsed = time.perf_counter() - t0
-        if args.timing_every > 0:
-            sel = kms[:, 0] >= 0
-            scan_ms, comb_ms, fin_ms = list(kms[sel, 0]), list(kms[sel, 1]), list(kms[sel, 2])
+        last_ll = float(ll_seq[-1])
     else:
-        for i in range(args.warmup):
+        for i in range(warmup):
             step(i)
-        fence()
+        run.fence()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            timed = args.timing_every > 0 and (i % args.timing_every == 0)
-            if timed:
-                eng.set_timing(True)
+        for i in range(steps):
             res = step(i)
-            if timed:
-                ms = eng.last_kernel_ms()
-                scan_ms.append(ms[0])
-                comb_ms.append(ms[1])
-                fin_ms.append(ms[2])
-                eng.set_timing(False)
-        fence()
+        run.fence()
         elapsed = time.perf_counter() - t0
-    # the same loop driven from Python through the allocation-free closure (what a NumPy sampler pays per step)
-    n_py = min(args.steps, 2000)
+        last_ll = float(res[0])
+    elapsed = run.max_over_ranks(elapsed)
+
+    # ---- latency distribution: >= 1000 evaluations timed one by one inside the library (median, p5/p95)
+    n_lat = max(1000, steps)
+    lat_seq = np.stack([thetas[i % len(thetas)] for i in range(n_lat)])
+    if in_library:
+        lat = eng.evaluate_latencies(lat_seq, total, min_neff_cut=False)
+    else:
+        lat = np.empty(n_lat)
+        for i in range(n_lat):
+            t0 = time.perf_counter()
+            step(i)
+            lat[i] = time.perf_counter() - t0
+    # ---- kernel durations: every timing_every-th of a further block (>= 20 timed launches), begin/end of each launch
+    n_timed = max(20, min(200, steps // max(timing_every, 1)))
+    if in_library and timing_every > 0:
+        blk = np.stack([thetas[i % len(thetas)] for i in range(n_timed * timing_every)])
+        _, _, kms = eng.evaluate_sequence(blk, total, min_neff_cut=False, timing_every=timing_every)
+        sel = kms[:, 0] >= 0
+        scan_ms, comb_ms, fin_ms = list(kms[sel, 0]), list(kms[sel, 1]), list(kms[sel, 2])
+    elif timing_every > 0:
+        for i in range(n_timed):
+            eng.set_timing(True)
+            step(i)
+            ms = eng.last_kernel_ms()
+            scan_ms.append(ms[0]), comb_ms.append(ms[1]), fin_ms.append(ms[2])
+            eng.set_timing(False)
+    clocks_after = read_clocks() if rank == 0 else None
+    per_rank = run.gather_rows({"rank": rank, "device": dev, "n_ev": int(eng.n_ev), "n_inj": int(eng.n_inj),
+                                "avg_kernel_us": {"scan": 1e3 * float(np.mean(scan_ms)) if scan_ms else None, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None,
+                                                  "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
+                                "median_ms_per_step": float(np.median(lat) * 1e3)})
+
+    # ---- the same loop driven from Python through the allocation-free closure (what a NumPy sampler pays per step)
+    n_py = min(max(steps, 200), 2000)
     for i in range(min(50, n_py)):
         step(i)
-    fence()
+    run.fence()
     t0p = time.perf_counter()
     for i in range(n_py):
-        res = step(i)
-    fence()
-    python_driven = n_py / (time.perf_counter() - t0p)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        step(i)
+    run.fence()
+    python_driven = n_py / run.max_over_ranks(time.perf_counter() - t0p)
 
-    # N > 1, secondary figure: the other way N GPUs are used for this workload -- one independent chain per GPU,
-    # each over the WHOLE catalog (numpyro chain_method="parallel"); no collective, per-GPU work fixed (weak scaling)
-    replicas = None
+    # ---- N > 1, secondary figures: (a) one independent chain per GPU over the WHOLE catalog (numpyro
+    # chain_method="parallel"): no exchange, per-GPU work fixed (weak scaling); (b) the same sharded evaluation with the
+    # in-engine ncclAllGather instead of the shared-memory exchange
+    replicas, rccl_variant = None, None
     if dist is not None:
         rep = COMPOSITIONS[comp_name](pe, inj)
-        eng_rep = rep.engine(device=local_rank)
-        vg_rep = eng_rep.configure(total, min_neff_cut=False)
-        n_rep = max(200, args.steps // 2)
-        for i in range(50):
-            vg_rep(thetas[i % len(thetas)])
-        fence()
+        eng_rep = rep.engine(device=dev)
+        n_rep = max(200, steps // 2)
+        eng_rep.evaluate_sequence(seq[:50], total, min_neff_cut=False)
+        run.fence()
         t0r = time.perf_counter()
-        for i in range(n_rep):
-            vg_rep(thetas[i % len(thetas)])
-        fence()
-        tr = torch.tensor([time.perf_counter() - t0r], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-        replicas = {"evals_per_s": world * n_rep / float(tr.item()), "scaling": "weak", "what": "one independent chain per GPU over the whole catalog, no collective"}
+        eng_rep.evaluate_sequence(np.stack([thetas[i % len(thetas)] for i in range(n_rep)]), total, min_neff_cut=False)
+        run.fence()
+        tr = run.max_over_ranks(time.perf_counter() - t0r)
+        replicas = {"evals_per_s": world * n_rep / tr, "scaling": "weak", "what": "one independent chain per GPU over the whole catalog, no exchange"}
         eng_rep.close()
+        if exchange.startswith("host shared-memory") and run.backend == "nccl" and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0":
+            alt = COMPOSITIONS[comp_name](pe, inj)
+            eng_alt = alt.engine(device=dev, rank=rank, world=world)
+            try:
+                init_engine_communicator(eng_alt)
+                ok = True
+            except Exception as exc:
+                print(f"[rank {rank}] in-engine RCCL communicator unavailable ({exc})", file=sys.stderr)
+                ok = False
+            if run.all_agree(ok):
+                n_alt = max(200, steps // 2)
+                blk = np.stack([thetas[i % len(thetas)] for i in range(n_alt)])
+                eng_alt.evaluate_sequence(blk[:50], total, min_neff_cut=False)
+                run.fence()
+                t0a = time.perf_counter()
+                ll_alt, _ = eng_alt.evaluate_sequence(blk, total, min_neff_cut=False)
+                run.fence()
+                ta = run.max_over_ranks(time.perf_counter() - t0a)
+                rccl_variant = {"evals_per_s": n_alt / ta, "ms_per_step": 1e3 * ta / n_alt, "rccl_ranks": world,
+                                "what": "same sharded evaluation, records exchanged by one ncclAllGather on the engine's stream"}
+            eng_alt.close()
 
     out = None
     if rank == 0:
-        evals_per_s = args.steps / elapsed
         scan_us = 1e3 * float(np.mean(scan_ms)) if scan_ms else float("nan")
         alg_bytes = 8.0 * c_alg * (n_ev * n_pe + n_inj) / world  # per launch on one GPU
         achieved = alg_bytes / (scan_us * 1e-6) / 1e9 if scan_ms else float("nan")
+        pmc = pmc_table(cfg) if world == 1 else {}
+        flop = pmc.get("fp64_flop_per_launch")
         out = {
-            "metric": "log-likelihood evals/sec (value + gradient + diagnostic sites, host theta -> host results)",
-            "value": evals_per_s,
+            "value": steps / elapsed,
             "unit": "evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            **percentiles(lat),
+            "warm_spin": {"seconds_requested": spin_s, "evaluations": n_spin},
             "step_loop": "gwi_eval_sequence: K blocking evaluations in a C loop inside the library" if in_library else "Python loop over the configured closure",
             "python_driven_evals_per_s": python_driven,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
             "config": {
                 "workload": desc,
                 "composition": comp_name,
@@ -320,7 +487,7 @@ def main():
                 "n_inj": int(n_inj),
                 "n_theta": int(eng.n_theta),
                 "flags": "min_neff_cut=False (tests/inference_test.py:185)",
-                "parallelism": f"events+injections sharded over {world} GPU(s), one all-gather of partial records per eval ({collective})" if dist is not None else "single GPU",
+                "parallelism": f"events+injections sharded over {world} rank(s), one exchange of partial records per eval" if dist is not None else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -329,110 +496,175 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.config)[0] if world == 1 else None,
-                "traffic_source": pmc_traffic(args.config)[1] if world == 1 else None,
+                "traffic": pmc.get("hbm_bytes_per_launch"),
+                "traffic_source": pmc.get("source"),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_read_per_launch": float(eng.bytes_per_sample) * (eng.n_ev * eng.n_pe + eng.n_inj),
                 "avg_kernel_us": {"scan": scan_us, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None, "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
                 "median_scan_us": 1e3 * float(np.median(scan_ms)) if scan_ms else None,
-                "timing": (f"kernel begin/end of every {args.timing_every}th timed step: dispatch timestamps of the engine's AQL queue "
+                "timing": (f"kernel begin/end of every {timing_every}th step of a block after the timed region: dispatch timestamps of the engine's AQL queue "
                            "(hsa_amd_profiling_get_dispatch_time, what rocprofv3's kernel trace reports)" if eng.dispatch_info() == "aql: active" else
-                           f"HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's stream, every {args.timing_every}th timed step"),
+                           f"HIP start/stop events attached to each launch (hipExtLaunchKernelGGL) on the engine's stream, every {timing_every}th step of a block after the timed region"),
                 "dispatch": eng.dispatch_info(),
                 "host_thread_pinned_to_gpu_numa_node": bool(pinned),
                 "timed_launches": len(scan_ms),
                 # second view: the scan is fp64-issue/latency bound, not HBM bound
-                "fp64_vector": {
-                    "peak_tflops": 78.6,
-                    "flop_per_launch_pmc": pmc_table(args.config).get("fp64_flop_per_launch") if world == 1 else None,
-                    "achieved_tflops": (pmc_table(args.config).get("fp64_flop_per_launch", 0.0) / (scan_us * 1e-6) / 1e12) if (world == 1 and scan_ms and pmc_table(args.config).get("fp64_flop_per_launch")) else None,
-                },
+                "fp64_vector": {"peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "flop_per_launch_pmc": flop,
+                                "achieved_tflops": (flop / (scan_us * 1e-6) / 1e12) if (flop and scan_ms) else None},
             },
-            "last_log_likelihood": float(res[0]) if isinstance(res, tuple) else float(res.log_likelihood),
-            "sharded_vs_single_gpu": sharded_check,
-            "independent_chains": replicas,
-            "c_loop_us_per_eval": (1e6 * eng.selftime(thetas[0], total, n_iter=min(args.steps, 2000), min_neff_cut=False)) if dist is None else None,
+            "clocks": {"before": clocks_before, "after": clocks_after},
+            "last_log_likelihood": last_ll,
         }
-        if dist is None and args.k_batch > 1:
-            # secondary number: vectorised chains -- K hyper-points per launch (not the headline `value`,
-            # which is one sequential chain)
-            K = args.k_batch
+        if dist is not None:
+            out["multi_gpu"] = {"ranks": world, "rccl_ranks": world if run.backend == "nccl" else 0, "rendezvous_backend": run.backend, "exchange": exchange,
+                                "devices_shared_between_ranks": run.shared_devices, "per_rank": per_rank, "sharded_vs_single_gpu": sharded_check,
+                                "independent_chains": replicas, "rccl_allgather_variant": rccl_variant}
+        else:
+            out["c_loop_us_per_eval"] = 1e6 * eng.selftime(thetas[0], total, n_iter=min(max(steps, 200), 2000), min_neff_cut=False)
+        if dist is None and k_batch > 1:
+            # secondary number: vectorised chains -- K hyper-points per launch (not the headline `value`, which is one
+            # sequential chain)
+            K = k_batch
             tb = np.stack(thetas[:K] if len(thetas) >= K else (thetas * K)[:K])
             vgb = eng.configure_batch(K, total, min_neff_cut=False)  # values_and_grads(thetas[K]) -> (log_l[K], grad[K, n_theta])
-            for _ in range(30):
+            for _ in range(10):
                 vgb(tb)
-            n_b = max(20, args.steps // (4 * K))
+            n_b = max(20, min(200, steps // (4 * K)))
             t0 = time.perf_counter()
             for _ in range(n_b):
                 vgb(tb)
             dt = time.perf_counter() - t0
-            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
-        if dist is None and args.chains > 1:
-            # secondary number: C independent chains on this one GPU, each with its own engine, their evaluations in
-            # flight together (gwi_eval_begin / gwi_eval_end); no lock step, every chain follows its own theta sequence
-            C = args.chains
-            extra = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C - 1)]
-            pairs = [e.configure_async(total, min_neff_cut=False) for e in [eng] + [c.engine(device=local_rank) for c in extra]]
-            n_c = max(200, args.steps // 2)
-            for rep in range(2):
-                for b, _ in pairs:
-                    b(thetas[0])
-                t0 = time.perf_counter()
-                for i in range(n_c):
-                    for c, (b, e) in enumerate(pairs):
-                        e()
-                        b(thetas[(i + c) % len(thetas)])
-                for _, e in pairs:
-                    e()
-                dt = time.perf_counter() - t0
-            out["interleaved_chains"] = {"chains": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c), "host_threads": 1}
-            # the same C engines, one HOST THREAD each running blocking evaluations in a C loop (the GIL is released inside
-            # the library): launch costs spread over cores, the GPU interleaves the chains' kernels
-            import threading
-
-            all_engines = [eng] + [c.engine() for c in extra]
-            gate = threading.Barrier(C + 1)
-
-            def chain(e, th):
-                e.selftime(th, total, n_iter=50, min_neff_cut=False)
-                gate.wait()
-                e.selftime(th, total, n_iter=n_c, min_neff_cut=False)
-                gate.wait()
-
-            workers = [threading.Thread(target=chain, args=(e, thetas[i])) for i, e in enumerate(all_engines)]
-            for w in workers:
-                w.start()
-            gate.wait()
-            t0 = time.perf_counter()
-            gate.wait()
-            dt = time.perf_counter() - t0
-            for w in workers:
-                w.join()
-            out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
-            # the same engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain
-            # per engine and host thread, flat priors wide enough not to matter; trees capped at 2^6 leapfrogs so that the
-            # line stays within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second
-            # as a sampler sees them (every leapfrog = one value + gradient)
-            from gwinferno_amd.sampling import GaussianSmoothingPrior, nuts_engine
-
-            prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), 10.0)
-            starts = np.stack(thetas[:C])
-            kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
-            nuts_engine(all_engines, total, prior, None, starts, n_warmup=5, n_samples=5, **kw)
-            t0 = time.perf_counter()
-            res = nuts_engine(all_engines, total, prior, None, starts, n_warmup=60, n_samples=60, **kw)
-            dt = time.perf_counter() - t0
-            n_lf = sum(r["n_evals"] for r in res)
-            out["native_nuts"] = {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf}
-            for c in extra:
-                c.engine().close()
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
-            out["cpu_baseline"] = cpu_baseline(comp, thetas, total)
+            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path() if hasattr(eng, "batch_path") else None}
+        if dist is None and headline and chains > 1:
+            out.update(multi_chain(eng, comp_name, pe, inj, total, thetas, chains, steps, dev))
+        if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
+            out["cpu_baseline"] = cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0 if headline else 5.0, numpy_reference=cfg != "c5")
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
     eng.close()
-    if rank == 0:
+    return out
+
+
+def multi_chain(eng, comp_name, pe, inj, total, thetas, C, steps, dev):
+    """Secondary numbers (N = 1): C independent chains on the one GPU, each with its own engine."""
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.sampling import GaussianSmoothingPrior, nuts_engine
+
+    out = {}
+    extra = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C - 1)]
+    # (a) evaluations in flight together from ONE host thread (gwi_eval_begin / gwi_eval_end); no lock step, every chain
+    # follows its own theta sequence
+    pairs = [e.configure_async(total, min_neff_cut=False) for e in [eng] + [c.engine(device=dev) for c in extra]]
+    n_c = max(200, min(2000, steps // 2))
+    for rep in range(2):
+        for b, _ in pairs:
+            b(thetas[0])
+        t0 = time.perf_counter()
+        for i in range(n_c):
+            for c, (b, e) in enumerate(pairs):
+                e()
+                b(thetas[(i + c) % len(thetas)])
+        for _, e in pairs:
+            e()
+        dt = time.perf_counter() - t0
+    out["interleaved_chains"] = {"chains": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c), "host_threads": 1}
+    # (b) the same C engines, one HOST THREAD each running blocking evaluations in a C loop (the GIL is released inside
+    # the library): launch costs spread over cores, the GPU interleaves the chains' kernels
+    all_engines = [eng] + [c.engine() for c in extra]
+    gate = threading.Barrier(C + 1)
+
+    def chain(e, th):
+        e.selftime(th, total, n_iter=50, min_neff_cut=False)
+        gate.wait()
+        e.selftime(th, total, n_iter=n_c, min_neff_cut=False)
+        gate.wait()
+
+    workers = [threading.Thread(target=chain, args=(e, thetas[i])) for i, e in enumerate(all_engines)]
+    for w in workers:
+        w.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    gate.wait()
+    dt = time.perf_counter() - t0
+    for w in workers:
+        w.join()
+    out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
+    # (c) the same engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain per
+    # engine and host thread, flat priors wide enough not to matter; trees capped at 2^6 leapfrogs so that the line stays
+    # within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second as a sampler sees them
+    prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), 10.0)
+    starts = np.stack(thetas[:C])
+    kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
+    nuts_engine(all_engines, total, prior, None, starts, n_warmup=5, n_samples=5, **kw)
+    t0 = time.perf_counter()
+    res = nuts_engine(all_engines, total, prior, None, starts, n_warmup=60, n_samples=60, **kw)
+    dt = time.perf_counter() - t0
+    n_lf = sum(r["n_evals"] for r in res)
+    out["native_nuts"] = {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf}
+    for c in extra:
+        c.engine().close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="headline configuration (default: BASELINE config 2, the one the metric is quoted on)")
+    ap.add_argument("--also", default=None, help="comma-separated further configs reported under `configs` (default: c3,c5 when the headline is c2; 'none' disables)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
+    ap.add_argument("--chains", type=int, default=4, help="also time this many independent chains interleaved on one GPU (begin/end); <= 1 disables")
+    ap.add_argument("--timing-every", type=int, default=10, help="kernel begin/end timing on every n-th step of the kernel-timing block")
+    ap.add_argument("--spin", type=float, default=0.6, help="seconds of untimed evaluations before the timed region (GPU clocks up)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and os.environ.get("GWI_FORCE_SHARDED") != "1":
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    run = Run(args)
+    if run.world != args.gpus and not (run.world == 1 and os.environ.get("GWI_FORCE_SHARDED") == "1"):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={run.world}")
+    also = args.also
+    if also is None:
+        also = "c3,c5" if args.config == "c2" else "none"
+    extra_cfgs = [c for c in also.split(",") if c and c != "none" and c != args.config]
+
+    head = measure(run, args.config, args.steps, args.warmup, args.timing_every, spin_s=args.spin, headline=True, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch,
+                   chains=args.chains)
+    blocks = {}
+    for cfg in extra_cfgs:
+        # the other BASELINE configurations with the same procedure (their own warm-up, K and latency blocks: sized so that
+        # the default run stays within minutes)
+        k = {"c5": 300, "c3": 600}.get(cfg, 600)
+        blocks[cfg] = measure(run, cfg, k, 50, args.timing_every, spin_s=min(args.spin, 0.3), headline=False, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch, chains=0)
+
+    if run.rank == 0:
+        out = {
+            "metric": "log-likelihood evals/sec (value + gradient + diagnostic sites, host theta -> host results)",
+            "value": head["value"],
+            "unit": "evals/s",
+            "n_gpus": run.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+        }
+        for k, v in head.items():
+            out.setdefault(k, v)
+        if blocks:
+            out["configs"] = blocks
+    if run.dist is not None:
+        run.dist.barrier()
+        run.dist.destroy_process_group()
+    if run.rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last
         import ctypes
 

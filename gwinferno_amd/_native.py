@@ -11,7 +11,7 @@ import numpy as np
 
 GWI_ABI_VERSION = 1
 GWI_MAX_TERMS = 12
-GWI_MAX_THETA = 160
+GWI_MAX_THETA = 256
 GWI_MAX_NORMS = 8
 GWI_MAX_COLS = 16
 
@@ -171,6 +171,10 @@ EXPORTED_SYMBOLS = [
     "gwi_comm_unique_id",
     "gwi_comm_init",
     "gwi_eval_sharded",
+    "gwi_shm_comm_init",
+    "gwi_shm_comm_unlink",
+    "gwi_shm_exchange",
+    "gwi_eval_latencies",
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
@@ -244,6 +248,14 @@ def load_library():
     lib.gwi_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.gwi_eval_sharded.restype = C.c_int32
     lib.gwi_eval_sharded.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    lib.gwi_shm_comm_init.restype = C.c_int32
+    lib.gwi_shm_comm_init.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    lib.gwi_shm_comm_unlink.restype = C.c_int32
+    lib.gwi_shm_comm_unlink.argtypes = [C.c_char_p]
+    lib.gwi_shm_exchange.restype = C.c_int32
+    lib.gwi_shm_exchange.argtypes = [vp, _DP, _DP]
+    lib.gwi_eval_latencies.restype = C.c_int32
+    lib.gwi_eval_latencies.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), _DP]
     lib.gwi_selftime.restype = C.c_int32
     lib.gwi_selftime.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.c_int32, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32

@@ -180,6 +180,14 @@ class BSplineFull(BSplineTest):
         return self.mag_model(p["a1_coefs"], p["a2_coefs"], pe_samples=pe_samples) * self.tilt_model(p["t1_coefs"], p["t2_coefs"], pe_samples=pe_samples)
 
 
+class BSplineDefaults(BSplineFull):
+    """The reference's DEFAULT B-spline run: ``nspline_dict`` of ``load_pe_and_injections_as_dict`` consumers
+    (pipeline/utils.py:29-33: m1 50, q 30, a1 = a2 = 16, tilt1 = tilt2 = 16, redshift 20), ``IID=False``
+    (examples/simple_bspline_example.py:50): 165 hyper-parameters."""
+
+    NM, NQ, NA, NT, NZ = 50, 30, 16, 16, 20
+
+
 class BSplineIID(Composition):
     """BASELINE configs 3/4."""
 
@@ -472,6 +480,7 @@ COMPOSITIONS = {
     "bspline_test": BSplineTest,
     "bspline_iid": BSplineIID,
     "bspline_full": BSplineFull,
+    "bspline_defaults": BSplineDefaults,
     "plpeak_default_tilt": PLPeakDefaultTilt,
     "bspline_chieff": BSplineChiEff,
     "bspline_component_masses": BSplineComponentMasses,
@@ -524,6 +533,7 @@ def draw_params(name, rng):
         "bspline_test": {"m1_coefs": 10, "q_coefs": 5, "z_coefs": 5},
         "bspline_iid": {"m1_coefs": 30, "a_coefs": 16, "t_coefs": 16},
         "bspline_full": {"m1_coefs": 30, "q_coefs": 14, "a1_coefs": 12, "a2_coefs": 12, "t1_coefs": 12, "t2_coefs": 12, "z_coefs": 12},
+        "bspline_defaults": {"m1_coefs": 50, "q_coefs": 30, "a1_coefs": 16, "a2_coefs": 16, "t1_coefs": 16, "t2_coefs": 16, "z_coefs": 20},
     }[name]
     p = {k: rng.normal(size=n) for k, n in shapes.items()}
     if "z_coefs" in p:

@@ -13,8 +13,8 @@
 //    HIP fat binary inside the .so is a bundle the HSA loader does not read), loaded into an HSA executable of ours;
 //    kernel symbols are found by the names HIP reports for the host-side function pointers.
 //  * kernel arguments: a ring of 4 KiB slots in DEVICE memory that the host writes through the PCIe BAR (arguments in
-//    host memory cost the scan 5-7 us of scalar loads over PCIe); an sfence orders those write-combined stores before
-//    the doorbell.  The engine's kernels take no implicit arguments (llvm-readelf --notes: by_value only).
+//    host memory cost the scan 5-7 us of scalar loads over PCIe); an sfence + a read-back of the last byte hand them
+//    over before the packet header is published (see dispatch()).  The engine's kernels take no implicit arguments (llvm-readelf --notes: by_value only).
 //  * queues: a small process-wide pool (four by default) shared by all engines on the device, see pool_size().
 //  * ordering: every packet carries the barrier bit and agent-scope acquire/release fences, i.e. what a HIP stream gives
 //    consecutive kernels.  Results reach the host through the kernels' own write-through stores and stamps, as before.
@@ -31,6 +31,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -394,13 +395,40 @@ inline void close_queue(Queue& q) {
 
 // One kernel dispatch: arguments -> next ring slot, packet -> queue, doorbell.  Returns false (nothing submitted) when the
 // queue has reported an error.
+//
+// Order (the queue is multi-producer: once this packet's header turns valid, ANOTHER engine's doorbell may already cover
+// its index, so everything the packet refers to must have landed before the header is published):
+//   1. arguments into the ring slot (write-combined stores through the PCIe BAR);
+//   2. sfence (drain the write-combining buffers), then READ BACK the last argument byte through the BAR: a non-posted
+//      read cannot pass the posted writes ahead of it, and it forces the device's host data path to retire them to
+//      memory -- the same hand-off HIP's own device-kernarg path performs before it rings (read-back or HDP flush);
+//   3. packet body, then the header with release order;
+//   4. doorbell.
+// GWI_AQL_READBACK=0 drops the read of step 2 (A/B timing only: the hand-off then rests on the sfence + in-order posted writes).
+inline bool readback_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("GWI_AQL_READBACK");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
                      hsa_signal_t completion = hsa_signal_t{0}) {
-  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u) return false;
+  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u || arg_bytes == 0) return false;
   Api& a = api();
   hsa_queue_t* hq = q.sq->q;
   char* ka = q.kernarg + (size_t)(q.next_slot++ % kSlots) * kSlotBytes;
   std::memcpy(ka, args, arg_bytes);
+  _mm_sfence();
+  if (readback_enabled()) {
+    const volatile unsigned char* last = reinterpret_cast<const volatile unsigned char*>(ka + arg_bytes - 1);
+    const unsigned char seen = *last;
+    if (seen != static_cast<const unsigned char*>(args)[arg_bytes - 1]) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
+      q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
+      q.sq->failed = true;
+      return false;
+    }
+  }
   const uint64_t idx = a.add_write_index(hq, 1);  // atomic: several engines (host threads) may produce into one queue
   while (idx - a.load_read_index(hq) >= hq->size) _mm_pause();
   auto* p = static_cast<hsa_kernel_dispatch_packet_t*>(hq->base_address) + (idx & (hq->size - 1));
@@ -417,9 +445,22 @@ inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_byt
   constexpr uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                               (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
-  _mm_sfence();  // the arguments went out as write-combined stores through the BAR: drain them before the doorbell
   a.signal_store(hq->doorbell_signal, (hsa_signal_value_t)idx);
   return true;
+}
+
+// All packets of this process's queues retired?  (gwi_destroy after a timed-out evaluation must not free buffers a
+// kernel may still write.)  Bounded wait; returns whether the queue drained.
+inline bool drain(Queue& q, double seconds) {
+  if (!q.sq || !q.sq->q) return true;
+  Api& a = api();
+  hsa_queue_t* hq = q.sq->q;
+  const uint64_t target = a.add_write_index(hq, 0);
+  for (uint64_t spin = 0; spin < (uint64_t)(seconds * 2.0e7); ++spin) {
+    if (a.load_read_index(hq) >= target) return true;
+    _mm_pause();
+  }
+  return false;
 }
 
 }  // namespace aql

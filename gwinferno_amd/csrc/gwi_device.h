@@ -20,7 +20,7 @@ namespace gwi {
 
 constexpr int kBlock = 256;            // 4 wavefronts of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxDerived = 8;
+constexpr int kMaxDerived = 7;          // PLPEAK uses d0..d6; 7 keeps KArgs with 256 hyper-parameters inside 4 KiB
 constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerators in a record
 
 struct TermD {
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
 
   // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
-  const int vp = pow2_at_least(a.n_theta < 8 ? 8 : a.n_theta);  // <= 256 (GWI_MAX_THETA = 160)
+  const int vp = pow2_at_least(a.n_theta < 8 ? 8 : a.n_theta);  // <= 256 = GWI_MAX_THETA
   const int rows = THREADS / vp;
   const int row = tid / vp, col = tid - row * vp;
   double acc = 0.0;

@@ -6,7 +6,11 @@
 #include <hip/hip_ext.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -14,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <new>
 #include <string>
@@ -282,6 +287,13 @@ struct gwi_engine {
   bool aql_now = false;     // the pipeline being issued / awaited went through the AQL queue
   bool force_hip_stream = false;  // gwi_set_timing(h, 2): time with HIP events on the HIP stream (A/B against the AQL path)
   std::string aql_note;     // why not, when not
+  bool poisoned = false;    // an evaluation timed out or the queue failed with work possibly in flight: no further evaluations
+  // single-node record exchange through a POSIX shared-memory segment (gwi_shm_comm_init)
+  char* shm_base = nullptr;
+  size_t shm_bytes = 0, shm_slot_bytes = 0;
+  int shm_rank = 0, shm_world = 0;
+  unsigned long long shm_seq = 0;
+  std::vector<double> shm_gather;
   KArgs kargs;
 };
 
@@ -445,10 +457,10 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
 // brackets the kernel's own begin/end as the dispatch reports it -- the quantity rocprofv3's kernel
 // trace shows -- instead of stream positions around it, which add 1-3 us of launch gap per bracket.
 template <typename F, typename A>
-void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args) {
+void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args, size_t used_bytes = sizeof(A)) {
   if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
     const aql::Kernel& k = slot == 0 ? h->aq_scan : (slot == 1 ? h->aq_combine : h->aq_final);
-    if (aql::dispatch(h->aq, k, &args, sizeof(A), grid.x, grid.y, block.x, (uint32_t)lds, h->timing ? h->aq.done[slot] : hsa_signal_t{0})) return;
+    if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, h->timing ? h->aq.done[slot] : hsa_signal_t{0})) return;
     // the queue reported an error: nothing was submitted; the waiters surface it
     return;
   }
@@ -462,7 +474,9 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   ScanFn fn = logw ? h->variant->logw : (batch ? h->variant->scan_batch : h->variant->scan);
-  launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs);
+  // theta is the LAST member of the argument block: only the hyper-parameters in use travel through the BAR
+  const size_t used = offsetof(KArgs, theta) + sizeof(double) * (size_t)h->spec.n_theta;
+  launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs, used);
   GWI_HIP(hipGetLastError());
   return GWI_OK;
 }
@@ -575,10 +589,17 @@ gwi_status aql_wait_slow(gwi_handle h, Ready ready, const char* what) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned long long spin = 1;; ++spin) {
     if (ready()) return GWI_OK;
-    if (h->aq.failed()) return fail(h, GWI_ERR_HIP, h->aq.why());
+    // packets of this evaluation may still be in flight: the handle takes no further evaluations, and gwi_destroy
+    // waits for the queue to drain (or leaks the buffers) instead of freeing memory a kernel may still write
+    if (h->aq.failed()) {
+      h->poisoned = true;
+      return fail(h, GWI_ERR_HIP, h->aq.why());
+    }
     __builtin_ia32_pause();
-    if ((spin & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+    if ((spin & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+      h->poisoned = true;
       return fail(h, GWI_ERR_TIMEOUT, std::string(what) + " did not arrive from the AQL queue within 10 s");
+    }
   }
 }
 
@@ -843,10 +864,19 @@ gwi_status wait_for_rows(gwi_handle h, int K) {
 void destroy_impl(gwi_engine* h) {
   if (!h) return;
   if (h->host_only) {
+    if (h->shm_base) munmap(h->shm_base, h->shm_bytes);
     delete h;
     return;
   }
   (void)hipSetDevice(h->device);
+  if (h->shm_base) munmap(h->shm_base, h->shm_bytes);
+  if (h->poisoned && !aql::drain(h->aq, 2.0)) {
+    // a kernel of the timed-out evaluation may still be running: leak the device buffers rather than free them under it
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return;
+  }
+  if (h->poisoned) (void)hipDeviceSynchronize();
   aql::close_queue(h->aq);
   for (double* p : h->d_cols_pe) (void)hipFree(p);
   for (double* p : h->d_cols_inj) (void)hipFree(p);
@@ -882,6 +912,14 @@ gwi_status upload(gwi_handle h, const double* src, size_t n, double** dst, std::
   keep->push_back(d);
   if (n) GWI_HIP(hipMemcpy(d, src, sizeof(double) * n, hipMemcpyHostToDevice));
   *dst = d;
+  return GWI_OK;
+}
+
+// Every evaluating entry point: the handle must not hold an uncollected gwi_eval_begin (its kernel arguments, sequence
+// stamp and dispatch path would be overwritten under the evaluation in flight) and must not be poisoned by a time-out.
+gwi_status busy_guard(gwi_handle h, const char* who) {
+  if (h->poisoned) return fail(h, GWI_ERR_INVALID, std::string(who) + ": an earlier evaluation of this handle timed out or its queue failed; destroy the handle");
+  if (h->pending) return fail(h, GWI_ERR_INVALID, std::string(who) + ": an evaluation begun with gwi_eval_begin has not been collected (gwi_eval_end)");
   return GWI_OK;
 }
 
@@ -1082,6 +1120,15 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   // experiment knobs: exact tile sizes (the kernel takes any size; a trip covers samples_per_lane * 256 samples)
   if (const char* env = std::getenv("GWI_PE_CHUNK")) h->chunk_pe = std::max(1, std::atoi(env));
   if (const char* env = std::getenv("GWI_INJ_CHUNK")) h->chunk_inj = std::max(1, std::atoi(env));
+  // the tail kernels map the tile records of one group to the lanes of ONE wave: an event may have at most 64 tiles, the
+  // injections at most 64 groups x 64 tiles.  Few events with very many posterior samples (3 events x 1 M) or a very long
+  // injection set exceed that with the default tile size: grow the tiles (whole trips) until they fit.
+  {
+    auto round_up = [&](long long v) { return ((v + gran - 1) / gran) * gran; };
+    const long long min_pe = round_up((n_pe + 63) / 64), min_inj = round_up((n_inj + 64 * 64 - 1) / (64 * 64));
+    if (h->chunk_pe < min_pe) h->chunk_pe = (int)min_pe;
+    if (h->chunk_inj < min_inj) h->chunk_inj = (int)min_inj;
+  }
   h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
   h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
@@ -1096,8 +1143,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     h->tiles_per_inj_group = (h->n_inj_tiles + 63) / 64;
     h->n_inj_groups = (h->n_inj_tiles + h->tiles_per_inj_group - 1) / h->tiles_per_inj_group;
   }
-  if (h->tiles_per_event > 64 || h->tiles_per_inj_group > 64)
-    return fail(h, GWI_ERR_INVALID, "launch geometry: more than 64 tile records per group (raise GWI_SAMPLES_PER_BLOCK)");
+  if (h->tiles_per_event > 64 || h->tiles_per_inj_group > 64 || h->n_inj_groups > 64)
+    return fail(h, GWI_ERR_INVALID, "launch geometry: more than 64 tile records per group (internal error: the tile sizes above should have prevented this)");
   // spline-gradient LDS rows: replicas per wave (see scan_kernel); 8 by default, <= 16
   int rep = 8;
   if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
@@ -1294,8 +1341,10 @@ gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
 gwi_status gwi_eval_partial(gwi_handle h, const double* theta, double* record_host, double* log_bfs, double* log_neffs, double* variances) {
   if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
+  gwi_status st = busy_guard(h, "gwi_eval_partial");
+  if (st != GWI_OK) return st;
   GWI_HIP(hipSetDevice(h->device));
-  gwi_status st = run_pipeline(h, theta);
+  st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
   if (record_host) std::memcpy(record_host, h->h_record, sizeof(double) * record_len(h));
   const size_t n = (size_t)h->n_ev;
@@ -1319,6 +1368,7 @@ gwi_status gwi_combine(gwi_handle h, const double* records, int32_t n_ranks, con
 gwi_status gwi_eval_begin(gwi_handle h, const double* theta, const gwi_options* opt, int32_t want_grad) {
   if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
   if (h->pending) return fail(h, GWI_ERR_INVALID, "gwi_eval_begin: the previous evaluation of this handle has not been collected (gwi_eval_end)");
+  if (h->poisoned) return busy_guard(h, "gwi_eval_begin");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
@@ -1376,8 +1426,9 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
+  gwi_status st = busy_guard(h, "gwi_eval_batch");
+  if (st != GWI_OK) return st;
   GWI_HIP(hipSetDevice(h->device));
-  gwi_status st;
   const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
   const bool need_sq = opt->marginalize_selection && grads;
   if (need_sq) {
@@ -1432,37 +1483,111 @@ gwi_status gwi_comm_init(gwi_handle h, const char* rccl_path, const void* id128,
   return GWI_OK;
 }
 
+
+// ---- single-node record exchange through POSIX shared memory ------------------------------------------------------
+// Segment: [2 parities][world ranks] slots of { u64 stamp; double record[len] }, each padded to a multiple of 128 B.
+// Exchange s (s = 1, 2, ...): write the record into slot [s & 1][rank], release-store the stamp s, then acquire-poll
+// the stamps of all ranks.  Two parities suffice: a rank can only reach exchange s + 2 after every rank has published
+// s + 1, i.e. after every rank has finished READING exchange s.
+gwi_status gwi_shm_comm_unlink(const char* name) {
+  if (!name || !*name) return GWI_ERR_INVALID;
+  return shm_unlink(name) == 0 ? GWI_OK : GWI_ERR_INVALID;
+}
+
+gwi_status gwi_shm_comm_init(gwi_handle h, const char* name, int32_t rank, int32_t world) {
+  if (!h || !name || !*name || world < 1 || rank < 0 || rank >= world) return GWI_ERR_INVALID;
+  if (h->shm_base) return fail(h, GWI_ERR_INVALID, "gwi_shm_comm_init: already attached");
+  const size_t len = (size_t)record_len(h);
+  const size_t slot = ((sizeof(unsigned long long) + sizeof(double) * len + 127) / 128) * 128;
+  const size_t bytes = slot * 2 * (size_t)world;
+  const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fail(h, GWI_ERR_INVALID, std::string("shm_open(") + name + "): " + std::strerror(errno));
+  struct stat sb;
+  // every rank sizes the (zero-filled) segment to the same length; whoever comes later finds it sized already
+  if (fstat(fd, &sb) != 0 || ((size_t)sb.st_size != bytes && ftruncate(fd, (off_t)bytes) != 0)) {
+    const std::string why = std::strerror(errno);
+    close(fd);
+    return fail(h, GWI_ERR_INVALID, std::string("sizing shared-memory segment ") + name + ": " + why);
+  }
+  void* base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (base == MAP_FAILED) return fail(h, GWI_ERR_INVALID, std::string("mmap of shared-memory segment ") + name + ": " + std::strerror(errno));
+  h->shm_base = static_cast<char*>(base);
+  h->shm_bytes = bytes;
+  h->shm_slot_bytes = slot;
+  h->shm_rank = rank;
+  h->shm_world = world;
+  h->shm_seq = 0;
+  h->shm_gather.assign(len * (size_t)world, 0.0);
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return GWI_OK;
+}
+
+gwi_status gwi_shm_exchange(gwi_handle h, const double* record, double* gathered) {
+  if (!h || !record || !gathered) return GWI_ERR_INVALID;
+  if (!h->shm_base) return fail(h, GWI_ERR_INVALID, "gwi_shm_comm_init has not been called");
+  const size_t len = (size_t)record_len(h);
+  const unsigned long long s = ++h->shm_seq;
+  char* const bank = h->shm_base + (size_t)(s & 1) * h->shm_slot_bytes * (size_t)h->shm_world;
+  char* mine = bank + (size_t)h->shm_rank * h->shm_slot_bytes;
+  std::memcpy(mine + sizeof(unsigned long long), record, sizeof(double) * len);
+  __atomic_store_n(reinterpret_cast<unsigned long long*>(mine), s, __ATOMIC_RELEASE);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < h->shm_world; ++r) {
+    const char* theirs = bank + (size_t)r * h->shm_slot_bytes;
+    const unsigned long long* stamp = reinterpret_cast<const unsigned long long*>(theirs);
+    for (unsigned long long spin = 1; __atomic_load_n(stamp, __ATOMIC_ACQUIRE) != s; ++spin) {
+      __builtin_ia32_pause();
+      if ((spin & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+        return fail(h, GWI_ERR_TIMEOUT, "shared-memory exchange: rank " + std::to_string(r) + " did not publish exchange " + std::to_string(s) + " within 60 s");
+    }
+    std::memcpy(gathered + (size_t)r * len, theirs + sizeof(unsigned long long), sizeof(double) * len);
+  }
+  return GWI_OK;
+}
+
 gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary, double* grad, double* log_bfs,
                             double* log_neffs, double* variances, double* norms) {
   if (!h || !theta || !opt || !h->variant) return GWI_ERR_INVALID;
-  if (!h->nccl_comm) return fail(h, GWI_ERR_INVALID, "gwi_comm_init has not been called");
+  if (!h->nccl_comm && !h->shm_base) return fail(h, GWI_ERR_INVALID, "neither gwi_shm_comm_init nor gwi_comm_init has been called");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
+  if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
+  gwi_status st = busy_guard(h, "gwi_eval_sharded");
+  if (st != GWI_OK) return st;
   GWI_HIP(hipSetDevice(h->device));
   const size_t len = (size_t)record_len(h);
-  // scan -> combine -> final (record stays on the device) -> all-gather -> publish, all on one stream
-  auto exchange = [&](bool square) -> gwi_status {
-    gwi_status st = run_pipeline(h, theta, h->d_send, /*wait=*/false, 1, false, square);
-    if (st != GWI_OK) return st;
+  const double* const gathered = h->shm_base ? h->shm_gather.data() : h->h_gather;
+  auto run = [&](bool square) -> gwi_status {
+    if (h->shm_base) {
+      // this rank's shard through the regular fast path (AQL dispatch, host-final where it applies): its record ends up
+      // in host memory anyway, so the exchange is a publish + poll between host cores of the node -- no collective launch
+      gwi_status st_ = run_pipeline(h, theta, nullptr, /*wait=*/true, 1, false, square);
+      if (st_ != GWI_OK) return st_;
+      return gwi_shm_exchange(h, h->h_record, h->shm_gather.data());
+    }
+    // scan -> combine -> final (record stays on the device) -> all-gather -> publish, all on one stream
+    gwi_status st_ = run_pipeline(h, theta, h->d_send, /*wait=*/false, 1, false, square);
+    if (st_ != GWI_OK) return st_;
     const int rc = g_nccl.AllGather(h->d_send, h->d_recv, len, kNcclDouble, h->nccl_comm, h->stream);
     if (rc != 0) return fail(h, GWI_ERR_HIP, std::string("ncclAllGather: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "error"));
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->d_recv, h->h_gather_dev, (int)(len * h->comm_world), h->seq);
     GWI_HIP(hipGetLastError());
-    st = wait_for_stamp(h, h->h_gather);
-    if (st != GWI_OK) return st;
+    st_ = wait_for_stamp(h, h->h_gather);
+    if (st_ != GWI_OK) return st_;
     return wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
   };
-  gwi_status st;
   const bool need_sq = opt->marginalize_selection && grad;
   if (need_sq) {  // a second exchange carries the squared-weight numerators
-    st = exchange(true);
+    st = run(true);
     if (st != GWI_OK) return st;
-    h->sq_records.assign(h->h_gather, h->h_gather + len * h->comm_world);
+    h->sq_records.assign(gathered, gathered + len * h->comm_world);
   }
-  st = exchange(false);
+  st = run(false);
   if (st != GWI_OK) return st;
   gwi_summary s;
-  assemble(h, h->h_gather, h->comm_world, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);
+  assemble(h, gathered, h->comm_world, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);
   if (summary) *summary = s;
   const size_t n = (size_t)h->n_ev;
   const double shift = s.log_norm_const - std::log((double)h->n_pe);
@@ -1500,7 +1625,7 @@ gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, cons
     h->timing = timed;
     double* g = grads ? grads + (size_t)i * nt : scratch.data();
     const double* th = thetas + (size_t)i * nt;
-    const gwi_status st = h->nccl_comm ? gwi_eval_sharded(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr) : gwi_eval(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr);
+    const gwi_status st = (h->nccl_comm || h->shm_base) ? gwi_eval_sharded(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr) : gwi_eval(h, th, opt, &s, g, nullptr, nullptr, nullptr, nullptr);
     if (st != GWI_OK) {
       h->timing = was_timing;
       return st;
@@ -1510,6 +1635,22 @@ gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, cons
       for (int k = 0; k < 3; ++k) kernel_ms[(size_t)i * 3 + k] = timed ? h->last_ms[k] : -1.0f;
   }
   h->timing = was_timing;
+  return GWI_OK;
+}
+
+gwi_status gwi_eval_latencies(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* seconds) {
+  if (!h || !thetas || !opt || n < 1 || !seconds) return GWI_ERR_INVALID;
+  const int nt = h->spec.n_theta;
+  std::vector<double> g(nt);
+  gwi_summary s;
+  const bool sharded = h->nccl_comm || h->shm_base;
+  for (int i = 0; i < n; ++i) {
+    const double* th = thetas + (size_t)i * nt;
+    const auto t0 = std::chrono::steady_clock::now();
+    const gwi_status st = sharded ? gwi_eval_sharded(h, th, opt, &s, g.data(), nullptr, nullptr, nullptr, nullptr) : gwi_eval(h, th, opt, &s, g.data(), nullptr, nullptr, nullptr, nullptr);
+    seconds[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st != GWI_OK) return st;
+  }
   return GWI_OK;
 }
 
@@ -1535,12 +1676,14 @@ gwi_status gwi_debug_stamps(gwi_handle h, unsigned long long* out, int64_t n_wor
 gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, double* inj_logw) {
   if (!h || !theta || !h->variant) return GWI_ERR_INVALID;
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
+  gwi_status st = busy_guard(h, "gwi_log_weights");
+  if (st != GWI_OK) return st;
   GWI_HIP(hipSetDevice(h->device));
   const size_t n_pe_tot = (size_t)(h->n_ev * h->n_pe), n_inj = (size_t)h->n_inj;
   if (!h->d_logw_pe) GWI_HIP(hipMalloc(&h->d_logw_pe, sizeof(double) * (n_pe_tot ? n_pe_tot : 1)));
   if (!h->d_logw_inj) GWI_HIP(hipMalloc(&h->d_logw_inj, sizeof(double) * (n_inj ? n_inj : 1)));
   // normaliser values come from a regular evaluation
-  gwi_status st = run_pipeline(h, theta);
+  st = run_pipeline(h, theta);
   if (st != GWI_OK) return st;
   double log_const = h->host_consts[0];
   const double* nrm = h->h_record + kRecNormOff;

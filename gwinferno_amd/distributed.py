@@ -47,6 +47,32 @@ def init_engine_communicator(engine, group=None):
     engine.comm_init(box[0], rank, world, rccl_path=path)
 
 
+def init_shared_memory_exchange(engine, group=None):
+    """Single-node exchange without a collective launch (``gwi_shm_comm_init``): rank 0 names a POSIX shared-memory
+    segment, torch.distributed (any backend) hands the name around, every rank attaches, rank 0 unlinks the name once all
+    have (the segment lives until the last rank unmaps it).  Afterwards ``engine.evaluate_sharded`` / the ``configure``
+    closure publish this rank's ~1 KiB record there and poll the other ranks' stamps: the records end up in host memory
+    anyway, so this costs a few cache-line transfers between host cores where an all-gather costs a launch plus the
+    collective's small-message latency.  All ranks must be processes of ONE node."""
+    import os
+    import uuid
+
+    import torch.distributed as dist
+
+    from . import _native as N
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [None]
+    if rank == 0:
+        box[0] = f"/gwi_{os.getpid()}_{uuid.uuid4().hex[:12]}"
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.shm_comm_init(box[0], rank, world)
+    dist.barrier(group=group)
+    if rank == 0:
+        N.load_library().gwi_shm_comm_unlink(box[0].encode())
+    return box[0]
+
+
 class ShardedLikelihood:
     """Wraps this rank's :class:`NativePopulationLikelihood` (built with ``rank=``/``world=``)."""
 

@@ -481,6 +481,29 @@ class NativePopulationLikelihood:
         self._check(self.lib.gwi_comm_init(self.handle, path, buf, int(rank), int(world)))
         self._comm = True
 
+    def shm_comm_init(self, name, rank, world):
+        """Attach to the node-local shared-memory segment ``name`` (``gwi_shm_comm_init``): afterwards
+        :meth:`evaluate_sharded` / the :meth:`configure` closure exchange the partial records through it -- publish +
+        poll between host cores, no collective launch.  Every rank attaches, then one of them unlinks the name."""
+        self._check(self.lib.gwi_shm_comm_init(self.handle, name.encode(), int(rank), int(world)))
+        self._comm = True
+
+    def shm_exchange(self, record):
+        """Publish this rank's record, return all ranks' ``(world, partial_len)`` (host-only handles included)."""
+        rec = N.f64(record)
+        out = np.zeros((self.world, self.partial_len))
+        self._check(self.lib.gwi_shm_exchange(self.handle, N.as_dp(rec), N.as_dp(out)))
+        return out
+
+    def evaluate_latencies(self, thetas, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """Wall-clock seconds of each of ``len(thetas)`` sequential blocking evaluations, measured inside the library
+        (``gwi_eval_latencies``)."""
+        thetas = N.f64(np.atleast_2d(thetas))
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        out = np.zeros(thetas.shape[0])
+        self._check(self.lib.gwi_eval_latencies(self.handle, N.as_dp(thetas), thetas.shape[0], C.byref(opt), N.as_dp(out)))
+        return out
+
     def evaluate_sharded(self, theta, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, want_grad=True, copy=True):
         """Like :meth:`evaluate`, for an engine built with ``rank=/world=`` after :meth:`comm_init`:
         scan of this rank's shard, ncclAllGather of the partial records on the engine's stream,

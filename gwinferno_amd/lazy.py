@@ -104,7 +104,7 @@ class LogValues:
     """A theta-independent per-sample array that is ALREADY a logarithm (``jnp.log(samps["prior"])`` in the
     log-space model functions, examples/config_files/model.py:21-22; analysis.py:401-402).  ``key`` identifies it
     for the engine cache: the identity of the array the logarithm was taken of (:func:`log`; the logarithm itself is
-    then only computed when an engine is bound), or a content fingerprint for an anonymous array (a model function
+    then only computed when an engine is bound), or a content hash (blake2b over the bytes) for an anonymous array (a model function
     recomputes ``log(prior)`` on every call)."""
 
     __slots__ = ("_values", "key", "_source")
@@ -114,9 +114,12 @@ class LogValues:
         if source is not None:
             self.key = ("log-of", id(source))
         else:
-            v = self._values = np.asarray(values, dtype=np.float64)
-            with np.errstate(all="ignore"):
-                self.key = ("log-values", v.shape, float(v.flat[0]) if v.size else 0.0, float(v.flat[-1]) if v.size else 0.0, float(np.sum(v[np.isfinite(v)])))
+            import hashlib
+
+            v = self._values = np.ascontiguousarray(values, dtype=np.float64)
+            # content hash of the whole array (one pass at memory bandwidth): two different log(prior) arrays can never
+            # share a cached engine.  Arrays keyed by identity (`log(source)`, model data) must not be mutated in place.
+            self.key = ("log-values", v.shape, hashlib.blake2b(v.tobytes() if v.size < (1 << 16) else memoryview(v).cast("B"), digest_size=16).hexdigest())
 
     @property
     def values(self):

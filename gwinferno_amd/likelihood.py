@@ -13,8 +13,9 @@ Three ways to drive it
     ``jit(value_and_grad(potential_fn))`` (what NUTS runs) works unchanged.
   * No NumPyro: the same call with concrete numbers records its sites in :func:`last_sites`.
   * Framework-free: :class:`gwinferno_amd.engine.NativePopulationLikelihood` ``.evaluate(theta)``.
-Out of scope: the categorical / mixture branch (analysis.py:246-254) and the
-posterior-predictive-check branch (:321-355) raise NotImplementedError.
+The posterior-predictive-check branch (analysis.py:321-355) draws its per-event sample indices on the host from the
+engine's per-sample weights (``gwi_log_weights``).  Out of scope: the categorical / mixture
+branch (analysis.py:246-254) raises NotImplementedError.
 """
 import os
 
@@ -48,11 +49,10 @@ def last_sites():
 
 
 def clear_engine_cache():
-    for eng, *_ in _ENGINES.values():
-        eng.close()
+    """Forget every cached engine.  Handles are NOT destroyed here: an engine may still be referenced by a caller of
+    :func:`engine_for` or captured in a jitted sampler step (the custom_vjp closure of :func:`_evaluate_jax`); its device
+    memory is released when the last reference goes (``NativePopulationLikelihood.__del__``)."""
     _ENGINES.clear()
-    for _, eng, _ in _ONE_SIDED.values():
-        eng.close()
     _ONE_SIDED.clear()
 
 
@@ -86,8 +86,7 @@ def engine_for(pe_weights, inj_weights, surveyed_hypervolume=None, device=-1):
         _ENGINES[key] = hit = (eng, pe_weights, inj_weights, surveyed_hypervolume)
         limit = max(1, int(os.environ.get("GWI_ENGINE_CACHE", "8")))
         while len(_ENGINES) > limit:
-            old_key = next(iter(_ENGINES))
-            _ENGINES.pop(old_key)[0].close()
+            _ENGINES.pop(next(iter(_ENGINES)))  # dropped, not closed: whoever still holds the engine keeps a live handle
     else:
         _ENGINES[key] = _ENGINES.pop(key)  # most recently used last
     return hit[0]
@@ -169,6 +168,52 @@ def _evaluate_jax(eng, params, total_inj, Nobs, flags):
     return {"summary": summary, "log_bfs": per_event[0], "log_neffs": per_event[1], "variances": per_event[2], "grad": None}
 
 
+def _ppc_indices(eng, theta, pedata, injdata, n_obs, m1min, m2min, mmax):
+    """analysis.py:321-344 on the host: per-sample weights from the engine (``gwi_log_weights``), the reference's mass
+    cuts, then one index per event from the PE weights and one from the injection weights.  The reference draws with
+    ``jax.random.choice`` keyed by ``PRNGKey(ev)``; here the stream is ``numpy.random.default_rng([ev, 0 | 1])`` and the
+    draw an inverse-CDF lookup -- the same distribution, not JAX's threefry bits.  Returns int64 ``(2, n_obs)``."""
+    lw_pe, lw_inj = eng.log_weights(theta)
+    with np.errstate(all="ignore"):
+        m1, q = np.asarray(pedata["mass_1"]), np.asarray(pedata["mass_ratio"])
+        w_pe = np.exp(lw_pe - np.max(lw_pe, axis=1, keepdims=True))
+        w_pe = np.where((m1 < m1min) | (m1 > mmax) | (m1 * q < m2min) | ~np.isfinite(w_pe), 0.0, w_pe)
+        m1i, qi = np.asarray(injdata["mass_1"]), np.asarray(injdata["mass_ratio"])
+        w_inj = np.exp(lw_inj - np.max(lw_inj))
+        w_inj = np.where((m1i < m1min) | (m1i > mmax) | (m1i * qi < m2min) | ~np.isfinite(w_inj), 0.0, w_inj)
+    out = np.zeros((2, n_obs), dtype=np.int64)
+    cdf_inj = np.cumsum(w_inj)
+    for ev in range(n_obs):
+        cdf = np.cumsum(w_pe[ev])
+        out[0, ev] = min(int(np.searchsorted(cdf, np.random.default_rng([ev, 0]).uniform() * cdf[-1], side="right")), cdf.size - 1)
+        out[1, ev] = min(int(np.searchsorted(cdf_inj, np.random.default_rng([ev, 1]).uniform() * cdf_inj[-1], side="right")), cdf_inj.size - 1)
+    return out
+
+
+def _posterior_predictive_sites(eng, params, n_obs, param_names, pedata, injdata, m1min, m2min, mmax, traced):
+    """The ``{p}_obs_event_{ev}`` / ``{p}_pred_event_{ev}`` sites of analysis.py:350-355."""
+    if traced:
+        import jax
+        import jax.numpy as jnp
+
+        theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=jnp.float64)) for p in params])
+        idx = jax.pure_callback(lambda th: _ppc_indices(eng, np.asarray(th, dtype=np.float64), pedata, injdata, n_obs, m1min, m2min, mmax),
+                                jax.ShapeDtypeStruct((2, n_obs), jnp.int64), theta)
+        take_pe = lambda p, ev: jnp.asarray(pedata[p])[ev, idx[0, ev]]  # noqa: E731
+        take_inj = lambda p, ev: jnp.asarray(injdata[p])[idx[1, ev]]  # noqa: E731
+    else:
+        theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in params])
+        idx = _ppc_indices(eng, theta, pedata, injdata, n_obs, m1min, m2min, mmax)
+        take_pe = lambda p, ev: np.asarray(pedata[p])[ev, idx[0, ev]]  # noqa: E731
+        take_inj = lambda p, ev: np.asarray(injdata[p])[idx[1, ev]]  # noqa: E731
+    sites = {}
+    for ev in range(n_obs):
+        for p in param_names:
+            sites[f"{p}_obs_event_{ev}"] = take_pe(p, ev)
+            sites[f"{p}_pred_event_{ev}"] = take_inj(p, ev)
+    return sites
+
+
 def hierarchical_likelihood(
     pe_weights,
     inj_weights,
@@ -206,8 +251,8 @@ def hierarchical_likelihood(
         )
     if categorical:
         raise NotImplementedError("categorical sub-population assignment (analysis.py:246-254) is outside the accelerated path")
-    if posterior_predictive_check and param_names is not None and injdata is not None and pedata is not None:
-        raise NotImplementedError("posterior-predictive resampling (analysis.py:321-355) is outside the accelerated path; run it with the reference")
+    if marginal_qs:
+        raise NotImplementedError("marginal_qs belongs to the categorical branch (analysis.py:246-254, :347-349), outside the accelerated path")
     if not isinstance(pe_weights, Density) or not isinstance(inj_weights, Density):
         raise TypeError("pe_weights / inj_weights must be lazy densities from gwinferno_amd.models")
     if reconstruct_rate and not isinstance(surveyed_hypervolume, LazyNorm):
@@ -237,6 +282,8 @@ def hierarchical_likelihood(
 
     sites = _sites_from_result(res, Nobs, Tobs, unscaled_rate, flags, xp=xp)
     log_l = res["summary"]["log_likelihood"]
+    if posterior_predictive_check and param_names is not None and injdata is not None and pedata is not None:  # analysis.py:320-355
+        sites.update(_posterior_predictive_sites(eng, params, int(Nobs), param_names, pedata, injdata, m1min, m2min, mmax, traced=xp is not np))
     if npro is not None:
         for name, value in sites.items():
             npro.deterministic(name, value)
@@ -269,8 +316,8 @@ def construct_hierarchical_model(
     ``log_prob`` returns a lazy log-density).  Hyper-parameters with a ``PopPrior`` are drawn with
     ``numpyro.sample`` where NumPyro is installed and read from ``SAMPLE_VALUES[name]`` where it is not.
     Mixture models (``PopMixtureModel``, :383-389) are NumPyro mixture distributions, not part of the
-    accelerated path.  The reference's default ``posterior_predictive_check=True`` draws per-event samples
-    with ``jax.random`` (analysis.py:321-355) and is refused here as in :func:`hierarchical_likelihood`."""
+    accelerated path.  The reference's default ``posterior_predictive_check=True`` (analysis.py:321-355) is honoured:
+    the per-event draws are made on the host from the engine's per-sample weights (see :func:`_ppc_indices`)."""
     from .lazy import log as lazy_log
     from .parser import PopMixtureModel, PopModel
 
@@ -366,7 +413,7 @@ def _one_sided(weights):
         eng = NativePopulationLikelihood(weights, mirror) if side == PE else NativePopulationLikelihood(mirror, weights)
         hit = _ONE_SIDED[key] = (mirror, eng, weights)  # the originals stay referenced: keys are object ids
         while len(_ONE_SIDED) > max(1, int(os.environ.get("GWI_ENGINE_CACHE", "8"))):  # bounded like the two-sided cache
-            _ONE_SIDED.pop(next(iter(_ONE_SIDED)))[1].close()
+            _ONE_SIDED.pop(next(iter(_ONE_SIDED)))
     eng = hit[1]
     theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in _collect_params(eng.bound, weights)])
     return side, eng, theta

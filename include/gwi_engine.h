@@ -38,7 +38,7 @@ extern "C" {
 
 #define GWI_ABI_VERSION 1
 #define GWI_MAX_TERMS 12
-#define GWI_MAX_THETA 160
+#define GWI_MAX_THETA 256
 #define GWI_MAX_NORMS 8
 #define GWI_MAX_COLS 16
 
@@ -263,6 +263,19 @@ gwi_status gwi_comm_init(gwi_handle h, const char* rccl_path, const void* id128,
 gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options* opt, gwi_summary* summary,
                             double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
+/* Single-node exchange without a collective launch: the ranks of ONE node publish their partial records into a POSIX
+ * shared-memory segment (`name`, created by whichever rank gets there first; unlink it with gwi_shm_comm_unlink once every
+ * rank has attached) and poll each other's sequence stamps -- the records are ~1 KiB and already end up in host memory, so
+ * the exchange costs a few cache-line transfers between host cores instead of a collective's launch + small-message latency.
+ * After gwi_shm_comm_init(), gwi_eval_sharded() evaluates this rank's shard through the engine's regular (AQL) fast path
+ * and exchanges through the segment; it takes precedence over a communicator set up with gwi_comm_init().  Works on
+ * host-only handles too (gwi_shm_exchange with caller-made records: the CPU test-suite).  Every rank must issue the same
+ * sequence of exchanges.  Same partitioning contract as above (pipeline/analysis.py:78-86, :126-134). */
+gwi_status gwi_shm_comm_init(gwi_handle h, const char* name, int32_t rank, int32_t world);
+gwi_status gwi_shm_comm_unlink(const char* name);
+/* publish `record` (gwi_partial_len() doubles) as this rank's, wait for every rank's, copy them to gathered[world][len] */
+gwi_status gwi_shm_exchange(gwi_handle h, const double* record, double* gathered);
+
 /* Timing of the most recent gwi_eval*: milliseconds between the start/stop HIP events attached to each
  * launch on the engine's stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce; 0 when the
  * host does the final sum). */
@@ -283,6 +296,10 @@ gwi_status gwi_selftime(gwi_handle h, const double* theta, const gwi_options* op
  * `timing_every`-th evaluation (event timing switched on for those only), -1 for the others. */
 gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* log_likelihoods, double* grads, int32_t timing_every,
                              float* kernel_ms);
+
+/* The same loop, recording the wall-clock seconds of every evaluation (host theta in -> host results out) into
+ * seconds[n]: the latency distribution (median, p5/p95) of SURVEY.md section 8(d). */
+gwi_status gwi_eval_latencies(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* seconds);
 
 /* Host tuning: restrict the CALLING thread to the CPUs next to the engine's GPU (the local_cpulist of its PCI function,
  * intersected with the thread's current affinity).  Every evaluation is a few PCIe round trips driven by that thread.

@@ -576,6 +576,12 @@ class BSplineFull(BSplineTest):
         return mags * tilts
 
 
+class BSplineDefaults(BSplineFull):
+    """The reference's default spline counts (pipeline/utils.py:29-33; IID=False): 165 hyper-parameters."""
+
+    NM, NQ, NA, NT, NZ = 50, 30, 16, 16, 20
+
+
 class BSplineIID(Composition):
     """BASELINE configs 3/4 (separable.py:295-365, 17-79, 156-218; parametric.py:112-145)."""
 
@@ -863,6 +869,7 @@ COMPOSITIONS = {
     "bspline_test": BSplineTest,
     "bspline_iid": BSplineIID,
     "bspline_full": BSplineFull,
+    "bspline_defaults": BSplineDefaults,
 }
 
 

@@ -227,6 +227,14 @@ class BSplineFull(Composition):
         return out
 
 
+class BSplineDefaults(BSplineFull):
+    """The reference's default spline counts: `nspline_dict` of pipeline/utils.py:29-33 (m1 50, q 30, a1 = a2 = 16,
+    tilt1 = tilt2 = 16, redshift 20) with IID=False (examples/simple_bspline_example.py:50) -- 165 hyper-parameters."""
+
+    NM, NQ, NA, NT, NZ = 50, 30, 16, 16, 20
+    params = {"m1_coefs": (NM,), "q_coefs": (NQ,), "a1_coefs": (NA,), "a2_coefs": (NA,), "t1_coefs": (NT,), "t2_coefs": (NT,), "z_coefs": (NZ,), "lamb": ()}
+
+
 class PLPeakDefaultTilt(PLPeak):
     """PL+Peak x PL q x default_spin_tilt (parametric.py:97-102) x PL z."""
 
@@ -544,6 +552,7 @@ COMPOSITIONS = {
     "bspline_test": BSplineTest,
     "bspline_iid": BSplineIID,
     "bspline_full": BSplineFull,
+    "bspline_defaults": BSplineDefaults,
 }
 
 # likelihood flag sets exercised per case (analysis.py:139-163 kwargs)
@@ -958,7 +967,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "gwtc3", "catalog", "ppd", "pipeline"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline"]
     if "ppd" in todo:
         make_ppd_fixture()
     if "pipeline" in todo:
@@ -1000,6 +1009,9 @@ def main(which):
         make_case("case_bspline_misc.npz", "bspline_misc", pe, inj, tot, seed=17, n_points=3, n_grad=1)
         make_case("case_plpeak_iid_spins.npz", "plpeak_iid_spins", pe, inj, tot, seed=19, n_points=3, n_grad=1)
         make_case("case_bspline_independent_masses.npz", "bspline_independent_masses", pe, inj, tot, seed=18, n_points=3, n_grad=1)
+    if "cases7" in todo:
+        pe, inj, tot = make_catalog(6, 96, 768, seed=BASE_SEED + 12)
+        make_case("case_bspline_defaults.npz", "bspline_defaults", pe, inj, tot, seed=21, n_points=3, n_grad=1)
     if "gwtc3" in todo:
         pe = load_gwtc3(64)
         _, inj, tot = make_catalog(2, 8, 2048, seed=BASE_SEED + 13)

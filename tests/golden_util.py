@@ -13,6 +13,7 @@ CASES = [
     "bspline_test",
     "bspline_iid",
     "bspline_full",
+    "bspline_defaults",
     "plpeak_default_tilt",
     "bspline_chieff",
     "bspline_component_masses",

@@ -104,3 +104,66 @@ def test_world2_gloo_matches_oracle(tmp_path, comp_name):
     assert list(r0["ev"]) == [0, 4] and list(r1["ev"]) == [4, 7]
     got = np.concatenate([r0["log_bfs"], r1["log_bfs"]])
     assert np.max(np.abs(got - ref["logBFs"])) < 1e-10
+
+
+def _shm_worker(rank, world, port, out_path, rounds):
+    """Host-only handles, records made with NumPy: exercises gwi_shm_comm_init / gwi_shm_exchange / gwi_combine
+    -- the node-local exchange gwi_eval_sharded uses instead of a collective launch -- without a GPU."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from gwinferno_amd import _native as N
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.distributed import init_shared_memory_exchange
+    from gwinferno_amd.engine import NativePopulationLikelihood
+    from gwinferno_amd.synthetic import make_catalog
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pe, inj, total = make_catalog(7, 96, 1001, seed=31)
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = NativePopulationLikelihood(comp.weights(draw_params("plpeak", np.random.default_rng(9)), True), comp.weights(draw_params("plpeak", np.random.default_rng(9)), False),
+                                     None, device=N.DEVICE_HOST_ONLY, rank=rank, world=world)
+    name = init_shared_memory_exchange(eng)
+    dist.barrier()
+    assert not os.path.exists("/dev/shm" + name)  # unlinked once every rank is attached
+    rng = np.random.default_rng(5)
+    vals = []
+    for i in range(rounds):
+        p = draw_params("plpeak", rng)  # same stream on every rank
+        theta = eng.bound.theta_of(comp.weights(p, True))
+        eng.prepare_combine(theta)
+        rec, lse, _, _ = _numpy_partial_record(eng, eng.bound, theta)
+        if rank == 1 and i % 7 == 3:
+            import time
+
+            time.sleep(0.01)  # ranks drift apart; the stamps keep them in step
+        gathered = eng.shm_exchange(rec)
+        assert np.array_equal(gathered[rank], rec)
+        res = eng.combine(gathered, total, nobs=eng.n_ev_global, min_neff_cut=False, want_grad=False)
+        vals.append(res.log_likelihood)
+    np.save(f"{out_path}.{rank}.npy", np.array(vals))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shared_memory_exchange_matches_oracle_and_agrees_across_ranks(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from gwinferno_amd.compositions import draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle import numpy_oracle as O
+
+    out, rounds = str(tmp_path / "s"), 40
+    mp.spawn(_shm_worker, args=(world, _free_port(), out, rounds), nprocs=world, join=True)
+    got = [np.load(f"{out}.{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(got[0], got[r])  # every rank assembles identical bits, round after round
+    pe, inj, total = make_catalog(7, 96, 1001, seed=31)
+    orc = O.COMPOSITIONS["plpeak"](pe, inj)
+    rng = np.random.default_rng(5)
+    for i in range(rounds):
+        ref = float(orc.evaluate(draw_params("plpeak", rng), total, min_neff_cut=False)["log_likelihood"])
+        assert abs(got[0][i] - ref) < 1e-10 * abs(ref)

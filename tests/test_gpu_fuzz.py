@@ -40,7 +40,7 @@ def _wide(name, p, rng):
     return p
 
 
-@pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_chieff",
+@pytest.mark.parametrize("name", ["pl_test", "plpeak", "plpeak_full", "plpeak_default_tilt", "bspline_test", "bspline_iid", "bspline_full", "bspline_defaults", "bspline_chieff",
                                   "bspline_component_masses", "bspline_redshift", "bspline_redshift_raw", "plpeak_smooth", "chm_powerlaw", "chm_bspline", "bspline_misc", "bspline_independent_masses", "plpeak_iid_spins"])
 def test_randomised_parity_against_c_oracle(name):
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params

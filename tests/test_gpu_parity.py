@@ -6,6 +6,8 @@
   (3) size-independent properties at the BASELINE sizes.
 Tolerances (fp64): 1e-9 relative on values (BASELINE.json north_star), 1e-6 on gradients vs the
 finite-difference oracle (whose own truncation error is ~1e-8)."""
+import os
+
 import numpy as np
 import pytest
 from golden_util import CASES, GoldenCase, rel_err
@@ -349,16 +351,46 @@ def test_launch_geometry_extremes(n_ev, n_pe, n_inj, env, monkeypatch):
     eng.close()
 
 
-def test_geometry_over_the_tile_limit_is_refused(monkeypatch):
-    """More than 64 tile records per event cannot be combined by one wave: gwi_create says so."""
-    from gwinferno_amd._native import NativeEngineError
-    from gwinferno_amd.compositions import COMPOSITIONS
+def test_few_events_with_very_many_posterior_samples_need_no_knob():
+    """3 events x 1 M posterior samples (+ 50 k injections) with NO environment knob: the default tile size would give an
+    event 490 tile records, more than the 64 one wave combines -- gwi_create grows the tiles instead of refusing
+    (VERDICT r1 weak 7).  Checked against the C oracle: value, sites, gradient."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
 
-    monkeypatch.setenv("GWI_SAMPLES_PER_BLOCK", "512")  # = one trip of the two-samples-per-lane kernel
-    pe, inj, _ = make_catalog(2, 512 * 70, 100, seed=1)
-    with pytest.raises(NativeEngineError, match="more than 64 tile records"):
-        COMPOSITIONS["pl_test"](pe, inj).engine()
+    for k in ("GWI_SAMPLES_PER_BLOCK", "GWI_PE_CHUNK", "GWI_INJ_CHUNK"):
+        assert k not in os.environ
+    pe, inj, total = make_catalog(3, 1_000_000, 50_000, seed=29)
+    for name in ("plpeak", "bspline_test"):
+        comp = COMPOSITIONS[name](pe, inj)
+        eng = comp.engine()
+        th = comp.theta(draw_params(name, np.random.default_rng(8)))
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = COracle(eng.bound).evaluate(th, total, min_neff_cut=False)
+        assert rel_err(got.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        assert rel_err(got.log_bfs, ref["logBFs"]) < VALUE_RTOL
+        assert rel_err(got.log_neffs, ref["log_nEffs"]) < 1e-8
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+        eng.close()
+
+
+def test_a_tile_size_knob_below_the_group_limit_is_raised(monkeypatch):
+    """GWI_SAMPLES_PER_BLOCK=512 on 2 events x 35 840 samples asks for 70 tiles per event: the engine raises the tile
+    size to what one wave can combine (64 records) and evaluates correctly."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle import numpy_oracle as O
+
+    monkeypatch.setenv("GWI_SAMPLES_PER_BLOCK", "512")
+    pe, inj, total = make_catalog(2, 512 * 70, 100, seed=1)
+    comp = COMPOSITIONS["pl_test"](pe, inj)
+    p = draw_params("pl_test", np.random.default_rng(2))
+    res = comp.engine().evaluate(comp.theta(p), total, min_neff_cut=False)
+    ref = O.COMPOSITIONS["pl_test"](pe, inj).evaluate(p, total, min_neff_cut=False)
+    assert rel_err(res.log_bfs, ref["logBFs"]) < VALUE_RTOL
+    assert rel_err(res.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
 
 
 def test_degenerate_samples_do_not_poison_the_gradient():

@@ -158,3 +158,57 @@ def test_full_size_against_c_oracle(cfg, comp_name):
         scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
         assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
     eng.close()
+
+
+@pytest.mark.parametrize("cfg,comp_name,blocks", [("c3", "bspline_iid", [9, 9, 9, 9, 9, 8, 8, 8]), ("c5", "bspline_full", [25] * 8)])
+def test_eight_shards_equal_the_unsharded_engine_and_the_c_oracle(cfg, comp_name, blocks):
+    """BASELINE config 4 (and the config-5 form of it): the B-spline catalogs split over EIGHT ranks -- contiguous event
+    blocks 9,9,9,9,9,8,8,8 / 8 x 25 and equal injection slices (pipeline/analysis.py:78-86, :126-134) -- each
+    shard scanned by its own engine (here all on one GPU), records combined as every rank does after the exchange.
+    Against the unsharded engine AND the C oracle on the whole catalog: value, every site, the whole gradient."""
+    from golden_util import rel_err
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import NativePopulationLikelihood
+    from gwinferno_amd.synthetic import make_config_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_config_catalog(cfg)
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    full = comp.engine()
+    orc = COracle(full.bound)
+    p = draw_params(comp_name, np.random.default_rng(11))
+    th = comp.theta(p)
+    a = full.evaluate(th, total)  # reference defaults (min_neff_cut=True)
+    ref = orc.evaluate(th, total)
+    world = 8
+    shards = [NativePopulationLikelihood(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p), rank=r, world=world) for r in range(world)]
+    assert [e.n_ev for e in shards] == blocks
+    n_inj = inj["mass_1"].shape[0]
+    assert [e.n_inj for e in shards] == [n_inj // world] * world
+    recs, lbs, lns, lvs = [], [], [], []
+    for e in shards:
+        rec, lb, ln, lv = e.eval_partial(th)
+        recs.append(rec), lbs.append(lb), lns.append(ln), lvs.append(lv)
+    for e in shards:  # every rank assembles the same result from the gathered records
+        out = e.combine(np.stack(recs), total, nobs=full.n_ev)
+        for want in (a, None):
+            w_ll = want.log_likelihood if want else ref["log_likelihood"]
+            w_grad = want.grad if want else ref["grad"]
+            w_s = want.summary if want else ref["summary"]
+            assert rel_err(out.log_likelihood, w_ll) < 1e-10
+            assert rel_err(out.summary.sum_logBFs, w_s.sum_logBFs) < 1e-10
+            assert abs(out.summary.log_det_eff - w_s.log_det_eff) < 1e-9 * abs(w_s.log_det_eff)
+            assert abs(out.summary.log_nEff_inj - w_s.log_nEff_inj) < 1e-9 * abs(w_s.log_nEff_inj)
+            assert rel_err(out.summary.variance_log_likelihood, w_s.variance_log_likelihood) < 1e-8
+            assert abs(out.summary.min_log_nEff - w_s.min_log_nEff) < 1e-9 * max(1.0, abs(w_s.min_log_nEff))
+            scale = max(1.0, float(np.max(np.abs(w_grad))))
+            assert float(np.max(np.abs(out.grad - w_grad))) / scale < 1e-8
+    shift = a.summary.log_norm_const - np.log(full.n_pe)
+    assert np.allclose(np.concatenate(lbs) + shift, a.log_bfs, rtol=1e-12, atol=1e-11)
+    assert rel_err(np.concatenate(lbs) + shift, ref["logBFs"]) < 1e-9
+    assert np.allclose(np.concatenate(lns), a.log_neffs, rtol=1e-10)
+    assert np.allclose(np.concatenate(lvs), a.variances, rtol=1e-9, atol=1e-14)
+    for e in shards:
+        e.close()
+    full.close()
