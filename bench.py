@@ -96,11 +96,24 @@ def pmc_table(config):
     return {}
 
 
-def read_clocks():
-    """Current shader / memory clock of every amdgpu card from sysfs (the `*` line of pp_dpm_sclk / pp_dpm_mclk)."""
+def read_clocks(device=None):
+    """Current shader / memory clock from sysfs (the `*` line of pp_dpm_sclk / pp_dpm_mclk) of the amdgpu card at the
+    PCI address of HIP device `device` (the box may show more cards than this process may use), or of every card when
+    the address is unknown."""
+    want = None
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(device if device is not None else 0)
+        want = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}."
+    except Exception:
+        pass
     out = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device")):
-        row = {}
+        addr = os.path.basename(os.path.realpath(d))
+        if want and not addr.startswith(want):
+            continue
+        row = {"pci": addr}
         for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
             try:
                 for ln in open(os.path.join(d, fn)):
@@ -108,8 +121,7 @@ def read_clocks():
                         row[key] = ln.split(":")[1].replace("*", "").strip()
             except Exception:
                 pass
-        if row:
-            row["card"] = os.path.basename(os.path.dirname(d))
+        if len(row) > 1:
             out.append(row)
     return out or None
 
@@ -336,7 +348,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
 
     in_library = sharded is None and os.environ.get("GWI_BENCH_PYTHON_LOOP") != "1"
     seq = np.stack([thetas[i % len(thetas)] for i in range(max(steps, warmup, 64))])
-    clocks_before = read_clocks() if rank == 0 else None
+    clocks_before = read_clocks(dev) if rank == 0 else None
 
     # ---- clocks up: >= spin_s seconds of evaluations whatever --steps / --warmup say (a 20-step run lasts 0.4 ms, during
     # which the GPU would still be at its idle clocks).  Rank 0 decides the count so that all ranks issue the same number.
@@ -407,7 +419,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             ms = eng.last_kernel_ms()
             scan_ms.append(ms[0]), comb_ms.append(ms[1]), fin_ms.append(ms[2])
             eng.set_timing(False)
-    clocks_after = read_clocks() if rank == 0 else None
+    clocks_after = read_clocks(dev) if rank == 0 else None
     per_rank = run.gather_rows({"rank": rank, "device": dev, "n_ev": int(eng.n_ev), "n_inj": int(eng.n_inj),
                                 "avg_kernel_us": {"scan": 1e3 * float(np.mean(scan_ms)) if scan_ms else None, "combine": 1e3 * float(np.mean(comb_ms)) if comb_ms else None,
                                                   "final": 1e3 * float(np.mean(fin_ms)) if fin_ms else None},
@@ -514,6 +526,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             },
             "clocks": {"before": clocks_before, "after": clocks_after},
             "last_log_likelihood": last_ll,
+            "two_pass_repeats": eng.two_pass_repeats(),
         }
         if dist is not None:
             out["multi_gpu"] = {"ranks": world, "rccl_ranks": world if run.backend == "nccl" else 0, "rendezvous_backend": run.backend, "exchange": exchange,
@@ -534,7 +547,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             for _ in range(n_b):
                 vgb(tb)
             dt = time.perf_counter() - t0
-            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path() if hasattr(eng, "batch_path") else None}
+            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
         if dist is None and headline and chains > 1:
             out.update(multi_chain(eng, comp_name, pe, inj, total, thetas, chains, steps, dev))
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks

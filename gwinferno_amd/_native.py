@@ -175,6 +175,7 @@ EXPORTED_SYMBOLS = [
     "gwi_shm_comm_unlink",
     "gwi_shm_exchange",
     "gwi_eval_latencies",
+    "gwi_two_pass_repeats",
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
@@ -256,6 +257,8 @@ def load_library():
     lib.gwi_shm_exchange.argtypes = [vp, _DP, _DP]
     lib.gwi_eval_latencies.restype = C.c_int32
     lib.gwi_eval_latencies.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), _DP]
+    lib.gwi_two_pass_repeats.restype = C.c_int64
+    lib.gwi_two_pass_repeats.argtypes = [vp]
     lib.gwi_selftime.restype = C.c_int32
     lib.gwi_selftime.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.c_int32, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32

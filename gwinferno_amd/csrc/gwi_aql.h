@@ -412,12 +412,10 @@ inline bool readback_enabled() {
   }();
   return on;
 }
-inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
-                     hsa_signal_t completion = hsa_signal_t{0}) {
-  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u || arg_bytes == 0) return false;
-  Api& a = api();
-  hsa_queue_t* hq = q.sq->q;
-  char* ka = q.kernarg + (size_t)(q.next_slot++ % kSlots) * kSlotBytes;
+// steps 1-2: copy an argument block into ring slot `slot` and hand it over to the device; nullptr on failure
+inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_bytes) {
+  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes == 0 || slot >= kSlots) return nullptr;
+  char* ka = q.kernarg + (size_t)slot * kSlotBytes;
   std::memcpy(ka, args, arg_bytes);
   _mm_sfence();
   if (readback_enabled()) {
@@ -426,9 +424,18 @@ inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_byt
     if (seen != static_cast<const unsigned char*>(args)[arg_bytes - 1]) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
       q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
       q.sq->failed = true;
-      return false;
+      return nullptr;
     }
   }
+  return ka;
+}
+
+// steps 3-4 for an argument block that is already in place (stage_args)
+inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
+                            hsa_signal_t completion = hsa_signal_t{0}) {
+  if (!q.sq || q.sq->failed || !ka) return false;
+  Api& a = api();
+  hsa_queue_t* hq = q.sq->q;
   const uint64_t idx = a.add_write_index(hq, 1);  // atomic: several engines (host threads) may produce into one queue
   while (idx - a.load_read_index(hq) >= hq->size) _mm_pause();
   auto* p = static_cast<hsa_kernel_dispatch_packet_t*>(hq->base_address) + (idx & (hq->size - 1));
@@ -447,6 +454,16 @@ inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_byt
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
   a.signal_store(hq->doorbell_signal, (hsa_signal_value_t)idx);
   return true;
+}
+
+// the rotating slots hold per-evaluation argument blocks; the last kPersistentSlots are written once (gwi_create) for
+// launches whose arguments never change -- those dispatches need no per-evaluation hand-off at all
+constexpr unsigned kPersistentSlots = 2;
+inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
+                     hsa_signal_t completion = hsa_signal_t{0}) {
+  if (arg_bytes > k.kernarg_bytes + 0u) return false;
+  char* ka = stage_args(q, q.next_slot++ % (kSlots - kPersistentSlots), args, arg_bytes);
+  return dispatch_staged(q, k, ka, grid_x_blocks, grid_y_blocks, block_threads, dynamic_lds, completion);
 }
 
 // All packets of this process's queues retired?  (gwi_destroy after a timed-out evaluation must not free buffers a

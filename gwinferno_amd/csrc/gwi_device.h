@@ -60,7 +60,11 @@ struct TailArgs {
   // a = logsumexp | M, b = log n_eff | S1, c = variance | S2
   double* host_rows;  // nullptr: device-final mode
   double* record;     // device-final mode: pinned host record (or the device send buffer when sharded)
-  unsigned long long seq;        // completion stamp of this evaluation
+  // completion stamp of this evaluation: read from a device word the scan launch of the same evaluation wrote
+  // (KArgs::seq_dev), so that this argument block is CONSTANT across evaluations -- on the AQL path it is written
+  // through the PCIe BAR once, at gwi_create, and needs no per-evaluation hand-off
+  const unsigned long long* seq_ptr;
+  const unsigned long long* redo_ptr;  // KArgs::redo_dev
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   int n_norms, record_len;
@@ -85,10 +89,14 @@ struct KArgs {
   long long n_inj;
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
-  int gacc_rep, gacc_pad;  // spline-gradient LDS rows: replicas per wave (power of two), row stride (odd)
+  int gacc_rep, gacc_shift;  // spline-gradient LDS rows: replicas per coefficient (power of two <= 64) and log2 of it
   double* norm_out_host;               // pinned host: Z_j of hyper-parameter point k at [k * n_norms + j]
   unsigned long long* norm_stamps_host;  // pinned host: completion stamp per (k, j)
-  unsigned long long norm_seq;
+  unsigned long long norm_seq;            // = the evaluation's sequence number
+  unsigned long long* seq_dev;            // device word: the scan publishes norm_seq here for the tail launches
+  unsigned long long* redo_host;          // pinned host word: a workgroup whose fixed reference exponent turned out too low stores norm_seq here
+  unsigned long long* redo_dev;           // ... and here (device word, read by final_kernel: the sharded path's record carries the request to every rank)
+  int two_pass, deterministic;            // two_pass: find each tile's exact maximum first; deterministic: waves take turns at the shared rows
   int square, pad_;        // square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
@@ -117,6 +125,12 @@ __device__ __forceinline__ double dpp_take(double v) {
 __device__ __forceinline__ double lane63(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// a value every lane holds identically -> scalar registers (v_readfirstlane): comparisons on it become scalar branches
+__device__ __forceinline__ double uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -250,9 +264,28 @@ struct Ctx {
   const double* theta;          // scalar hyper-parameters: uniform index -> scalar loads, never LDS
   const double (*derived)[kMaxDerived];  // host-precomputed theta-only scalars per term
   const double* coefs;          // LDS copy of theta for the lane-varying spline coefficient reads
-  double* gacc;                 // this wave's LDS gradient-numerator row [n_theta]
+  double* gacc;                 // LDS gradient numerators [n_theta][rep] + this lane's replica: coefficient p lives at gacc[p << rep_shift]
+  int rep_shift;
   const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
 };
+
+// ---- spline-coefficient gradient numerators ------------------------------------------------------
+// G_p += w B_p(x) for the four non-zero bases of a sample: ds_add_f64 into the workgroup's rows in LDS.  Layout
+// [coefficient][replica], replica = lane & (rep - 1): the LDS bank of an address then depends on the LANE alone
+// (8-byte words: bank pair = replica mod 32), never on the knot interval the sample falls in.  With rep = 64 every lane
+// owns its replica: no two lanes of a wave instruction share an address or -- beyond the two passes a 64 x 8-byte access
+// takes anyway -- a bank, whatever the data looks like (posterior samples of one event cluster in a few knot intervals:
+// per-wave rows [replica][coefficient] with 8 replicas serialised up to 8 lanes per address and collided on banks at
+// random; config 5 spent 30 % of its scan there).  The four waves of the workgroup share the rows (the adds are atomic),
+// which is what makes 64 replicas fit: n_theta x 512 B per WORKGROUP.
+__device__ __forceinline__ void spline_scatter(const Ctx& c, int first, const Taps& b) {
+  double* g = c.gacc + (first << c.rep_shift);
+  const int step = 1 << c.rep_shift;
+  unsafeAtomicAdd(g, b.b0);
+  unsafeAtomicAdd(g + step, b.b1);
+  unsafeAtomicAdd(g + 2 * step, b.b2);
+  unsafeAtomicAdd(g + 3 * step, b.b3);
+}
 
 // ---- term library --------------------------------------------------------------------------
 // A sample's weight is  w = L * exp(l - m):  each term either adds to the log part l (power laws,
@@ -586,14 +619,7 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     return v;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-    if (s.k >= 0 && w != 0.0) {
-      const Taps b = cubic_taps_weighted(s.t, w);
-      double* g = c.gacc + t.th0 + s.k;
-      unsafeAtomicAdd(g + 0, b.b0);
-      unsafeAtomicAdd(g + 1, b.b1);
-      unsafeAtomicAdd(g + 2, b.b2);
-      unsafeAtomicAdd(g + 3, b.b3);
-    }
+    if (s.k >= 0 && w != 0.0) spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, w));
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
@@ -631,14 +657,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
     return 0.0;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-    if (w != 0.0) {
-      const Taps b = cubic_taps_weighted(s.t, w * s.inv_f);
-      double* g = c.gacc + t.th0 + s.k;
-      unsafeAtomicAdd(g + 0, b.b0);
-      unsafeAtomicAdd(g + 1, b.b1);
-      unsafeAtomicAdd(g + 2, b.b2);
-      unsafeAtomicAdd(g + 3, b.b3);
-    }
+    if (w != 0.0) spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, w * s.inv_f));
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
@@ -883,22 +902,8 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
     if (w != 0.0) {
-      if (s.k0 >= 0) {
-        const Taps b = cubic_taps_weighted(s.t0, w * (1.0 - s.f));
-        double* g = c.gacc + t.th0 + s.k0;
-        unsafeAtomicAdd(g + 0, b.b0);
-        unsafeAtomicAdd(g + 1, b.b1);
-        unsafeAtomicAdd(g + 2, b.b2);
-        unsafeAtomicAdd(g + 3, b.b3);
-      }
-      if (s.k1 >= 0) {
-        const Taps b = cubic_taps_weighted(s.t1, w * s.f);
-        double* g = c.gacc + t.th0 + s.k1;
-        unsafeAtomicAdd(g + 0, b.b0);
-        unsafeAtomicAdd(g + 1, b.b1);
-        unsafeAtomicAdd(g + 2, b.b2);
-        unsafeAtomicAdd(g + 3, b.b3);
-      }
+      if (s.k0 >= 0) spline_scatter(c, t.th0 + s.k0, cubic_taps_weighted(s.t0, w * (1.0 - s.f)));
+      if (s.k1 >= 0) spline_scatter(c, t.th0 + s.k1, cubic_taps_weighted(s.t1, w * s.f));
     }
   }
   __device__ static void init(Acc&) {}
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
     __syncthreads();
     double* o = host_rows + (long long)e * (4 + a.n_theta);
     for (int i = tid + 1; i < 4 + a.n_theta; i += kBlock) store_sys(o + i, s_row[i]);
-    publish_stamp(o, a.seq, tid);
+    publish_stamp(o, *a.seq_ptr, tid);
   }
 }
 
@@ -1178,7 +1183,8 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
       store_sys(r + 1, sum);
       store_sys(r + 2, var);
       store_sys(r + 3, mn);
-      store_sys(r + 7, (double)a.n_ev);
+      // a negative event count asks whoever assembles the gathered records to repeat the evaluation in two-pass mode
+      store_sys(r + 7, (*a.redo_ptr == *a.seq_ptr) ? -(double)(a.n_ev + 1) : (double)a.n_ev);
     }
   }
   // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups.  Everything this thread
@@ -1228,7 +1234,7 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
     for (int q = 0; q < rows; ++q) g += s_tile[q * vp + col];  // fixed order
     store_sys(r + off_gpe + col, g);
   }
-  publish_stamp(r, a.seq, tid);
+  publish_stamp(r, *a.seq_ptr, tid);
 }
 
 // ---- one grid normaliser Z_j(theta), integrated by one workgroup (see the comment above NormD's users):
@@ -1283,19 +1289,27 @@ constexpr int kRedChunk = 8;  // values per pass of the block-level transposed r
 #ifndef GWI_SCAN_WAVES_PER_EU
 #define GWI_SCAN_WAVES_PER_EU 1
 #endif
-template <bool WRITE_LOGW, bool BATCH, int U, int... Ks>
+// SAFE (spline models only): the fallback instantiation with the two-pass sweep and the replay (deterministic) mode as
+// run-time options -- and the batch index as one too, so that there is ONE such kernel per term sequence.  Carrying these
+// options in the regular kernel cost it 50-90 VGPRs (config 5: 125 -> 213), i.e. one or two resident waves per SIMD.
+template <bool WRITE_LOGW, bool BATCH, bool SAFE, int U, int... Ks>
 __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(const KArgs a) {
   using ChainT = Chain<U, Ks...>;
   constexpr int kU = U;
-  // Spline-coefficient gradient numerators: per wave, gacc_rep replicas of a row of gacc_pad
-  // doubles.  Lane l adds into replica l % gacc_rep, so the 64 ds_add_f64 of one wave instruction
-  // that target ONE coefficient (posterior samples of an event cluster in a few knot intervals)
-  // are spread over gacc_rep addresses in different banks (gacc_pad is odd).
+  // Models with spline terms ("shared" mode): the workgroup keeps ONE set of gradient rows in LDS ([coefficient][replica],
+  // see spline_scatter) that all four waves add into, so every wave must weigh its samples against the SAME reference
+  // exponent.  That reference is fixed when the workgroup first sees a live sample (one barrier, in the first trip) and
+  // never moves: no per-trip wave maximum, no rescaling of running sums or rows.  Any reference within ~150 of the
+  // tile's true maximum is exact to rounding (the sums hold e^{l-ref} and e^{2(l-ref)}, far from fp64's range); if a
+  // later sample exceeds the reference by more than that, the workgroup says so (redo_host) and the host repeats the
+  // evaluation in two-pass mode, where a first sweep over the tile finds the exact maximum.  Parametric models keep the
+  // per-wave online maximum (registers only, no barrier in the loop).
+  constexpr bool kShared = ChainT::kSpline && !WRITE_LOGW;
   extern __shared__ double s_gacc[];
   __shared__ double s_theta[GWI_MAX_THETA];
   __shared__ double s_out[GWI_MAX_THETA];
   // spline models carry few scalar sums (their gradient lives in the s_gacc rows): a narrower staging
-  // area leaves the LDS to those rows (3 workgroups per CU still fit with 16 replicas per wave)
+  // area leaves the LDS to those rows
   constexpr int kNVals = 2 + ChainT::kNumAcc;
   constexpr int kChunk = ChainT::kSpline ? (kNVals < 4 ? kNVals : 4) : kRedChunk;
   __shared__ double s_red[kChunk][kBlock];
@@ -1315,9 +1329,11 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 #endif
   GWI_STAMP(0);
   // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
-  const int kb = BATCH ? (int)blockIdx.y : 0;
-  const double* theta_src = BATCH ? a.tblocks[kb].theta : a.theta;
+  const bool batch = BATCH || (SAFE && a.tblocks != nullptr);
+  const int kb = batch ? (int)blockIdx.y : 0;
+  const double* theta_src = batch ? a.tblocks[kb].theta : a.theta;
   const int n_norm_blocks = WRITE_LOGW ? 0 : a.n_norms;
+  if (!WRITE_LOGW && blockIdx.x == 0 && kb == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // the tail launches stamp their results with it
   if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
     const int j = blockIdx.x;
     norm_block(a.norms, theta_src, a.n_theta, j, a.norm_out_host + kb * a.n_norms + j, a.norm_stamps_host + kb * a.n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
@@ -1329,10 +1345,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
   if (ChainT::kSpline)
     for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
-  const int wave_span = a.gacc_rep * a.gacc_pad;
-  double* const wave_rows = s_gacc + wave * wave_span;
-  if (ChainT::kSpline)
-    for (int p = lane; p < wave_span; p += 64) wave_rows[p] = 0.0;
+  const int n_rows = a.n_theta << a.gacc_shift;  // doubles in the shared rows
+  if (kShared)
+    for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
   if (ChainT::kSpline) __syncthreads();
 
@@ -1340,9 +1355,10 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   Ctx ctx;
   ctx.a = &a;
   ctx.theta = theta_src;
-  ctx.derived = BATCH ? a.tblocks[kb].derived : a.derived;
+  ctx.derived = batch ? a.tblocks[kb].derived : a.derived;
   ctx.coefs = s_theta;
-  ctx.gacc = wave_rows + (lane & (a.gacc_rep - 1)) * a.gacc_pad;
+  ctx.gacc = s_gacc + (lane & (a.gacc_rep - 1));
+  ctx.rep_shift = a.gacc_shift;
   double* logw;
   if (b < n_pe_blocks) {
     const int e = b / a.tiles_per_event;
@@ -1367,8 +1383,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   chain.init();
 
   // Trip structure: lane `lane` of the workgroup handles samples i, i + 256, ... (U of them) per trip;
-  // every condition on (i - lane) is wave-uniform.  Loads for the NEXT trip are issued before the
-  // current trip is evaluated (register double buffer).
+  // every condition on (i - lane) is wave-uniform, every condition on (i - tid) workgroup-uniform.  Loads for the
+  // NEXT trip are issued before the current trip is evaluated (register double buffer).
   double kap[2][kU];
   auto issue_loads = [&](int buf, long long i) {
 #pragma unroll
@@ -1382,79 +1398,155 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   };
   const long long i0 = start + tid;
   GWI_STAMP(1);
-  if (i0 - lane < end) issue_loads(0, i0);
+
+  // shared mode: the workgroup-wide reference exponent and whether it has been fixed yet.  Both are workgroup-uniform
+  // and kept in SCALAR registers (uniform()): the branches on them are scalar branches, which a barrier inside needs.
+  double m_ref = GWI_NEG_INF;
+  int ref_set = 0;
+  int over = 0;                    // some live sample exceeded the reference by more than kRefSlack (wave-uniform)
+  double lane_max = GWI_NEG_INF;   // two-pass mode, pass 0 only: this lane's largest live exponent
+  constexpr double kRefSlack = 150.0;
+  // two-pass mode (shared only): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
+  for (int pass_ = (SAFE && kShared && a.two_pass) ? 0 : 1; pass_ < 2; ++pass_) {
+    if (i0 - lane < end) issue_loads(0, i0);
 #ifdef GWI_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
-  GWI_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
+    GWI_STAMP(2);
 #endif
-  for (long long i = i0; i - lane < end; i += kU * kBlock) {
-    const long long i_next = i + kU * kBlock;
-    const bool has_next = i_next - lane < end;  // wave-uniform
-    if (has_next) issue_loads(1, i_next);
-    double ell[kU], lin[kU];
-    bool live[kU];
-    double mx_lane = GWI_NEG_INF;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const long long iu = i + (long long)u * kBlock;
-      if (u > 0 && iu - lane >= end) {  // wave-uniform: this wave has no u-th sample
-        live[u] = false;
-        ell[u] = GWI_NEG_INF;
-        lin[u] = 0.0;
-        continue;
-      }
-      const bool valid = iu < end;
-      lin[u] = 1.0;
-      ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
-      // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
-      live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
-      if (!live[u]) ell[u] = GWI_NEG_INF;
-      if (WRITE_LOGW) {
-        if (valid) logw[base + iu] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
-      }
-      mx_lane = fmax(mx_lane, ell[u]);
-    }
-    if (!WRITE_LOGW) {
-      const double mx = wave_max(mx_lane);
-      if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
-        if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
-          double sc = fast_exp(m - mx);
-          if (a.square) sc *= sc;
-          s1 *= sc;
-          s2 *= sc * sc;
-          chain.rescale(sc);
-          if (ChainT::kSpline)
-            for (int p = lane; p < wave_span; p += 64) wave_rows[p] *= sc;
-        }
-        m = mx;
-      }
+    int trip = 0;
+    // shared mode iterates whole-workgroup trips (a barrier may sit inside); otherwise a wave stops with its samples
+    for (long long i = i0; kShared ? (i - tid < end) : (i - lane < end); i += kU * kBlock, ++trip) {
+      // loop-invariant mode flags, laundered so that the compiler keeps ONE copy of the loop body instead of one per
+      // combination (unswitching): the branches on them are scalar and cost nothing next to the body
+      int pass = pass_, det = (SAFE && kShared) ? a.deterministic : 0;
+      if (SAFE) asm volatile("" : "+s"(pass), "+s"(det));
+      const bool wave_has = i - lane < end;  // wave-uniform
+      const long long i_next = i + kU * kBlock;
+      const bool has_next = i_next - lane < end;  // wave-uniform
+      if (has_next) issue_loads(1, i_next);
+      double ell[kU], lin[kU];
+      bool live[kU];
+      double mx_lane = GWI_NEG_INF;
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
-        double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
-        if (a.square) w *= w;
-        s1 += w;
-        s2 += w * w;
-        chain.accumulate(u, 0, ctx, w);
+        const long long iu = i + (long long)u * kBlock;
+        if ((kShared && !wave_has) || (u > 0 && iu - lane >= end)) {  // wave-uniform: this wave has no u-th sample
+          live[u] = false;
+          ell[u] = GWI_NEG_INF;
+          lin[u] = 0.0;
+          continue;
+        }
+        const bool valid = iu < end;
+        lin[u] = 1.0;
+        ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
+        // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
+        live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
+        if (!live[u]) ell[u] = GWI_NEG_INF;
+        if (WRITE_LOGW) {
+          if (valid) logw[base + iu] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
+        }
+        mx_lane = fmax(mx_lane, ell[u]);
+      }
+      if (kShared) {
+        if (SAFE && pass == 0) {
+          lane_max = fmax(lane_max, mx_lane);
+        } else {
+          if (!ref_set) {  // workgroup-uniform: nothing live seen so far -- agree on the reference exponent
+            const double mx = wave_max(mx_lane);
+            if (lane == 0) s_wrec[wave][trip & 1] = mx;  // slot by trip parity: a fast wave's next trip cannot overwrite what a slow one still reads
+            __syncthreads();
+            const int q = trip & 1;
+            const double mm = uniform(fmax(fmax(s_wrec[0][q], s_wrec[1][q]), fmax(s_wrec[2][q], s_wrec[3][q])));
+            if (mm != GWI_NEG_INF) {
+              m_ref = mm;
+              ref_set = 1;
+            }
+          } else if (__builtin_amdgcn_ballot_w64(mx_lane > m_ref + kRefSlack) != 0) {
+            over = 1;
+          }
+          if (ref_set) {
+            // replay mode (det): the waves take turns, so every row slot receives its additions in one fixed order
+            // (with rep = 64 a wave instruction never has two lanes on one address)
+            const int n_turns = (SAFE && det) ? kWaves : 1;
+            for (int turn = 0; turn < n_turns; ++turn) {
+              if (wave_has && (!det || turn == wave)) {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                  if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+                  double w = live[u] ? lin[u] * fast_exp(ell[u] - m_ref) : 0.0;
+                  if (a.square) w *= w;
+                  s1 += w;
+                  s2 += w * w;
+                  chain.accumulate(u, 0, ctx, w);
+                }
+              }
+              if (SAFE && det) __syncthreads();
+            }
+          }
+        }
+      } else if (!WRITE_LOGW) {
+        const double mx = wave_max(mx_lane);
+        if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
+          if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
+            double sc = fast_exp(m - mx);
+            if (a.square) sc *= sc;
+            s1 *= sc;
+            s2 *= sc * sc;
+            chain.rescale(sc);
+          }
+          m = mx;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+          double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+          if (a.square) w *= w;
+          s1 += w;
+          s2 += w * w;
+          chain.accumulate(u, 0, ctx, w);
+        }
+      }
+      if (has_next) {
+        chain.advance();
+#pragma unroll
+        for (int u = 0; u < kU; ++u) kap[0][u] = kap[1][u];
       }
     }
-    if (has_next) {
-      chain.advance();
-#pragma unroll
-      for (int u = 0; u < kU; ++u) kap[0][u] = kap[1][u];
+    if (SAFE && kShared && pass_ == 0) {  // two-pass mode: the tile's exact maximum becomes the reference
+      const double mx = wave_max(lane_max);
+      if (lane == 0) s_wrec[wave][2] = mx;
+      __syncthreads();
+      const double mm = uniform(fmax(fmax(s_wrec[0][2], s_wrec[1][2]), fmax(s_wrec[2][2], s_wrec[3][2])));
+      if (mm != GWI_NEG_INF) {
+        m_ref = mm;
+        ref_set = 1;
+      }
     }
   }
   if (WRITE_LOGW) return;
   GWI_STAMP(3);
 
   // ---- workgroup record: common exponent M, then a transposed LDS reduction of every scalar sum
-  if (lane == 0) s_wrec[wave][0] = m;
-  __syncthreads();
-  double M = s_wrec[0][0];
+  double M, f;
+  if (kShared) {
+    // every wave already used the workgroup's reference; if a live sample outran it by more than the slack, ask the host
+    // for the two-pass repeat (any wave that saw one says so; the stores carry the same value)
+    if (over && lane == 0) {
+      __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    M = m_ref;
+    f = 1.0;
+  } else {
+    if (lane == 0) s_wrec[wave][0] = m;
+    __syncthreads();
+    M = s_wrec[0][0];
 #pragma unroll
-  for (int w_ = 1; w_ < kWaves; ++w_) M = fmax(M, s_wrec[w_][0]);
-  double f = (m == GWI_NEG_INF) ? 0.0 : fast_exp(m - M);  // this wave's rescale factor
-  if (a.square) f *= f;
+    for (int w_ = 1; w_ < kWaves; ++w_) M = fmax(M, s_wrec[w_][0]);
+    f = (m == GWI_NEG_INF) ? 0.0 : fast_exp(m - M);  // this wave's rescale factor
+    if (a.square) f *= f;
+  }
 
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
@@ -1490,25 +1582,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   }
   if (tid == 0) out[0] = a.square ? 2.0 * M : M;
   __syncthreads();
-  // gradient numerators: scalar sums from s_out, spline-coefficient sums from the per-wave rows
-  double fw[kWaves];
-  if (ChainT::kSpline) {
-#pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) {
-      fw[w_] = (s_wrec[w_][0] == GWI_NEG_INF) ? 0.0 : fast_exp(s_wrec[w_][0] - M);
-      if (a.square) fw[w_] *= fw[w_];
-    }
-  }
+  // gradient numerators: scalar sums from s_out, spline-coefficient sums from the shared rows (replicas in fixed order)
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double g = s_out[p];
-    if (ChainT::kSpline) {
-#pragma unroll
-      for (int w_ = 0; w_ < kWaves; ++w_) {
-        const double* rows = s_gacc + w_ * wave_span + p;
-        double gw = 0.0;
-        for (int r = 0; r < a.gacc_rep; ++r) gw += rows[r * a.gacc_pad];
-        g += fw[w_] * gw;
-      }
+    if (kShared) {
+      const double* rows = s_gacc + ((long)p << a.gacc_shift);
+      double gw = 0.0;
+      for (int r = 0; r < a.gacc_rep; ++r) gw += rows[(r + p) & (a.gacc_rep - 1)];  // rotated start: the threads of a wave read different banks
+      g += gw;
     }
     out[kRecHeader + p] = g;
   }

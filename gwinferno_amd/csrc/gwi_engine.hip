@@ -41,7 +41,17 @@ struct Variant {
   ScanFn scan;
   ScanFn logw;
   ScanFn scan_batch;
+  ScanFn scan_safe;  // spline models: two-pass / replay instantiation (single and batched launches), nullptr otherwise
 };
+
+// the SAFE instantiation exists for spline term sequences only
+template <int U, int... Ks>
+constexpr ScanFn safe_scan() {
+  if constexpr (Chain<U, Ks...>::kSpline)
+    return &scan_kernel<false, false, true, U, Ks...>;
+  else
+    return nullptr;
+}
 
 #define K_PL GWI_TERM_POWERLAW
 #define K_PP GWI_TERM_PLPEAK
@@ -60,8 +70,9 @@ struct Variant {
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
-  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, false, U, __VA_ARGS__>, \
-    &scan_kernel<true, false, U, __VA_ARGS__>, &scan_kernel<false, true, U, __VA_ARGS__> }
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, false, false, U, __VA_ARGS__>, \
+    &scan_kernel<true, false, false, U, __VA_ARGS__>, &scan_kernel<false, true, false, U, __VA_ARGS__>,                          \
+    safe_scan<U, __VA_ARGS__>() }
 #define GWI_VARIANT(NAME, ...) GWI_VARIANT_U(NAME, 2, __VA_ARGS__)
 
 // Term sequences are canonical: the host sorts a model's terms by kind id (stable).
@@ -256,6 +267,11 @@ struct gwi_engine {
   int n_inj_groups = 1, tiles_per_inj_group = 1;
 
   size_t scan_lds_bytes = 0;
+  int gacc_rep = 1;
+  bool deterministic = false;   // GWI_DETERMINISTIC=1: replay mode of the shared gradient rows (scan_kernel)
+  unsigned long long* d_seq = nullptr;                              // device words: [0] sequence number of the evaluation in flight, [1] redo request
+  unsigned long long *h_redo = nullptr, *h_redo_dev = nullptr;      // pinned: a scan workgroup asks for the two-pass repeat
+  long redo_count = 0;          // evaluations repeated in two-pass mode so far
   unsigned long long seq = 0;
   // results of the last prelude (one per hyper-parameter point of the last launch)
   std::vector<double> host_consts = std::vector<double>(1, 0.0);
@@ -282,8 +298,10 @@ struct gwi_engine {
   std::string err;
   // the engine's own AQL queue (gwi_aql.h): plain single-point evaluations are dispatched through it
   aql::Queue aq;
-  aql::Kernel aq_scan, aq_combine, aq_final;
+  aql::Kernel aq_scan, aq_scan_safe, aq_combine, aq_final;
+  bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
   bool aql_active = false;  // queue, argument ring and the three kernels are ready
+  char* aq_tail_args = nullptr;  // persistent kernel-argument slot holding this engine's (constant) TailArgs
   bool aql_now = false;     // the pipeline being issued / awaited went through the AQL queue
   bool force_hip_stream = false;  // gwi_set_timing(h, 2): time with HIP events on the HIP stream (A/B against the AQL path)
   std::string aql_note;     // why not, when not
@@ -459,8 +477,13 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
 template <typename F, typename A>
 void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args, size_t used_bytes = sizeof(A)) {
   if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
-    const aql::Kernel& k = slot == 0 ? h->aq_scan : (slot == 1 ? h->aq_combine : h->aq_final);
-    if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, h->timing ? h->aq.done[slot] : hsa_signal_t{0})) return;
+    const aql::Kernel& k = slot == 0 ? (h->scan_is_safe ? h->aq_scan_safe : h->aq_scan) : (slot == 1 ? h->aq_combine : h->aq_final);
+    const hsa_signal_t done = h->timing ? h->aq.done[slot] : hsa_signal_t{0};
+    if (slot > 0 && h->aq_tail_args) {  // constant arguments, staged once at gwi_create
+      if (aql::dispatch_staged(h->aq, k, h->aq_tail_args, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
+      return;
+    }
+    if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
     // the queue reported an error: nothing was submitted; the waiters surface it
     return;
   }
@@ -473,7 +496,10 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
-  ScanFn fn = logw ? h->variant->logw : (batch ? h->variant->scan_batch : h->variant->scan);
+  // two-pass repeats and the replay mode run the SAFE instantiation (spline models; it takes single and batched launches)
+  const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic);
+  ScanFn fn = logw ? h->variant->logw : (safe ? h->variant->scan_safe : (batch ? h->variant->scan_batch : h->variant->scan));
+  h->scan_is_safe = safe;
   // theta is the LAST member of the argument block: only the hyper-parameters in use travel through the BAR
   const size_t used = offsetof(KArgs, theta) + sizeof(double) * (size_t)h->spec.n_theta;
   launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs, used);
@@ -508,7 +534,36 @@ long g_phase_calls = 0;
   } while (0)
 #endif
 
-gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+// Arguments of the combine / final launches.  Nothing in them changes from one evaluation to the next (the completion
+// stamp travels through a device word the scan writes): on the AQL path they sit in two persistent kernel-argument slots.
+TailArgs tail_args(const gwi_engine* h, double* record_dev) {
+  TailArgs ta;
+  std::memset(&ta, 0, sizeof(ta));
+  ta.partials = h->d_partials;
+  ta.ev_out = h->d_ev_out;
+  ta.ev_grad = h->d_ev_grad;
+  ta.inj_out = h->d_inj_out;
+  ta.inj_grad = h->d_inj_grad;
+  ta.ev_host = h->h_ev_dev;
+  ta.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
+  ta.record = record_dev ? record_dev : h->h_record_dev;
+  ta.seq_ptr = h->d_seq;
+  ta.redo_ptr = h->d_seq + 1;
+  ta.n_ev = (int)h->n_ev;
+  ta.tiles_per_event = h->tiles_per_event;
+  ta.n_inj_tiles = h->n_inj_tiles;
+  ta.n_inj_groups = h->n_inj_groups;
+  ta.tiles_per_inj_group = h->tiles_per_inj_group;
+  ta.n_theta = h->spec.n_theta;
+  ta.rec_stride = h->rec_stride;
+  ta.n_scan_blocks = h->n_scan_blocks;
+  ta.n_norms = h->spec.n_norms;
+  ta.record_len = record_len(h);
+  ta.n_pe = (double)h->n_pe;
+  return ta;
+}
+
+gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_dev, bool wait, int K, bool batch, bool square) {
 #ifdef GWI_HOST_PHASES
   auto phase_t_ = std::chrono::steady_clock::now();
   ++g_phase_calls;
@@ -535,28 +590,8 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
     h->kargs.tblocks = h->d_tblocks;
   }
   const unsigned gy = batch ? (unsigned)K : 1u;
-  TailArgs ta;
-  ta.partials = h->d_partials;
-  ta.ev_out = h->d_ev_out;
-  ta.ev_grad = h->d_ev_grad;
-  ta.inj_out = h->d_inj_out;
-  ta.inj_grad = h->d_inj_grad;
-  ta.ev_host = h->h_ev_dev;
-  ta.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
+  const TailArgs ta = tail_args(h, record_dev);
   h->last_host_rows = ta.host_rows != nullptr;
-  ta.record = record_dev ? record_dev : h->h_record_dev;
-  ta.seq = h->seq + 1;
-  ta.n_ev = (int)h->n_ev;
-  ta.tiles_per_event = h->tiles_per_event;
-  ta.n_inj_tiles = h->n_inj_tiles;
-  ta.n_inj_groups = h->n_inj_groups;
-  ta.tiles_per_inj_group = h->tiles_per_inj_group;
-  ta.n_theta = n_theta;
-  ta.rec_stride = h->rec_stride;
-  ta.n_scan_blocks = h->n_scan_blocks;
-  ta.n_norms = h->spec.n_norms;
-  ta.record_len = record_len(h);
-  ta.n_pe = (double)h->n_pe;
   h->kargs.norm_seq = h->seq + 1;  // the normaliser workgroups of this launch stamp their results with it
   GWI_PHASE(0);
   gwi_status st = launch_scan(h, false, K, batch);
@@ -580,6 +615,23 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
   gwi_status st_ = wait_for_stamp(h, h->h_record, K);
   if (st_ != GWI_OK) return st_;
   return wait_for_norms(h, h->h_record, K);
+}
+
+// A scan workgroup whose fixed reference exponent turned out too low for a later sample (models with spline terms:
+// scan_kernel, shared mode) has stored this evaluation's sequence number in the pinned redo word.
+bool redo_requested(const gwi_engine* h) { return *reinterpret_cast<volatile unsigned long long*>(h->h_redo) == h->seq; }
+
+// launches scan -> combine [-> final]; with `wait`, repeats the evaluation in two-pass mode (exact tile maxima) when a
+// workgroup asked for it.  Callers that pass wait = false check redo_requested() themselves once their results are in.
+gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+  gwi_status st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
+  if (st == GWI_OK && wait && redo_requested(h)) {
+    ++h->redo_count;
+    h->kargs.two_pass = 1;
+    st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
+    h->kargs.two_pass = 0;
+  }
+  return st;
 }
 
 // The AQL path has no HIP stream behind it: when the quick poll gives up, keep polling (with the queue's error flag in
@@ -901,6 +953,8 @@ void destroy_impl(gwi_engine* h) {
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   (void)hipFree(h->d_tblocks);
+  (void)hipFree(h->d_seq);
+  if (h->h_redo) (void)hipHostFree(h->h_redo);
   if (h->h_tblocks) (void)hipHostFree(h->h_tblocks);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -971,11 +1025,20 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
   aql::Kernel* out[3] = {&h->aq_scan, &h->aq_combine, &h->aq_final};
   for (int i = 0; i < 3; ++i)
     if (!aql::find_kernel(dev, hipKernelNameRefByPtr(fns[i], h->stream), *out[i], h->aql_note)) return;
+  if (h->variant->scan_safe && !aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->scan_safe), h->stream), h->aq_scan_safe, h->aql_note)) return;
   if (h->aq_scan.kernarg_bytes != sizeof(KArgs) || h->aq_combine.kernarg_bytes != sizeof(TailArgs) || h->aq_final.kernarg_bytes != sizeof(TailArgs)) {
     h->aql_note = "kernel argument sizes of the code object differ from this build (stale gwi_kernels.hsaco?)";
     return;
   }
   if (!aql::open_queue(dev, h->aq, h->aql_note)) return;
+  {
+    const TailArgs ta = tail_args(h, nullptr);  // the AQL path never publishes to a device record (that is the RCCL exchange, on the HIP stream)
+    h->aq_tail_args = aql::stage_args(h->aq, aql::kSlots - 1, &ta, sizeof(ta));
+    if (!h->aq_tail_args) {
+      h->aql_note = "staging the tail kernels' arguments failed";
+      return;
+    }
+  }
   h->aql_active = true;
   h->aql_note = "active";
 }
@@ -1074,18 +1137,40 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipMalloc(&h->d_norms, sizeof(NormD) * nd.size()));
   GWI_HIP(hipMemcpy(h->d_norms, nd.data(), sizeof(NormD) * nd.size(), hipMemcpyHostToDevice));
 
-  // dynamic LDS of the scan kernel (spline-gradient rows), needed by the occupancy query below
+  // dynamic LDS of the scan kernel: the workgroup's spline-gradient rows, [n_theta][rep] doubles (spline_scatter in
+  // gwi_device.h).  rep = 64 would give every lane its own replica; 16 (four lanes per replica, bank = replica) measured
+  // the same or better on the BASELINE catalogs (config 5 scan: rep 8 / 16 / 32 / 64 = 61.5 / 51.2 / 51.7 / 70.0 us, config 3:
+  // 15.5 / 14.6 / 15.3 / 16.1) because the rows must also fit next to the kernel's static LDS as many times as the
+  // register budget allows workgroups on a CU, and are zeroed and summed once per workgroup.
+  bool has_spline = false;
+  for (int t = 0; t < spec->n_terms; ++t)
+    has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
+  if (const char* env = std::getenv("GWI_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
   size_t scan_lds = 0;
-  {
-    int rep0 = 8;
-    if (const char* env = std::getenv("GWI_GACC_REP")) rep0 = std::atoi(env);
-    if (rep0 < 1) rep0 = 1;
-    if (rep0 > 16) rep0 = 16;
-    while (rep0 & (rep0 - 1)) rep0 &= rep0 - 1;
-    bool spl = false;
-    for (int t = 0; t < spec->n_terms; ++t) spl = spl || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
-    scan_lds = spl ? sizeof(double) * (size_t)kWaves * rep0 * (spec->n_theta | 1) : 0;
+  int rep = 1;
+  if (has_spline) {
+    size_t lds_per_cu = 160 * 1024, static_lds = 14 * 1024;  // gfx950: 160 KiB per CU; static: s_theta + s_out + s_red + s_wrec
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(h->variant->scan)) == hipSuccess && fa.sharedSizeBytes > 0) static_lds = fa.sharedSizeBytes;
+    int occ0 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, h->variant->scan, kBlock, 0) != hipSuccess || occ0 < 1) occ0 = 2;
+    rep = 16;
+    while (rep > 1 && (sizeof(double) * (size_t)spec->n_theta * rep + static_lds) * (size_t)occ0 > lds_per_cu) rep >>= 1;
+    if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
+    if (h->deterministic) rep = 64;  // one replica per lane: a wave instruction never meets itself on an address
+    if (rep < 1) rep = 1;
+    if (rep > 64) rep = 64;
+    while (rep & (rep - 1)) rep &= rep - 1;  // power of two
+    while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + static_lds > lds_per_cu) rep >>= 1;
+    scan_lds = sizeof(double) * (size_t)spec->n_theta * rep;
+    if (scan_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a HIP launch (the AQL packets carry any size)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->logw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+      if (h->variant->scan_safe) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_safe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+    }
   }
+  h->gacc_rep = rep;
   // ---- launch geometry.  Default: ~2048 scan workgroups (8 per CU).  A step lasts only ~10 us, so a
   // partial second dispatch round (a few workgroups that can only start when the first finishers
   // retire) costs a large fraction of it: when one round of resident workgroups can hold the whole
@@ -1145,18 +1230,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   }
   if (h->tiles_per_event > 64 || h->tiles_per_inj_group > 64 || h->n_inj_groups > 64)
     return fail(h, GWI_ERR_INVALID, "launch geometry: more than 64 tile records per group (internal error: the tile sizes above should have prevented this)");
-  // spline-gradient LDS rows: replicas per wave (see scan_kernel); 8 by default, <= 16
-  int rep = 8;
-  if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
-  if (rep < 1) rep = 1;
-  if (rep > 16) rep = 16;
-  while (rep & (rep - 1)) rep &= rep - 1;  // power of two
-  const int pad = spec->n_theta | 1;        // odd row stride: replicas land in different banks
-  bool has_spline = false;
-  for (int t = 0; t < spec->n_terms; ++t)
-    has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
-  if (!has_spline) rep = 1;
-  h->scan_lds_bytes = has_spline ? sizeof(double) * (size_t)kWaves * rep * pad : 0;
+  h->scan_lds_bytes = scan_lds;
 
   const size_t KB = (size_t)h->max_batch;  // every per-evaluation buffer holds max_batch hyper-parameter points
   GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * KB * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
@@ -1173,6 +1247,11 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * KB * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_ev_dev, h->h_ev, 0));
   std::memset(h->h_record, 0, sizeof(double) * KB * record_len(h));
+  GWI_HIP(hipMalloc(&h->d_seq, 2 * sizeof(unsigned long long)));
+  GWI_HIP(hipMemset(h->d_seq, 0, 2 * sizeof(unsigned long long)));
+  GWI_HIP(hipHostMalloc((void**)&h->h_redo, sizeof(unsigned long long), hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_redo_dev, h->h_redo, 0));
+  *h->h_redo = 0;
   // host-final mode for small problems: the per-group rows fit a few KiB, so the host sums them and
   // the third launch (final_kernel: ~1.5 us boundary + ~6-9 us of latency chain) disappears
   {
@@ -1225,7 +1304,12 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipMemset(k.stamps, 0, sizeof(unsigned long long) * (size_t)(h->n_scan_blocks + spec->n_norms + 1) * kWaves * 8));
 #endif
   k.gacc_rep = rep;
-  k.gacc_pad = pad;
+  k.gacc_shift = __builtin_ctz((unsigned)rep);
+  k.seq_dev = h->d_seq;
+  k.redo_host = h->h_redo_dev;
+  k.redo_dev = h->d_seq + 1;
+  k.two_pass = 0;
+  k.deterministic = h->deterministic ? 1 : 0;
   for (int t = 0; t < spec->n_terms; ++t) {
     const gwi_term& tm = spec->terms[t];
     TermD& d = k.terms[t];
@@ -1331,6 +1415,7 @@ gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]) {
 }
 
 int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
+int64_t gwi_two_pass_repeats(gwi_handle h) { return h ? h->redo_count : 0; }
 
 gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
   if (!h || !theta) return GWI_ERR_INVALID;
@@ -1400,6 +1485,14 @@ gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double
     if (st == GWI_OK) st = wait_for_norms(h, h->h_record, 1);
   }
   if (st != GWI_OK) return st;
+  if (redo_requested(h)) {  // repeat in two-pass mode, blocking (the squared-weight pass, if any, ran through run_pipeline and is exact already)
+    const std::vector<double> th(h->kargs.theta, h->kargs.theta + h->spec.n_theta);
+    ++h->redo_count;
+    h->kargs.two_pass = 1;
+    st = run_pipeline_once(h, th.data(), nullptr, true, 1, false, false);
+    h->kargs.two_pass = 0;
+    if (st != GWI_OK) return st;
+  }
   gwi_summary s;
   assemble(h, h->h_record, 1, &h->pending_opt, &s, grad, norms, h->host_consts[0], (h->pending_sq && grad) ? h->sq_records.data() : nullptr);
   if (summary) *summary = s;
@@ -1578,13 +1671,27 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
     if (st_ != GWI_OK) return st_;
     return wait_for_norms(h, h->h_gather);  // every rank integrates the same grids; rank-0 slots are what assemble() reads
   };
+  // in-engine RCCL path: a rank whose scan asked for the two-pass repeat marked its record (negative event count), so
+  // every rank sees the request in the gathered records and all repeat the exchange together
+  auto run_checked = [&](bool square) -> gwi_status {
+    gwi_status st_ = run(square);
+    if (st_ != GWI_OK || h->shm_base) return st_;
+    bool redo = false;
+    for (int r = 0; r < h->comm_world; ++r) redo = redo || h->h_gather[(size_t)r * len + 7] < 0.0;
+    if (!redo) return GWI_OK;
+    ++h->redo_count;
+    h->kargs.two_pass = 1;
+    st_ = run(square);
+    h->kargs.two_pass = 0;
+    return st_;
+  };
   const bool need_sq = opt->marginalize_selection && grad;
   if (need_sq) {  // a second exchange carries the squared-weight numerators
-    st = run(true);
+    st = run_checked(true);
     if (st != GWI_OK) return st;
     h->sq_records.assign(gathered, gathered + len * h->comm_world);
   }
-  st = run(false);
+  st = run_checked(false);
   if (st != GWI_OK) return st;
   gwi_summary s;
   assemble(h, gathered, h->comm_world, opt, &s, grad, norms, h->host_consts[0], need_sq ? h->sq_records.data() : nullptr);

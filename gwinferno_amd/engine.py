@@ -564,6 +564,10 @@ class NativePopulationLikelihood:
         self._check(self.lib.gwi_selftime(self.handle, N.as_dp(N.f64(theta)), C.byref(opt), int(n_iter), N.as_dp(out)))
         return float(out[0])
 
+    def two_pass_repeats(self):
+        """Evaluations this engine had to repeat with the two-pass scan (``gwi_two_pass_repeats``; 0 in ordinary runs)."""
+        return int(self.lib.gwi_two_pass_repeats(self.handle))
+
     def set_timing(self, on=True):
         self._check(self.lib.gwi_set_timing(self.handle, int(on)))
 

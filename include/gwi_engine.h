@@ -301,6 +301,12 @@ gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, cons
  * seconds[n]: the latency distribution (median, p5/p95) of SURVEY.md section 8(d). */
 gwi_status gwi_eval_latencies(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* seconds);
 
+/* Models with spline terms: the scan weighs a tile's samples against a reference exponent fixed at the tile's first live
+ * sample (so that the four wavefronts of a workgroup can share one set of gradient rows); when a later sample of the tile
+ * exceeds it by more than e^150 the evaluation is repeated with a two-pass kernel that finds each tile's exact maximum
+ * first.  Results are identical to rounding either way; this counts the repeats (0 in any ordinary run). */
+int64_t gwi_two_pass_repeats(gwi_handle h);
+
 /* Host tuning: restrict the CALLING thread to the CPUs next to the engine's GPU (the local_cpulist of its PCI function,
  * intersected with the thread's current affinity).  Every evaluation is a few PCIe round trips driven by that thread.
  * GWI_ERR_UNSUPPORTED (and no change) when sysfs does not say. */

@@ -320,8 +320,23 @@ def test_construct_hierarchical_model_matches_the_reference(name):
     # one engine per constructed model (each construct call makes its own redshift grid, analysis.py:371-372), however
     # many times the model function ran: nothing is keyed on the per-call distribution objects
     assert len(L._ENGINES) == len(case.flagsets)
-    with pytest.raises(NotImplementedError):
-        L.construct_hierarchical_model(model_dict, prior_dict)(case.pe, case.inj, case.total_inj, case.nobs, case.tobs)  # the reference's default asks for the PPC draws
+    # the reference's DEFAULT call, construct_hierarchical_model(model_dict, prior_dict): posterior_predictive_check=True
+    # (analysis.py:359-366) -- runs, gives the same likelihood sites, and adds one observed / predicted draw per event
+    # and source parameter (:350-355), taken from the catalog with the per-sample weights of the engine
+    L.construct_hierarchical_model(model_dict, prior_dict)(case.pe, case.inj, case.total_inj, case.nobs, case.tobs)
+    sites = L.last_sites()
+    assert rel_err(sites["log_l"], case.sites["log_neff"]["log_l"][case.n_points - 1]) < 1e-9  # defaults == the "log_neff" flag set, last hyper-point
+    eng, pe_w, _, _ = L._ENGINES[next(reversed(L._ENGINES))]
+    lw_pe, _ = eng.log_weights(eng.bound.theta_of(pe_w))
+    for ev in range(case.nobs):
+        for p in model_dict:
+            obs, pred = sites[f"{p}_obs_event_{ev}"], sites[f"{p}_pred_event_{ev}"]
+            j = np.nonzero(case.pe[p][ev] == obs)[0]
+            assert j.size >= 1 and pred in case.inj[p]
+        j_obs = int(np.nonzero(case.pe["mass_1"][ev] == sites[f"mass_1_obs_event_{ev}"])[0][0])
+        assert np.isfinite(lw_pe[ev, j_obs])  # a drawn sample carries weight
+        m1, q = case.pe["mass_1"][ev, j_obs], case.pe["mass_ratio"][ev, j_obs]
+        assert 2.0 <= m1 <= 100.0 and m1 * q >= 2.0  # the mass cuts construct_hierarchical_model passes (analysis.py:417-419)
     L.clear_engine_cache()
 
 
