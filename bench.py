@@ -547,7 +547,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             for _ in range(n_b):
                 vgb(tb)
             dt = time.perf_counter() - t0
-            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b}
+            out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
         if dist is None and headline and chains > 1:
             out.update(multi_chain(eng, comp_name, pe, inj, total, thetas, chains, steps, dev))
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks

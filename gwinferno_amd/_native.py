@@ -176,6 +176,7 @@ EXPORTED_SYMBOLS = [
     "gwi_shm_exchange",
     "gwi_eval_latencies",
     "gwi_two_pass_repeats",
+    "gwi_batch_path",
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
@@ -257,6 +258,8 @@ def load_library():
     lib.gwi_shm_exchange.argtypes = [vp, _DP, _DP]
     lib.gwi_eval_latencies.restype = C.c_int32
     lib.gwi_eval_latencies.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), _DP]
+    lib.gwi_batch_path.restype = C.c_char_p
+    lib.gwi_batch_path.argtypes = [vp, C.c_int32]
     lib.gwi_two_pass_repeats.restype = C.c_int64
     lib.gwi_two_pass_repeats.argtypes = [vp]
     lib.gwi_selftime.restype = C.c_int32

@@ -97,7 +97,7 @@ struct KArgs {
   unsigned long long* redo_host;          // pinned host word: a workgroup whose fixed reference exponent turned out too low stores norm_seq here
   unsigned long long* redo_dev;           // ... and here (device word, read by final_kernel: the sharded path's record carries the request to every rank)
   int two_pass, deterministic;            // two_pass: find each tile's exact maximum first; deterministic: waves take turns at the shared rows
-  int square, pad_;        // square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
+  int square, k_batch;     // k_batch: hyper-parameter points of a batched launch (scan_mfma_kernel: 16 per grid row); square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   TermD terms[GWI_MAX_TERMS];

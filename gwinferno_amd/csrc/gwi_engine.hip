@@ -1,6 +1,7 @@
 // gwi_engine.hip -- host side + C ABI of the population-likelihood engine (see include/gwi_engine.h).
 // gfx950 only; no CPU fallback: every entry point that computes needs a live HIP device.
 #include "gwi_device.h"
+#include "gwi_mfma.h"
 #include "gwi_aql.h"
 
 #include <hip/hip_ext.h>
@@ -144,6 +145,61 @@ const Variant kVariants[] = {
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+// ---- batched launches of spline models on the matrix cores (gwi_mfma.h): term sequences with the number of 16-basis
+// gradient tiles of every spline term fixed at compile time.  A model qualifies when its kinds match and every spline
+// term has n_basis <= 16 * tiles; the first qualifying entry is used (entries with fewer tiles first).
+struct MfmaVariant {
+  const char* name;
+  int n;
+  int kinds[GWI_MAX_TERMS];
+  int tiles[GWI_MAX_TERMS];
+  ScanFn fn;
+};
+#define T1(K) (100 + (K))
+#define T2(K) (200 + (K))
+#define T4(K) (400 + (K))
+#define GWI_MFMA(NAME, U, ...) \
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, {0}, &scan_mfma_kernel<U, __VA_ARGS__> }
+MfmaVariant kMfmaVariants[] = {
+    // tests/inference_test.py:244-285 model and the mass-only models
+    GWI_MFMA("plz+spline3 (16,16,16)", 1, K_PZ, T1(K_SP), T1(K_SP), T1(K_SP)),
+    GWI_MFMA("plz+spline2 (32,16)", 1, K_PZ, T2(K_SP), T1(K_SP)),
+    // BASELINE config 3/4: PL q x PL z x {m1 (30), IID spin magnitudes (16, 16), IID tilts (16, 16)}
+    GWI_MFMA("plq+plz+spline5 (32,16,16,16,16)", 1, K_PQ, K_PZ, T2(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP)),
+    GWI_MFMA("plq+plz+spline3 (32,16,16)", 1, K_PQ, K_PZ, T2(K_SP), T1(K_SP), T1(K_SP)),
+    // BASELINE config 5: PL z x {m1 (30), q (14), a1, a2, ct1, ct2 (12 each), z (12)}
+    GWI_MFMA("plz+spline7 (32,16,16,16,16,16,16)", 1, K_PZ, T2(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP)),
+    // the reference's default spline counts (pipeline/utils.py:29-33): m1 50, q 30, spins 16, z 20
+    GWI_MFMA("plz+spline7 (64,32,16,16,16,16,32)", 1, K_PZ, T4(K_SP), T2(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T2(K_SP)),
+    // linear (chi_eff / chi_p) splines and the grid-interpolated BSplineDistribution
+    GWI_MFMA("plz+spline2+lspline2 (16,16,16,16)", 1, K_PZ, T1(K_SP), T1(K_SP), T1(K_LS), T1(K_LS)),
+    GWI_MFMA("plz+lerp2 (16,16)", 1, K_PZ, T1(K_SL), T1(K_SL)),
+};
+constexpr int kNumMfmaVariants = (int)(sizeof(kMfmaVariants) / sizeof(kMfmaVariants[0]));
+struct MfmaTableInit {
+  MfmaTableInit() {
+    for (auto& v : kMfmaVariants)
+      for (int t = 0; t < v.n; ++t) {
+        v.tiles[t] = v.kinds[t] / 100;
+        v.kinds[t] %= 100;
+      }
+  }
+} g_mfma_table_init;
+
+const MfmaVariant* find_mfma_variant(const gwi_spec& s) {
+  for (int v = 0; v < kNumMfmaVariants; ++v) {
+    const MfmaVariant& m = kMfmaVariants[v];
+    if (m.n != s.n_terms) continue;
+    bool ok = true;
+    for (int t = 0; t < s.n_terms && ok; ++t) {
+      ok = m.kinds[t] == s.terms[t].kind;
+      if (ok && m.tiles[t] > 0) ok = s.terms[t].n_basis <= 16 * m.tiles[t];
+    }
+    if (ok) return &m;
+  }
+  return nullptr;
+}
+
 // First entry whose kind sequence matches; GWI_SAMPLES_PER_LANE=1|2 prefers that unroll where compiled.
 const Variant* find_variant(const gwi_spec& s) {
   int prefer = 0;
@@ -244,6 +300,10 @@ bool load_nccl(const char* path, std::string* err) {
 struct gwi_engine {
   gwi_spec spec;
   const Variant* variant = nullptr;
+  const MfmaVariant* mfma = nullptr;  // batched launches on the matrix cores, when the model qualifies
+  int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
+  size_t mfma_lds_bytes = 0;
+  bool batch_used_mfma = false;       // path of the most recent batched launch
   int device = 0;
   hipStream_t stream = nullptr;
   long long n_ev = 0, n_pe = 0, n_inj = 0;
@@ -500,6 +560,15 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic);
   ScanFn fn = logw ? h->variant->logw : (safe ? h->variant->scan_safe : (batch ? h->variant->scan_batch : h->variant->scan));
   h->scan_is_safe = safe;
+  h->kargs.k_batch = batch ? K : 1;
+  if (batch && !safe && !logw) {
+    h->batch_used_mfma = h->mfma && K >= h->mfma_min_batch;
+    if (h->batch_used_mfma) {  // 16 points per wavefront: the grid's second dimension counts groups of 16
+      launch_timed(h, 0, h->mfma->fn, dim3(grid, (K + kPts - 1) / kPts), dim3(kBlock), h->mfma_lds_bytes, h->kargs, offsetof(KArgs, theta));
+      GWI_HIP(hipGetLastError());
+      return GWI_OK;
+    }
+  }
   // theta is the LAST member of the argument block: only the hyper-parameters in use travel through the BAR
   const size_t used = offsetof(KArgs, theta) + sizeof(double) * (size_t)h->spec.n_theta;
   launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs, used);
@@ -1171,6 +1240,18 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     }
   }
   h->gacc_rep = rep;
+  if (has_spline) {
+    h->mfma = find_mfma_variant(*spec);
+    if (const char* env = std::getenv("GWI_BATCH_MFMA")) {
+      if (std::atoi(env) == 0) h->mfma = nullptr;
+      else h->mfma_min_batch = 1;
+    }
+    if (h->mfma) {
+      const size_t th_pad = (size_t)spec->n_theta | 1, der_pad = (size_t)(spec->n_terms * kMaxDerived) | 1;
+      h->mfma_lds_bytes = sizeof(double) * (kPts * th_pad + kPts * der_pad + (size_t)kPts * spec->n_theta + kWaves * 256);
+      if (h->mfma_lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->mfma->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mfma_lds_bytes);
+    }
+  }
   // ---- launch geometry.  Default: ~2048 scan workgroups (8 per CU).  A step lasts only ~10 us, so a
   // partial second dispatch round (a few workgroups that can only start when the first finishers
   // retire) costs a large fraction of it: when one round of resident workgroups can hold the whole
@@ -1416,6 +1497,11 @@ gwi_status gwi_last_kernel_ms(gwi_handle h, float ms[3]) {
 
 int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
 int64_t gwi_two_pass_repeats(gwi_handle h) { return h ? h->redo_count : 0; }
+const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
+  if (!h || h->host_only) return "none";
+  const bool safe = h->variant && h->variant->scan_safe && h->kargs.deterministic;
+  return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? "mfma" : "taps";
+}
 
 gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
   if (!h || !theta) return GWI_ERR_INVALID;

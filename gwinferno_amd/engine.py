@@ -564,6 +564,10 @@ class NativePopulationLikelihood:
         self._check(self.lib.gwi_selftime(self.handle, N.as_dp(N.f64(theta)), C.byref(opt), int(n_iter), N.as_dp(out)))
         return float(out[0])
 
+    def batch_path(self, k_batch=16):
+        """"mfma" or "taps": the kernel a batched launch of ``k_batch`` points uses (``gwi_batch_path``)."""
+        return self.lib.gwi_batch_path(self.handle, int(k_batch)).decode()
+
     def two_pass_repeats(self):
         """Evaluations this engine had to repeat with the two-pass scan (``gwi_two_pass_repeats``; 0 in ordinary runs)."""
         return int(self.lib.gwi_two_pass_repeats(self.handle))

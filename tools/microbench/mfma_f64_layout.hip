@@ -3,7 +3,7 @@
 // The batched spline-gradient GEMM of gwi_device.h (scan_mfma_kernel) relies on:
 //   A (16 x 4):  lane l holds A[i = l % 16][k = l / 16]
 //   B (4 x 16):  lane l holds B[k = l / 16][j = l % 16]
-//   D (16 x 16): lane l, register r holds D[i = 4 * (l / 16) + r][j = l % 16]
+//   D (16 x 16): lane l, register r holds D[i = l / 16 + 4 * r][j = l % 16]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -38,10 +38,11 @@ __global__ void rate(double* out, int n) {
 
 int main() {
   std::vector<double> A(64), B(64), D(256);
+  // D[i][j] = 100 (j + 1) + (i + 1): every element identifies itself
   for (int i = 0; i < 16; ++i)
-    for (int k = 0; k < 4; ++k) A[i * 4 + k] = 1.0 + i + 100.0 * k;  // distinct values
+    for (int k = 0; k < 4; ++k) A[i * 4 + k] = k == 0 ? 1.0 : (k == 1 ? 1.0 + i : 0.0);
   for (int k = 0; k < 4; ++k)
-    for (int j = 0; j < 16; ++j) B[k * 16 + j] = (k == 0 ? 1.0 : 0.0) * (1.0 + 0.001 * j) + (k == 1 ? 7.0 : 0.0);
+    for (int j = 0; j < 16; ++j) B[k * 16 + j] = k == 0 ? 100.0 * (j + 1) : (k == 1 ? 1.0 : 0.0);
   double *dA, *dB, *dD;
   hipMalloc(&dA, 64 * 8), hipMalloc(&dB, 64 * 8), hipMalloc(&dD, 256 * 8);
   hipMemcpy(dA, A.data(), 64 * 8, hipMemcpyHostToDevice), hipMemcpy(dB, B.data(), 64 * 8, hipMemcpyHostToDevice);
@@ -50,12 +51,17 @@ int main() {
   int bad = 0;
   for (int l = 0; l < 64; ++l)
     for (int r = 0; r < 4; ++r) {
-      const int i = 4 * (l / 16) + r, j = l % 16;
+      const int i = l / 16 + 4 * r, j = l % 16;
       double want = 0;
       for (int k = 0; k < 4; ++k) want += A[i * 4 + k] * B[k * 16 + j];
       if (D[l * 4 + r] != want) ++bad;
     }
-  std::printf("layout D[i = 4 (l / 16) + r][j = l %% 16]: %s (%d mismatches)\n", bad ? "NO" : "confirmed", bad);
+  std::printf("layout A[i = l %% 16][k = l / 16], B[k = l / 16][j = l %% 16], D[i = l / 16 + 4 r][j = l %% 16]: %s (%d mismatches)\n", bad ? "NO" : "confirmed", bad);
+  for (int l = 0; l < 64; l += 5)
+    for (int r = 0; r < 4; ++r) {
+      const int v = (int)D[l * 4 + r];
+      std::printf("lane %2d reg %d holds D[i = %2d][j = %2d]\n", l, r, v % 100 - 1, v / 100 - 1);
+    }
   // issue rate: 4 independent accumulators per wave, 1 and 4 waves per SIMD
   double* out;
   hipMalloc(&out, ((1 << 20) + 8) * 8);
