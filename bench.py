@@ -548,6 +548,23 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
+            # the same batch on the matrix cores where the model has an MFMA instantiation (spline models; opt-in path)
+            os.environ["GWI_BATCH_MFMA"] = "1"
+            try:
+                alt = COMPOSITIONS[comp_name](pe, inj).engine(device=dev)
+                if alt.batch_path(K) == "mfma":
+                    vgm = alt.configure_batch(K, total, min_neff_cut=False)
+                    for _ in range(10):
+                        vgm(tb)
+                    t0 = time.perf_counter()
+                    for _ in range(n_b):
+                        vgm(tb)
+                    dtm = time.perf_counter() - t0
+                    out["batched_mfma"] = {"k_batch": K, "evals_per_s": n_b * K / dtm, "us_per_eval": 1e6 * dtm / (n_b * K), "launch_sets": n_b, "path": "mfma",
+                                           "what": "spline-coefficient gradient as v_mfma_f64_16x16x4 GEMM, 16 points per wavefront (gwi_mfma.h)"}
+                alt.close()
+            finally:
+                del os.environ["GWI_BATCH_MFMA"]
         if dist is None and headline and chains > 1:
             out.update(multi_chain(eng, comp_name, pe, inj, total, thetas, chains, steps, dev))
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks

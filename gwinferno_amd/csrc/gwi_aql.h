@@ -103,7 +103,7 @@ struct Device {
 struct Queue {
   Device* dev = nullptr;
   SharedQueue* sq = nullptr;
-  char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable
+  char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable; followed by kExtraBytes of host-writable device memory for the engine (theta blocks of batched launches)
   unsigned next_slot = 0;
   hsa_signal_t done[3] = {{0}, {0}, {0}};  // completion signals of the scan / combine / final packets of a TIMED evaluation
   bool have_signals = false;
@@ -111,6 +111,8 @@ struct Queue {
   const std::string& why() const { return sq->why; }
 };
 constexpr unsigned kSlots = 16, kSlotBytes = 4096;
+constexpr size_t kExtraBytes = 256 * 1024;
+inline char* extra_area(const Queue& q) { return q.kernarg ? q.kernarg + (size_t)kSlots * kSlotBytes : nullptr; }
 
 inline Api& api() {
   static Api a;
@@ -344,7 +346,7 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
     if (d->queues.empty()) return false;
     out.sq = d->queues[d->next_engine++ % d->queues.size()];
   }
-  hsa_status_t st = a.pool_allocate(d->pool, (size_t)kSlots * kSlotBytes, 0, reinterpret_cast<void**>(&out.kernarg));
+  hsa_status_t st = a.pool_allocate(d->pool, (size_t)kSlots * kSlotBytes + kExtraBytes, 0, reinterpret_cast<void**>(&out.kernarg));
   if (st == HSA_STATUS_SUCCESS) st = a.allow_access(1, &d->cpu, nullptr, out.kernarg);  // needs a host window into device memory (large BAR)
   if (st != HSA_STATUS_SUCCESS) {
     why = "kernel-argument ring in device memory: " + status_text(st);
@@ -353,7 +355,7 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
     out.sq = nullptr;
     return false;
   }
-  std::memset(out.kernarg, 0, (size_t)kSlots * kSlotBytes);
+  std::memset(out.kernarg, 0, (size_t)kSlots * kSlotBytes + kExtraBytes);
   out.have_signals = true;
   for (auto& sg : out.done)
     if (a.signal_create(1, 0, nullptr, &sg) != HSA_STATUS_SUCCESS) out.have_signals = false;
@@ -430,6 +432,12 @@ inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_by
   return ka;
 }
 
+// hand over bytes the caller wrote itself into host-writable device memory (the extra area): drain + read back the last byte
+inline void handoff(const char* last_byte_written) {
+  _mm_sfence();
+  if (readback_enabled()) (void)*reinterpret_cast<const volatile unsigned char*>(last_byte_written);
+}
+
 // steps 3-4 for an argument block that is already in place (stage_args)
 inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
                             hsa_signal_t completion = hsa_signal_t{0}) {
@@ -458,7 +466,7 @@ inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x
 
 // the rotating slots hold per-evaluation argument blocks; the last kPersistentSlots are written once (gwi_create) for
 // launches whose arguments never change -- those dispatches need no per-evaluation hand-off at all
-constexpr unsigned kPersistentSlots = 2;
+constexpr unsigned kPersistentSlots = 4;
 inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
                      hsa_signal_t completion = hsa_signal_t{0}) {
   if (arg_bytes > k.kernarg_bytes + 0u) return false;

@@ -68,6 +68,7 @@ struct TailArgs {
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   int n_norms, record_len;
+  int publish_events, pad_;  // device-final mode: also store the per-event sites to pinned host memory (3 small PCIe writes per event)
   double n_pe;
 };
 
@@ -998,7 +999,8 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wav
 //      into runs of <= tiles_per_inj_group.  Latency is everything here (a few KB per group), so there
 //      is NO workgroup barrier: tiles run across the lanes of a wave, record values across the
 //      waves; every wave derives the group's exponent and S1 itself (DPP reductions, fixed order).
-//      One workgroup of kBlock threads per group (e = group, kb = hyper-parameter point).
+//      One workgroup per group (e = group, kb = hyper-parameter point): 64 threads (one wave) when the gradient has at most
+//      60 slots, else kBlock -- a wave per group is all the parametric models need, and a batched launch runs K x groups of them.
 __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, const int kb, const int tid) {
   const int lane = tid & 63;
   const bool is_inj = e >= a.n_ev;
@@ -1048,7 +1050,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   const double inv_s1 = S1 > 0.0 ? 1.0 / S1 : 0.0;
   // phase 2: threads <- gradient slots (coalesced across p), tiles in order with f_t broadcast from
   // its lane: no cross-lane reduction, no barrier, fixed summation order
-  for (int p = tid; p < a.n_theta; p += kBlock) {
+  for (int p = tid; p < a.n_theta; p += (int)blockDim.x) {
     double acc = 0.0;
     const double* col = rec + kRecHeader + p;
     int t = 0;
@@ -1098,16 +1100,18 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
         o[1] = log_neff;
         o[2] = var;
         o[3] = S1;
-        store_sys(ev_host + e, log_s1 + M);
-        store_sys(ev_host + a.n_ev + e, log_neff);
-        store_sys(ev_host + 2 * a.n_ev + e, var);
+        if (a.publish_events) {
+          store_sys(ev_host + e, log_s1 + M);
+          store_sys(ev_host + a.n_ev + e, log_neff);
+          store_sys(ev_host + 2 * a.n_ev + e, var);
+        }
       }
     }
   }
   if (host_rows) {  // the whole row leaves in one coalesced sweep, then the stamp
     __syncthreads();
     double* o = host_rows + (long long)e * (4 + a.n_theta);
-    for (int i = tid + 1; i < 4 + a.n_theta; i += kBlock) store_sys(o + i, s_row[i]);
+    for (int i = tid + 1; i < 4 + a.n_theta; i += (int)blockDim.x) store_sys(o + i, s_row[i]);
     publish_stamp(o, *a.seq_ptr, tid);
   }
 }

@@ -304,6 +304,7 @@ struct gwi_engine {
   int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
   size_t mfma_lds_bytes = 0;
   bool batch_used_mfma = false;       // path of the most recent batched launch
+  bool batch_events = true;           // gwi_eval_batch: the caller wants the per-event sites
   int device = 0;
   hipStream_t stream = nullptr;
   long long n_ev = 0, n_pe = 0, n_inj = 0;
@@ -358,7 +359,11 @@ struct gwi_engine {
   std::string err;
   // the engine's own AQL queue (gwi_aql.h): plain single-point evaluations are dispatched through it
   aql::Queue aq;
-  aql::Kernel aq_scan, aq_scan_safe, aq_combine, aq_final;
+  aql::Kernel aq_scan, aq_scan_safe, aq_scan_batch, aq_combine, aq_final;
+  bool aql_batch = false;          // batched launches (4-tap kernel) can go through the AQL queue too
+  char* aq_tail_batch[2] = {nullptr, nullptr};  // persistent TailArgs of batched launches: [publish_events]
+  bool scan_is_batch = false;
+  int aql_tail_variant = 0;        // 0: single evaluation, 1 / 2: batched without / with the per-event sites
   bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
   bool aql_active = false;  // queue, argument ring and the three kernels are ready
   char* aq_tail_args = nullptr;  // persistent kernel-argument slot holding this engine's (constant) TailArgs
@@ -537,10 +542,11 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
 template <typename F, typename A>
 void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args, size_t used_bytes = sizeof(A)) {
   if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
-    const aql::Kernel& k = slot == 0 ? (h->scan_is_safe ? h->aq_scan_safe : h->aq_scan) : (slot == 1 ? h->aq_combine : h->aq_final);
+    const aql::Kernel& k = slot == 0 ? (h->scan_is_safe ? h->aq_scan_safe : (h->scan_is_batch ? h->aq_scan_batch : h->aq_scan)) : (slot == 1 ? h->aq_combine : h->aq_final);
     const hsa_signal_t done = h->timing ? h->aq.done[slot] : hsa_signal_t{0};
     if (slot > 0 && h->aq_tail_args) {  // constant arguments, staged once at gwi_create
-      if (aql::dispatch_staged(h->aq, k, h->aq_tail_args, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
+      char* staged = h->aql_tail_variant == 0 ? h->aq_tail_args : h->aq_tail_batch[h->aql_tail_variant - 1];
+      if (aql::dispatch_staged(h->aq, k, staged, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
       return;
     }
     if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
@@ -629,6 +635,7 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.n_norms = h->spec.n_norms;
   ta.record_len = record_len(h);
   ta.n_pe = (double)h->n_pe;
+  ta.publish_events = 1;
   return ta;
 }
 
@@ -642,7 +649,12 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
   // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
   // (batched theta uploads, the sharded path's exchange behind record_dev) stays on the stream, and so does everything
   // after gwi_set_timing(h, 2)
-  h->aql_now = h->aql_active && !h->aq.failed() && !h->force_hip_stream && !batch && K == 1 && record_dev == nullptr;
+  // batched launches of the 4-tap kernel follow once their theta blocks can be written through the BAR (K >= 4: the
+  // device-final form whose tail arguments are staged)
+  const bool batch_on_aql = batch && K >= 4 && h->aql_batch && !h->kargs.two_pass && !h->kargs.deterministic && !(h->mfma && K >= h->mfma_min_batch);
+  h->aql_now = h->aql_active && !h->aq.failed() && !h->force_hip_stream && record_dev == nullptr && ((!batch && K == 1) || batch_on_aql);
+  h->scan_is_batch = batch;
+  h->aql_tail_variant = batch_on_aql ? (h->batch_events ? 2 : 1) : 0;
   if (h->aql_now && h->timing && !aql::timed_prepare(h->aq)) h->aql_now = false;  // no dispatch timestamps: time this one with HIP events
   if ((int)h->host_consts.size() < K) h->host_consts.resize(K);
   if (!batch) {
@@ -650,23 +662,42 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
     h->kargs.tblocks = nullptr;
   } else {
     for (int k = 0; k < K; ++k) prelude(h, theta + (size_t)k * n_theta, h->h_tblocks[k].theta, h->h_tblocks[k].derived, &h->host_consts[k]);
-    if (h->stage_kernel && K >= 10) {  // below ~20 KiB the runtime's small-copy path is quicker than a launch
+    if (h->aql_now) {
+      // theta blocks straight into device memory through the BAR (only the parts in use: a few hundred bytes per point),
+      // one hand-off for all of them; the scan packet that reads them is published afterwards
+      ThetaBlock* dev = reinterpret_cast<ThetaBlock*>(aql::extra_area(h->aq));
+      const size_t th_bytes = sizeof(double) * (size_t)n_theta, der_bytes = sizeof(double) * kMaxDerived * (size_t)h->spec.n_terms;
+      for (int k = 0; k < K; ++k) {
+        std::memcpy(dev[k].theta, h->h_tblocks[k].theta, th_bytes);
+        std::memcpy(dev[k].derived, h->h_tblocks[k].derived, der_bytes);
+      }
+      aql::handoff(reinterpret_cast<const char*>(dev[K - 1].derived) + der_bytes - 1);
+      h->kargs.tblocks = dev;
+    } else if (h->stage_kernel && K >= 10) {  // below ~20 KiB the runtime's small-copy path is quicker than a launch
       hipLaunchKernelGGL(stage_theta_kernel, dim3(K), dim3(kBlock), 0, h->stream, (const ThetaBlock*)h->h_tblocks_dev, h->d_tblocks);
       GWI_HIP(hipGetLastError());
     } else {
       GWI_HIP(hipMemcpyAsync(h->d_tblocks, h->h_tblocks, sizeof(ThetaBlock) * K, hipMemcpyHostToDevice, h->stream));
     }
-    h->kargs.tblocks = h->d_tblocks;
+    if (!h->aql_now) h->kargs.tblocks = h->d_tblocks;
   }
   const unsigned gy = batch ? (unsigned)K : 1u;
-  const TailArgs ta = tail_args(h, record_dev);
+  TailArgs ta = tail_args(h, record_dev);
+  if (batch && K >= 4) {
+    // Many points per launch: sum over groups on the DEVICE whatever the problem size.  Host-final mode publishes one row
+    // per (group, point) -- K x (N_ev + injection groups) rows of two small posted PCIe writes each, which is what a
+    // 16-point batch of config 2 spent a quarter of its time on (1216 rows) -- against one record per point here; the
+    // per-event sites travel (three more small writes per event and point) only when the caller asked for them.
+    ta.host_rows = nullptr;
+    ta.publish_events = h->batch_events ? 1 : 0;
+  }
   h->last_host_rows = ta.host_rows != nullptr;
   h->kargs.norm_seq = h->seq + 1;  // the normaliser workgroups of this launch stamp their results with it
   GWI_PHASE(0);
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
   GWI_PHASE(1);
-  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(kBlock), 0, ta);
+  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(n_theta + 4 <= 64 ? 64 : kBlock), 0, ta);
   GWI_HIP(hipGetLastError());
   ++h->seq;
   h->timed_final = false;
@@ -1099,7 +1130,18 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
     h->aql_note = "kernel argument sizes of the code object differ from this build (stale gwi_kernels.hsaco?)";
     return;
   }
+  const bool have_batch_kernel = aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->scan_batch), h->stream), h->aq_scan_batch, h->aql_note);
   if (!aql::open_queue(dev, h->aq, h->aql_note)) return;
+  if (have_batch_kernel && sizeof(ThetaBlock) * (size_t)h->max_batch <= aql::kExtraBytes) {
+    for (int ev = 0; ev < 2; ++ev) {
+      TailArgs tb = tail_args(h, nullptr);
+      tb.host_rows = nullptr;
+      tb.publish_events = ev;
+      h->aq_tail_batch[ev] = aql::stage_args(h->aq, aql::kSlots - 2 - ev, &tb, sizeof(tb));
+    }
+    h->aql_batch = h->aq_tail_batch[0] && h->aq_tail_batch[1];
+    if (const char* env = std::getenv("GWI_AQL_BATCH")) h->aql_batch = h->aql_batch && std::atoi(env) != 0;
+  }
   {
     const TailArgs ta = tail_args(h, nullptr);  // the AQL path never publishes to a device record (that is the RCCL exchange, on the HIP stream)
     h->aq_tail_args = aql::stage_args(h->aq, aql::kSlots - 1, &ta, sizeof(ta));
@@ -1241,10 +1283,13 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   }
   h->gacc_rep = rep;
   if (has_spline) {
-    h->mfma = find_mfma_variant(*spec);
+    // Opt-in (GWI_BATCH_MFMA=1; =2: for every batch size, not only >= 9 points): measured against the 4-tap batched kernel
+    // on the BASELINE catalogs at K = 16 it loses (config 5: 57.0 vs 44.6 us per evaluation, config 3: 14.6 vs 11.6) --
+    // the 16 point-lanes of a sample repeat its knot lookup and taps, and forming the A operand costs more vector
+    // instructions than the four atomics it replaces now that those are conflict-free.
     if (const char* env = std::getenv("GWI_BATCH_MFMA")) {
-      if (std::atoi(env) == 0) h->mfma = nullptr;
-      else h->mfma_min_batch = 1;
+      if (std::atoi(env) >= 1) h->mfma = find_mfma_variant(*spec);
+      if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
     if (h->mfma) {
       const size_t th_pad = (size_t)spec->n_theta | 1, der_pad = (size_t)(spec->n_terms * kMaxDerived) | 1;
@@ -1610,6 +1655,7 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
   GWI_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
   const bool need_sq = opt->marginalize_selection && grads;
+  h->batch_events = log_bfs || log_neffs || variances;
   if (need_sq) {
     st = run_pipeline(h, thetas, nullptr, true, k_batch, true, /*square=*/true);
     if (st != GWI_OK) return st;

@@ -234,10 +234,10 @@ gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double
 gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries,
                           double* grads, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
-/* Which kernel a batched launch of k_batch points would use: "mfma" (models with spline terms whose term sequence and
- * basis counts have a matrix-core instantiation, k_batch >= 9: the spline-coefficient gradient as a v_mfma_f64_16x16x4
- * GEMM over 16 points per wavefront, gwinferno_amd/csrc/gwi_mfma.h) or "taps" (one grid row per point, 4-tap gradient).
- * GWI_BATCH_MFMA=0 / 1 forces the choice where both exist. */
+/* Which kernel a batched launch of k_batch points would use: "taps" (one grid row per point, 4-tap gradient into LDS rows;
+ * the default) or "mfma" (GWI_BATCH_MFMA=1 at gwi_create, models with spline terms whose term sequence and basis counts
+ * have a matrix-core instantiation, k_batch >= 9: the spline-coefficient gradient as a v_mfma_f64_16x16x4 GEMM over 16
+ * points per wavefront, gwinferno_amd/csrc/gwi_mfma.h).  Both are kept because both are measured: see DESIGN.md. */
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
 
 /* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the

@@ -368,6 +368,7 @@ def test_batched_launch_on_the_matrix_cores(comp_name, monkeypatch):
     from oracle.c_oracle import COracle
 
     monkeypatch.setenv("GWI_MAX_BATCH", "40")
+    monkeypatch.setenv("GWI_BATCH_MFMA", "1")
     pe, inj, total = make_catalog(11, 700, 5003, seed=41)
     rng = np.random.default_rng(6)
     comp = COMPOSITIONS[comp_name](pe, inj)
@@ -396,8 +397,8 @@ def test_batched_launch_on_the_matrix_cores(comp_name, monkeypatch):
                 scale = max(1.0, float(np.max(np.abs(r["grad"]))))
                 assert float(np.max(np.abs(b.grad - r["grad"]))) / scale < 1e-8
     eng.close()
-    # the same batch through the 4-tap kernel
-    monkeypatch.setenv("GWI_BATCH_MFMA", "0")
+    # the same batch through the 4-tap kernel (the default)
+    monkeypatch.delenv("GWI_BATCH_MFMA")
     eng2 = COMPOSITIONS[comp_name](pe, inj).engine()
     assert eng2.batch_path(16) == "taps"
     taps = eng2.evaluate_batch(thetas[:16], total, min_neff_cut=False)

@@ -1,20 +1,40 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root:  bash tools/profile_round.sh [configs...]
-# Produces, under gpurun_out/prof/<config>/{trace,fetch,write}, the rocprofv3 kernel-trace stats
-# and the two PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC slots,
-# /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots").  Counter passes use only --pmc.
-# tools/summarize_profiles.py turns the CSVs into the files committed under profiles/.
+# Produces, under gpurun_out/prof/<config>/{trace,fetch,write,sq_a,sq_b,lds}, the rocprofv3 kernel-trace stats and the
+# PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC slots, /opt/skills/guides/MI355X_MICROARCH.md
+# "rocprofv3 PMC slots"), and under gpurun_out/prof/batch_<config>_{taps,mfma}/ the same for the batched kernels
+# (K = 16 points per launch; 4-tap gradient vs the v_mfma_f64_16x16x4 gradient GEMM).  Counter passes use only --pmc;
+# the profiled program comes directly after `--`.  tools/summarize_profiles.py turns the CSVs into profiles/<round>/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CONFIGS=${@:-c2 c3 c5}
 cd /tmp && export TMPDIR=/tmp
+B="--no-cpu-baseline --k-batch 0 --chains 0 --also none --spin 0.2"
 for c in $CONFIGS; do
   out=$R/gpurun_out/prof/$c
   mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --config $c --steps 400 --warmup 50 --no-cpu-baseline --k-batch 0 --chains 0 > $out/bench_under_trace.json 2> /dev/null
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --chains 0 --timing-every 0 > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --chains 0 --timing-every 0 > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS --output-format csv -d $out/sq_a -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --chains 0 --timing-every 0 > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $out/sq_b -- python3 $R/bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline --k-batch 0 --chains 0 --timing-every 0 > /dev/null 2>&1
-  python3 $R/bench.py --config $c --steps 2000 --warmup 200 > $out/bench.json 2> /dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --config $c --steps 200 --warmup 20 $B > $out/bench_under_trace.json 2> /dev/null
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS --output-format csv -d $out/sq_a -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $out/sq_b -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $out/lds -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
+  python3 $R/bench.py --config $c --steps 2000 --warmup 200 --also none > $out/bench.json 2> /dev/null
 done
+for c in c3 c5; do
+  for path in taps mfma; do
+    out=$R/gpurun_out/prof/batch_${c}_$path
+    mkdir -p $out
+    flag=""; [ $path = mfma ] && flag="--mfma"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/batch_run.py --config $c --k 16 --n 40 $flag > $out/run_under_trace.json 2> /dev/null
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d $out/mfma -- python3 $R/tools/batch_run.py --config $c --k 16 --n 10 $flag > /dev/null 2>&1
+    python3 $R/tools/batch_run.py --config $c --k 16 --n 100 $flag > $out/run.json 2> /dev/null
+  done
+done
+# the driver's own command, for the record
+cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_form.json 2> /dev/null
+# summarise on the box (the raw traces exceed what gpurun carries back) and keep only the summary
+python3 tools/summarize_profiles.py ${ROUND:-round2} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
+cp gpurun_out/prof/bench_driver_form.json gpurun_out/profile_summary/ 2>/dev/null
+rm -rf $R/gpurun_out/prof
+ls -la $R/gpurun_out/profile_summary

@@ -26,13 +26,13 @@ def mean_counter(path_glob, kernel_substr, counter):
     return sum(vals) / len(vals) if vals else None
 
 
-def main(round_name):
+def main(round_name, dst=None):
     src = os.path.join(ROOT, "gpurun_out", "prof")
-    dst = os.path.join(ROOT, "profiles", round_name)
+    dst = dst or os.path.join(ROOT, "profiles", round_name)
     os.makedirs(dst, exist_ok=True)
     traffic = {}
     lines = ["| config | kernel | calls | avg us (rocprofv3) | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes/launch (2*F+W)*1024 |", "|---|---|---|---|---|---|---|"]
-    for cfg in sorted(os.listdir(src)):
+    for cfg in sorted(c for c in os.listdir(src) if not c.startswith("batch_")):
         stats = glob.glob(os.path.join(src, cfg, "trace", "*", "*_kernel_stats.csv"))
         if not stats:
             continue
@@ -55,7 +55,7 @@ def main(round_name):
                 traffic[cfg] = {"scan_avg_us_rocprof": float(r["AverageNs"]) / 1e3, "fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_per_launch": hbm}
     # ---- SQ counters of the scan kernel: instruction mix, fp64 rate, where wave time goes
     sq_lines = ["| config | waves | VALU/wave | SALU/wave | LDS/wave | fp64 GFLOP per launch | fp64 TFLOP/s (of 78.6 peak) | wave time waiting (s_waitcnt/barrier) | issuing | LDS bank-conflict share |", "|---|---|---|---|---|---|---|---|---|---|"]
-    for cfg in sorted(os.listdir(src)):
+    for cfg in sorted(c for c in os.listdir(src) if not c.startswith("batch_")):
         def c(name, part):
             return mean_counter(os.path.join(src, cfg, part, "*", "*_counter_collection.csv"), "scan_kernel", name)
         w = c("SQ_WAVES", "sq_a")
@@ -68,7 +68,56 @@ def main(round_name):
         wc, wa, ai = c("SQ_WAVE_CYCLES", "sq_b"), c("SQ_WAIT_ANY", "sq_b"), c("SQ_ACTIVE_INST_ANY", "sq_b")
         bc, ia = c("SQ_LDS_BANK_CONFLICT", "sq_b"), c("SQ_LDS_IDX_ACTIVE", "sq_b")
         traffic[cfg].update(fp64_flop_per_launch=flop, fp64_tflops=flop / (t_us * 1e-6) / 1e12)
+        if any(ln.startswith(f"| {cfg} |") for ln in sq_lines):
+            continue
         sq_lines.append(f"| {cfg} | {w:.0f} | {valu / w:.0f} | {salu / w:.0f} | {lds / w:.0f} | {flop / 1e9:.2f} | {flop / (t_us * 1e-6) / 1e12:.2f} | {wa / wc:.0%} | {ai / wc:.0%} | {(bc / ia if ia else 0):.0%} |")
+    # ---- LDS pipe of the scan kernel (spline-gradient atomics): address / bank conflicts and time waiting on LDS
+    lds_lines = ["| config | SQ_LDS_ADDR_CONFLICT / SQ_LDS_IDX_ACTIVE | SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE | SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES | SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES |", "|---|---|---|---|---|"]
+    for cfg in sorted(c for c in os.listdir(src) if not c.startswith("batch_")):
+        def c(name):
+            return mean_counter(os.path.join(src, cfg, "lds", "*", "*_counter_collection.csv"), "scan_kernel", name)
+        ia, wc = c("SQ_LDS_IDX_ACTIVE"), c("SQ_WAVE_CYCLES")
+        if not ia or not wc:
+            continue
+        ac, bc, wl, al = c("SQ_LDS_ADDR_CONFLICT") or 0.0, c("SQ_LDS_BANK_CONFLICT") or 0.0, c("SQ_WAIT_INST_LDS") or 0.0, c("SQ_ACTIVE_INST_LDS") or 0.0
+        lds_lines.append(f"| {cfg} | {ac / ia:.1%} | {bc / ia:.1%} | {wl / wc:.1%} | {al / wc:.1%} |")
+        if cfg in traffic:
+            traffic[cfg].update(lds_addr_conflict_share=ac / ia, lds_bank_conflict_share=bc / ia, wait_inst_lds_share=wl / wc)
+    # ---- batched kernels (K = 16 points per launch): 4-tap gradient vs the MFMA gradient GEMM
+    b_lines = ["| config | path | kernel | calls | avg us (rocprofv3) | us per evaluation (untraced loop) | MFMA instr / launch | fp64 MFMA GFLOP / launch | MFMA TFLOP/s | of the 78.6 TFLOP/s matrix peak | SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES |",
+               "|---|---|---|---|---|---|---|---|---|---|---|"]
+    batched = {}
+    for name in sorted(c for c in os.listdir(src) if c.startswith("batch_")):
+        _, cfg, path = name.split("_")
+        stats = glob.glob(os.path.join(src, name, "trace", "*", "*_kernel_stats.csv"))
+        if not stats:
+            continue
+        shutil.copy(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+        run = {}
+        try:
+            run = json.loads(open(os.path.join(src, name, "run.json")).read().strip().splitlines()[-1])
+        except Exception:
+            pass
+        for r in csv.DictReader(open(stats[0])):
+            if "gwi::scan_" not in r["Name"]:
+                continue
+            short = r["Name"].split("(")[0].replace("void ", "")
+            key = "scan_mfma_kernel" if "scan_mfma_kernel" in short else "scan_kernel"
+            def c(cn):
+                return mean_counter(os.path.join(src, name, "mfma", "*", "*_counter_collection.csv"), key, cn)
+            n_mfma, mops = c("SQ_INSTS_MFMA"), c("SQ_INSTS_VALU_MFMA_MOPS_F64")
+            busy, tot = c("SQ_VALU_MFMA_BUSY_CYCLES"), c("SQ_BUSY_CYCLES")
+            t_us = float(r["AverageNs"]) / 1e3
+            flop = 2048.0 * n_mfma if n_mfma else 0.0  # v_mfma_f64_16x16x4: 16 x 16 x 4 x 2 flop per wave instruction
+            tf = flop / (t_us * 1e-6) / 1e12 if flop else 0.0
+            b_lines.append(f"| {cfg} | {path} | {short[:60]} | {r['Calls']} | {t_us:.1f} | {run.get('us_per_eval', float('nan')):.2f} | {n_mfma or 0:.0f} | {flop / 1e9:.2f} | {tf:.2f} | {tf / 78.6:.1%} | "
+                           f"{(busy / tot if busy and tot else 0):.1%} |")
+            batched[f"{cfg}_{path}"] = {"scan_avg_us_rocprof": t_us, "us_per_eval": run.get("us_per_eval"), "mfma_instructions_per_launch": n_mfma, "mfma_mops_f64_counter": mops,
+                                        "mfma_tflops": tf, "mfma_utilisation_of_78.6": tf / 78.6, "mfma_busy_share": (busy / tot if busy and tot else None)}
+    if batched:
+        traffic["batched_k16"] = batched
+    lines += ["", "LDS pipe of the scan kernel (`--pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES`):", ""] + lds_lines
+    lines += ["", "Batched launches, K = 16 hyper-parameter points (tools/batch_run.py; `--mfma` = GWI_BATCH_MFMA=1, gwi_mfma.h). MFMA FLOP = 2048 x SQ_INSTS_MFMA:", ""] + b_lines
     lines += ["", "Scan-kernel SQ counters (separate `--pmc` passes; fp64 FLOP = 64 x (ADD + MUL + 2 FMA + TRANS) wave-instructions):", ""] + sq_lines
     with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
         fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  The traced launches are AQL dispatches from the engine's own queues (gwinferno_amd/csrc/gwi_aql.h); `<config>_bench.json` holds the untraced run of the same command, whose live kernel durations come from the same dispatch timestamps.\n\n")
@@ -79,4 +128,4 @@ def main(round_name):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "round1")
+    main(sys.argv[1] if len(sys.argv) > 1 else "round1", sys.argv[2] if len(sys.argv) > 2 else None)
