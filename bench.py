@@ -439,7 +439,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
     # ---- N > 1, secondary figures: (a) one independent chain per GPU over the WHOLE catalog (numpyro
     # chain_method="parallel"): no exchange, per-GPU work fixed (weak scaling); (b) the same sharded evaluation with the
     # in-engine ncclAllGather instead of the shared-memory exchange
-    replicas, rccl_variant = None, None
+    replicas = None
     if dist is not None:
         rep = COMPOSITIONS[comp_name](pe, inj)
         eng_rep = rep.engine(device=dev)
@@ -452,27 +452,6 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
         tr = run.max_over_ranks(time.perf_counter() - t0r)
         replicas = {"evals_per_s": world * n_rep / tr, "scaling": "weak", "what": "one independent chain per GPU over the whole catalog, no exchange"}
         eng_rep.close()
-        if exchange.startswith("host shared-memory") and run.backend == "nccl" and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0":
-            alt = COMPOSITIONS[comp_name](pe, inj)
-            eng_alt = alt.engine(device=dev, rank=rank, world=world)
-            try:
-                init_engine_communicator(eng_alt)
-                ok = True
-            except Exception as exc:
-                print(f"[rank {rank}] in-engine RCCL communicator unavailable ({exc})", file=sys.stderr)
-                ok = False
-            if run.all_agree(ok):
-                n_alt = max(200, steps // 2)
-                blk = np.stack([thetas[i % len(thetas)] for i in range(n_alt)])
-                eng_alt.evaluate_sequence(blk[:50], total, min_neff_cut=False)
-                run.fence()
-                t0a = time.perf_counter()
-                ll_alt, _ = eng_alt.evaluate_sequence(blk, total, min_neff_cut=False)
-                run.fence()
-                ta = run.max_over_ranks(time.perf_counter() - t0a)
-                rccl_variant = {"evals_per_s": n_alt / ta, "ms_per_step": 1e3 * ta / n_alt, "rccl_ranks": world,
-                                "what": "same sharded evaluation, records exchanged by one ncclAllGather on the engine's stream"}
-            eng_alt.close()
 
     out = None
     if rank == 0:
@@ -531,7 +510,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
         if dist is not None:
             out["multi_gpu"] = {"ranks": world, "rccl_ranks": world if run.backend == "nccl" else 0, "rendezvous_backend": run.backend, "exchange": exchange,
                                 "devices_shared_between_ranks": run.shared_devices, "per_rank": per_rank, "sharded_vs_single_gpu": sharded_check,
-                                "independent_chains": replicas, "rccl_allgather_variant": rccl_variant}
+                                "independent_chains": replicas}
         else:
             out["c_loop_us_per_eval"] = 1e6 * eng.selftime(thetas[0], total, n_iter=min(max(steps, 200), 2000), min_neff_cut=False)
         if dist is None and k_batch > 1:
@@ -638,6 +617,64 @@ def multi_chain(eng, comp_name, pe, inj, total, thetas, C, steps, dev):
     return out
 
 
+def rccl_variant(run, cfg, steps, out):
+    """N > 1 on one GPU per rank, last thing before the line is printed: the same sharded evaluation with the records
+    exchanged by ONE ncclAllGather (RCCL over xGMI) on the engine's own stream instead of the host shared-memory segment.
+    The in-engine communicator has never run across several GPUs in the build environment (1-GPU boxes), so it runs under
+    a watchdog: if it does not come back within the time limit every rank leaves -- rank 0 after printing the line, whose
+    main results are complete by then -- instead of hanging the run."""
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.distributed import init_engine_communicator
+    from gwinferno_amd.synthetic import make_config_catalog
+
+    limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", "90"))
+
+    def bail():
+        if run.rank == 0:
+            out["multi_gpu"]["rccl_allgather_variant"] = {"error": f"did not finish within {limit:.0f} s; abandoned"}
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(limit, bail)
+    dog.daemon = True
+    dog.start()
+    res = None
+    try:
+        comp_name, cat_name, _, _ = CONFIGS[cfg]
+        pe, inj, total = make_config_catalog(cat_name)
+        comp = COMPOSITIONS[comp_name](pe, inj)
+        eng = comp.engine(device=run.local_rank, rank=run.rank, world=run.world)
+        try:
+            init_engine_communicator(eng)
+            ok = True
+        except Exception as exc:
+            print(f"[rank {run.rank}] in-engine RCCL communicator unavailable ({exc})", file=sys.stderr)
+            ok = False
+        if run.all_agree(ok):
+            rng = np.random.default_rng(1234)
+            thetas = [comp.theta(draw_params(comp_name, rng)) for _ in range(64)]
+            n_alt = max(200, steps // 2)
+            blk = np.stack([thetas[i % len(thetas)] for i in range(n_alt)])
+            eng.evaluate_sequence(blk[:50], total, min_neff_cut=False)
+            run.fence()
+            t0 = time.perf_counter()
+            eng.evaluate_sequence(blk, total, min_neff_cut=False)
+            run.fence()
+            ta = run.max_over_ranks(time.perf_counter() - t0)
+            res = {"evals_per_s": n_alt / ta, "ms_per_step": 1e3 * ta / n_alt, "rccl_ranks": run.world,
+                   "what": "same sharded evaluation, records exchanged by one ncclAllGather on the engine's stream"}
+        else:
+            res = {"error": "ncclCommInitRank failed on some rank"}
+        eng.close()
+    finally:
+        dog.cancel()
+    if run.rank == 0:
+        out["multi_gpu"]["rccl_allgather_variant"] = res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -691,6 +728,8 @@ def main():
             out.setdefault(k, v)
         if blocks:
             out["configs"] = blocks
+    if run.dist is not None and run.backend == "nccl" and run.shared_devices is None and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0":
+        rccl_variant(run, args.config, args.steps, out if run.rank == 0 else {"multi_gpu": {}})
     if run.dist is not None:
         run.dist.barrier()
         run.dist.destroy_process_group()

@@ -81,6 +81,7 @@ struct Kernel {
 // engines on one queue take turns -- exactly what HIP streams that share a hardware queue do).
 struct SharedQueue {
   hsa_queue_t* q = nullptr;
+  int users = 0;  // engines currently assigned (under Device::mu)
   volatile bool failed = false;
   bool profiling = false;  // dispatch timestamps are on (set when the queue is created)
   std::string why;
@@ -344,7 +345,12 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
       }
     }
     if (d->queues.empty()) return false;
-    out.sq = d->queues[d->next_engine++ % d->queues.size()];
+    // the queue with the fewest engines on it (engines come and go: plain round robin would double up two live engines
+    // on one queue -- whose barrier bits serialise them -- while another queue sits empty)
+    out.sq = d->queues[0];
+    for (SharedQueue* sq : d->queues)
+      if (sq->users < out.sq->users) out.sq = sq;
+    ++out.sq->users;
   }
   hsa_status_t st = a.pool_allocate(d->pool, (size_t)kSlots * kSlotBytes + kExtraBytes, 0, reinterpret_cast<void**>(&out.kernarg));
   if (st == HSA_STATUS_SUCCESS) st = a.allow_access(1, &d->cpu, nullptr, out.kernarg);  // needs a host window into device memory (large BAR)
@@ -352,6 +358,10 @@ inline bool open_queue(Device* d, Queue& out, std::string& why) {
     why = "kernel-argument ring in device memory: " + status_text(st);
     if (out.kernarg) a.pool_free(out.kernarg);
     out.kernarg = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(d->mu);
+      --out.sq->users;
+    }
     out.sq = nullptr;
     return false;
   }
@@ -392,6 +402,10 @@ inline void close_queue(Queue& q) {
   q.have_signals = false;
   if (q.kernarg) api().pool_free(q.kernarg);
   q.kernarg = nullptr;
+  if (q.sq && q.dev) {
+    std::lock_guard<std::mutex> lock(q.dev->mu);
+    --q.sq->users;
+  }
   q.sq = nullptr;  // the shared queues live as long as the process
 }
 

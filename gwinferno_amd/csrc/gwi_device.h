@@ -68,7 +68,8 @@ struct TailArgs {
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   int n_norms, record_len;
-  int publish_events, pad_;  // device-final mode: also store the per-event sites to pinned host memory (3 small PCIe writes per event)
+  int combine_threads;       // workgroup size of the combine launch (64 or kBlock): passed here, not read from blockDim, which would pull in implicit kernel arguments the AQL packets do not carry
+  int publish_events;        // device-final mode: also store the per-event sites to pinned host memory (3 small PCIe writes per event)
   double n_pe;
 };
 
@@ -1050,7 +1051,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   const double inv_s1 = S1 > 0.0 ? 1.0 / S1 : 0.0;
   // phase 2: threads <- gradient slots (coalesced across p), tiles in order with f_t broadcast from
   // its lane: no cross-lane reduction, no barrier, fixed summation order
-  for (int p = tid; p < a.n_theta; p += (int)blockDim.x) {
+  for (int p = tid; p < a.n_theta; p += a.combine_threads) {
     double acc = 0.0;
     const double* col = rec + kRecHeader + p;
     int t = 0;
@@ -1111,7 +1112,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   if (host_rows) {  // the whole row leaves in one coalesced sweep, then the stamp
     __syncthreads();
     double* o = host_rows + (long long)e * (4 + a.n_theta);
-    for (int i = tid + 1; i < 4 + a.n_theta; i += (int)blockDim.x) store_sys(o + i, s_row[i]);
+    for (int i = tid + 1; i < 4 + a.n_theta; i += a.combine_threads) store_sys(o + i, s_row[i]);
     publish_stamp(o, *a.seq_ptr, tid);
   }
 }

@@ -305,6 +305,7 @@ struct gwi_engine {
   size_t mfma_lds_bytes = 0;
   bool batch_used_mfma = false;       // path of the most recent batched launch
   bool batch_events = true;           // gwi_eval_batch: the caller wants the per-event sites
+  int combine_threads = kBlock;       // workgroup size of the combine launch
   int device = 0;
   hipStream_t stream = nullptr;
   long long n_ev = 0, n_pe = 0, n_inj = 0;
@@ -636,6 +637,7 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.record_len = record_len(h);
   ta.n_pe = (double)h->n_pe;
   ta.publish_events = 1;
+  ta.combine_threads = h->combine_threads;
   return ta;
 }
 
@@ -697,7 +699,7 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
   GWI_PHASE(1);
-  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3(n_theta + 4 <= 64 ? 64 : kBlock), 0, ta);
+  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3((unsigned)ta.combine_threads), 0, ta);
   GWI_HIP(hipGetLastError());
   ++h->seq;
   h->timed_final = false;
@@ -1458,6 +1460,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
     }
   }
+  h->combine_threads = spec->n_theta + 4 <= 64 ? 64 : kBlock;
+  if (const char* env = std::getenv("GWI_COMBINE_THREADS")) h->combine_threads = std::atoi(env) == 64 ? 64 : kBlock;
   setup_aql(h, prop);
   return GWI_OK;
 }

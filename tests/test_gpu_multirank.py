@@ -70,3 +70,17 @@ def test_three_ranks_torch_collective_fallback():
     assert d["n_gpus"] == 3 and d["multi_gpu"]["exchange"].startswith("torch.distributed")
     chk = d["multi_gpu"]["sharded_vs_single_gpu"]
     assert chk["log_likelihood_rel_err"] < 1e-12 and chk["grad_max_err_over_scale"] < 1e-12, chk
+
+
+def test_forced_sharded_world1_runs_the_rccl_variant():
+    """GWI_FORCE_SHARDED=1: one process, one GPU, the N > 1 code path with a nccl (RCCL) process group of one rank --
+    shared-memory exchange for the headline, then the in-engine ncclAllGather variant under its watchdog."""
+    env = dict(os.environ, GWI_FORCE_SHARDED="1", MASTER_PORT=str(29800 + os.getpid() % 90))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--config", "c1", "--spin", "0.05", "--also", "none"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    mg = d["multi_gpu"]
+    assert mg["exchange"].startswith("host shared-memory") and mg["rccl_ranks"] == 1
+    assert mg["rccl_allgather_variant"]["evals_per_s"] > 0 and mg["rccl_allgather_variant"]["rccl_ranks"] == 1
+    assert mg["sharded_vs_single_gpu"]["log_likelihood_rel_err"] < 1e-12
