@@ -13,8 +13,13 @@ where xarray / arviz / h5py are not installed.
 * :func:`dl_2_prior_on_z`, :func:`pe_sampling_prior` -- the per-sample PE prior of
   ``preprocess/data_collection.py:93-132``.
 
-Reading the LVK HDF5 files themselves needs h5py (:func:`read_hdf5_group`, gated on its presence); the cut
-and prior arithmetic does not.
+* :func:`load_pe_and_injections_as_dict` -- the reference's loader of the same name (``pipeline/utils.py:51-96``) for the
+  arviz InferenceData file (NetCDF-4 = HDF5, groups ``pe_data`` / ``inj_data``) that
+  ``preprocess/data_collection.py:203-207`` writes: same arguments, same four return values, read through the HDF5 C library
+  itself (:mod:`gwinferno_amd._hdf5`, ctypes) -- no h5py, xarray or arviz.
+
+Reading the LVK HDF5 injection files goes through the same binding (:func:`read_hdf5_group`, h5py if it happens to be
+installed); the cut and prior arithmetic needs neither.
 """
 import numpy as np
 
@@ -33,14 +38,43 @@ def read_pe_netcdf3(path, n_samples=None):
 
 
 def read_hdf5_group(path, group):
-    """Columns and attributes of one HDF5 group as plain dicts (needs h5py)."""
-    try:
-        import h5py
-    except ImportError as exc:  # pragma: no cover - h5py is absent in the build container
-        raise RuntimeError("reading LVK injection files needs h5py; pass the columns as a mapping instead") from exc
-    with h5py.File(path, "r") as ff:  # pragma: no cover
-        g = ff[group]
-        return {k: g[k][()] for k in g}, dict(g.attrs), dict(ff.attrs)
+    """Columns and attributes of one HDF5 group as plain dicts -- ``(columns, group attributes, file attributes)``, what
+    ``preprocess/selection.py:24-36, :105-118`` reads from the LVK injection files -- through the HDF5 C library
+    (:mod:`gwinferno_amd._hdf5`)."""
+    from . import _hdf5
+
+    with _hdf5.File(path) as f:
+        cols = {k: f[f"{group}/{k}"] for k in f.keys(group) if f.is_dataset(f"{group}/{k}")}
+        return cols, f.attrs(group), f.attrs("/")
+
+
+def load_pe_and_injections_as_dict(file, ignore=None):
+    """``pipeline/utils.py:51-96``: ``(pedict, injdict, constants, param_names)`` from the InferenceData file
+    ``save_posterior_samples_and_injection_datasets_as_idata`` wrote.  ``pedict[param] : (N_ev, N_pe)`` =
+    ``pe_data.posteriors.sel(param=k).values`` (events named in ``ignore`` dropped, :76-81), ``injdict[param] : (N_inj,)`` =
+    ``inj_data.injections.sel(param=k).values``, ``constants = {total_inj, obs_time, nObs}`` from the ``inj_data``
+    attributes ``total_generated`` / ``analysis_time`` and the number of events (:88-92; as in the reference ``nObs``
+    counts the events in the file, ignored ones included)."""
+    from . import _hdf5
+
+    with _hdf5.File(file) as f:
+        post = np.asarray(f["pe_data/posteriors"], dtype=np.float64)  # (event, param, samples)
+        pe_params = [str(p) for p in f["pe_data/param"]]
+        events = np.array([str(e) for e in f["pe_data/event"]]) if f.exists("pe_data/event") else np.arange(post.shape[0]).astype(str)
+        injs = np.asarray(f["inj_data/injections"], dtype=np.float64)  # (param, injection)
+        inj_params = [str(p) for p in f["inj_data/param"]]
+        total_inj = f.attr("inj_data", "total_generated")
+        obs_time = f.attr("inj_data", "analysis_time")
+    if post.ndim != 3 or post.shape[1] != len(pe_params) or injs.ndim != 2 or injs.shape[0] != len(inj_params):
+        raise ValueError(f"{file}: posteriors {post.shape} / injections {injs.shape} do not match their `param` coordinates")
+    sel = np.ones(post.shape[0], dtype=bool)
+    if ignore is not None:
+        for gw in ignore:
+            sel &= events != gw
+    pedict = {k: np.ascontiguousarray(post[sel, i, :]) for i, k in enumerate(pe_params)}
+    injdict = {k: np.ascontiguousarray(injs[i]) for i, k in enumerate(inj_params)}
+    constants = {"total_inj": total_inj, "obs_time": obs_time, "nObs": post.shape[0]}
+    return pedict, injdict, constants, list(pe_params)
 
 
 def _spins(table, found, injs, param_names, zeros_ok):

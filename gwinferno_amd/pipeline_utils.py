@@ -11,12 +11,14 @@ return values -- over this package's models, so that a model function written fo
 * :func:`bspline_example_prior` describes the same priors to the library's own sampler
   (``sampling.nuts_engine``): a ``GaussianSmoothingPrior`` + ``Bijector`` over the flat theta of a composition.
 
-The file readers of that module (``load_pe_and_injections_as_dict``: an arviz InferenceData with NetCDF-4 groups)
-need arviz / h5py and are not restated; ``gwinferno_amd.catalog`` reads the PE tensor and applies the injection cuts.
+``load_pe_and_injections_as_dict`` (:51-96: the arviz InferenceData file with NetCDF-4 groups ``pe_data`` / ``inj_data``) is
+here under its own name too, read through the HDF5 C library (``gwinferno_amd.catalog``, ``gwinferno_amd._hdf5``); the same
+module reads the NetCDF-3 PE tensor and applies the injection cuts.
 """
 import numpy as np
 
 from . import likelihood as L
+from .catalog import load_pe_and_injections_as_dict  # noqa: F401  (pipeline/utils.py:51-96)
 from .interpolation import LogXLogYBSpline, LogYBSpline
 from .models import (BSplineIIDSpinMagnitudes, BSplineIIDSpinTilts, BSplineIndependentSpinMagnitudes, BSplineIndependentSpinTilts, BSplinePrimaryBSplineRatio,
                      PowerlawSplineRedshiftModel)

@@ -103,3 +103,46 @@ def test_reader_on_the_reference_pe_file():
     assert len(events) == 69
     for k, v in case.pe.items():
         assert np.array_equal(pe[k], v), k
+
+
+def _hdf5_or_skip():
+    from gwinferno_amd import _hdf5
+
+    try:
+        _hdf5.lib()
+    except _hdf5.Hdf5Unavailable as exc:
+        pytest.skip(str(exc))
+    return _hdf5
+
+
+def test_inference_data_file_loads_like_the_reference_loader():
+    """f4: ``load_pe_and_injections_as_dict`` (pipeline/utils.py:51-96) on the InferenceData layout of
+    preprocess/data_collection.py:203-207 -- a NetCDF-4 (HDF5) file with groups pe_data / inj_data.  The fixture
+    (tests/golden/idata_small.h5) was written by the HDF5 C library itself (tests/golden/make_idata_fixture.py: variable-length
+    string coordinates, a chunked + deflated variable, 1-element attribute arrays as netCDF-4 stores them)."""
+    _hdf5_or_skip()
+    from gwinferno_amd.catalog import load_pe_and_injections_as_dict, read_hdf5_group
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(here, "idata_small.npz"))
+    path = os.path.join(here, "idata_small.h5")
+    pedict, injdict, constants, names = load_pe_and_injections_as_dict(path)
+    assert names == list(want["params"]) and list(pedict) == names and list(injdict) == names
+    for i, k in enumerate(names):
+        assert pedict[k].shape == (5, 40) and pedict[k].flags.c_contiguous
+        assert np.array_equal(pedict[k], want["posteriors"][:, i, :])
+        assert np.array_equal(injdict[k], want["injections"][i])
+    assert constants == {"total_inj": int(want["total_generated"]), "obs_time": float(want["analysis_time"]), "nObs": 5}
+    # ignore=[...] drops events by name (:76-81); nObs still counts the events of the file, as in the reference
+    drop = [str(want["events"][1]), str(want["events"][4])]
+    pe2, _, c2, _ = load_pe_and_injections_as_dict(path, ignore=drop)
+    assert pe2["mass_1"].shape == (3, 40) and np.array_equal(pe2["mass_1"], want["posteriors"][[0, 2, 3], 0, :]) and c2["nObs"] == 5
+    # the generic group reader (LVK injection files: selection.py:24-36)
+    cols, attrs, _ = read_hdf5_group(path, "inj_data")
+    assert set(cols) == {"injections", "param", "injection"} and attrs["total_generated"] == int(want["total_generated"]) and abs(attrs["analysis_time"] - 0.75) < 1e-15
+    assert list(cols["param"]) == names and np.array_equal(cols["injection"], np.arange(300))
+    # ... and the loaded catalog binds to a model like any other
+    from gwinferno_amd.compositions import COMPOSITIONS
+
+    comp = COMPOSITIONS["plpeak"](pedict, injdict)
+    assert comp.pe["mass_1"].shape == (5, 40)
