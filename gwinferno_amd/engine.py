@@ -393,6 +393,27 @@ class NativePopulationLikelihood:
                                                kms.ctypes.data_as(C.POINTER(C.c_float)) if kms is not None else None))
         return (ll, grads, kms) if kms is not None else (ll, grads)
 
+    def configure_sequence(self, thetas, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """:meth:`evaluate_sequence` with everything prepared beforehand: returns ``run() -> (log_likelihoods, grads)`` that is
+        ONE library call over the given points (buffers and argument marshalling done here, outside any timed region)."""
+        thetas = N.f64(np.atleast_2d(thetas))
+        n = thetas.shape[0]
+        if thetas.shape[1] != self.n_theta:
+            raise ValueError(f"thetas must be (n, {self.n_theta})")
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        ll, grads = np.empty(n), np.empty((n, self.n_theta))
+        args = (self.handle, N.as_dp(thetas), n, C.byref(opt), N.as_dp(ll), N.as_dp(grads), 0, None)
+        fn = self.lib.gwi_eval_sequence
+
+        def run():
+            st = fn(*args)
+            if st != 0:
+                self._check(st)
+            return ll, grads
+
+        run._keepalive = (thetas, opt)
+        return run
+
     def configure(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
         """Fix the likelihood options once; :meth:`value_and_grad` then has the smallest possible
         per-call overhead (what a sampler's inner loop wants)."""

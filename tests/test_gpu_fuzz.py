@@ -2,13 +2,15 @@
 benchmark priors (steep slopes, narrow / wide peaks, mixing fractions near 0 and 1, large spline
 coefficients), HIP engine vs the C oracle (itself pinned to the reference's golden vectors, tests/test_c_oracle.py)
 on one seeded mid-size catalog.  Values to 1e-9, analytic gradients to 1e-8 of their scale."""
+import os
+
 import numpy as np
 import pytest
 from golden_util import rel_err
 
 pytestmark = pytest.mark.gpu
 
-N_POINTS = 48
+N_POINTS = int(os.environ.get("GWI_FUZZ_POINTS", "48"))  # the long sweep: GWI_FUZZ_POINTS=400
 
 
 def _wide(name, p, rng):
