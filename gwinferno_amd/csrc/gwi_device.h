@@ -55,9 +55,10 @@ struct TailArgs {
   double* inj_out;    // [n_inj_groups][4]: M, S1, S2
   double* inj_grad;   // [n_inj_groups][n_theta]: G_p relative to that group's M
   double* ev_host;    // pinned host [3][n_ev]: logsumexp, log n_eff, variance
-  // host-final mode (small problems): every group publishes its whole result row
-  // [stamp, a, b, c, grad[n_theta]] to pinned host memory and the HOST sums over groups;
-  // a = logsumexp | M, b = log n_eff | S1, c = variance | S2
+  // host-final mode (small problems): every group publishes its whole result row (a, b, c, grad[n_theta]) to pinned host
+  // memory and the HOST sums over groups; a = logsumexp | M, b = log n_eff | S1, c = variance | S2.  The row travels as
+  // 64-byte LINES of seven values + the evaluation's sequence number in the eighth slot: every line validates itself, so a
+  // row is one store instruction per 8 lines with nothing to drain and no separate stamp write behind it
   double* host_rows;  // nullptr: device-final mode
   double* record;     // device-final mode: pinned host record (or the device send buffer when sharded)
   // completion stamp of this evaluation: read from a device word the scan launch of the same evaluation wrote
@@ -68,6 +69,7 @@ struct TailArgs {
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   int n_norms, record_len;
+  int row_lines;             // host-final mode: 64-byte lines per result row
   int combine_threads;       // workgroup size of the combine launch (64 or kBlock): passed here, not read from blockDim, which would pull in implicit kernel arguments the AQL packets do not carry
   int publish_events;        // device-final mode: also store the per-event sites to pinned host memory (3 small PCIe writes per event)
   double n_pe;
@@ -1023,7 +1025,8 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
   double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
   double* const ev_host = a.ev_host + (long long)kb * 3 * a.n_ev;
-  double* const host_rows = a.host_rows ? a.host_rows + (long long)kb * n_groups * (4 + a.n_theta) : nullptr;
+  const int row_doubles = 8 * a.row_lines;  // row_lines = ceil((3 + n_theta) / 7)
+  double* const host_rows = a.host_rows ? a.host_rows + (long long)kb * n_groups * row_doubles : nullptr;
   // host-final mode publishes one row per group: the row is staged in LDS and leaves in one contiguous sweep (2
   // PCIe writes per row instead of 5).  Small posted writes are what the host waits for: config 2, 76 rows:
   // 26.0 -> 21.1 us per evaluation on the same box; 16-point batches 111 -> 93 us
@@ -1064,7 +1067,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
 #pragma unroll 4
     for (; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
     if (host_rows)
-      s_row[4 + p] = is_inj ? acc : acc * inv_s1;
+      s_row[3 + p] = is_inj ? acc : acc * inv_s1;
     else if (is_inj)
       inj_grad[(long long)(e - a.n_ev) * a.n_theta + p] = acc;
     else
@@ -1074,15 +1077,15 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
     const double S2 = wave_sum(f * f * r2);
     if (lane == 0 && host_rows) {
       if (is_inj) {
-        s_row[1] = M;
-        s_row[2] = S1;
-        s_row[3] = S2;
+        s_row[0] = M;
+        s_row[1] = S1;
+        s_row[2] = S2;
       } else {
         const double log_s1 = log(S1);
         const double log_neff = 2.0 * log_s1 - log(S2);  // analysis.py:79
-        s_row[1] = log_s1 + M;
-        s_row[2] = log_neff;
-        s_row[3] = 1.0 / exp(log_neff) - 1.0 / a.n_pe;  // :87
+        s_row[0] = log_s1 + M;
+        s_row[1] = log_neff;
+        s_row[2] = 1.0 / exp(log_neff) - 1.0 / a.n_pe;  // :87
       }
     } else if (lane == 0) {
       if (is_inj) {
@@ -1109,11 +1112,16 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
       }
     }
   }
-  if (host_rows) {  // the whole row leaves in one coalesced sweep, then the stamp
+  if (host_rows) {  // the whole row leaves as self-validating 64-byte lines (seven values + the sequence number)
     __syncthreads();
-    double* o = host_rows + (long long)e * (4 + a.n_theta);
-    for (int i = tid + 1; i < 4 + a.n_theta; i += a.combine_threads) store_sys(o + i, s_row[i]);
-    publish_stamp(o, *a.seq_ptr, tid);
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(host_rows + (long long)e * row_doubles);
+    const unsigned long long seq = *a.seq_ptr;
+    const int n_vals = 3 + a.n_theta;
+    for (int slot = tid; slot < row_doubles; slot += a.combine_threads) {
+      const int line = slot >> 3, j = slot & 7, i = line * 7 + j;
+      const unsigned long long bits = j == 7 ? seq : (i < n_vals ? (unsigned long long)__double_as_longlong(s_row[i]) : 0ull);
+      __hip_atomic_store(o + slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

@@ -638,6 +638,7 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.n_pe = (double)h->n_pe;
   ta.publish_events = 1;
   ta.combine_threads = h->combine_threads;
+  ta.row_lines = (3 + h->spec.n_theta + 6) / 7;
   return ta;
 }
 
@@ -938,31 +939,35 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
 // into h_record so that assemble() is shared with the device-final and sharded paths.
 gwi_status wait_for_rows(gwi_handle h, int K) {
   const int n_groups = (int)h->n_ev + h->n_inj_groups;
-  const int stride = 4 + h->spec.n_theta, n_theta = h->spec.n_theta;
-  const int total = n_groups * K;
+  const int n_theta = h->spec.n_theta, n_lines = (3 + n_theta + 6) / 7, stride = 8 * n_lines;
+  const size_t total_lines = (size_t)n_groups * K * n_lines;
+  // every 64-byte line carries the evaluation's sequence number in its eighth slot
+  auto line_ok = [&](size_t ln) { return *reinterpret_cast<volatile unsigned long long*>(h->h_rows + ln * 8 + 7) == h->seq; };
   bool done = false;
   if (!h->timing && h->spin_wait) {
-    int g = 0;
+    size_t g = 0;
     for (long spin = 0; spin < 400000 && !done; ++spin) {
-      while (g < total && *reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) == h->seq) ++g;
-      done = g == total;
+      while (g < total_lines && line_ok(g)) ++g;
+      done = g == total_lines;
       if (!done) __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
+  auto all_ok = [&] {
+    for (size_t g = 0; g < total_lines; ++g)
+      if (!line_ok(g)) return false;
+    return true;
+  };
   if (!done && h->aql_now) {
-    const gwi_status sw = aql_wait_slow(h, [&] {
-      for (int g = 0; g < total; ++g)
-        if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq) return false;
-      return true;
-    }, "group result rows");
+    const gwi_status sw = aql_wait_slow(h, all_ok, "group result rows");
     if (sw != GWI_OK) return sw;
     std::atomic_thread_fence(std::memory_order_acquire);
   } else if (!done) {
     GWI_HIP(hipStreamSynchronize(h->stream));
-    for (int g = 0; g < total; ++g)
-      if (*reinterpret_cast<volatile unsigned long long*>(h->h_rows + (size_t)g * stride) != h->seq)
-        return fail(h, GWI_ERR_HIP, "group stamp mismatch after stream synchronise");
+    // the lines are posted writes behind the stream's completion: give the last ones a moment to land
+    for (long spin = 0; spin < 4000000 && !all_ok(); ++spin) __builtin_ia32_pause();
+    if (!all_ok()) return fail(h, GWI_ERR_HIP, "group row stamp mismatch after stream synchronise");
+    std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (h->timing && h->aql_now) {
     h->last_ms[2] = 0.0f;
@@ -976,33 +981,34 @@ gwi_status wait_for_rows(gwi_handle h, int K) {
   for (int k = 0; k < K; ++k) {
     double* r = h->h_record + (size_t)k * len;
     const double* rows = h->h_rows + (size_t)k * n_groups * stride;
+    auto val = [&](int g, int i) { return rows[(size_t)g * stride + (i / 7) * 8 + (i % 7)]; };  // value i of group g's row
     double* ev = h->h_ev + (size_t)k * 3 * n_ev;
     double sum = 0.0, var = 0.0, mn = INFINITY;
     double* gpe = r + kRecNormOff + n_norms;
     double* ginj = gpe + n_theta;
     for (int p = 0; p < n_theta; ++p) gpe[p] = ginj[p] = 0.0;
     for (int e = 0; e < n_ev; ++e) {
-      const double* row = rows + (size_t)e * stride;
-      sum += row[1];
-      var += row[3];
-      double le = row[2];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
+      const double lse = val(e, 0), lneff = val(e, 1), v = val(e, 2);
+      sum += lse;
+      var += v;
+      double le = lneff;  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
       if (le != le) le = 0.0;
       le = std::fmin(std::fmax(le, -1.7976931348623157e308), 1.7976931348623157e308);
       mn = std::fmin(mn, le);
-      ev[e] = row[1];
-      ev[n_ev + e] = row[2];
-      ev[2 * n_ev + e] = row[3];
-      for (int p = 0; p < n_theta; ++p) gpe[p] += row[4 + p];
+      ev[e] = lse;
+      ev[n_ev + e] = lneff;
+      ev[2 * n_ev + e] = v;
+      for (int p = 0; p < n_theta; ++p) gpe[p] += val(e, 3 + p);
     }
     double M = -INFINITY;
-    for (int j = 0; j < h->n_inj_groups; ++j) M = std::fmax(M, rows[(size_t)(n_ev + j) * stride + 1]);
+    for (int j = 0; j < h->n_inj_groups; ++j) M = std::fmax(M, val(n_ev + j, 0));
     double S1 = 0.0, S2 = 0.0;
     for (int j = 0; j < h->n_inj_groups; ++j) {
-      const double* row = rows + (size_t)(n_ev + j) * stride;
-      const double f = (row[1] == -INFINITY) ? 0.0 : std::exp(row[1] - M);
-      S1 += f * row[2];
-      S2 += f * f * row[3];
-      for (int p = 0; p < n_theta; ++p) ginj[p] += f * row[4 + p];
+      const double mj = val(n_ev + j, 0);
+      const double f = (mj == -INFINITY) ? 0.0 : std::exp(mj - M);
+      S1 += f * val(n_ev + j, 1);
+      S2 += f * f * val(n_ev + j, 2);
+      for (int p = 0; p < n_theta; ++p) ginj[p] += f * val(n_ev + j, 3 + p);
     }
     r[1] = sum;
     r[2] = var;
@@ -1384,7 +1390,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   // the third launch (final_kernel: ~1.5 us boundary + ~6-9 us of latency chain) disappears
   {
     const size_t n_groups = (size_t)n_ev + h->n_inj_groups;
-    const size_t row_bytes = sizeof(double) * n_groups * (4 + spec->n_theta);
+    const size_t row_bytes = 64 * n_groups * (size_t)((3 + spec->n_theta + 6) / 7);  // self-validating 64-byte lines: 7 values + the sequence number
     size_t host_final_limit = 64 * 1024;  // measured: config 3 (41 KB of rows) gains 2 us from host-final, config 5 (195 KB) loses 5
     if (const char* env = std::getenv("GWI_HOST_FINAL_BYTES")) host_final_limit = (size_t)std::atoll(env);
     h->host_final = row_bytes <= host_final_limit;

@@ -603,6 +603,16 @@ def test_begin_end_and_interleaved_engines():
         assert v0 == refs[i].log_likelihood and np.allclose(g0, refs[i].grad, rtol=1e-12, atol=1e-13)
     with pytest.raises(NativeEngineError, match="without gwi_eval_begin"):
         e0()
+    # while an evaluation begun with gwi_eval_begin is in flight, EVERY other evaluating entry point of that
+    # handle is refused (it would overwrite the kernel arguments and the sequence stamp under it) -- and the pending
+    # evaluation still collects the right result afterwards
+    b0(ths[0])
+    for call in (lambda: engs[0].evaluate_batch(np.stack(ths[:4]), total, min_neff_cut=False), lambda: engs[0].log_weights(ths[1]), lambda: engs[0].eval_partial(ths[1]),
+                 lambda: engs[0].evaluate(ths[1], total, min_neff_cut=False)):
+        with pytest.raises(NativeEngineError, match="has not been collected"):
+            call()
+    v0, g0 = e0()
+    assert v0 == refs[0].log_likelihood and np.allclose(g0, refs[0].grad, rtol=1e-12, atol=1e-13)
     for e in engs:
         e.close()
 
