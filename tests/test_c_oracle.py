@@ -3,7 +3,7 @@ the golden vectors of the unmodified reference: every site of every case / hyper
 gradient against the reference's finite differences."""
 import numpy as np
 import pytest
-from golden_util import CASES, GoldenCase, rel_err
+from golden_util import CASES, GoldenCase, fd_gradient_tolerance, rel_err
 
 from gwinferno_amd.compositions import COMPOSITIONS
 from gwinferno_amd.engine import bind
@@ -35,7 +35,7 @@ def test_c_oracle_sites_and_gradient(name):
         g = comp.named_gradient(orc.evaluate(bm.theta_of(comp.weights(case.point(i), True)), case.total_inj, min_neff_cut=False)["grad"], p=case.point(i))
         for pname, ref in fd.items():
             scale = max(1.0, float(np.max(np.abs(ref))))
-            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname)
+            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < fd_gradient_tolerance(name, pname) * scale, (name, i, pname)
 
 
 def test_thread_count_does_not_change_values():

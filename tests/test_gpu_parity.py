@@ -4,13 +4,14 @@
       and the 4th-order finite-difference gradients;
   (2) the NumPy oracle on seeded mid-size catalogs;
   (3) size-independent properties at the BASELINE sizes.
-Tolerances (fp64): 1e-9 relative on values (BASELINE.json north_star), 1e-6 on gradients vs the
-finite-difference oracle (whose own truncation error is ~1e-8)."""
+Tolerances (fp64): 1e-9 relative on values (BASELINE.json north_star); gradients vs the reference's own
+finite differences 1e-9 (2e-7 for the PL+Peak mixture parameters, where the differences' truncation error dominates:
+golden_util.fd_gradient_tolerance)."""
 import os
 
 import numpy as np
 import pytest
-from golden_util import CASES, GoldenCase, rel_err
+from golden_util import CASES, GoldenCase, fd_gradient_tolerance, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -93,7 +94,7 @@ def test_gradient_matches_finite_differences_of_reference(name):
         g = comp.named_gradient(res.grad, p=case.point(i))
         for pname, ref in fd.items():
             scale = max(1.0, float(np.max(np.abs(ref))))
-            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < 1e-6 * scale, (name, i, pname, g[pname], ref)
+            assert np.max(np.abs(np.asarray(g[pname]) - ref)) < fd_gradient_tolerance(name, pname) * scale, (name, i, pname, g[pname], ref)
     eng.close()
 
 
