@@ -283,6 +283,9 @@ struct Ctx {
 // random; config 5 spent 30 % of its scan there).  The four waves of the workgroup share the rows (the adds are atomic),
 // which is what makes 64 replicas fit: n_theta x 512 B per WORKGROUP.
 __device__ __forceinline__ void spline_scatter(const Ctx& c, int first, const Taps& b) {
+#ifdef GWI_ABL_NO_SCATTER  // timing-only ablation build (tools/build_ablations.sh): results are wrong by construction
+  return;
+#endif
   double* g = c.gacc + (first << c.rep_shift);
   const int step = 1 << c.rep_shift;
   unsafeAtomicAdd(g, b.b0);
