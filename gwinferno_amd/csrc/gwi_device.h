@@ -69,6 +69,7 @@ struct TailArgs {
   int n_ev, tiles_per_event, n_inj_tiles, n_inj_groups, tiles_per_inj_group, n_theta, rec_stride;
   int n_scan_blocks;  // records per hyper-parameter point (batched launches: blockIdx.y = point)
   int n_norms, record_len;
+  int final_groups;          // workgroups of the final launch: each publishes a partial record
   int row_lines;             // host-final mode: 64-byte lines per result row
   int combine_threads;       // workgroup size of the combine launch (64 or kBlock): passed here, not read from blockDim, which would pull in implicit kernel arguments the AQL packets do not carry
   int publish_events;        // device-final mode: also store the per-event sites to pinned host memory (3 small PCIe writes per event)
@@ -1138,14 +1139,22 @@ __device__ __forceinline__ int pow2_at_least(int v) {
   return p;
 }
 
+// Workgroup g of G takes the events [g n_ev / G, (g + 1) n_ev / G) and the injection groups [g n_ig / G, (g + 1) n_ig / G)
+// and publishes a partial record of its own (same layout); the host merges the G records as it merges the records of
+// ranks.  One workgroup over everything (G = 1: the sharded path, whose record feeds the all-gather) spent 7.4 us on
+// config 5 -- 200 event rows x 105 slots through one CU, two dependent rounds of loads -- against 5.8 for G = 4.
 template <int THREADS>
-__device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, const int tid, double* s_tile /* [THREADS] */) {
+__device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, const int g, const int tid, double* s_tile /* [THREADS] */) {
   const int lane = tid & 63, wave = tid >> 6;
-  double* r = a.record + (long long)kb * a.record_len;
+  const int G = a.final_groups;
+  const int e_lo = (int)((long long)g * a.n_ev / G), e_hi = (int)((long long)(g + 1) * a.n_ev / G);
+  const int j_lo = (int)((long long)g * a.n_inj_groups / G), j_hi = (int)((long long)(g + 1) * a.n_inj_groups / G);
+  const int n_ig = j_hi - j_lo;
+  double* r = a.record + ((long long)kb * G + g) * a.record_len;
   const double* const ev_out = a.ev_out + (long long)kb * a.n_ev * 4;
   const double* const ev_grad = a.ev_grad + (long long)kb * a.n_ev * a.n_theta;
-  const double* const inj_out = a.inj_out + (long long)kb * a.n_inj_groups * 4;
-  const double* const inj_grad = a.inj_grad + (long long)kb * a.n_inj_groups * a.n_theta;
+  const double* const inj_out = a.inj_out + ((long long)kb * a.n_inj_groups + j_lo) * 4;
+  const double* const inj_grad = a.inj_grad + ((long long)kb * a.n_inj_groups + j_lo) * a.n_theta;
   const int off_norm = 8, off_gpe = off_norm + a.n_norms, off_ginj = off_gpe + a.n_theta;
 
   // ---- gradient sums over events: threads <- (event row, slot p); p fast => coalesced; one barrier
@@ -1155,12 +1164,12 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   double acc = 0.0;
   if (col < a.n_theta) {
     // chunks of 16 events: the 16 loads go out together (one memory round trip), then the ordered sum
-    for (int e0 = row; e0 < a.n_ev; e0 += 16 * rows) {
+    for (int e0 = e_lo + row; e0 < e_hi; e0 += 16 * rows) {
       double v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int e = e0 + q * rows;
-        v[q] = e < a.n_ev ? ev_grad[(long long)e * a.n_theta + col] : 0.0;
+        v[q] = e < e_hi ? ev_grad[(long long)e * a.n_theta + col] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc += v[q];
@@ -1171,19 +1180,19 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   // ---- meanwhile wave 0: scalar sums over events; wave 1: injection groups
   if (wave == 0) {
     double sum = 0.0, var = 0.0, mn = GWI_POS_INF;
-    for (int e0 = lane; e0 < a.n_ev; e0 += 4 * 64) {  // four events per lane per round trip
+    for (int e0 = e_lo + lane; e0 < e_hi; e0 += 4 * 64) {  // four events per lane per round trip
       double o0[4], o1[4], o2[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = e0 + 64 * q;
-        const double* o = ev_out + (long long)(e < a.n_ev ? e : 0) * 4;
+        const double* o = ev_out + (long long)(e < e_hi ? e : e_lo) * 4;
         o0[q] = o[0];
         o1[q] = o[1];
         o2[q] = o[2];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (e0 + 64 * q >= a.n_ev) continue;
+        if (e0 + 64 * q >= e_hi) continue;
         sum += o0[q];
         var += o2[q];
         double le = o1[q];  // jnp.min(jnp.nan_to_num(logn_effs)) (analysis.py:295)
@@ -1200,19 +1209,19 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
       store_sys(r + 2, var);
       store_sys(r + 3, mn);
       // a negative event count asks whoever assembles the gathered records to repeat the evaluation in two-pass mode
-      store_sys(r + 7, (*a.redo_ptr == *a.seq_ptr) ? -(double)(a.n_ev + 1) : (double)a.n_ev);
+      store_sys(r + 7, (*a.redo_ptr == *a.seq_ptr) ? -(double)(e_hi - e_lo + 1) : (double)(e_hi - e_lo));
     }
   }
   // injection groups (host guarantees n_inj_groups <= 64): lanes <- groups.  Everything this thread
   // will need from memory is requested before the first dependent instruction (one round trip).
-  const bool hasg = lane < a.n_inj_groups;
+  const bool hasg = lane < n_ig;
   const double m_j = hasg ? inj_out[lane * 4] : GWI_NEG_INF;
   const double s1_j = hasg ? inj_out[lane * 4 + 1] : 0.0, s2_j = hasg ? inj_out[lane * 4 + 2] : 0.0;
   constexpr int kEarly = 32;
   double early[kEarly];
   const bool early_on = tid < a.n_theta;
 #pragma unroll
-  for (int j = 0; j < kEarly; ++j) early[j] = (early_on && j < a.n_inj_groups) ? inj_grad[(long long)j * a.n_theta + tid] : 0.0;
+  for (int j = 0; j < kEarly; ++j) early[j] = (early_on && j < n_ig) ? inj_grad[(long long)j * a.n_theta + tid] : 0.0;
   const double Minj = wave_max(m_j);
   const double fj = (m_j == GWI_NEG_INF) ? 0.0 : exp(m_j - Minj);
   if (wave == 1) {
@@ -1226,29 +1235,29 @@ __device__ __forceinline__ void final_reduce(const TailArgs& a, const int kb, co
   }
   // injection gradient numerators: threads <- slots, groups in order with f_j broadcast
   for (int p = tid; p < a.n_theta; p += THREADS) {
-    double g = 0.0;
+    double gsum = 0.0;
     int j = 0;
     if (p == tid) {
 #pragma unroll
       for (; j < kEarly; ++j)
-        if (j < a.n_inj_groups) g += lane_bcast(fj, j) * early[j];
-      j = a.n_inj_groups < kEarly ? a.n_inj_groups : kEarly;
+        if (j < n_ig) gsum += lane_bcast(fj, j) * early[j];
+      j = n_ig < kEarly ? n_ig : kEarly;
     }
-    for (; j < a.n_inj_groups; j += 8) {  // eight independent loads per round trip, then the ordered sum
+    for (; j < n_ig; j += 8) {  // eight independent loads per round trip, then the ordered sum
       double v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (j + q < a.n_inj_groups) ? inj_grad[(long long)(j + q) * a.n_theta + p] : 0.0;
+      for (int q = 0; q < 8; ++q) v[q] = (j + q < n_ig) ? inj_grad[(long long)(j + q) * a.n_theta + p] : 0.0;
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (j + q < a.n_inj_groups) g += lane_bcast(fj, j + q) * v[q];
+        if (j + q < n_ig) gsum += lane_bcast(fj, j + q) * v[q];
     }
-    store_sys(r + off_ginj + p, g);
+    store_sys(r + off_ginj + p, gsum);
   }
   __syncthreads();
   if (row == 0 && col < a.n_theta) {
-    double g = 0.0;
-    for (int q = 0; q < rows; ++q) g += s_tile[q * vp + col];  // fixed order
-    store_sys(r + off_gpe + col, g);
+    double gsum = 0.0;
+    for (int q = 0; q < rows; ++q) gsum += s_tile[q * vp + col];  // fixed order
+    store_sys(r + off_gpe + col, gsum);
   }
   publish_stamp(r, *a.seq_ptr, tid);
 }
@@ -1618,7 +1627,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const TailArgs a) { com
 constexpr int kFinalThreads = 1024;
 __global__ __launch_bounds__(kFinalThreads) void final_kernel(const TailArgs a) {
   __shared__ double s_tile[kFinalThreads];
-  final_reduce<kFinalThreads>(a, blockIdx.y, threadIdx.x, s_tile);
+  final_reduce<kFinalThreads>(a, blockIdx.y, blockIdx.x, threadIdx.x, s_tile);
 }
 
 // ---- batched launches: pull the K theta blocks from pinned host memory into device memory (one

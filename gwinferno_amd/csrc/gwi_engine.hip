@@ -318,6 +318,9 @@ struct gwi_engine {
   double *d_logw_pe = nullptr, *d_logw_inj = nullptr;
   // pinned, device-visible host memory
   double *h_record = nullptr, *h_record_dev = nullptr;
+  // device-final mode: the final launch's G workgroups publish one partial record each here; the host merges them into h_record
+  double *h_fin = nullptr, *h_fin_dev = nullptr;
+  int final_groups = 1;
   double *h_ev = nullptr, *h_ev_dev = nullptr;
   // host-final mode: per-group result rows + normaliser values in pinned host memory
   bool host_final = false;
@@ -584,6 +587,7 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
 }
 
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K = 1);
+void merge_final_records(gwi_handle h, int K);
 gwi_status wait_for_rows(gwi_handle h, int K = 1);
 gwi_status wait_for_norms(gwi_handle h, double* record, int K = 1);
 
@@ -622,7 +626,8 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.inj_grad = h->d_inj_grad;
   ta.ev_host = h->h_ev_dev;
   ta.host_rows = h->host_final && !record_dev ? h->h_rows_dev : nullptr;
-  ta.record = record_dev ? record_dev : h->h_record_dev;
+  ta.record = record_dev ? record_dev : h->h_fin_dev;
+  ta.final_groups = record_dev ? 1 : h->final_groups;  // the sharded path's single record feeds the all-gather
   ta.seq_ptr = h->d_seq;
   ta.redo_ptr = h->d_seq + 1;
   ta.n_ev = (int)h->n_ev;
@@ -711,11 +716,12 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
     GWI_PHASE(4);
     return sw;
   }
-  launch_timed(h, 2, final_kernel, dim3(1, gy), dim3(kFinalThreads), 0, ta);
+  launch_timed(h, 2, final_kernel, dim3((unsigned)ta.final_groups, gy), dim3(kFinalThreads), 0, ta);
   GWI_HIP(hipGetLastError());
   h->timed_final = true;
   if (!wait) return GWI_OK;
-  gwi_status st_ = wait_for_stamp(h, h->h_record, K);
+  gwi_status st_ = wait_for_stamp(h, h->h_fin, K * h->final_groups);
+  if (st_ == GWI_OK) merge_final_records(h, K);
   if (st_ != GWI_OK) return st_;
   return wait_for_norms(h, h->h_record, K);
 }
@@ -786,6 +792,51 @@ gwi_status wait_for_norms(gwi_handle h, double* record, int K) {
   for (int k = 0; k < K; ++k)
     for (int j = 0; j < n; ++j) record[(size_t)k * len + kRecNormOff + j] = h->h_norm[k * n + j];
   return GWI_OK;
+}
+
+// Device-final mode: the G partial records of point k (h_fin) -> one record (h_record), merged exactly as assemble() merges the
+// records of ranks: sums, the minimum, the injection triples brought to their common exponent, gradients in workgroup order.
+void merge_final_records(gwi_handle h, int K) {
+  const int G = h->final_groups, n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
+  const size_t len = (size_t)record_len(h);
+  for (int k = 0; k < K; ++k) {
+    double* out = h->h_record + (size_t)k * len;
+    const double* in = h->h_fin + (size_t)k * G * len;
+    double sum = 0.0, var = 0.0, mn = INFINITY, n_ev = 0.0, M = -INFINITY;
+    bool redo = false;
+    for (int g = 0; g < G; ++g) {
+      const double* r = in + (size_t)g * len;
+      sum += r[1];
+      var += r[2];
+      mn = std::fmin(mn, r[3]);
+      M = std::fmax(M, r[4]);
+      redo = redo || r[7] < 0.0;
+      n_ev += r[7] < 0.0 ? -r[7] - 1.0 : r[7];
+    }
+    double S1 = 0.0, S2 = 0.0;
+    double* gpe = out + kRecNormOff + n_norms;
+    double* ginj = gpe + n_theta;
+    for (int p = 0; p < n_theta; ++p) gpe[p] = ginj[p] = 0.0;
+    for (int g = 0; g < G; ++g) {
+      const double* r = in + (size_t)g * len;
+      const double f = (r[4] == -INFINITY) ? 0.0 : std::exp(r[4] - M);
+      S1 += f * r[5];
+      S2 += f * f * r[6];
+      const double* rp = r + kRecNormOff + n_norms;
+      const double* ri = rp + n_theta;
+      for (int p = 0; p < n_theta; ++p) {
+        gpe[p] += rp[p];
+        ginj[p] += f * ri[p];
+      }
+    }
+    out[1] = sum;
+    out[2] = var;
+    out[3] = mn;
+    out[4] = M;
+    out[5] = S1;
+    out[6] = S2;
+    out[7] = redo ? -(n_ev + 1.0) : n_ev;
+  }
 }
 
 gwi_status wait_for_stamp(gwi_handle h, double* host_buf, int K) {
@@ -1054,6 +1105,7 @@ void destroy_impl(gwi_engine* h) {
   (void)hipFree(h->d_recv);
   if (h->h_gather) (void)hipHostFree(h->h_gather);
   if (h->h_record) (void)hipHostFree(h->h_record);
+  if (h->h_fin) (void)hipHostFree(h->h_fin);
   if (h->h_ev) (void)hipHostFree(h->h_ev);
   if (h->h_rows) (void)hipHostFree(h->h_rows);
   if (h->h_norm) (void)hipHostFree(h->h_norm);
@@ -1381,6 +1433,13 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipHostMalloc((void**)&h->h_ev, sizeof(double) * KB * 3 * (size_t)(n_ev ? n_ev : 1), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_ev_dev, h->h_ev, 0));
   std::memset(h->h_record, 0, sizeof(double) * KB * record_len(h));
+  // the final launch: one workgroup per ~48 events (at most 8), each publishing a partial record (config 5, 200 events:
+  // 1 / 4 / 8 / 16 workgroups = 7.6 / 5.8 / 5.9 / 6.7 us -- more records are more small PCIe writes)
+  h->final_groups = (int)std::max<long long>(1, std::min<long long>(8, n_ev / 48));
+  if (const char* env = std::getenv("GWI_FINAL_GROUPS")) h->final_groups = std::max(1, std::min(64, std::atoi(env)));
+  GWI_HIP(hipHostMalloc((void**)&h->h_fin, sizeof(double) * KB * h->final_groups * record_len(h), hipHostMallocMapped));
+  GWI_HIP(hipHostGetDevicePointer((void**)&h->h_fin_dev, h->h_fin, 0));
+  std::memset(h->h_fin, 0, sizeof(double) * KB * h->final_groups * record_len(h));
   GWI_HIP(hipMalloc(&h->d_seq, 2 * sizeof(unsigned long long)));
   GWI_HIP(hipMemset(h->d_seq, 0, 2 * sizeof(unsigned long long)));
   GWI_HIP(hipHostMalloc((void**)&h->h_redo, sizeof(unsigned long long), hipHostMallocMapped));
@@ -1622,7 +1681,8 @@ gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double
   if (h->last_host_rows) {
     st = wait_for_rows(h, 1);
   } else {
-    st = wait_for_stamp(h, h->h_record, 1);
+    st = wait_for_stamp(h, h->h_fin, h->final_groups);
+    if (st == GWI_OK) merge_final_records(h, 1);
     if (st == GWI_OK) st = wait_for_norms(h, h->h_record, 1);
   }
   if (st != GWI_OK) return st;
