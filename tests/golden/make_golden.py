@@ -590,10 +590,24 @@ def run_likelihood(comp, p, nobs, total_inj, flags):
 
 
 def fd_gradient(comp, p, nobs, total_inj, flags, rel=1e-3):
-    """4th-order central differences of the `log_likelihood` factor w.r.t. every hyper-parameter."""
+    """Central differences of the `log_likelihood` factor w.r.t. every hyper-parameter: the 4th-order five-point stencil at
+    steps h and h / 2, Richardson-extrapolated ((16 D_{h/2} - D_h) / 15: 6th order).  Where log_l is smooth over the
+    stencil the result is good to ~1e-11 of the gradient's scale (the plain stencil at h left ~6e-8 on the position of the
+    PL+Peak Gaussian, whose fifth derivative is large)."""
 
     def f(q):
         return float(run_likelihood(comp, q, nobs, total_inj, flags)[0]["log_likelihood"])
+
+    def stencil(name, val, arr, i, h):
+        vals = []
+        for k in (-2, -1, 1, 2):
+            q = {n: (np.array(v, dtype=np.float64, copy=True) if np.ndim(v) else float(v)) for n, v in p.items()}
+            if np.ndim(val):
+                q[name][i] = arr[i] + k * h
+            else:
+                q[name] = arr[i] + k * h
+            vals.append(f(q))
+        return (vals[0] - 8 * vals[1] + 8 * vals[2] - vals[3]) / (12 * h)
 
     grads = {}
     for name, val in p.items():
@@ -604,17 +618,14 @@ def fd_gradient(comp, p, nobs, total_inj, flags, rel=1e-3):
         for i in range(arr.size):
             # per-parameter step override: the taper `delta` moves a singularity of the reference's `smooth`
             # (x = xmin + delta) across samples, so log_l is only piecewise smooth in it; a step of 1e-6 keeps
-            # the stencil inside one piece (rounding error ~1e-9) where 1e-3 does not
-            h = getattr(comp, "fd_rel", {}).get(name, rel) * max(1.0, abs(arr[i]))
-            vals = []
-            for k in (-2, -1, 1, 2):
-                q = {n: (np.array(v, dtype=np.float64, copy=True) if np.ndim(v) else float(v)) for n, v in p.items()}
-                if np.ndim(val):
-                    q[name][i] = arr[i] + k * h
-                else:
-                    q[name] = arr[i] + k * h
-                vals.append(f(q))
-            g[i] = (vals[0] - 8 * vals[1] + 8 * vals[2] - vals[3]) / (12 * h)
+            # the stencil inside one piece (rounding error ~1e-9) where 1e-3 does not -- and no extrapolation there
+            # (halving such a step only doubles the rounding error)
+            step_rel = getattr(comp, "fd_rel", {}).get(name, rel)
+            h = step_rel * max(1.0, abs(arr[i]))
+            if step_rel < rel:
+                g[i] = stencil(name, val, arr, i, h)
+            else:
+                g[i] = (16.0 * stencil(name, val, arr, i, 0.5 * h) - stencil(name, val, arr, i, h)) / 15.0
         grads[name] = g.reshape(np.shape(val))
     return grads
 
