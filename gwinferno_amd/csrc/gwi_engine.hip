@@ -99,6 +99,9 @@ const Variant kVariants[] = {
     GWI_VARIANT_U("plz+spline7/u2", 2, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
     // PLPeakPrimaryBSplineRatio (separable.py:368-443) x PL z
     GWI_VARIANT("plpeak+plz+spline", K_PP, K_PZ, K_SP),
+    // plpeak_primary_ratio_pdf (parametric.py:39-46) x B-spline spin magnitudes and tilts (IID or independent:
+    // separable.py:17-292) x PL z -- parametric masses with non-parametric spins
+    GWI_VARIANT("plpeak+plq+plz+spline4", K_PP, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP),
     // mass-only B-spline models: BSplinePrimaryBSplineRatio / BSplinePrimaryPowerlawRatio x PL z
     GWI_VARIANT("plz+spline2", K_PZ, K_SP, K_SP),
     GWI_VARIANT("plq+plz+spline", K_PQ, K_PZ, K_SP),
@@ -142,6 +145,7 @@ const Variant kVariants[] = {
     GWI_VARIANT("truncnorm", K_TN),
     GWI_VARIANT("smooth", K_SM),
     GWI_VARIANT("plpeaksmooth", K_PS),
+#include "gwi_user_variants.inc"
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -1240,7 +1244,11 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (!h->variant) {
     std::string seq;
     for (int t = 0; t < spec->n_terms; ++t) seq += (t ? "," : "") + std::to_string(spec->terms[t].kind);
-    return fail(h, GWI_ERR_UNSUPPORTED, "no compiled kernel for term-kind sequence [" + seq + "]; add it to kVariants in gwi_engine.hip");
+    std::string cmd = seq;
+    for (char& ch : cmd)
+      if (ch == ',') ch = ' ';
+    return fail(h, GWI_ERR_UNSUPPORTED, "no compiled kernel for term-kind sequence [" + seq + "]: add it with `python -m gwinferno_amd.add_variant " + cmd +
+                                            "` (appends to gwinferno_amd/csrc/gwi_user_variants.inc and rebuilds the library; ~1 min), then restart the process");
   }
   if (device < 0) {
     GWI_HIP(hipGetDevice(&h->device));

@@ -161,6 +161,55 @@ def test_run_to_run_bit_stability():
     eng.close()
 
 
+@pytest.mark.parametrize("iid", [True, False])
+def test_parametric_masses_with_bspline_spins(iid):
+    """A product written directly against the drop-in model API, as a user of the reference would: plpeak_primary_ratio_pdf
+    (parametric.py:39-46) x B-spline spin magnitudes x B-spline tilts (separable.py:17-292, IID or independent) x
+    PowerlawRedshiftModel -- its kind sequence (PL+Peak, PL q, PL z, four splines) has a compiled kernel of its own.  Checked
+    against the C oracle, which evaluates any bound model."""
+    from gwinferno_amd.engine import NativePopulationLikelihood
+    from gwinferno_amd.lazy import where_finite
+    from gwinferno_amd.models import (BSplineIIDSpinMagnitudes, BSplineIIDSpinTilts, BSplineIndependentSpinMagnitudes, BSplineIndependentSpinTilts, PowerlawRedshiftModel,
+                                      plpeak_primary_ratio_pdf)
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(12, 900, 8000, seed=5)
+    rng = np.random.default_rng(3)
+    if iid:
+        mag = BSplineIIDSpinMagnitudes(10, pe["a_1"], pe["a_2"], inj["a_1"], inj["a_2"], normalize=True)
+        tilt = BSplineIIDSpinTilts(8, pe["cos_tilt_1"], pe["cos_tilt_2"], inj["cos_tilt_1"], inj["cos_tilt_2"], normalize=True)
+    else:
+        mag = BSplineIndependentSpinMagnitudes(10, 9, pe["a_1"], pe["a_2"], inj["a_1"], inj["a_2"], normalize=True)
+        tilt = BSplineIndependentSpinTilts(8, 7, pe["cos_tilt_1"], pe["cos_tilt_2"], inj["cos_tilt_1"], inj["cos_tilt_2"], normalize=True)
+    z_model = PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+
+    def weights(p, d, flag):
+        p_m = plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=p["alpha"], beta=p["beta"], mmin=5.0, mmax=100.0, mpp=p["mpp"], sigpp=p["sigpp"], lam=p["lam"])
+        p_a = mag(p["a"], pe_samples=flag) if iid else mag(p["a"], p["a2"], pe_samples=flag)
+        p_t = tilt(p["t"], pe_samples=flag) if iid else tilt(p["t"], p["t2"], pe_samples=flag)
+        return where_finite(p_m * p_a * p_t * z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+    def draw():
+        return dict(alpha=rng.normal(-2.5, 1.0), beta=rng.normal(1.0, 1.0), mpp=rng.uniform(20.0, 50.0), sigpp=rng.uniform(1.0, 10.0), lam=rng.uniform(0.0, 0.2), lamb=rng.normal(2.7, 1.0),
+                    a=rng.normal(size=10), a2=rng.normal(size=9), t=rng.normal(size=8), t2=rng.normal(size=7))
+
+    p0 = draw()
+    wpe = weights(p0, pe, True)
+    eng = NativePopulationLikelihood(wpe, weights(p0, inj, False), z_model.normalization(p0["lamb"]))
+    orc = COracle(eng.bound)
+    for _ in range(4):
+        p = draw()
+        th = eng.bound.theta_of(weights(p, pe, True))
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = orc.evaluate(th, total, min_neff_cut=False)
+        assert rel_err(got.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        assert rel_err(got.log_bfs, ref["logBFs"]) < VALUE_RTOL
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    eng.close()
+
+
 @pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_full", "bspline_chieff", "chm_bspline"])
 def test_replay_mode_is_bit_reproducible(comp_name, monkeypatch):
     """GWI_DETERMINISTIC=1: the shared gradient rows are filled in one fixed order -- one replica per

@@ -4,6 +4,8 @@ weights and hierarchical_likelihood sites (golden vectors), when evaluated by th
 BoundModel evaluator in tests/bound_eval.py.  The HIP kernels are checked against the same
 vectors in test_gpu_parity.py (-m gpu)."""
 import numpy as np
+import os
+
 import pytest
 from bound_eval import log_weights
 from golden_util import CASES, GoldenCase, rel_err
@@ -152,3 +154,19 @@ def test_distribution_log_prob_faces_bind_to_the_reference_values():
         D.BSplineDistribution(0.0, 1.0, cs, gr, np.asarray(I.BSpline(20).bases(gr)))  # a bare matrix: origin unknown
     with pytest.raises(ValueError):
         D.BSplineDistribution(0.0, 1.0, cs, grx, I.BSpline(20).bases(gr))
+
+
+def test_add_variant_line_for_an_unsupported_sequence():
+    """A model whose sorted term-kind sequence has no compiled kernel is refused by gwi_create with the command that adds
+    it; gwinferno_amd.add_variant validates the sequence and writes the GWI_VARIANT line (build not run here)."""
+    from gwinferno_amd import add_variant as A
+
+    assert A.variant_line([2, 3, 6, 7, 7, 7, 7]) == '    GWI_VARIANT_U("user:2,3,6,7,7,7,7", 2, 2, 3, 6, 7, 7, 7, 7),\n'
+    assert ", 1, 3, 6, 7, 7, 7, 7, 7, 7)" in A.variant_line([3, 6, 7, 7, 7, 7, 7, 7])  # six splines: one sample per lane
+    for bad in ([7, 3], [0], [15], list(range(1, 14))):
+        with pytest.raises(ValueError):
+            A.variant_line(bad)
+    inc = open(A.INC).read()
+    assert "GWI_VARIANT" in inc.split("\n")[0] or inc.startswith("//")  # the include file exists and is part of kVariants
+    src = open(os.path.join(os.path.dirname(A.INC), "gwi_engine.hip")).read()
+    assert '#include "gwi_user_variants.inc"' in src
