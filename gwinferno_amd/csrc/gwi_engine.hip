@@ -102,6 +102,16 @@ const Variant kVariants[] = {
     // plpeak_primary_ratio_pdf (parametric.py:39-46) x B-spline spin magnitudes and tilts (IID or independent:
     // separable.py:17-292) x PL z -- parametric masses with non-parametric spins
     GWI_VARIANT("plpeak+plq+plz+spline4", K_PP, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT("plpeak+plq+plz+spline2", K_PP, K_PQ, K_PZ, K_SP, K_SP),                      // ... magnitudes only (or tilts only)
+    GWI_VARIANT("plpeak+plq+plz+spline5", K_PP, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),    // ... and the redshift spline
+    // other products of the separable B-spline models (separable.py) the reference's factories allow (pipeline/utils.py:104-155):
+    // B-spline masses with spin magnitudes / tilts and a power-law or spline redshift model
+    GWI_VARIANT("plz+spline4", K_PZ, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT("plz+spline5", K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plz+spline6", 1, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT("plq+plz+spline2", K_PQ, K_PZ, K_SP, K_SP),
+    GWI_VARIANT("plq+plz+spline4", K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plq+plz+spline6", 1, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
     // mass-only B-spline models: BSplinePrimaryBSplineRatio / BSplinePrimaryPowerlawRatio x PL z
     GWI_VARIANT("plz+spline2", K_PZ, K_SP, K_SP),
     GWI_VARIANT("plq+plz+spline", K_PQ, K_PZ, K_SP),
