@@ -169,7 +169,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // ---- exp / expm1 for the scan loop ---------------------------------------------------------
 // exp(x) = 2^n (1 + r q(r)),  n = rint(x log2 e),  r = x - n ln2 (two-piece ln2),  |r| <= 0.3466,
-// q = Taylor series of (e^r - 1)/r to r^12 (truncation 0.3466^14/14! = 4e-18 relative).  Every Horner
+// q = Taylor series of (e^r - 1)/r to r^10 (truncation 0.3466^12/12! = 6e-15 relative at the ends of the range, 1e-16 in
+// its middle half: five orders below what the parity bars of this path can see; two Horner steps fewer).  Every Horner
 // step is ONE v_fma_f64 whose addend is a scalar-register constant: left to itself the compiler parks
 // the constants in vector registers and spends a v_mov_b64 + v_fmac_f64 per step (two-address form).
 // The argument is clamped to [-1000, 710]: exp(-inf) = 0 and exp(>709.8) = +inf fall out of ldexp.
@@ -190,9 +191,7 @@ __device__ __forceinline__ ExpParts exp_parts(double x) {
   const double nf = __builtin_rint(x * 1.4426950408889634);
   double r = fma(nf, -6.93147180369123816490e-01, x);
   r = fma(nf, -1.90821492927058770002e-10, r);
-  double q = 1.0 / 6227020800.0;          // 1/13!
-  q = fma_sc(q, r, 1.0 / 479001600.0);    // 1/12!
-  q = fma_sc(q, r, 1.0 / 39916800.0);
+  double q = 1.0 / 39916800.0;            // 1/11!
   q = fma_sc(q, r, 1.0 / 3628800.0);
   q = fma_sc(q, r, 1.0 / 362880.0);
   q = fma_sc(q, r, 1.0 / 40320.0);
@@ -262,6 +261,15 @@ __device__ __forceinline__ void spline_locate(double x, double lo, double inv_dx
 // address space and would emit flat_load; they are HBM (global) pointers.
 typedef const double __attribute__((address_space(1))) * gptr_t;
 __device__ __forceinline__ double gload(const double* p, long long idx) { return ((gptr_t)p)[idx]; }
+// A sample inside a workgroup's tile: `origin` (elements) is workgroup-uniform, `boff` the lane's BYTE offset from it.  The
+// load then takes its base from a scalar register pair and a 32-bit vector offset (global_load ... v_off, s[base:base+1]):
+// no 64-bit address arithmetic per column and lane (it was 22 v_lshl_add_u64 per trip at config 2).
+struct SIdx {
+  long long origin;
+  unsigned boff;
+};
+typedef const char __attribute__((address_space(1))) * gbytes_t;
+__device__ __forceinline__ double gload(const double* p, SIdx i) { return *(gptr_t)((gbytes_t)(p + i.origin) + i.boff); }
 
 // ---- evaluation context --------------------------------------------------------------------
 struct Ctx {
@@ -317,7 +325,7 @@ struct Term<GWI_TERM_POWERLAW> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double lx;
   };
@@ -345,7 +353,7 @@ struct Term<GWI_TERM_PLPEAK> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -403,7 +411,7 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -447,7 +455,7 @@ struct Term<GWI_TERM_BETA> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -488,7 +496,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double dxi, dsg;
   };
@@ -533,7 +541,7 @@ struct Term<GWI_TERM_TRUNCNORM> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double dmu, dsg;
   };
@@ -573,7 +581,7 @@ struct Term<GWI_TERM_POWERLAW_REDSHIFT> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double l1pz;
   };
@@ -601,7 +609,7 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double t;
     int k;  // -1: outside the domain of a zero-outside basis (factor 1, no gradient)
@@ -643,7 +651,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double t, inv_f;
     int k;
@@ -681,7 +689,7 @@ struct Term<GWI_TERM_TILT_JOINT> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -741,7 +749,7 @@ struct Term<GWI_TERM_SMOOTH> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double dd;
   };
@@ -769,7 +777,7 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -838,7 +846,7 @@ struct Term<GWI_TERM_POWERLAW_BOUNDS> {
   struct In {
     double x0, x1;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) {
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
     in.x0 = gload(tc[0], idx);
     in.x1 = gload(tc[1], idx);
   }
@@ -876,7 +884,7 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   struct In {
     double x0;
   };
-  __device__ static void load(const double* const* tc, long long idx, In& in) { in.x0 = gload(tc[0], idx); }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x0 = gload(tc[0], idx); }
   struct State {
     double t0, t1, f;
     int k0, k1;  // -1: node contributes nothing (outside a zero-outside basis, or zero blend weight)
@@ -930,7 +938,7 @@ struct Chain<U> {
   static constexpr bool kSpline = false;
   static constexpr int kNumAcc = 0;
   __device__ void init() {}
-  __device__ void load(int, int, int, const Ctx&, long long) {}
+  __device__ void load(int, int, int, const Ctx&, SIdx) {}
   __device__ void advance() {}
   __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
   __device__ void accumulate(int, int, const Ctx&, double) {}
@@ -949,7 +957,7 @@ struct Chain<U, K, Rest...> {
     Term<K>::init(acc);
     rest.init();
   }
-  __device__ void load(int buf, int u, int ti, const Ctx& c, long long idx) {
+  __device__ void load(int buf, int u, int ti, const Ctx& c, SIdx idx) {
     Term<K>::load(c.tcols[ti], idx, in[buf][u]);
     rest.load(buf, u, ti + 1, c, idx);
   }
@@ -1411,17 +1419,19 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // every condition on (i - lane) is wave-uniform, every condition on (i - tid) workgroup-uniform.  Loads for the
   // NEXT trip are issued before the current trip is evaluated (register double buffer).
   double kap[2][kU];
-  auto issue_loads = [&](int buf, long long i) {
+  // sample positions are 32-bit offsets from the tile's first sample (`start`): every comparison below is a 32-bit one
+  const int n_tile = (int)(end - start);
+  auto issue_loads = [&](int buf, int i) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const long long iu = i + (long long)u * kBlock;
-      if (iu - lane >= end) continue;  // wave-uniform: no u-th sample for this wave
-      const long long idx = base + (iu < end ? iu : end - 1);
+      const int iu = i + u * kBlock;
+      if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
+      const SIdx idx{base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
       kap[buf][u] = gload(kappa_col, idx);
       chain.load(buf, u, 0, ctx, idx);
     }
   };
-  const long long i0 = start + tid;
+  const int i0 = tid;
   GWI_STAMP(1);
 
   // shared mode: the workgroup-wide reference exponent and whether it has been fixed yet.  Both are workgroup-uniform
@@ -1433,42 +1443,42 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   constexpr double kRefSlack = 150.0;
   // two-pass mode (shared only): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
   for (int pass_ = (SAFE && kShared && a.two_pass) ? 0 : 1; pass_ < 2; ++pass_) {
-    if (i0 - lane < end) issue_loads(0, i0);
+    if (i0 - lane < n_tile) issue_loads(0, i0);
 #ifdef GWI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
     GWI_STAMP(2);
 #endif
     int trip = 0;
     // shared mode iterates whole-workgroup trips (a barrier may sit inside); otherwise a wave stops with its samples
-    for (long long i = i0; kShared ? (i - tid < end) : (i - lane < end); i += kU * kBlock, ++trip) {
+    for (int i = i0; kShared ? (i - tid < n_tile) : (i - lane < n_tile); i += kU * kBlock, ++trip) {
       // loop-invariant mode flags, laundered so that the compiler keeps ONE copy of the loop body instead of one per
       // combination (unswitching): the branches on them are scalar and cost nothing next to the body
       int pass = pass_, det = (SAFE && kShared) ? a.deterministic : 0;
       if (SAFE) asm volatile("" : "+s"(pass), "+s"(det));
-      const bool wave_has = i - lane < end;  // wave-uniform
-      const long long i_next = i + kU * kBlock;
-      const bool has_next = i_next - lane < end;  // wave-uniform
+      const bool wave_has = i - lane < n_tile;  // wave-uniform
+      const int i_next = i + kU * kBlock;
+      const bool has_next = i_next - lane < n_tile;  // wave-uniform
       if (has_next) issue_loads(1, i_next);
       double ell[kU], lin[kU];
       bool live[kU];
       double mx_lane = GWI_NEG_INF;
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const long long iu = i + (long long)u * kBlock;
-        if ((kShared && !wave_has) || (u > 0 && iu - lane >= end)) {  // wave-uniform: this wave has no u-th sample
+        const int iu = i + u * kBlock;
+        if ((kShared && !wave_has) || (u > 0 && iu - lane >= n_tile)) {  // wave-uniform: this wave has no u-th sample
           live[u] = false;
           ell[u] = GWI_NEG_INF;
           lin[u] = 0.0;
           continue;
         }
-        const bool valid = iu < end;
+        const bool valid = iu < n_tile;
         lin[u] = 1.0;
         ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
         // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
         live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
         if (!live[u]) ell[u] = GWI_NEG_INF;
         if (WRITE_LOGW) {
-          if (valid) logw[base + iu] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
+          if (valid) logw[base + start + iu] = live[u] ? ell[u] + log(lin[u]) : GWI_NEG_INF;
         }
         mx_lane = fmax(mx_lane, ell[u]);
       }
@@ -1497,7 +1507,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
               if (wave_has && (!det || turn == wave)) {
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                  if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+                  if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
                   double w = live[u] ? lin[u] * fast_exp(ell[u] - m_ref) : 0.0;
                   if (a.square) w *= w;
                   s1 += w;
@@ -1523,7 +1533,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          if (u > 0 && i + (long long)u * kBlock - lane >= end) continue;
+          if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
           double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
           if (a.square) w *= w;
           s1 += w;

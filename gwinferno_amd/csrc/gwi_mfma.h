@@ -87,7 +87,7 @@ template <int U>
 struct MChain<U> {
   static constexpr int kNumAcc = 0, kTiles = 0;
   __device__ void init() {}
-  __device__ void load(int, int, int, const Ctx&, long long) {}
+  __device__ void load(int, int, int, const Ctx&, SIdx) {}
   __device__ void advance() {}
   __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
   __device__ void accumulate(int, int, const Ctx&, double, int) {}
@@ -113,7 +113,7 @@ struct MChain<U, KT, Rest...> {
     for (int t = 0; t < NT; ++t) tile[t] = v4d{0.0, 0.0, 0.0, 0.0};
     rest.init();
   }
-  __device__ void load(int buf, int u, int ti, const Ctx& c, long long idx) {
+  __device__ void load(int buf, int u, int ti, const Ctx& c, SIdx idx) {
     Term<K>::load(c.tcols[ti], idx, in[buf][u]);
     rest.load(buf, u, ti + 1, c, idx);
   }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const long long s = first + 16 * u + 4 * wave + q;
-      const long long idx = base + (s < end ? s : end - 1);
+      const SIdx idx{base + start, (unsigned)((s < end ? s : end - 1) - start) << 3};
       kap[buf][u] = gload(kappa_col, idx);
       chain.load(buf, u, 0, ctx, idx);
     }

@@ -11,11 +11,12 @@ for i,l in enumerate(lines):
     m=re.match(r'^(\.LBB\d+_\d+):',l)
     if m: labels[m.group(1)]=i
 best=None
+def valu(span): return sum(1 for l in lines[span[0]:span[1]] if l.strip().startswith('v_'))
 for i,l in enumerate(lines):
     m=re.search(r's_cbranch_\w+\s+(\.LBB\d+_\d+)',l) or re.search(r's_branch\s+(\.LBB\d+_\d+)',l)
     if m and m.group(1) in labels and labels[m.group(1)]<i:
         span=(labels[m.group(1)],i)
-        if best is None or span[1]-span[0]>best[1]-best[0]: best=span
+        if best is None or valu(span)>valu(best): best=span   # the loop with the most vector instructions (the sample loop)
 def stats(a,b):
     c=Counter()
     for l in lines[a:b]:
