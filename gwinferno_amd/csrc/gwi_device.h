@@ -313,6 +313,14 @@ __device__ __forceinline__ void spline_scatter(const Ctx& c, int first, const Ta
 // (spline coefficients).
 template <int K>
 struct Term;
+// Terms whose linear factor is a SUM of exponentials (the PL+Peak mixtures) can take the sample's closing factor
+// exp(l - m) into their own exponents: (1-lam) e^{a1 + E} + lam e^{a2 + E} instead of ((1-lam) e^{a1} + lam e^{a2}) e^{E},
+// one exp per sample less (a quarter of config 2's).  The chain evaluates the first such term LAST (Chain::finish), once
+// E = l - m is known; its gradient states are ratios of the shifted parts, which the common factor leaves alone.
+template <int K>
+struct Absorbs {
+  static constexpr bool value = false;
+};
 
 #define GWI_ACC1(member)                                                                    \
   __device__ static void init(Acc& a) { a.member = 0; }                                     \
@@ -364,13 +372,17 @@ struct Term<GWI_TERM_PLPEAK> {
     double g[4];
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    return eval_shifted<false>(t, d, c, in, s, lin, 0.0);
+  }
+  template <bool SHIFT>
+  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E) {
     const double x = in.x0;
     const double lx = in.x1;
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;
-    const double e_pl = fast_exp(alpha * lx + d[0]);
-    const double e_tn = fast_exp(-0.5 * dx2 * d[5] + d[2]);
+    const double e_pl = fast_exp(SHIFT ? fma(alpha, lx, d[0] + E) : alpha * lx + d[0]);
+    const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
     const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
@@ -788,6 +800,10 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     double g[5];
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
+    return eval_shifted<false>(t, d, c, in, s, lin, 0.0);
+  }
+  template <bool SHIFT>
+  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E) {
     const double x = in.x0;
     const double lx = in.x1;
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
@@ -795,8 +811,8 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     const double dx2 = dx * dx;
     double dlogS;
     const double S = taper(x - t.p0, c.theta[t.th4], dlogS);
-    const double e_pl = fast_exp(alpha * lx + d[0]) * S;
-    const double e_tn = fast_exp(-0.5 * dx2 * d[5] + d[2]);
+    const double e_pl = fast_exp(SHIFT ? fma(alpha, lx, d[0] + E) : alpha * lx + d[0]) * S;
+    const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
     const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
@@ -833,6 +849,15 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     th[3] = t.th3;
     th[4] = t.th4;
   }
+};
+
+template <>
+struct Absorbs<GWI_TERM_PLPEAK> {
+  static constexpr bool value = true;
+};
+template <>
+struct Absorbs<GWI_TERM_PLPEAK_SMOOTH> {
+  static constexpr bool value = true;
 };
 
 // x^alpha on [lo, hi] with the bounds themselves hyper-parameters (numpyro_distributions.py:101-136: Powerlaw with
@@ -931,28 +956,35 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
 // ---- compile-time chain of terms.  U = samples per lane per trip; inputs are double-buffered in
 //      registers (in[0] = current trip, in[1] = next trip) so the column loads of trip k+1 are in
 //      flight while trip k is being evaluated. ----------------------------------------------------------
-template <int U, int... Ks>
-struct Chain;
-template <int U>
-struct Chain<U> {
+//      TAKEN: a term further up the chain already absorbs the closing exponent (Absorbs<K>); the first absorbing term is
+//      left out of eval() and evaluated by finish(), with the exponent l - m folded into its own.
+template <int U, bool TAKEN, int... Ks>
+struct ChainImpl;
+template <int U, bool TAKEN>
+struct ChainImpl<U, TAKEN> {
   static constexpr bool kSpline = false;
+  static constexpr bool kAbsorb = false;
   static constexpr int kNumAcc = 0;
   __device__ void init() {}
   __device__ void load(int, int, int, const Ctx&, SIdx) {}
   __device__ void advance() {}
   __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
+  __device__ void finish(int, int, const Ctx&, double&, double) {}
   __device__ void accumulate(int, int, const Ctx&, double) {}
   __device__ void rescale(double) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
 };
-template <int U, int K, int... Rest>
-struct Chain<U, K, Rest...> {
-  static constexpr bool kSpline = Term<K>::kSpline || Chain<U, Rest...>::kSpline;
-  static constexpr int kNumAcc = Term<K>::kNumAcc + Chain<U, Rest...>::kNumAcc;
+template <int U, bool TAKEN, int K, int... Rest>
+struct ChainImpl<U, TAKEN, K, Rest...> {
+  static constexpr bool kDefer = !TAKEN && Absorbs<K>::value;
+  using RestT = ChainImpl<U, TAKEN || kDefer, Rest...>;
+  static constexpr bool kSpline = Term<K>::kSpline || RestT::kSpline;
+  static constexpr bool kAbsorb = kDefer || RestT::kAbsorb;
+  static constexpr int kNumAcc = Term<K>::kNumAcc + RestT::kNumAcc;
   typename Term<K>::In in[2][U];
   typename Term<K>::State st[U];
   typename Term<K>::Acc acc;
-  Chain<U, Rest...> rest;
+  RestT rest;
   __device__ void init() {
     Term<K>::init(acc);
     rest.init();
@@ -967,8 +999,19 @@ struct Chain<U, K, Rest...> {
     rest.advance();
   }
   __device__ double eval(int u, int ti, const Ctx& c, double& lin) {
-    const double l = Term<K>::eval(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin);
-    return l + rest.eval(u, ti + 1, c, lin);
+    if constexpr (kDefer) {
+      return rest.eval(u, ti + 1, c, lin);
+    } else {
+      const double l = Term<K>::eval(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin);
+      return l + rest.eval(u, ti + 1, c, lin);
+    }
+  }
+  // the deferred term: lin *= its density times exp(E)
+  __device__ void finish(int u, int ti, const Ctx& c, double& lin, double E) {
+    if constexpr (kDefer)
+      Term<K>::template eval_shifted<true>(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin, E);
+    else
+      rest.finish(u, ti + 1, c, lin, E);
   }
   __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
     Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
@@ -983,6 +1026,9 @@ struct Chain<U, K, Rest...> {
     rest.collect(ti + 1, c, vals + Term<K>::kNumAcc, th + Term<K>::kNumAcc);
   }
 };
+
+template <int U, int... Ks>
+using Chain = ChainImpl<U, false, Ks...>;
 
 // ---- grid normalisers (interpolation.py:280-291, parametric.py:123-124, spline_perturbation.py:323-336):
 //      Z_j = sum_g tw_g exp(lb_g + (theta+add) l1_g + spline(us_g)), one workgroup per normaliser.
@@ -1474,6 +1520,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         const bool valid = iu < n_tile;
         lin[u] = 1.0;
         ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
+        if constexpr (WRITE_LOGW && ChainT::kAbsorb) chain.finish(u, 0, ctx, lin[u], 0.0);  // the log-weight wants the plain density
         // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
         live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
         if (!live[u]) ell[u] = GWI_NEG_INF;
@@ -1482,6 +1529,17 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         }
         mx_lane = fmax(mx_lane, ell[u]);
       }
+      // the weight of sample u against the reference exponent: L exp(l - ref), the exponential folded into the chain's
+      // absorbing term where it has one (which is evaluated here, last); a zero, overflowing or NaN density counts as 0
+      auto weight = [&](int u, double ref) -> double {
+        if constexpr (ChainT::kAbsorb && !WRITE_LOGW) {
+          double f = lin[u];
+          chain.finish(u, 0, ctx, f, ell[u] - ref);
+          return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+        } else {
+          return live[u] ? lin[u] * fast_exp(ell[u] - ref) : 0.0;
+        }
+      };
       if (kShared) {
         if (SAFE && pass == 0) {
           lane_max = fmax(lane_max, mx_lane);
@@ -1508,7 +1566,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                   if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
-                  double w = live[u] ? lin[u] * fast_exp(ell[u] - m_ref) : 0.0;
+                  double w = weight(u, m_ref);
                   if (a.square) w *= w;
                   s1 += w;
                   s2 += w * w;
@@ -1520,21 +1578,26 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
           }
         }
       } else if (!WRITE_LOGW) {
-        const double mx = wave_max(mx_lane);
-        if (mx > m) {  // wave-uniform: move every running sum to the new reference exponent
-          if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
-            double sc = fast_exp(m - mx);
-            if (a.square) sc *= sc;
-            s1 *= sc;
-            s2 *= sc * sc;
-            chain.rescale(sc);
+        // The wave's reference exponent m is set by the first trip that holds a live sample and moves only when a later
+        // sample outruns it by more than kRefSlack (any reference within that distance is exact to rounding, see above):
+        // the other trips pay one compare + ballot instead of the 20-instruction DPP maximum.
+        if (m == GWI_NEG_INF || __builtin_amdgcn_ballot_w64(mx_lane > m + kRefSlack) != 0) {  // wave-uniform
+          const double mx = wave_max(mx_lane);
+          if (mx > m) {  // move every running sum to the new reference exponent
+            if (m != GWI_NEG_INF) {  // nothing accumulated yet on the first trip
+              double sc = fast_exp(m - mx);
+              if (a.square) sc *= sc;
+              s1 *= sc;
+              s2 *= sc * sc;
+              chain.rescale(sc);
+            }
+            m = mx;
           }
-          m = mx;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
-          double w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+          double w = weight(u, m);
           if (a.square) w *= w;
           s1 += w;
           s2 += w * w;
