@@ -237,6 +237,13 @@ class Run:
                 dist.init_process_group(backend)
             self.dist = dist
             self.backend = backend
+        # Bring torch's device context (and, for N > 1, the barrier's communicator) up NOW: their lazy start-up inside the
+        # fence just ahead of the timed region would leave the GPU idle for tens to hundreds of milliseconds after the warm-up,
+        # long enough for its clocks to drop, and the first timed steps would run at them.
+        if torch.cuda.is_available():
+            if self.dist is not None:
+                self.dist.barrier()
+            torch.cuda.synchronize()
 
     def fence(self):
         if self.dist is not None:
