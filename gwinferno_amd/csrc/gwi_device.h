@@ -1363,7 +1363,8 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
 // injections.  Loads are coalesced: lane i of a wave reads element base+i of each column; each lane
 // carries kU samples (256 apart) per trip so polynomial constants, the wave maximum and the loop
 // overhead are shared between them.
-constexpr int kRedChunk = 8;  // values per pass of the block-level transposed reduction (16 KiB LDS)
+constexpr int kRedChunk = 8;
+constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular (non-SAFE) scan kernels  // values per pass of the block-level transposed reduction (16 KiB LDS)
 
 #ifndef GWI_SCAN_WAVES_PER_EU
 #define GWI_SCAN_WAVES_PER_EU 1
@@ -1424,7 +1425,12 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
   if (ChainT::kSpline)
     for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
-  const int n_rows = a.n_theta << a.gacc_shift;  // doubles in the shared rows
+  // Replicas per coefficient: the regular kernels are built for 16 (the four rows of a sample then sit at immediate
+  // offsets of one LDS address: three address adds per spline term and sample less); the SAFE instantiation takes the
+  // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
+  const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
+  const int rep = 1 << rep_shift;
+  const int n_rows = a.n_theta << rep_shift;  // doubles in the shared rows
   if (kShared)
     for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
@@ -1436,8 +1442,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   ctx.theta = theta_src;
   ctx.derived = batch ? a.tblocks[kb].derived : a.derived;
   ctx.coefs = s_theta;
-  ctx.gacc = s_gacc + (lane & (a.gacc_rep - 1));
-  ctx.rep_shift = a.gacc_shift;
+  ctx.gacc = s_gacc + (lane & (rep - 1));
+  ctx.rep_shift = rep_shift;
   double* logw;
   if (b < n_pe_blocks) {
     const int e = b / a.tiles_per_event;
@@ -1684,9 +1690,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double g = s_out[p];
     if (kShared) {
-      const double* rows = s_gacc + ((long)p << a.gacc_shift);
+      const double* rows = s_gacc + ((long)p << rep_shift);
       double gw = 0.0;
-      for (int r = 0; r < a.gacc_rep; ++r) gw += rows[(r + p) & (a.gacc_rep - 1)];  // rotated start: the threads of a wave read different banks
+      for (int r = 0; r < rep; ++r) gw += rows[(r + p) & (rep - 1)];  // rotated start: the threads of a wave read different banks
       g += gw;
     }
     out[kRecHeader + p] = g;

@@ -581,7 +581,8 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   // two-pass repeats and the replay mode run the SAFE instantiation (spline models; it takes single and batched launches)
-  const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic);
+  // ... and so does any replica count other than the 16 the regular kernels are built for (GWI_GACC_REP)
+  const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
   ScanFn fn = logw ? h->variant->logw : (safe ? h->variant->scan_safe : (batch ? h->variant->scan_batch : h->variant->scan));
   h->scan_is_safe = safe;
   h->kargs.k_batch = batch ? K : 1;
@@ -1343,8 +1344,11 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(h->variant->scan)) == hipSuccess && fa.sharedSizeBytes > 0) static_lds = fa.sharedSizeBytes;
     int occ0 = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, h->variant->scan, kBlock, 0) != hipSuccess || occ0 < 1) occ0 = 2;
-    rep = 16;
-    while (rep > 1 && (sizeof(double) * (size_t)spec->n_theta * rep + static_lds) * (size_t)occ0 > lds_per_cu) rep >>= 1;
+    // 16 replicas: what the regular scan kernels are compiled for (immediate row offsets).  Where rows that wide cost a
+    // resident workgroup (n_theta beyond ~100), that is the cheaper loss: 8 replicas measured 20 % slower at config 5.
+    // Any other count (GWI_GACC_REP, the replay mode's 64) runs the SAFE instantiation, which takes it at run time.
+    rep = 1 << kRegularRepShift;
+    (void)occ0;
     if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
     if (h->deterministic) rep = 64;  // one replica per lane: a wave instruction never meets itself on an address
     if (rep < 1) rep = 1;
