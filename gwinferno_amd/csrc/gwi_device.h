@@ -251,7 +251,7 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
 __device__ __forceinline__ void spline_locate(double x, double lo, double inv_dx, int n_basis, int& k, double& t) {
   const double u = (x - lo) * inv_dx;
   const int last = n_basis - 4;  // index of the last interval
-  int kk = (int)floor(u);
+  int kk = (int)u;  // truncation == floor wherever the clamp below does not decide anyway (u < 0 -> 0; NaN -> 0; overflow saturates)
   kk = max(0, min(kk, last));
   k = kk;
   t = u - (double)kk;
@@ -635,13 +635,11 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-    if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {
-      // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175)
-      if (!((x >= t.p0) && (x <= t.p1))) {
-        k = -1;
-        v = 0.0;
-      }
-    }
+    // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175).  ONE predicate (the flag is
+    // wave-uniform: a scalar AND with the lane mask), so each of k and v costs one select, not two
+    const bool outside = (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0 && !((x >= t.p0) && (x <= t.p1));
+    k = outside ? -1 : k;
+    v = outside ? 0.0 : v;
     s.t = tt;
     s.k = k;
     return v;
