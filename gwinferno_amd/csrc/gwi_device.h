@@ -635,9 +635,12 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-    // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175).  ONE predicate (the flag is
-    // wave-uniform: a scalar AND with the lane mask), so each of k and v costs one select, not two
-    const bool outside = (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0 && !((x >= t.p0) && (x <= t.p1));
+    // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175).  The flag is wave-uniform: it
+    // picks the bounds (scalar selects) instead of entering the lane predicate, so each of k and v costs ONE vector
+    // select (as `if (flag) if (outside)` it was two; as `flag && outside` the config-3 kernel went from 165 to 193 VGPRs)
+    const bool chk = (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0;
+    const double lo_eff = chk ? t.p0 : GWI_NEG_INF, hi_eff = chk ? t.p1 : GWI_POS_INF;
+    const bool outside = !((x >= lo_eff) && (x <= hi_eff));
     k = outside ? -1 : k;
     v = outside ? 0.0 : v;
     s.t = tt;
