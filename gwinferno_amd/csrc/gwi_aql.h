@@ -36,6 +36,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <vector>
 
 namespace gwi {
 namespace aql {
@@ -98,6 +99,7 @@ struct Device {
   std::mutex mu;
   std::vector<SharedQueue*> queues;  // created together on first use, never destroyed (process lifetime)
   unsigned next_engine = 0;
+  volatile uint32_t* hdp_mem_flush = nullptr;  // HSA_AMD_AGENT_INFO_HDP_FLUSH: the device's host-data-path flush register (user-mode mapping), if exposed
 };
 
 // one per engine: its queue (shared) and its own ring of kernel-argument slots
@@ -106,6 +108,7 @@ struct Queue {
   SharedQueue* sq = nullptr;
   char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable; followed by kExtraBytes of host-writable device memory for the engine (theta blocks of batched launches)
   unsigned next_slot = 0;
+  std::vector<char> tail_shadow[2];  // dispatch_tail: the fixed head last written into each of its two slots
   hsa_signal_t done[3] = {{0}, {0}, {0}};  // completion signals of the scan / combine / final packets of a TIMED evaluation
   bool have_signals = false;
   bool failed() const { return sq && sq->failed; }
@@ -239,6 +242,10 @@ inline Device* open_device(uint32_t domain, uint32_t bus, uint32_t device, uint3
     return d;
   }
   d->gpu = as.gpu, d->cpu = as.cpu;
+  {
+    hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
+    if (a.agent_get_info(d->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp) == HSA_STATUS_SUCCESS) d->hdp_mem_flush = hdp.HDP_MEM_FLUSH_CNTL;
+  }
   PoolSearch ps;
   a.iterate_pools(d->gpu, visit_pool, &ps);
   if (!ps.have) {
@@ -428,28 +435,52 @@ inline bool readback_enabled() {
   }();
   return on;
 }
+// How bytes written through the BAR are handed over before a packet that reads them is published (GWI_AQL_HANDOFF):
+//   readback (default): read the last byte written back through the BAR -- a non-posted read cannot pass the posted writes
+//                       ahead of it, and its completion means the device's host data path has retired them;
+//   hdp:                write the device's HDP flush register and read it back (what ROCclr's device-kernarg path does);
+//   none:               sfence only (A/B timing; GWI_AQL_READBACK=0 is the older spelling).
+enum class Handoff { kReadback, kHdp, kNone };
+inline Handoff handoff_mode() {
+  static const Handoff m = [] {
+    if (!readback_enabled()) return Handoff::kNone;
+    const char* e = std::getenv("GWI_AQL_HANDOFF");
+    if (e && std::strcmp(e, "hdp") == 0) return Handoff::kHdp;
+    if (e && std::strcmp(e, "none") == 0) return Handoff::kNone;
+    return Handoff::kReadback;
+  }();
+  return m;
+}
+// after the sfence: true unless the read-back saw a byte other than `expect`
+inline bool settle(const Device* dev, const char* last_byte_written, unsigned char expect) {
+  const Handoff m = handoff_mode();
+  if (m == Handoff::kHdp && dev && dev->hdp_mem_flush) {
+    *dev->hdp_mem_flush = 1u;
+    (void)*dev->hdp_mem_flush;
+    return true;
+  }
+  if (m == Handoff::kNone) return true;
+  return *reinterpret_cast<const volatile unsigned char*>(last_byte_written) == expect;
+}
+
 // steps 1-2: copy an argument block into ring slot `slot` and hand it over to the device; nullptr on failure
 inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_bytes) {
   if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes == 0 || slot >= kSlots) return nullptr;
   char* ka = q.kernarg + (size_t)slot * kSlotBytes;
   std::memcpy(ka, args, arg_bytes);
   _mm_sfence();
-  if (readback_enabled()) {
-    const volatile unsigned char* last = reinterpret_cast<const volatile unsigned char*>(ka + arg_bytes - 1);
-    const unsigned char seen = *last;
-    if (seen != static_cast<const unsigned char*>(args)[arg_bytes - 1]) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
-      q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
-      q.sq->failed = true;
-      return nullptr;
-    }
+  if (!settle(q.dev, ka + arg_bytes - 1, static_cast<const unsigned char*>(args)[arg_bytes - 1])) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
+    q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
+    q.sq->failed = true;
+    return nullptr;
   }
   return ka;
 }
 
 // hand over bytes the caller wrote itself into host-writable device memory (the extra area): drain + read back the last byte
-inline void handoff(const char* last_byte_written) {
+inline void handoff(const Queue& q, const char* last_byte_written) {
   _mm_sfence();
-  if (readback_enabled()) (void)*reinterpret_cast<const volatile unsigned char*>(last_byte_written);
+  (void)settle(q.dev, last_byte_written, 0);
 }
 
 // steps 3-4 for an argument block that is already in place (stage_args)
@@ -481,10 +512,48 @@ inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x
 // the rotating slots hold per-evaluation argument blocks; the last kPersistentSlots are written once (gwi_create) for
 // launches whose arguments never change -- those dispatches need no per-evaluation hand-off at all
 constexpr unsigned kPersistentSlots = 4;
+constexpr unsigned kTailSlots = 2;  // dispatch_tail's two slots sit below the persistent ones
+constexpr unsigned kRingSlots = kSlots - kPersistentSlots - kTailSlots;
 inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_bytes, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
                      hsa_signal_t completion = hsa_signal_t{0}) {
   if (arg_bytes > k.kernarg_bytes + 0u) return false;
-  char* ka = stage_args(q, q.next_slot++ % (kSlots - kPersistentSlots), args, arg_bytes);
+  char* ka = stage_args(q, q.next_slot++ % kRingSlots, args, arg_bytes);
+  return dispatch_staged(q, k, ka, grid_x_blocks, grid_y_blocks, block_threads, dynamic_lds, completion);
+}
+
+// An argument block whose first `head_bytes` never change between launches (pointers, sizes, descriptors) and whose tail
+// does (the hyper-parameters): the block keeps its place in one of two slots (`parity` alternates, so the block of the
+// launch before is never the one being rewritten) and only the `n_ranges` byte ranges of the tail travel through the BAR --
+// a few hundred bytes instead of 3.5 KB per evaluation (the BAR write of the whole block was 1.2 us of host time on the
+// critical path).  The head is compared with what the slot holds (a host-side copy) and rewritten whole when it differs.
+// Same hand-off as stage_args: sfence, read-back of the last byte written.
+inline bool dispatch_tail(Queue& q, const Kernel& k, unsigned parity, const void* args, size_t head_bytes, size_t arg_bytes, const size_t (*ranges)[2], int n_ranges,
+                          uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds, hsa_signal_t completion = hsa_signal_t{0}) {
+  if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u || head_bytes > arg_bytes || n_ranges < 1) return false;
+  parity &= 1u;
+  char* ka = q.kernarg + (size_t)(kRingSlots + parity) * kSlotBytes;
+  const char* src = static_cast<const char*>(args);
+  std::vector<char>& shadow = q.tail_shadow[parity];
+  size_t last;
+  if (shadow.size() != head_bytes || std::memcmp(shadow.data(), src, head_bytes) != 0) {
+    std::memcpy(ka, src, arg_bytes);
+    shadow.assign(src, src + head_bytes);
+    last = arg_bytes - 1;
+  } else {
+    last = 0;
+    for (int r = 0; r < n_ranges; ++r) {
+      if (ranges[r][1] == 0) continue;
+      if (ranges[r][0] < head_bytes || ranges[r][0] + ranges[r][1] > arg_bytes) return false;
+      std::memcpy(ka + ranges[r][0], src + ranges[r][0], ranges[r][1]);
+      if (ranges[r][0] + ranges[r][1] - 1 > last) last = ranges[r][0] + ranges[r][1] - 1;
+    }
+  }
+  _mm_sfence();
+  if (!settle(q.dev, ka + last, static_cast<const unsigned char*>(args)[last])) {
+    q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
+    q.sq->failed = true;
+    return false;
+  }
   return dispatch_staged(q, k, ka, grid_x_blocks, grid_y_blocks, block_threads, dynamic_lds, completion);
 }
 

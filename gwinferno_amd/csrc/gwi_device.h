@@ -97,15 +97,18 @@ struct KArgs {
   int gacc_rep, gacc_shift;  // spline-gradient LDS rows: replicas per coefficient (power of two <= 64) and log2 of it
   double* norm_out_host;               // pinned host: Z_j of hyper-parameter point k at [k * n_norms + j]
   unsigned long long* norm_stamps_host;  // pinned host: completion stamp per (k, j)
-  unsigned long long norm_seq;            // = the evaluation's sequence number
   unsigned long long* seq_dev;            // device word: the scan publishes norm_seq here for the tail launches
   unsigned long long* redo_host;          // pinned host word: a workgroup whose fixed reference exponent turned out too low stores norm_seq here
   unsigned long long* redo_dev;           // ... and here (device word, read by final_kernel: the sharded path's record carries the request to every rank)
+  TermD terms[GWI_MAX_TERMS];
+  // ---- everything ABOVE is fixed at gwi_create; what follows changes from one evaluation to the next.  On the AQL path the
+  //      block lives in a persistent kernel-argument slot in device memory and only this tail is rewritten through the PCIe
+  //      BAR per evaluation (aql::dispatch_tail): a few hundred bytes instead of 3.5 KB
+  unsigned long long norm_seq;            // = the evaluation's sequence number
   int two_pass, deterministic;            // two_pass: find each tile's exact maximum first; deterministic: waves take turns at the shared rows
   int square, k_batch;     // k_batch: hyper-parameter points of a batched launch (scan_mfma_kernel: 16 per grid row); square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
-  TermD terms[GWI_MAX_TERMS];
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
 };

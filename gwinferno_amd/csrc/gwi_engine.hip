@@ -23,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace gwi;
@@ -383,6 +384,8 @@ struct gwi_engine {
   bool scan_is_batch = false;
   int aql_tail_variant = 0;        // 0: single evaluation, 1 / 2: batched without / with the per-event sites
   bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
+  bool aql_tail_only = true;  // scan launches rewrite only the per-evaluation tail of their argument block (GWI_AQL_TAIL=0: the whole block)
+  unsigned tail_parity = 0; // which of the two persistent scan-argument slots the next launch rewrites (aql::dispatch_tail)
   bool aql_active = false;  // queue, argument ring and the three kernels are ready
   char* aq_tail_args = nullptr;  // persistent kernel-argument slot holding this engine's (constant) TailArgs
   bool aql_now = false;     // the pipeline being issued / awaited went through the AQL queue
@@ -567,9 +570,23 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
       if (aql::dispatch_staged(h->aq, k, staged, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
       return;
     }
-    if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
-    // the queue reported an error: nothing was submitted; the waiters surface it
-    return;
+    if constexpr (std::is_same<A, KArgs>::value) if (!h->aql_tail_only) {  // GWI_AQL_TAIL=0: the whole block into a ring slot per launch (A/B only)
+      (void)aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done);
+      return;
+    }
+    if constexpr (std::is_same<A, KArgs>::value) {
+      // the scan's block: fixed head in place, only the per-evaluation tail through the BAR (aql::dispatch_tail)
+      const size_t off_theta = offsetof(KArgs, theta);
+      const size_t ranges[3][2] = {{offsetof(KArgs, norm_seq), offsetof(KArgs, derived) - offsetof(KArgs, norm_seq)},
+                                   {offsetof(KArgs, derived), sizeof(double) * kMaxDerived * (size_t)h->spec.n_terms},
+                                   {off_theta, used_bytes > off_theta ? used_bytes - off_theta : 0}};
+      (void)aql::dispatch_tail(h->aq, k, h->tail_parity++, &args, offsetof(KArgs, norm_seq), used_bytes, ranges, 3, grid.x, grid.y, block.x, (uint32_t)lds, done);
+      return;  // on a queue error nothing was submitted; the waiters surface it
+    } else {
+      if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
+      // the queue reported an error: nothing was submitted; the waiters surface it
+      return;
+    }
   }
   if (h->timing)
     hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, args);
@@ -694,7 +711,7 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
         std::memcpy(dev[k].theta, h->h_tblocks[k].theta, th_bytes);
         std::memcpy(dev[k].derived, h->h_tblocks[k].derived, der_bytes);
       }
-      aql::handoff(reinterpret_cast<const char*>(dev[K - 1].derived) + der_bytes - 1);
+      aql::handoff(h->aq, reinterpret_cast<const char*>(dev[K - 1].derived) + der_bytes - 1);
       h->kargs.tblocks = dev;
     } else if (h->stage_kernel && K >= 10) {  // below ~20 KiB the runtime's small-copy path is quicker than a launch
       hipLaunchKernelGGL(stage_theta_kernel, dim3(K), dim3(kBlock), 0, h->stream, (const ThetaBlock*)h->h_tblocks_dev, h->d_tblocks);
@@ -1234,6 +1251,7 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
       return;
     }
   }
+  if (const char* env = std::getenv("GWI_AQL_TAIL")) h->aql_tail_only = std::atoi(env) != 0;
   h->aql_active = true;
   h->aql_note = "active";
 }
