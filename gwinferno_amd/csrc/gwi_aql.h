@@ -102,9 +102,13 @@ struct Device {
   volatile uint32_t* hdp_mem_flush = nullptr;  // HSA_AMD_AGENT_INFO_HDP_FLUSH: the device's host-data-path flush register (user-mode mapping), if exposed
 };
 
+enum class Handoff { kReadback, kHdp, kNone };  // see settle()
+inline Handoff handoff_mode_from_env();
+
 // one per engine: its queue (shared) and its own ring of kernel-argument slots
 struct Queue {
   Device* dev = nullptr;
+  Handoff handoff = Handoff::kReadback;
   SharedQueue* sq = nullptr;
   char* kernarg = nullptr;  // ring of kSlots x kSlotBytes in device memory, host-writable; followed by kExtraBytes of host-writable device memory for the engine (theta blocks of batched launches)
   unsigned next_slot = 0;
@@ -331,6 +335,7 @@ inline unsigned pool_size() {
 inline bool open_queue(Device* d, Queue& out, std::string& why) {
   Api& a = api();
   out.dev = d;
+  out.handoff = handoff_mode_from_env();
   {
     std::lock_guard<std::mutex> lock(d->mu);
     if (d->queues.empty()) {
@@ -440,20 +445,15 @@ inline bool readback_enabled() {
 //                       ahead of it, and its completion means the device's host data path has retired them;
 //   hdp:                write the device's HDP flush register and read it back (what ROCclr's device-kernarg path does);
 //   none:               sfence only (A/B timing; GWI_AQL_READBACK=0 is the older spelling).
-enum class Handoff { kReadback, kHdp, kNone };
-inline Handoff handoff_mode() {
-  static const Handoff m = [] {
-    if (!readback_enabled()) return Handoff::kNone;
-    const char* e = std::getenv("GWI_AQL_HANDOFF");
-    if (e && std::strcmp(e, "hdp") == 0) return Handoff::kHdp;
-    if (e && std::strcmp(e, "none") == 0) return Handoff::kNone;
-    return Handoff::kReadback;
-  }();
-  return m;
+inline Handoff handoff_mode_from_env() {  // read when an engine opens its queue
+  if (!readback_enabled()) return Handoff::kNone;
+  const char* e = std::getenv("GWI_AQL_HANDOFF");
+  if (e && std::strcmp(e, "hdp") == 0) return Handoff::kHdp;
+  if (e && std::strcmp(e, "none") == 0) return Handoff::kNone;
+  return Handoff::kReadback;
 }
 // after the sfence: true unless the read-back saw a byte other than `expect`
-inline bool settle(const Device* dev, const char* last_byte_written, unsigned char expect) {
-  const Handoff m = handoff_mode();
+inline bool settle(const Device* dev, Handoff m, const char* last_byte_written, unsigned char expect) {
   if (m == Handoff::kHdp && dev && dev->hdp_mem_flush) {
     *dev->hdp_mem_flush = 1u;
     (void)*dev->hdp_mem_flush;
@@ -469,7 +469,7 @@ inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_by
   char* ka = q.kernarg + (size_t)slot * kSlotBytes;
   std::memcpy(ka, args, arg_bytes);
   _mm_sfence();
-  if (!settle(q.dev, ka + arg_bytes - 1, static_cast<const unsigned char*>(args)[arg_bytes - 1])) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
+  if (!settle(q.dev, q.handoff, ka + arg_bytes - 1, static_cast<const unsigned char*>(args)[arg_bytes - 1])) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
     q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
     q.sq->failed = true;
     return nullptr;
@@ -480,7 +480,7 @@ inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_by
 // hand over bytes the caller wrote itself into host-writable device memory (the extra area): drain + read back the last byte
 inline void handoff(const Queue& q, const char* last_byte_written) {
   _mm_sfence();
-  (void)settle(q.dev, last_byte_written, 0);
+  (void)settle(q.dev, q.handoff, last_byte_written, 0);
 }
 
 // steps 3-4 for an argument block that is already in place (stage_args)
@@ -549,7 +549,7 @@ inline bool dispatch_tail(Queue& q, const Kernel& k, unsigned parity, const void
     }
   }
   _mm_sfence();
-  if (!settle(q.dev, ka + last, static_cast<const unsigned char*>(args)[last])) {
+  if (!settle(q.dev, q.handoff, ka + last, static_cast<const unsigned char*>(args)[last])) {
     q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
     q.sq->failed = true;
     return false;

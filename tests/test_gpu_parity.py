@@ -820,3 +820,46 @@ def test_pinning_a_thread_next_to_the_gpu():
     assert out["subset"] and out["ll"] == ref.log_likelihood and out["changed"] == out["device"]
     assert os.sched_getaffinity(0) == before_main
     eng.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"GWI_AQL_TAIL": "0"},        # the scan's whole argument block into a ring slot per launch
+    {"GWI_AQL_HANDOFF": "hdp"},   # HDP flush register write + read-back instead of the kernel-argument read-back
+    {"GWI_GACC_REP": "8"},        # replica counts other than 16 run the SAFE instantiation of spline models
+    {"GWI_GACC_REP": "32"},
+    {"GWI_AQL": "0"},             # everything on the HIP stream
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_iid"])
+def test_launch_path_variants_agree(comp_name, env, monkeypatch):
+    """The launch-path knobs (argument hand-off, replica count, dispatch path) must not change results: a run of different
+    hyper-parameter points through an engine created under each knob equals the default engine's (values and scalar
+    gradients bit for bit where the reduction order is the same, everything to 1e-12) and the C oracle's (1e-8 of the
+    gradient's scale).  Consecutive DIFFERENT points are what would expose a stale kernel-argument slot."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(20, 700, 9000, seed=31)
+    rng = np.random.default_rng(8)
+    base = COMPOSITIONS[comp_name](pe, inj)
+    eng0 = base.engine()
+    thetas = [base.theta(draw_params(comp_name, rng)) for _ in range(12)]
+    ref = [eng0.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng1 = COMPOSITIONS[comp_name](pe, inj).engine()
+    if "GWI_AQL" in env:
+        assert not eng1.dispatch_info().startswith("aql: active")
+    orc = COracle(eng1.bound)
+    for t, r0 in zip(thetas, ref):
+        r1 = eng1.evaluate(t, total, min_neff_cut=False)
+        same_order = "GWI_GACC_REP" not in env
+        assert rel_err(r1.log_likelihood, r0.log_likelihood) < (1e-15 if same_order else 1e-12)
+        assert np.allclose(r1.log_bfs, r0.log_bfs, rtol=1e-12, atol=0)
+        assert np.allclose(r1.grad, r0.grad, rtol=1e-11, atol=1e-12 * max(1.0, float(np.max(np.abs(r0.grad)))))
+        c = orc.evaluate(t, total, min_neff_cut=False)
+        scale = max(1.0, float(np.max(np.abs(c["grad"]))))
+        assert float(np.max(np.abs(r1.grad - c["grad"]))) / scale < 1e-8
+        assert rel_err(r1.log_likelihood, c["log_likelihood"]) < VALUE_RTOL
+    eng0.close()
+    eng1.close()
