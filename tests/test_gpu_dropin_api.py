@@ -340,10 +340,14 @@ def test_construct_hierarchical_model_matches_the_reference(name):
     L.clear_engine_cache()
 
 
-def test_pipeline_factories_and_example_priors_end_to_end():
+def test_pipeline_factories_and_example_priors_end_to_end(monkeypatch):
     """The reference's B-spline example (examples/simple_bspline_example.py:26-94) through this package: models from
     the pipeline_utils factories (weights == the reference's, tests/golden/pipeline.npz), its priors handed to the
-    library's sampler (bspline_example_prior), the first redshift coefficient pinned to 0 through a FIXED slot."""
+    library's sampler (bspline_example_prior), the first redshift coefficient pinned to 0 through a FIXED slot.
+    The engine runs in replay mode: the test compares two NUTS chains sample by sample, and the last-bit run-to-run
+    differences of spline-coefficient gradients in the regular mode (LDS atomics from four wavefronts) are enough to move a
+    chaotic trajectory past 1e-8 now and then (2 runs in 10)."""
+    monkeypatch.setenv("GWI_DETERMINISTIC", "1")
     import json
     import os
 
