@@ -677,6 +677,8 @@ def rccl_variant(run, cfg, steps, out):
         else:
             res = {"error": "ncclCommInitRank failed on some rank"}
         eng.close()
+    except Exception as exc:  # the headline results are complete: report the variant's failure instead of losing the line
+        res = {"error": f"{type(exc).__name__}: {exc}"}
     finally:
         dog.cancel()
     if run.rank == 0:
