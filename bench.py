@@ -740,9 +740,6 @@ def main():
             out["configs"] = blocks
     if run.dist is not None and run.backend == "nccl" and run.shared_devices is None and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0":
         rccl_variant(run, args.config, args.steps, out if run.rank == 0 else {"multi_gpu": {}})
-    if run.dist is not None:
-        run.dist.barrier()
-        run.dist.destroy_process_group()
     if run.rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last
         import ctypes
@@ -753,6 +750,17 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
+    if run.dist is not None:
+        # the line is out: a rank that does not come back from the shutdown (a peer lost in the RCCL variant) must not
+        # hold the run
+        import threading
+
+        dog = threading.Timer(60.0, lambda: os._exit(0))
+        dog.daemon = True
+        dog.start()
+        run.dist.barrier()
+        run.dist.destroy_process_group()
+        dog.cancel()
 
 
 if __name__ == "__main__":
