@@ -339,6 +339,13 @@ struct gwi_engine {
   double *h_ev = nullptr, *h_ev_dev = nullptr;
   // host-final mode: per-group result rows + normaliser values in pinned host memory
   bool host_final = false;
+  // launch geometry of batched launches (K >= 4, device-final) where it differs from the single evaluation's: two trips
+  // per workgroup instead of one (gwi_create)
+  struct BatchGeometry {
+    bool distinct = false;
+    int chunk_pe = 0, chunk_inj = 0, tiles_per_event = 0, n_inj_tiles = 0, n_scan_blocks = 0, tiles_per_inj_group = 0, n_inj_groups = 0;
+  } bgeo;
+  bool use_bgeo = false;  // the pipeline being issued runs on bgeo
   double *h_rows = nullptr, *h_rows_dev = nullptr;
   double *h_norm = nullptr, *h_norm_dev = nullptr;                    // pinned: Z_j
   unsigned long long *h_norm_stamp = nullptr, *h_norm_stamp_dev = nullptr;  // pinned: per-normaliser stamps
@@ -596,7 +603,7 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
 
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
-  const int grid = h->n_scan_blocks + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
+  const int grid = (h->use_bgeo && !logw ? h->bgeo.n_scan_blocks : h->n_scan_blocks) + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   // two-pass repeats and the replay mode run the SAFE instantiation (spline models; it takes single and batched launches)
   // ... and so does any replica count other than the 16 the regular kernels are built for (GWI_GACC_REP)
   const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
@@ -648,7 +655,7 @@ long g_phase_calls = 0;
 
 // Arguments of the combine / final launches.  Nothing in them changes from one evaluation to the next (the completion
 // stamp travels through a device word the scan writes): on the AQL path they sit in two persistent kernel-argument slots.
-TailArgs tail_args(const gwi_engine* h, double* record_dev) {
+TailArgs tail_args(const gwi_engine* h, double* record_dev, bool batch_geometry = false) {
   TailArgs ta;
   std::memset(&ta, 0, sizeof(ta));
   ta.partials = h->d_partials;
@@ -663,13 +670,13 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.seq_ptr = h->d_seq;
   ta.redo_ptr = h->d_seq + 1;
   ta.n_ev = (int)h->n_ev;
-  ta.tiles_per_event = h->tiles_per_event;
-  ta.n_inj_tiles = h->n_inj_tiles;
-  ta.n_inj_groups = h->n_inj_groups;
-  ta.tiles_per_inj_group = h->tiles_per_inj_group;
+  ta.tiles_per_event = batch_geometry ? h->bgeo.tiles_per_event : h->tiles_per_event;
+  ta.n_inj_tiles = batch_geometry ? h->bgeo.n_inj_tiles : h->n_inj_tiles;
+  ta.n_inj_groups = batch_geometry ? h->bgeo.n_inj_groups : h->n_inj_groups;
+  ta.tiles_per_inj_group = batch_geometry ? h->bgeo.tiles_per_inj_group : h->tiles_per_inj_group;
   ta.n_theta = h->spec.n_theta;
   ta.rec_stride = h->rec_stride;
-  ta.n_scan_blocks = h->n_scan_blocks;
+  ta.n_scan_blocks = batch_geometry ? h->bgeo.n_scan_blocks : h->n_scan_blocks;
   ta.n_norms = h->spec.n_norms;
   ta.record_len = record_len(h);
   ta.n_pe = (double)h->n_pe;
@@ -677,6 +684,15 @@ TailArgs tail_args(const gwi_engine* h, double* record_dev) {
   ta.combine_threads = h->combine_threads;
   ta.row_lines = (3 + h->spec.n_theta + 6) / 7;
   return ta;
+}
+
+// which launch geometry the scan's argument block describes: the batched one (bgeo) or the single evaluation's
+void set_geometry(gwi_engine* h, bool batched) {
+  h->use_bgeo = batched;
+  h->kargs.tiles_per_event = batched ? h->bgeo.tiles_per_event : h->tiles_per_event;
+  h->kargs.chunk_pe = batched ? h->bgeo.chunk_pe : h->chunk_pe;
+  h->kargs.n_inj_tiles = batched ? h->bgeo.n_inj_tiles : h->n_inj_tiles;
+  h->kargs.chunk_inj = batched ? h->bgeo.chunk_inj : h->chunk_inj;
 }
 
 gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_dev, bool wait, int K, bool batch, bool square) {
@@ -722,7 +738,9 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
     if (!h->aql_now) h->kargs.tblocks = h->d_tblocks;
   }
   const unsigned gy = batch ? (unsigned)K : 1u;
-  TailArgs ta = tail_args(h, record_dev);
+  // batched device-final launches run on their own geometry where gwi_create found one (two trips per workgroup)
+  set_geometry(h, batch && K >= 4 && h->bgeo.distinct);
+  TailArgs ta = tail_args(h, record_dev, h->use_bgeo);
   if (batch && K >= 4) {
     // Many points per launch: sum over groups on the DEVICE whatever the problem size.  Host-final mode publishes one row
     // per (group, point) -- K x (N_ev + injection groups) rows of two small posted PCIe writes each, which is what a
@@ -737,7 +755,7 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
   gwi_status st = launch_scan(h, false, K, batch);
   if (st != GWI_OK) return st;
   GWI_PHASE(1);
-  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + h->n_inj_groups), gy), dim3((unsigned)ta.combine_threads), 0, ta);
+  launch_timed(h, 1, combine_kernel, dim3((unsigned)(h->n_ev + ta.n_inj_groups), gy), dim3((unsigned)ta.combine_threads), 0, ta);
   GWI_HIP(hipGetLastError());
   ++h->seq;
   h->timed_final = false;
@@ -1235,7 +1253,7 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
   if (!aql::open_queue(dev, h->aq, h->aql_note)) return;
   if (have_batch_kernel && sizeof(ThetaBlock) * (size_t)h->max_batch <= aql::kExtraBytes) {
     for (int ev = 0; ev < 2; ++ev) {
-      TailArgs tb = tail_args(h, nullptr);
+      TailArgs tb = tail_args(h, nullptr, h->bgeo.distinct);
       tb.host_rows = nullptr;
       tb.publish_events = ev;
       h->aq_tail_batch[ev] = aql::stage_args(h->aq, aql::kSlots - 2 - ev, &tb, sizeof(tb));
@@ -1411,7 +1429,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   // retire) costs a large fraction of it: when one round of resident workgroups can hold the whole
   // catalog with <= 4 trips each, size the workgroups for exactly one round instead.
   const long long gran = (long long)h->variant->samples_per_lane * kBlock;  // every lane carries U samples per trip
-  long long spb = 0;
+  long long spb = 0, spb_batch = 0;  // spb_batch != 0: batched launches use another tile size
   if (const char* env = std::getenv("GWI_SAMPLES_PER_BLOCK")) spb = std::atoll(env);
   if (spb <= 0) {
     const long long total = n_ev * n_pe + n_inj;
@@ -1430,14 +1448,15 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
           break;
         }
       }
-      // One trip per workgroup where two would still give every CU a workgroup: take two.  A single evaluation does not
-      // care (config 2: 16.9 vs 16.8 us), a batched launch does -- prologue and record reduction are a quarter of a
-      // one-trip workgroup's instructions (config 2, K = 16: scan 52.1 -> 45.3 us).
+      // One trip per workgroup where two would still give every CU a workgroup: BATCHED launches take two (bgeo below).
+      // Prologue and record reduction are a quarter of a one-trip workgroup's instructions (config 2, K = 16: scan 52.1 ->
+      // 45.3 us, 205 k -> 236 k evals/s); a single evaluation gains nothing from it (16.9 vs 16.8 us) and four concurrent
+      // chains lose ~10 %, so the single-evaluation geometry stays at one trip.
       if (spb == gran) {
         const long long c2 = 2 * gran, pad = ((n_pe + gran - 1) / gran) * gran;
         const long long cpe = c2 < pad ? c2 : pad;
         const long long blocks2 = n_ev * ((n_pe + cpe - 1) / cpe) + (n_inj + c2 - 1) / c2;
-        if (blocks2 >= (long long)prop.multiProcessorCount) spb = c2;
+        if (blocks2 >= (long long)prop.multiProcessorCount) spb_batch = c2;
       }
     }
   }
@@ -1475,6 +1494,22 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   if (h->tiles_per_event > 64 || h->tiles_per_inj_group > 64 || h->n_inj_groups > 64)
     return fail(h, GWI_ERR_INVALID, "launch geometry: more than 64 tile records per group (internal error: the tile sizes above should have prevented this)");
   h->scan_lds_bytes = scan_lds;
+  if (const char* env = std::getenv("GWI_BATCH_GEOMETRY")) {  // 0: batched launches on the single evaluation's geometry
+    if (std::atoi(env) == 0) spb_batch = 0;
+  }
+  if (spb_batch > 0 && !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK")) {
+    auto& b = h->bgeo;
+    b.chunk_pe = (int)(spb_batch < n_pe_pad ? spb_batch : n_pe_pad);
+    b.chunk_inj = (int)spb_batch;
+    b.tiles_per_event = (int)((n_pe + b.chunk_pe - 1) / b.chunk_pe);
+    b.n_inj_tiles = (int)((n_inj + b.chunk_inj - 1) / b.chunk_inj);
+    b.n_scan_blocks = (int)(n_ev * b.tiles_per_event + b.n_inj_tiles);
+    b.tiles_per_inj_group = 16;
+    b.n_inj_groups = std::max(1, (b.n_inj_tiles + b.tiles_per_inj_group - 1) / b.tiles_per_inj_group);
+    // larger tiles than the single geometry's: fewer records and groups than the buffers (sized for that one) hold
+    b.distinct = b.tiles_per_event <= h->tiles_per_event && b.n_scan_blocks <= h->n_scan_blocks && b.n_inj_groups <= h->n_inj_groups &&
+                 (b.chunk_pe != h->chunk_pe || b.chunk_inj != h->chunk_inj);
+  }
 
   const size_t KB = (size_t)h->max_batch;  // every per-evaluation buffer holds max_batch hyper-parameter points
   GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * KB * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
@@ -2058,6 +2093,7 @@ gwi_status gwi_log_weights(gwi_handle h, const double* theta, double* pe_logw, d
     if (h->spec.terms[t].norm >= 0) log_const -= std::log(nrm[h->spec.terms[t].norm]);
   h->kargs.logw_pe = h->d_logw_pe;
   h->kargs.logw_inj = h->d_logw_inj;
+  set_geometry(h, false);
   st = launch_scan(h, true);
   if (st != GWI_OK) return st;
   GWI_HIP(hipStreamSynchronize(h->stream));

@@ -212,3 +212,35 @@ def test_eight_shards_equal_the_unsharded_engine_and_the_c_oracle(cfg, comp_name
     for e in shards:
         e.close()
     full.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"GWI_BATCH_GEOMETRY": "0"}], ids=["own-geometry", "single-geometry"])
+def test_batched_launch_at_full_size_equals_single_evaluations(env, monkeypatch):
+    """Config 2 at full size, where batched launches (K >= 4) run on a launch geometry of their own (two trips per
+    workgroup, gwi_create): values, sites and gradients of 4- and 16-point batches equal the single evaluations' (the tile
+    boundaries differ, so summation-order rounding only), with and without that geometry, interleaved with single
+    evaluations (which must find their own geometry again) and with a log-weight launch in between."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_config_catalog
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pe, inj, total = make_config_catalog("c2")
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = comp.engine()
+    rng = np.random.default_rng(5)
+    thetas = np.stack([comp.theta(draw_params("plpeak", rng)) for _ in range(16)])
+    single = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    for K in (16, 4):
+        batch = eng.evaluate_batch(thetas[:K], total, min_neff_cut=False)
+        lw_pe, _ = eng.log_weights(thetas[0])  # a launch on the single geometry between batched ones
+        assert np.isfinite(lw_pe).any()
+        again = eng.evaluate(thetas[1], total, min_neff_cut=False)
+        assert again.log_likelihood == single[1].log_likelihood and np.array_equal(again.grad, single[1].grad)
+        for k in range(K):
+            assert abs(batch[k].log_likelihood - single[k].log_likelihood) <= 1e-12 * abs(single[k].log_likelihood)
+            assert np.allclose(batch[k].log_bfs, single[k].log_bfs, rtol=1e-12, atol=0)
+            assert np.allclose(batch[k].log_neffs, single[k].log_neffs, rtol=1e-11, atol=0)
+            scale = max(1.0, float(np.max(np.abs(single[k].grad))))
+            assert float(np.max(np.abs(batch[k].grad - single[k].grad))) / scale < 1e-12
+    eng.close()
