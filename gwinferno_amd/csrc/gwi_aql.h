@@ -13,7 +13,7 @@
 //    HIP fat binary inside the .so is a bundle the HSA loader does not read), loaded into an HSA executable of ours;
 //    kernel symbols are found by the names HIP reports for the host-side function pointers.
 //  * kernel arguments: a ring of 4 KiB slots in DEVICE memory that the host writes through the PCIe BAR (arguments in
-//    host memory cost the scan 5-7 us of scalar loads over PCIe); an sfence + a read-back of the last byte hand them
+//    host memory cost the scan 5-7 us of scalar loads over PCIe); an mfence + a read-back of the last byte hand them
 //    over before the packet header is published (see dispatch()).  The engine's kernels take no implicit arguments (llvm-readelf --notes: by_value only).
 //  * queues: a small process-wide pool (four by default) shared by all engines on the device, see pool_size().
 //  * ordering: every packet carries the barrier bit and agent-scope acquire/release fences, i.e. what a HIP stream gives
@@ -427,12 +427,12 @@ inline void close_queue(Queue& q) {
 // Order (the queue is multi-producer: once this packet's header turns valid, ANOTHER engine's doorbell may already cover
 // its index, so everything the packet refers to must have landed before the header is published):
 //   1. arguments into the ring slot (write-combined stores through the PCIe BAR);
-//   2. sfence (drain the write-combining buffers), then READ BACK the last argument byte through the BAR: a non-posted
+//   2. mfence (drain the write-combining buffers; mfence, not sfence: the read that follows is a load), then READ BACK the last argument byte through the BAR: a non-posted
 //      read cannot pass the posted writes ahead of it, and it forces the device's host data path to retire them to
 //      memory -- the same hand-off HIP's own device-kernarg path performs before it rings (read-back or HDP flush);
 //   3. packet body, then the header with release order;
 //   4. doorbell.
-// GWI_AQL_READBACK=0 drops the read of step 2 (A/B timing only: the hand-off then rests on the sfence + in-order posted writes).
+// GWI_AQL_READBACK=0 drops the read of step 2 (A/B timing only: the hand-off then rests on the fence + in-order posted writes).
 inline bool readback_enabled() {
   static const bool on = [] {
     const char* e = std::getenv("GWI_AQL_READBACK");
@@ -441,10 +441,11 @@ inline bool readback_enabled() {
   return on;
 }
 // How bytes written through the BAR are handed over before a packet that reads them is published (GWI_AQL_HANDOFF):
+//   (all modes start with an mfence: the write-combining buffers are drained before anything below executes)
 //   readback (default): read the last byte written back through the BAR -- a non-posted read cannot pass the posted writes
 //                       ahead of it, and its completion means the device's host data path has retired them;
 //   hdp:                write the device's HDP flush register and read it back (what ROCclr's device-kernarg path does);
-//   none:               sfence only (A/B timing; GWI_AQL_READBACK=0 is the older spelling).
+//   none:               the fence only (A/B timing; GWI_AQL_READBACK=0 is the older spelling).
 inline Handoff handoff_mode_from_env() {  // read when an engine opens its queue
   if (!readback_enabled()) return Handoff::kNone;
   const char* e = std::getenv("GWI_AQL_HANDOFF");
@@ -452,7 +453,7 @@ inline Handoff handoff_mode_from_env() {  // read when an engine opens its queue
   if (e && std::strcmp(e, "none") == 0) return Handoff::kNone;
   return Handoff::kReadback;
 }
-// after the sfence: true unless the read-back saw a byte other than `expect`
+// after the fence: true unless the read-back saw a byte other than `expect`
 inline bool settle(const Device* dev, Handoff m, const char* last_byte_written, unsigned char expect) {
   if (m == Handoff::kHdp && dev && dev->hdp_mem_flush) {
     *dev->hdp_mem_flush = 1u;
@@ -468,7 +469,7 @@ inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_by
   if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes == 0 || slot >= kSlots) return nullptr;
   char* ka = q.kernarg + (size_t)slot * kSlotBytes;
   std::memcpy(ka, args, arg_bytes);
-  _mm_sfence();
+  _mm_mfence();  // not sfence: the read-back below is a LOAD, which sfence does not order behind the write-combined stores
   if (!settle(q.dev, q.handoff, ka + arg_bytes - 1, static_cast<const unsigned char*>(args)[arg_bytes - 1])) {  // cannot happen on a coherent BAR mapping; refuse to launch on stale arguments
     q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
     q.sq->failed = true;
@@ -479,7 +480,7 @@ inline char* stage_args(Queue& q, unsigned slot, const void* args, size_t arg_by
 
 // hand over bytes the caller wrote itself into host-writable device memory (the extra area): drain + read back the last byte
 inline void handoff(const Queue& q, const char* last_byte_written) {
-  _mm_sfence();
+  _mm_mfence();  // not sfence: the read-back below is a LOAD, which sfence does not order behind the write-combined stores
   (void)settle(q.dev, q.handoff, last_byte_written, 0);
 }
 
@@ -526,7 +527,7 @@ inline bool dispatch(Queue& q, const Kernel& k, const void* args, size_t arg_byt
 // launch before is never the one being rewritten) and only the `n_ranges` byte ranges of the tail travel through the BAR --
 // a few hundred bytes instead of 3.5 KB per evaluation (the BAR write of the whole block was 1.2 us of host time on the
 // critical path).  The head is compared with what the slot holds (a host-side copy) and rewritten whole when it differs.
-// Same hand-off as stage_args: sfence, read-back of the last byte written.
+// Same hand-off as stage_args: mfence, read-back of the last byte written.
 inline bool dispatch_tail(Queue& q, const Kernel& k, unsigned parity, const void* args, size_t head_bytes, size_t arg_bytes, const size_t (*ranges)[2], int n_ranges,
                           uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds, hsa_signal_t completion = hsa_signal_t{0}) {
   if (!q.sq || q.sq->failed || arg_bytes > kSlotBytes || arg_bytes > k.kernarg_bytes + 0u || head_bytes > arg_bytes || n_ranges < 1) return false;
@@ -548,7 +549,7 @@ inline bool dispatch_tail(Queue& q, const Kernel& k, unsigned parity, const void
       if (ranges[r][0] + ranges[r][1] - 1 > last) last = ranges[r][0] + ranges[r][1] - 1;
     }
   }
-  _mm_sfence();
+  _mm_mfence();  // not sfence: the read-back below is a LOAD, which sfence does not order behind the write-combined stores
   if (!settle(q.dev, q.handoff, ka + last, static_cast<const unsigned char*>(args)[last])) {
     q.sq->why = "kernel-argument read-back through the BAR returned a stale byte";
     q.sq->failed = true;

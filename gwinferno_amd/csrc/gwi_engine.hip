@@ -727,7 +727,9 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
         std::memcpy(dev[k].theta, h->h_tblocks[k].theta, th_bytes);
         std::memcpy(dev[k].derived, h->h_tblocks[k].derived, der_bytes);
       }
-      aql::handoff(h->aq, reinterpret_cast<const char*>(dev[K - 1].derived) + der_bytes - 1);
+      // no hand-off of their own: the scan's argument block is written next and handed over with ONE sfence + read-back
+      // (aql::dispatch_tail / stage_args), which retires these posted writes as well -- a read cannot pass any posted write
+      // ahead of it, whatever its address (a second read-back here cost every batch 1.4 us)
       h->kargs.tblocks = dev;
     } else if (h->stage_kernel && K >= 10) {  // below ~20 KiB the runtime's small-copy path is quicker than a launch
       hipLaunchKernelGGL(stage_theta_kernel, dim3(K), dim3(kBlock), 0, h->stream, (const ThetaBlock*)h->h_tblocks_dev, h->d_tblocks);
