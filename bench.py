@@ -195,6 +195,23 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
     return out
 
 
+_MEASURED_PEAK = {}
+
+
+def measured_peak(dev):
+    """{"read_gbs", "triad_gbs"} of GPU ``dev``, measured once per process (gwi_hbm_bandwidth); None if it fails."""
+    if dev not in _MEASURED_PEAK:
+        try:
+            from gwinferno_amd.engine import hbm_bandwidth
+
+            r, t = hbm_bandwidth(dev)
+            _MEASURED_PEAK[dev] = {"read_gbs": r, "triad_gbs": t, "what": "read-only sweep / STREAM triad over 1 GiB arrays, best of 10 launches, HIP events"}
+        except Exception as exc:
+            print(f"[bench] HBM bandwidth probe failed: {exc}", file=sys.stderr)
+            _MEASURED_PEAK[dev] = None
+    return _MEASURED_PEAK[dev]
+
+
 def percentiles(seconds):
     ms = 1e3 * np.asarray(seconds)
     return {"median_ms_per_step": float(np.median(ms)), "p5_ms": float(np.percentile(ms, 5)), "p95_ms": float(np.percentile(ms, 95)), "n_evals": int(ms.size)}
@@ -495,6 +512,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # the box's own HBM bandwidth next to the vendor figure: read-only sweep and STREAM triad over
+                # 1 GiB arrays (gwi_hbm_bandwidth), and the fraction against the measured read bandwidth
+                "measured_peak": measured_peak(dev) if headline else None,
                 "traffic": pmc.get("hbm_bytes_per_launch"),
                 "traffic_source": pmc.get("source"),
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -183,6 +183,7 @@ EXPORTED_SYMBOLS = [
     "gwi_dispatch_info",
     "gwi_pin_thread_to_engine",
     "gwi_pin_thread_to_device",
+    "gwi_hbm_bandwidth",
     "gwi_last_error",
     "gwi_destroy",
     "gwi_abi_version",
@@ -272,6 +273,8 @@ def load_library():
     lib.gwi_pin_thread_to_engine.argtypes = [vp]
     lib.gwi_pin_thread_to_device.restype = C.c_int32
     lib.gwi_pin_thread_to_device.argtypes = [C.c_int32]
+    lib.gwi_hbm_bandwidth.restype = C.c_int32
+    lib.gwi_hbm_bandwidth.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gwi_dispatch_info.restype = C.c_char_p
     lib.gwi_dispatch_info.argtypes = [vp]
     lib.gwi_last_error.restype = C.c_char_p

@@ -1729,4 +1729,37 @@ __global__ __launch_bounds__(kBlock) void publish_kernel(const double* gathered,
   publish_stamp(host, seq, threadIdx.x);
 }
 
+// ---- measured HBM bandwidth (gwi_hbm_bandwidth): a read-only sweep and a STREAM triad, 16-byte accesses, grid-stride ----
+__global__ __launch_bounds__(kBlock) void bw_read_kernel(const double2* __restrict__ a, long long n2, double* out, int n_blocks /* = gridDim.x, passed explicitly: no implicit kernel arguments in this code object */) {
+  // four independent 16-byte NON-TEMPORAL loads in flight per lane, 32 workgroups per CU: the best of the variants in
+  // tools/microbench/hbm_read.hip (6.4 TB/s on the round-2 boxes; 5.7 with cached loads, 5.5 with 4 workgroups per CU)
+  double s0 = 0.0, s1 = 0.0;
+  const long long stride = (long long)n_blocks * kBlock;
+  long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < n2; i += 4 * stride) {
+    double vx[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vx[u] = __builtin_nontemporal_load(&a[i + u * stride].x);
+      vy[u] = __builtin_nontemporal_load(&a[i + u * stride].y);
+    }
+    s0 += (vx[0] + vx[1]) + (vx[2] + vx[3]);
+    s1 += (vy[0] + vy[1]) + (vy[2] + vy[3]);
+  }
+  for (; i < n2; i += stride) {
+    const double2 v = a[i];
+    s0 += v.x;
+    s1 += v.y;
+  }
+  const double w = wave_sum(s0 + s1);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out + (blockIdx.x & 63), w);
+}
+__global__ __launch_bounds__(kBlock) void bw_triad_kernel(double2* __restrict__ a, const double2* __restrict__ b, const double2* __restrict__ c, double s, long long n2, int n_blocks) {
+  const long long stride = (long long)n_blocks * kBlock;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    const double2 vb = b[i], vc = c[i];
+    a[i] = make_double2(vb.x + s * vc.x, vb.y + s * vc.y);
+  }
+}
+
 }  // namespace gwi

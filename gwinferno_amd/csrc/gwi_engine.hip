@@ -1686,6 +1686,57 @@ gwi_status gwi_pin_thread_to_engine(gwi_handle h) {
   return st;
 }
 
+gwi_status gwi_hbm_bandwidth(int32_t device, int64_t n_doubles, int32_t iters, double* read_gbs, double* triad_gbs) {
+  if (n_doubles < 1024 || iters < 1 || !read_gbs || !triad_gbs) return GWI_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return GWI_ERR_NO_DEVICE;
+  if (device == GWI_DEVICE_CURRENT && hipGetDevice(&device) != hipSuccess) return GWI_ERR_HIP;
+  if (device < 0 || device >= n_dev || hipSetDevice(device) != hipSuccess) return GWI_ERR_INVALID;
+  const long long n2 = n_doubles / 2;
+  double2 *a = nullptr, *b = nullptr, *c = nullptr;
+  double* out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;
+  gwi_status rc = GWI_ERR_HIP;
+  do {
+    if (hipMalloc(&a, sizeof(double2) * n2) != hipSuccess || hipMalloc(&b, sizeof(double2) * n2) != hipSuccess || hipMalloc(&c, sizeof(double2) * n2) != hipSuccess ||
+        hipMalloc(&out, 64 * sizeof(double)) != hipSuccess)
+      break;
+    if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+    if (hipMemsetAsync(a, 0, sizeof(double2) * n2, st) != hipSuccess || hipMemsetAsync(b, 0, sizeof(double2) * n2, st) != hipSuccess ||
+        hipMemsetAsync(c, 0, sizeof(double2) * n2, st) != hipSuccess || hipMemsetAsync(out, 0, 64 * sizeof(double), st) != hipSuccess)
+      break;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) break;
+    const unsigned grid = (unsigned)prop.multiProcessorCount * 32u;
+    float best_r = 1e30f, best_t = 1e30f;
+    bool ok = true;
+    for (int it = 0; it < iters + 2 && ok; ++it) {  // two untimed warm-up rounds
+      float ms = 0.0f;
+      ok = ok && hipEventRecord(e0, st) == hipSuccess;
+      hipLaunchKernelGGL(bw_read_kernel, dim3(grid), dim3(kBlock), 0, st, (const double2*)b, n2, out, (int)grid);
+      ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (it >= 2 && ms < best_r) best_r = ms;
+      ok = ok && hipEventRecord(e0, st) == hipSuccess;
+      hipLaunchKernelGGL(bw_triad_kernel, dim3(grid), dim3(kBlock), 0, st, a, (const double2*)b, (const double2*)c, 3.0, n2, (int)grid);
+      ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (it >= 2 && ms < best_t) best_t = ms;
+    }
+    if (!ok || hipGetLastError() != hipSuccess) break;
+    *read_gbs = 16.0 * (double)n2 / ((double)best_r * 1e-3) / 1e9;
+    *triad_gbs = 48.0 * (double)n2 / ((double)best_t * 1e-3) / 1e9;
+    rc = GWI_OK;
+  } while (false);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipFree(c);
+  (void)hipFree(out);
+  return rc;
+}
+
 const char* gwi_dispatch_info(gwi_handle h) {
   if (!h) return "no engine";
   return h->aql_active ? (h->aq.failed() ? h->aq.why().c_str() : "aql: active") : h->aql_note.c_str();

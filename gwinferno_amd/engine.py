@@ -213,6 +213,18 @@ def pin_thread_to_device(device=-1):
     return N.load_library().gwi_pin_thread_to_device(int(device)) == 0
 
 
+def hbm_bandwidth(device=-1, n_doubles=1 << 27, iters=10):
+    """Measured HBM bandwidth of GPU ``device`` in GB/s as ``(read_only, stream_triad)`` (``gwi_hbm_bandwidth``): the figure
+    SURVEY section 8(d) asks to report next to the vendor peak the roofline is normalised against.  Arrays of ``n_doubles``
+    (default 1 GiB each, far beyond the 256 MB Infinity Cache)."""
+    lib = N.load_library()
+    r, t = C.c_double(0.0), C.c_double(0.0)
+    st = lib.gwi_hbm_bandwidth(int(device), int(n_doubles), int(iters), C.byref(r), C.byref(t))
+    if st != 0:
+        raise N.NativeEngineError(f"gwi_hbm_bandwidth: {N.STATUS_NAMES.get(st, st)}")
+    return r.value, t.value
+
+
 def shard_bounds(n, rank, world):
     """Contiguous, balanced blocks: the first ``n % world`` ranks get one extra item."""
     base, extra = divmod(n, world)

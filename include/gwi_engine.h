@@ -321,6 +321,13 @@ gwi_status gwi_pin_thread_to_engine(gwi_handle h);
  * pinned host buffers are first touched on that side too */
 gwi_status gwi_pin_thread_to_device(int32_t device);
 
+/* Measured HBM bandwidth of the device, the number SURVEY.md section 8(d) asks to report next to the vendor figure the
+ * roofline is normalised against: a read-only sweep (sum of one array: what the scan kernel's traffic looks like) and a
+ * STREAM triad a = b + s c, each over arrays of n_doubles (>= 64 Mi doubles recommended: beyond the 256 MB Infinity Cache),
+ * best of `iters` launches timed with HIP events.  GB/s = bytes moved / time (triad: 24 B per element).  No reference
+ * counterpart (a measurement aid). */
+gwi_status gwi_hbm_bandwidth(int32_t device, int64_t n_doubles, int32_t iters, double* read_gbs, double* triad_gbs);
+
 /* How plain evaluations are dispatched: "aql: active" (AQL packets into a user-mode queue of the engine's own,
  * gwinferno_amd/csrc/gwi_aql.h: 0.4 us of host time per launch instead of 3.5) or the reason the HIP stream is used. */
 const char* gwi_dispatch_info(gwi_handle h);

@@ -20,3 +20,17 @@ def test_plain_c_program_through_the_abi(tmp_path):
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
+
+
+@pytest.mark.gpu
+def test_measured_hbm_bandwidth_is_plausible():
+    """gwi_hbm_bandwidth (the measured figure reported next to the vendor peak): a read-only sweep and a STREAM
+    triad over arrays beyond the Infinity Cache land between a quarter of and just above the 8 TB/s the roofline is
+    normalised against; bad arguments are refused."""
+    from gwinferno_amd import _native as N
+    from gwinferno_amd.engine import hbm_bandwidth
+
+    read, triad = hbm_bandwidth(0, n_doubles=1 << 26, iters=5)
+    assert 2000.0 < read < 9000.0 and 2000.0 < triad < 9000.0
+    with pytest.raises(N.NativeEngineError):
+        hbm_bandwidth(0, n_doubles=8)
