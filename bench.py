@@ -172,6 +172,7 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         "kind": "port",
         "sample": f"{n} value+gradient evals of the full catalog by the C/OpenMP oracle on {cores} threads ({t_used:.1f}s)",
         "single_thread_evals_per_s": 1.0 / t_single,
+        "host": host_description(),
     }
     if numpy_reference:
         # reference formulation (interpolation.py:304 einsum over a dense (N_basis, N) matrix), NumPy, one core, value only
@@ -193,6 +194,24 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         except Exception as exc:  # the dense matrices of config 5 need ~2 GB
             out["numpy_reference_formulation"] = {"error": repr(exc)}
     return out
+
+
+def host_description():
+    """CPU model, logical CPUs the box shows and CPUs this process may use (nproc and model next to the baseline)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable}
 
 
 _MEASURED_PEAK = {}
