@@ -210,7 +210,7 @@ def test_parametric_masses_with_bspline_spins(iid):
     eng.close()
 
 
-@pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_full", "bspline_chieff", "chm_bspline"])
+@pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_full", "bspline_chieff", "chm_bspline", "bspline_misc"])  # bspline_misc: a PL+Peak term that absorbs the closing exponential, in a spline chain
 def test_replay_mode_is_bit_reproducible(comp_name, monkeypatch):
     """GWI_DETERMINISTIC=1: the shared gradient rows are filled in one fixed order -- one replica per
     lane, the wavefronts of a workgroup take turns -- so every bit of the value, the sites AND the spline-coefficient
@@ -244,7 +244,7 @@ def test_replay_mode_is_bit_reproducible(comp_name, monkeypatch):
     fast.engine().close()
 
 
-@pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_iid"])
+@pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_iid", "bspline_misc"])
 def test_reference_exponent_outrun_triggers_the_two_pass_repeat(comp_name, monkeypatch):
     """Spline models fix a tile's reference exponent at the first trip of the tile that holds a live sample.  Here tiles
     are 2048 samples long (four trips of 512) and the first 512 samples of every tile carry a sampling prior 10^80 times
