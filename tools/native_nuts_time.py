@@ -23,7 +23,8 @@ comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(max(counts))]
 engines = [c.engine() for c in comps]
 n = engines[0].n_theta
 theta0 = comps[0].theta(draw_params(comp_name, rng))
-prior = GaussianSmoothingPrior(n).normal(slice(0, n), 10.0)
+# spline models: the reference's coefficient prior scale N(0, 1); a 10 times wider one measures the two-pass repeat path (bench.py:multi_chain)
+prior = GaussianSmoothingPrior(n).normal(slice(0, n), 1.0 if comp_name.startswith("bspline") else 10.0)
 kw = dict(n_warmup=150, n_samples=150, max_tree_depth=6, seed=1)
 flags = dict(min_neff_cut=False)
 
