@@ -339,6 +339,7 @@ struct gwi_engine {
   double *h_ev = nullptr, *h_ev_dev = nullptr;
   // host-final mode: per-group result rows + normaliser values in pinned host memory
   bool host_final = false;
+  int two_pass_streak = 0;  // evaluations that still go straight to the two-pass kernel (run_pipeline)
   // launch geometry of batched launches (K >= 4, device-final) where it differs from the single evaluation's: two trips
   // per workgroup instead of one (gwi_create)
   struct BatchGeometry {
@@ -784,10 +785,24 @@ bool redo_requested(const gwi_engine* h) { return *reinterpret_cast<volatile uns
 
 // launches scan -> combine [-> final]; with `wait`, repeats the evaluation in two-pass mode (exact tile maxima) when a
 // workgroup asked for it.  Callers that pass wait = false check redo_requested() themselves once their results are in.
+// A chain that has reached such a region (warm-up under a wide prior: spline coefficients whose weights span hundreds of
+// e-folds inside a tile) needs the repeat for most of its evaluations, each of which then costs a wasted single-pass attempt
+// on top of the two-pass run.  So a repeat puts the handle into two-pass mode for the next kTwoPassStreak evaluations
+// (they go straight to the two-pass kernel), after which the single-pass kernel is tried again.
+constexpr int kTwoPassStreak = 16;
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+  if (wait && h->two_pass_streak > 0 && h->variant->scan_safe && !h->kargs.two_pass) {
+    --h->two_pass_streak;
+    ++h->redo_count;
+    h->kargs.two_pass = 1;
+    const gwi_status st2 = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
+    h->kargs.two_pass = 0;
+    return st2;
+  }
   gwi_status st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
   if (st == GWI_OK && wait && redo_requested(h)) {
     ++h->redo_count;
+    h->two_pass_streak = kTwoPassStreak;
     h->kargs.two_pass = 1;
     st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
     h->kargs.two_pass = 0;

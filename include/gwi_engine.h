@@ -310,7 +310,9 @@ gwi_status gwi_eval_latencies(gwi_handle h, const double* thetas, int32_t n, con
 /* Models with spline terms: the scan weighs a tile's samples against a reference exponent fixed at the tile's first live
  * sample (so that the four wavefronts of a workgroup can share one set of gradient rows); when a later sample of the tile
  * exceeds it by more than e^150 the evaluation is repeated with a two-pass kernel that finds each tile's exact maximum
- * first.  Results are identical to rounding either way; this counts the repeats (0 in any ordinary run). */
+ * first.  Results are identical to rounding either way.  After a repeat the next 16 evaluations of the handle go straight
+ * to the two-pass kernel (a chain that has wandered into such a region would otherwise pay a wasted attempt every time).
+ * This counts the evaluations that ran in two-pass mode (0 in any ordinary run). */
 int64_t gwi_two_pass_repeats(gwi_handle h);
 
 /* Host tuning: restrict the CALLING thread to the CPUs next to the engine's GPU (the local_cpulist of its PCI function,
