@@ -1426,9 +1426,13 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   const int b = (int)blockIdx.x - n_norm_blocks;
   const int n_pe_blocks = a.n_ev * a.tiles_per_event;
 
-  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids)
-  if (ChainT::kSpline)
-    for (int p = tid; p < a.n_theta; p += kBlock) s_theta[p] = theta_src[p];
+  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids).  The loads go out HERE
+  // (one value per thread: n_theta <= kBlock), the LDS writes follow the first trip's column loads further down: the two
+  // memory round trips of a workgroup's start -- theta out of the argument block, then the columns -- overlap instead of
+  // queueing at the barrier (the caches were invalidated when the launch started: both come from memory)
+  static_assert(GWI_MAX_THETA <= kBlock, "one hyper-parameter per thread in the theta staging");
+  double theta_mine = 0.0;
+  if (ChainT::kSpline) theta_mine = theta_src[tid < a.n_theta ? tid : a.n_theta - 1];  // unconditional (clamped index): no control flow between this load and the columns', so the wait below can count
   // Replicas per coefficient: the regular kernels are built for 16 (the four rows of a sample then sit at immediate
   // offsets of one LDS address: three address adds per spline term and sample less); the SAFE instantiation takes the
   // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
@@ -1438,7 +1442,6 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   if (kShared)
     for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
-  if (ChainT::kSpline) __syncthreads();
 
   long long start, end, base;
   Ctx ctx;
@@ -1498,8 +1501,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   double lane_max = GWI_NEG_INF;   // two-pass mode, pass 0 only: this lane's largest live exponent
   constexpr double kRefSlack = 150.0;
   // two-pass mode (shared only): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
-  for (int pass_ = (SAFE && kShared && a.two_pass) ? 0 : 1; pass_ < 2; ++pass_) {
-    if (i0 - lane < n_tile) issue_loads(0, i0);
+  const int first_pass = (SAFE && kShared && a.two_pass) ? 0 : 1;
+  if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns, in flight before theta is waited for
+  if (ChainT::kSpline) {
+    if (tid < a.n_theta) s_theta[tid] = theta_mine;
+    __syncthreads();  // also covers the zeroing of the rows and of s_out above
+  }
+  for (int pass_ = first_pass; pass_ < 2; ++pass_) {
+    if (pass_ != first_pass && i0 - lane < n_tile) issue_loads(0, i0);
 #ifdef GWI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
     GWI_STAMP(2);
