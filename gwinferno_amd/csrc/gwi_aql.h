@@ -485,8 +485,10 @@ inline void handoff(const Queue& q, const char* last_byte_written) {
 }
 
 // steps 3-4 for an argument block that is already in place (stage_args)
+// `acquire`: whether the packet carries an agent-scope acquire fence (cache invalidate before the kernel starts).  A kernel
+// that reads everything the launch before it wrote with cache-bypassing loads (combine_group) goes without.
 inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x_blocks, uint32_t grid_y_blocks, uint32_t block_threads, uint32_t dynamic_lds,
-                            hsa_signal_t completion = hsa_signal_t{0}) {
+                            hsa_signal_t completion = hsa_signal_t{0}, bool acquire = true) {
   if (!q.sq || q.sq->failed || !ka) return false;
   Api& a = api();
   hsa_queue_t* hq = q.sq->q;
@@ -503,8 +505,9 @@ inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x
   p->kernarg_address = ka;
   p->reserved2 = 0;
   p->completion_signal = completion;
-  constexpr uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                              (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+  const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                          ((acquire ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                          (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
   a.signal_store(hq->doorbell_signal, (hsa_signal_value_t)idx);
   return true;

@@ -1066,6 +1066,12 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wav
 //      waves; every wave derives the group's exponent and S1 itself (DPP reductions, fixed order).
 //      One workgroup per group (e = group, kb = hyper-parameter point): 64 threads (one wave) when the gradient has at most
 //      60 slots, else kBlock -- a wave per group is all the parametric models need, and a batched launch runs K x groups of them.
+// Every value the scan launch wrote is read with a load that bypasses the caches (system scope: sc0 sc1) -- the same trip
+// to memory a miss would make right after the launch's cache invalidate, so it costs nothing; in exchange the combine
+// PACKET needs no acquire fence at all (gwi_aql.h: dispatch_staged, acquire = false): its constant argument block stays in
+// the scalar cache / L2 from one evaluation to the next instead of being fetched from memory first, and the packet
+// processor skips the invalidate.
+__device__ __forceinline__ double load_fresh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, const int kb, const int tid) {
   const int lane = tid & 63;
   const bool is_inj = e >= a.n_ev;
@@ -1098,8 +1104,8 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   // (host guarantees n_tiles <= 64 per group)
   const bool has = lane < n_tiles;
   const double* mine = rec + (long long)(has ? lane : 0) * a.rec_stride;
-  const double m_t = has ? mine[0] : GWI_NEG_INF;
-  const double r1 = has ? mine[1] : 0.0, r2 = has ? mine[2] : 0.0;
+  const double m_t = has ? load_fresh(mine) : GWI_NEG_INF;
+  const double r1 = has ? load_fresh(mine + 1) : 0.0, r2 = has ? load_fresh(mine + 2) : 0.0;
   // the first gradient slot of this thread: its tile values are requested NOW, together with the
   // headers, so that one memory round trip (not two) precedes the arithmetic
   constexpr int kEarly = 16;
@@ -1108,7 +1114,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   {
     const double* col0 = rec + kRecHeader + (early_on ? tid : 0);
 #pragma unroll
-    for (int t = 0; t < kEarly; ++t) early[t] = (early_on && t < n_tiles) ? col0[(long long)t * a.rec_stride] : 0.0;
+    for (int t = 0; t < kEarly; ++t) early[t] = (early_on && t < n_tiles) ? load_fresh(col0 + (long long)t * a.rec_stride) : 0.0;
   }
   const double M = wave_max(m_t);
   const double f = (m_t == GWI_NEG_INF) ? 0.0 : exp(m_t - M);
@@ -1127,7 +1133,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
       t = n_tiles < kEarly ? n_tiles : kEarly;
     }
 #pragma unroll 4
-    for (; t < n_tiles; ++t) acc += lane_bcast(f, t) * col[(long long)t * a.rec_stride];
+    for (; t < n_tiles; ++t) acc += lane_bcast(f, t) * load_fresh(col + (long long)t * a.rec_stride);
     if (host_rows)
       s_row[3 + p] = is_inj ? acc : acc * inv_s1;
     else if (is_inj)
@@ -1177,7 +1183,7 @@ __device__ __forceinline__ void combine_group(const TailArgs& a, const int e, co
   if (host_rows) {  // the whole row leaves as self-validating 64-byte lines (seven values + the sequence number)
     __syncthreads();
     unsigned long long* o = reinterpret_cast<unsigned long long*>(host_rows + (long long)e * row_doubles);
-    const unsigned long long seq = *a.seq_ptr;
+    const unsigned long long seq = __hip_atomic_load(a.seq_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int n_vals = 3 + a.n_theta;
     for (int slot = tid; slot < row_doubles; slot += a.combine_threads) {
       const int line = slot >> 3, j = slot & 7, i = line * 7 + j;

@@ -392,6 +392,7 @@ struct gwi_engine {
   bool scan_is_batch = false;
   int aql_tail_variant = 0;        // 0: single evaluation, 1 / 2: batched without / with the per-event sites
   bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
+  bool combine_acquire = false;  // the combine packet carries an acquire fence after all (A/B only)
   bool aql_tail_only = true;  // scan launches rewrite only the per-evaluation tail of their argument block (GWI_AQL_TAIL=0: the whole block)
   unsigned tail_parity = 0; // which of the two persistent scan-argument slots the next launch rewrites (aql::dispatch_tail)
   bool aql_active = false;  // queue, argument ring and the three kernels are ready
@@ -575,7 +576,8 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
     const hsa_signal_t done = h->timing ? h->aq.done[slot] : hsa_signal_t{0};
     if (slot > 0 && h->aq_tail_args) {  // constant arguments, staged once at gwi_create
       char* staged = h->aql_tail_variant == 0 ? h->aq_tail_args : h->aq_tail_batch[h->aql_tail_variant - 1];
-      if (aql::dispatch_staged(h->aq, k, staged, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
+      // the combine launch reads the scan's records with cache-bypassing loads: no acquire fence (GWI_AQL_COMBINE_ACQUIRE=1: with)
+      (void)aql::dispatch_staged(h->aq, k, staged, grid.x, grid.y, block.x, (uint32_t)lds, done, /*acquire=*/slot != 1 || h->combine_acquire);
       return;
     }
     if constexpr (std::is_same<A, KArgs>::value) if (!h->aql_tail_only) {  // GWI_AQL_TAIL=0: the whole block into a ring slot per launch (A/B only)
@@ -1287,6 +1289,7 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
     }
   }
   if (const char* env = std::getenv("GWI_AQL_TAIL")) h->aql_tail_only = std::atoi(env) != 0;
+  if (const char* env = std::getenv("GWI_AQL_COMBINE_ACQUIRE")) h->combine_acquire = std::atoi(env) != 0;
   h->aql_active = true;
   h->aql_note = "active";
 }
