@@ -160,6 +160,11 @@ __device__ __forceinline__ double wave_max(double v) {
   return lane63(v);
 }
 
+// Below this a mixture density counts as zero for its gradient states: fast_rcp returns NaN for subnormal arguments
+// (seed = inf, Newton step inf - inf), and a mixture term that has absorbed the closing exponential (Absorbs<K>) sees
+// densities times e^{l - m}, i.e. down to the bottom of the range for samples ~700 e-folds under the tile's best one
+// (a narrow peak: the 2000-point fuzz sweep found sigma = 0.33).  Such a sample's weight is < 1e-290 of the best one's.
+constexpr double kRcpFloor = 1e-290;
 // 1/x to ~1 ulp for normal x: hardware seed + two Newton steps (no IEEE special-case handling:
 // callers only need it where the weight is non-zero)
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -388,7 +393,7 @@ struct Term<GWI_TERM_PLPEAK> {
     const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
-    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
+    const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
     s.da = P * (lx + d[1]) * ip;
     s.dmu = T * (dx * d[5] + d[3]) * ip;
     s.dsg = T * (dx2 * d[6] + d[4]) * ip;
@@ -525,7 +530,7 @@ struct Term<GWI_TERM_TILT_MIXTURE> {
     const double dx2 = dx * dx;
     const double e_tn = fast_exp(-0.5 * dx2 * d[2] + d[0]);
     const double p = 0.5 * (1.0 - xi) + xi * e_tn;
-    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
+    const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
     s.dxi = (e_tn - 0.5) * ip;
     s.dsg = xi * e_tn * (dx2 * d[3] + d[1]) * ip;
     lin *= p;
@@ -721,7 +726,7 @@ struct Term<GWI_TERM_TILT_JOINT> {
     const double r2 = d1 * d1 + d2 * d2;
     const double A = fast_exp(-0.5 * r2 * d[2] + 2.0 * d[0]);
     const double p = 0.25 * (1.0 - xi) + xi * A;
-    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
+    const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
     s.dxi = (A - 0.25) * ip;
     s.dsg = xi * A * (r2 * d[3] + 2.0 * d[1]) * ip;
     lin *= p;
@@ -819,7 +824,7 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
-    const double ip = (p > 0.0) ? fast_rcp(p) : 0.0;  // p == 0: a dead sample (w = 0) must not carry NaN into the sums
+    const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
     s.da = P * (lx + d[1]) * ip;
     s.dmu = T * (dx * d[5] + d[3]) * ip;
     s.dsg = T * (dx2 * d[6] + d[4]) * ip;

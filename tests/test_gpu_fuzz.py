@@ -71,7 +71,11 @@ def test_randomised_parity_against_c_oracle(name):
         ok = np.isfinite(ref["logBFs"])
         assert np.array_equal(np.isfinite(got.log_bfs), ok), (name, i)
         assert rel_err(got.log_bfs[ok], ref["logBFs"][ok]) < 1e-9, (name, i, p)
-        assert rel_err(got.log_neffs[ok], ref["log_nEffs"][ok]) < 1e-8, (name, i)
+        # log n_eff = 2 log S1 - log S2 cancels when ONE sample carries an event (n_eff -> 1: a 0.4-wide peak holding 99.99 % of
+        # the mixture gave log n_eff = 2.8e-10, on which this engine, the C oracle and the NumPy oracle all differ at 1e-6
+        # relative): the error is measured against max(1, |log n_eff|)
+        d_neff = np.abs(got.log_neffs[ok] - ref["log_nEffs"][ok]) / np.maximum(1.0, np.abs(ref["log_nEffs"][ok]))
+        assert d_neff.size == 0 or float(np.max(d_neff)) < 1e-8, (name, i)
         if np.isfinite(rs.log_det_eff):
             assert abs(got.summary.log_det_eff - rs.log_det_eff) < 1e-9 * max(1.0, abs(rs.log_det_eff)), (name, i)
         assert got.log_likelihood == rs.log_likelihood or rel_err(got.log_likelihood, rs.log_likelihood) < 1e-9, (name, i, got.log_likelihood, rs.log_likelihood)
@@ -82,4 +86,33 @@ def test_randomised_parity_against_c_oracle(name):
             worst = max(worst, err)
             assert err < 1e-8, (name, i, err)
     assert n_finite >= N_POINTS // 2, (name, n_finite)  # the sweep must mostly land on live likelihoods
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["plpeak_smooth", "plpeak"])
+def test_narrow_peak_gradient_stays_finite(name):
+    """Found by the 2000-point sweep (GWI_FUZZ_POINTS=2000): a 0.33-wide Gaussian peak holding 0.09 % of the mixture.  The
+    mixture term carries the sample's closing factor e^{l - m} inside its density (scan_kernel, Absorbs<K>), so samples ~700
+    e-folds under the tile's best one present SUBNORMAL densities, whose reciprocal (fast_rcp: hardware seed + Newton) is NaN;
+    their gradient states must count as zero (kRcpFloor) instead of poisoning the sums."""
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(14, 600, 6000, seed=77)
+    comp = COMPOSITIONS[name](pe, inj)
+    eng = comp.engine()
+    orc = COracle(eng.bound)
+    p = {"alpha": -2.8556157475292885, "beta": -1.0778941566544196, "mpp": 39.23571240555825, "sigpp": 0.3296513261163328, "lam": 0.0008906616210867098, "lamb": 5.088845939224041}
+    if name == "plpeak_smooth":
+        p["delta"] = 9.250712517195849
+    for sig in (0.3296513261163328, 0.12, 0.05):
+        p["sigpp"] = sig
+        th = comp.theta(p)
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = orc.evaluate(th, total, min_neff_cut=False)
+        assert np.all(np.isfinite(got.grad)), (name, sig, got.grad)
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8, (name, sig)
+        assert rel_err(got.log_likelihood, ref["summary"].log_likelihood) < 1e-9
     eng.close()
