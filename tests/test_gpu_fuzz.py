@@ -56,6 +56,7 @@ def test_randomised_parity_against_c_oracle(name):
     rng = np.random.default_rng(sum(map(ord, name)))
     worst = 0.0
     n_finite = 0
+    pending = []
     for i in range(N_POINTS):
         p = draw_params(name, rng)
         if name == "chm_powerlaw":  # bounds that cut samples off but leave every event some: the catalog's events span m1 ~ 8 .. 80
@@ -85,6 +86,18 @@ def test_randomised_parity_against_c_oracle(name):
             err = float(np.max(np.abs(got.grad - ref["grad"]))) / scale
             worst = max(worst, err)
             assert err < 1e-8, (name, i, err)
+        # the same points eight at a time through the batched launch (its own kernel instantiation and tail): equal to the
+        # single evaluations up to summation-order rounding
+        pending.append((th, got))
+        if len(pending) == 8:
+            batch = eng.evaluate_batch(np.stack([t for t, _ in pending]), total, min_neff_cut=False)
+            for k, (_, single) in enumerate(pending):
+                b = batch[k]
+                assert b.log_likelihood == single.log_likelihood or rel_err(b.log_likelihood, single.log_likelihood) < 1e-11, (name, i, k)
+                if abs(single.log_likelihood) < 1e300:
+                    sc = max(1.0, float(np.max(np.abs(single.grad))))
+                    assert float(np.max(np.abs(b.grad - single.grad))) / sc < 1e-10, (name, i, k)
+            pending.clear()
     assert n_finite >= N_POINTS // 2, (name, n_finite)  # the sweep must mostly land on live likelihoods
     eng.close()
 
