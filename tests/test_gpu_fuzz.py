@@ -129,3 +129,50 @@ def test_narrow_peak_gradient_stays_finite(name):
         assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8, (name, sig)
         assert rel_err(got.log_likelihood, ref["summary"].log_likelihood) < 1e-9
     eng.close()
+
+
+N_SHAPES = int(os.environ.get("GWI_FUZZ_SHAPES", "24"))  # the long sweep: GWI_FUZZ_SHAPES=400
+
+
+@pytest.mark.parametrize("name", ["plpeak", "bspline_iid", "bspline_misc"])
+def test_randomised_catalog_shapes_against_c_oracle(name, monkeypatch):
+    """Random catalog shapes (events x posterior samples x injections, from a single sample per event to tens of thousands)
+    and, for a third of them, a random tile size: the tile / group bookkeeping of the scan and its tail against the C oracle
+    -- single evaluations and a 5-point batched launch."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    rng = np.random.default_rng(sum(map(ord, name)) + 17)
+    for s in range(N_SHAPES):
+        n_ev = int(rng.choice([1, 2, 3, 7, 8, 9, 33, 64, 65, int(rng.integers(1, 300))]))
+        n_pe = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 513, int(rng.integers(1, 3000))]))
+        n_inj = int(rng.choice([1, 63, 64, 65, 257, 4097, int(rng.integers(1, 20000))]))
+        env = {}
+        if s % 3 == 2:
+            env["GWI_SAMPLES_PER_BLOCK"] = str(int(rng.choice([256, 512, 768, 1024, 4096])))
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=1000 + s)
+        comp = COMPOSITIONS[name](pe, inj)
+        eng = comp.engine()
+        orc = COracle(eng.bound)
+        thetas = np.stack([comp.theta(draw_params(name, rng)) for _ in range(5)])
+        batch = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+        for k in range(2):
+            got = eng.evaluate(thetas[k], total, min_neff_cut=False)
+            ref = orc.evaluate(thetas[k], total, min_neff_cut=False)
+            tag = (name, s, n_ev, n_pe, n_inj, env)
+            ok = np.isfinite(ref["logBFs"])
+            assert np.array_equal(np.isfinite(got.log_bfs), ok), tag
+            assert rel_err(got.log_bfs[ok], ref["logBFs"][ok]) < 1e-9, tag
+            rs = ref["summary"]
+            assert got.log_likelihood == rs.log_likelihood or rel_err(got.log_likelihood, rs.log_likelihood) < 1e-9, tag
+            if abs(rs.log_likelihood) < 1e300:
+                scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+                assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8, tag
+                assert float(np.max(np.abs(batch[k].grad - ref["grad"]))) / scale < 1e-8, tag
+                assert rel_err(batch[k].log_likelihood, rs.log_likelihood) < 1e-9, tag
+        eng.close()
+        for k in env:
+            monkeypatch.delenv(k)
