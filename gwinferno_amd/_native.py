@@ -189,6 +189,7 @@ EXPORTED_SYMBOLS = [
     "gwi_abi_version",
     "gwi_kernel_variants",
     "gwi_kernel_variant_name",
+    "gwi_scan_kernel_name",
 ]
 # ... and include/gwi_sampler.h
 EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine"]
@@ -285,6 +286,9 @@ def load_library():
     lib.gwi_kernel_variants.restype = C.c_int32
     lib.gwi_kernel_variant_name.restype = C.c_char_p
     lib.gwi_kernel_variant_name.argtypes = [C.c_int32]
+    if hasattr(lib, "gwi_scan_kernel_name"):  # absent from older builds loaded through GWI_ENGINE_LIB for A/B timing
+        lib.gwi_scan_kernel_name.restype = C.c_char_p
+        lib.gwi_scan_kernel_name.argtypes = [vp]
     _IP = C.POINTER(C.c_int32)
     lib.gwi_nuts_run.restype = C.c_int32
     lib.gwi_nuts_run.argtypes = [GWI_TARGET_FN, vp, C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]

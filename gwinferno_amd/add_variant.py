@@ -1,8 +1,9 @@
 """Add a compiled kernel for a model whose term-kind sequence the library does not have yet.
 
 The scan kernel is a compile-time chain of terms (one instantiation per sorted sequence of term kinds: the BASELINE
-configurations, every model of the reference's tests, ...).  A product of population models that is not among them makes
-``gwi_create`` fail with ``GWI_ERR_UNSUPPORTED`` and the sequence in the message; this appends that sequence to
+configurations, every model of the reference's tests, ...).  A product of population models that is not among them runs on
+the generic scan kernel (term kinds read at run time: several times slower) and ``gwi_create`` prints the sequence once;
+this appends that sequence to
 ``gwinferno_amd/csrc/gwi_user_variants.inc`` and rebuilds ``libgwi_engine.so`` + ``gwi_kernels.hsaco`` (hipcc, about a
 minute; cross-compiles without a GPU):
 

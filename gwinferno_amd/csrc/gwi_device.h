@@ -24,11 +24,13 @@ constexpr int kMaxDerived = 7;          // PLPEAK uses d0..d6; 7 keeps KArgs wit
 constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerators in a record
 
 struct TermD {
-  int kind, col0, col1, n_basis;
+  int kind, n_basis;
   int th0, th1, th2, th3;  // EXP_SPLINE: th0 = coef_off
   int flags, th4;     // th4: fifth hyper-parameter (PLPEAK_SMOOTH: delta)
-  double p0, p1, p2;  // EXP_SPLINE: lo, hi, 1/dx of the spline coordinate
+  double p0, p1, p2;  // spline kinds: lo, hi, 1/dx of the spline coordinate
+  double p3;          // spline kinds: -lo/dx, so that the knot coordinate is one fma
 };
+static_assert(sizeof(TermD) == 64, "twelve of these sit in the 4 KiB kernel-argument block");
 
 struct NormD {
   int n_pts, expo_theta, n_basis, coef_off, flags, pad;
@@ -100,6 +102,11 @@ struct KArgs {
   unsigned long long* seq_dev;            // device word: the scan publishes norm_seq here for the tail launches
   unsigned long long* redo_host;          // pinned host word: a workgroup whose fixed reference exponent turned out too low stores norm_seq here
   unsigned long long* redo_dev;           // ... and here (device word, read by final_kernel: the sharded path's record carries the request to every rank)
+  // spline models: the reference exponent (in binades: powers of two) every tile weighs its samples against = the tile's
+  // exact maximum at the PREVIOUS evaluation of this handle, [1 + max_batch][nref_stride] (row 0: single evaluations,
+  // rows 1..K: the points of a batched launch); kNoRef where there is none yet
+  int* tile_nref;
+  int nref_stride, pad0;
   TermD terms[GWI_MAX_TERMS];
   // ---- everything ABOVE is fixed at gwi_create; what follows changes from one evaluation to the next.  On the AQL path the
   //      block lives in a persistent kernel-argument slot in device memory and only this tail is rewritten through the PCIe
@@ -108,6 +115,7 @@ struct KArgs {
   int two_pass, deterministic;            // two_pass: find each tile's exact maximum first; deterministic: waves take turns at the shared rows
   int square, k_batch;     // k_batch: hyper-parameter points of a batched launch (scan_mfma_kernel: 16 per grid row); square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
+  int nref_row0, pad1;     // first row of tile_nref this launch reads and writes (0: single evaluation, 1: batched launch)
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
@@ -219,6 +227,33 @@ __device__ __forceinline__ double fast_exp(double x) {
   const ExpParts p = exp_parts(x);
   return ldexp(p.rq + 1.0, p.n);
 }
+// exp(x) 2^-shift with the shift applied to the EXPONENT FIELD (v_ldexp): the result is exp(x) scaled by an exact power of
+// two, so sums of such weights scale exactly with the shift and every quantity derived from them is, to the bit,
+// independent of which shift was used (as long as nothing leaves the normal range -- the scan checks that).  That is what
+// lets spline models weigh a tile against a reference exponent remembered from the previous evaluation (scan_kernel)
+// without the results depending on the evaluation history.  The argument range is the full range of log-weights:
+// |x| <= 7e5 keeps n ln2_hi exact (ln2_hi has 21 trailing zero bits, |n| < 2^20).
+constexpr double kLog2e = 1.4426950408889634;
+constexpr double kLn2 = 0.6931471805599453;
+constexpr int kNoRef = -2147483647 - 1;  // tile_nref: no reference yet / tile without a live sample
+__device__ __forceinline__ double fast_exp_shift(double x, int shift) {
+  x = fmin(fmax(x, -7.0e5), 7.0e5);
+  const double nf = __builtin_rint(x * kLog2e);
+  double r = fma(nf, -6.93147180369123816490e-01, x);
+  r = fma(nf, -1.90821492927058770002e-10, r);
+  double q = 1.0 / 39916800.0;
+  q = fma_sc(q, r, 1.0 / 3628800.0);
+  q = fma_sc(q, r, 1.0 / 362880.0);
+  q = fma_sc(q, r, 1.0 / 40320.0);
+  q = fma_sc(q, r, 1.0 / 5040.0);
+  q = fma_sc(q, r, 1.0 / 720.0);
+  q = fma_sc(q, r, 1.0 / 120.0);
+  q = fma_sc(q, r, 1.0 / 24.0);
+  q = fma_sc(q, r, 1.0 / 6.0);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  return ldexp(fma(q, r, 1.0), (int)nf - shift);
+}
 __device__ __forceinline__ double fast_expm1(double x) {
   const ExpParts p = exp_parts(x);
   const double s = ldexp(1.0, p.n);
@@ -244,8 +279,14 @@ __device__ __forceinline__ Taps cubic_taps(double t) {
   r.b3 = t2 * (t * (1.0 / 6.0));
   return r;
 }
-// the same scaled by a weight w, for the gradient numerators (w folded into the 1/6 factors)
+// the same scaled by a weight w, for the gradient numerators (w folded into the 1/6 factors).  The fraction is laundered
+// through an empty asm so that the compiler cannot share sub-expressions with the cubic_taps() of the evaluation: shared,
+// they stay live across the sample's exponential -- 8-10 VGPRs per spline term, config 5: 108 -> 159, a resident wave per
+// SIMD -- for 7 of ~50 vector instructions per term (GWI_KEEP_TAPS=1 builds the other choice, for A/B timing)
 __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
+#ifndef GWI_KEEP_TAPS
+  asm("" : "+v"(t));
+#endif
   const double v = 1.0 - t;
   const double t2 = t * t, v2 = v * v;
   const double w6 = w * (1.0 / 6.0);
@@ -255,6 +296,15 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
   r.b2 = w * fma(v2, fma(v, 0.5, -1.0), 2.0 / 3.0);
   r.b3 = t2 * (t * w6);
   return r;
+}
+// knot coordinate of a term's sample in one fma: u = x / dx - lo / dx (p2, p3 of the term)
+__device__ __forceinline__ void spline_locate_term(double x, const TermD& td, int& k, double& t) {
+  const double u = fma(x, td.p2, td.p3);
+  const int last = td.n_basis - 4;
+  int kk = (int)u;
+  kk = max(0, min(kk, last));
+  k = kk;
+  t = u - (double)kk;
 }
 __device__ __forceinline__ void spline_locate(double x, double lo, double inv_dx, int n_basis, int& k, double& t) {
   const double u = (x - lo) * inv_dx;
@@ -288,6 +338,9 @@ struct Ctx {
   double* gacc;                 // LDS gradient numerators [n_theta][rep] + this lane's replica: coefficient p lives at gacc[p << rep_shift]
   int rep_shift;
   const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
+#ifdef GWI_ABL_SCATTER_TO_REG
+  mutable double sink = 0.0;  // timing-only ablation: the weighted taps end up here instead of in the LDS rows
+#endif
 };
 
 // ---- spline-coefficient gradient numerators ------------------------------------------------------
@@ -301,6 +354,10 @@ struct Ctx {
 // which is what makes 64 replicas fit: n_theta x 512 B per WORKGROUP.
 __device__ __forceinline__ void spline_scatter(const Ctx& c, int first, const Taps& b) {
 #ifdef GWI_ABL_NO_SCATTER  // timing-only ablation build (tools/build_ablations.sh): results are wrong by construction
+  return;
+#endif
+#ifdef GWI_ABL_SCATTER_TO_REG  // ... the same with the weighted taps still computed (isolates the cost of the LDS atomics)
+  c.sink += (b.b0 + b.b1) + (b.b2 + b.b3) + (double)first;
   return;
 #endif
   double* g = c.gacc + (first << c.rep_shift);
@@ -380,17 +437,18 @@ struct Term<GWI_TERM_PLPEAK> {
     double g[4];
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
-    return eval_shifted<false>(t, d, c, in, s, lin, 0.0);
+    return eval_shifted<false>(t, d, c, in, s, lin, 0.0, 0);
   }
+  // SHIFT: the sample's closing factor folded in: both exponents take E, and the result is scaled by 2^-nshift (fast_exp_shift)
   template <bool SHIFT>
-  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E) {
+  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E, int nshift) {
     const double x = in.x0;
     const double lx = in.x1;
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;
-    const double e_pl = fast_exp(SHIFT ? fma(alpha, lx, d[0] + E) : alpha * lx + d[0]);
-    const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
+    const double e_pl = SHIFT ? fast_exp_shift(fma(alpha, lx, d[0] + E), nshift) : fast_exp(alpha * lx + d[0]);
+    const double e_tn = SHIFT ? fast_exp_shift(fma(-0.5 * dx2, d[5], d[2] + E), nshift) : fast_exp(-0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
     const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
@@ -639,18 +697,28 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     const double x = in.x0;
     int k;
     double tt;
-    spline_locate(x, t.p0, t.p2, t.n_basis, k, tt);
+    spline_locate_term(x, t, k, tt);
     const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
-    // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175).  The flag is wave-uniform: it
-    // picks the bounds (scalar selects) instead of entering the lane predicate, so each of k and v costs ONE vector
-    // select (as `if (flag) if (outside)` it was two; as `flag && outside` the config-3 kernel went from 165 to 193 VGPRs)
+    // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175); LogY bases exclude the sample
+    // (kappa = -inf, decided when the catalog was bound).  The flag is wave-uniform and the block behind it is kept a real
+    // scalar branch (the empty asm cannot be speculated, so the compiler does not turn it into selects): terms without the
+    // flag -- six of config 5's seven, all five of config 3's -- skip two compares and three selects per sample
+#ifdef GWI_OUTSIDE_SELECT
     const bool chk = (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0;
     const double lo_eff = chk ? t.p0 : GWI_NEG_INF, hi_eff = chk ? t.p1 : GWI_POS_INF;
     const bool outside = !((x >= lo_eff) && (x <= hi_eff));
     k = outside ? -1 : k;
     v = outside ? 0.0 : v;
+#else
+    if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {
+      asm volatile("");
+      const bool outside = !((x >= t.p0) && (x <= t.p1));
+      k = outside ? -1 : k;
+      v = outside ? 0.0 : v;
+    }
+#endif
     s.t = tt;
     s.k = k;
     return v;
@@ -682,7 +750,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
     const double x = in.x0;
     int k;
     double tt;
-    spline_locate(x, t.p0, t.p2, t.n_basis, k, tt);
+    spline_locate_term(x, t, k, tt);
     const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double f = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
@@ -809,10 +877,10 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     double g[5];
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
-    return eval_shifted<false>(t, d, c, in, s, lin, 0.0);
+    return eval_shifted<false>(t, d, c, in, s, lin, 0.0, 0);
   }
   template <bool SHIFT>
-  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E) {
+  __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E, int nshift) {
     const double x = in.x0;
     const double lx = in.x1;
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
@@ -820,8 +888,8 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     const double dx2 = dx * dx;
     double dlogS;
     const double S = taper(x - t.p0, c.theta[t.th4], dlogS);
-    const double e_pl = fast_exp(SHIFT ? fma(alpha, lx, d[0] + E) : alpha * lx + d[0]) * S;
-    const double e_tn = fast_exp(SHIFT ? fma(-0.5 * dx2, d[5], d[2] + E) : -0.5 * dx2 * d[5] + d[2]);
+    const double e_pl = (SHIFT ? fast_exp_shift(fma(alpha, lx, d[0] + E), nshift) : fast_exp(alpha * lx + d[0])) * S;
+    const double e_tn = SHIFT ? fast_exp_shift(fma(-0.5 * dx2, d[5], d[2] + E), nshift) : fast_exp(-0.5 * dx2 * d[5] + d[2]);
     const double P = (1.0 - lam) * e_pl, T = lam * e_tn;
     const double p = P + T;
     const double ip = (p > kRcpFloor) ? fast_rcp(p) : 0.0;  // p == 0 (or next to it, see kRcpFloor): a dead sample must not carry NaN into the sums
@@ -925,7 +993,7 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   };
   struct Acc {};
   __device__ static double node(const TermD& t, const Ctx& c, double sx, double wt, int& k, double& tt, double& lin) {
-    spline_locate(sx, t.p0, t.p2, t.n_basis, k, tt);
+    spline_locate_term(sx, t, k, tt);
     const double* cf = c.coefs + t.th0 + k;
     const Taps b = cubic_taps(tt);
     double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
@@ -978,7 +1046,7 @@ struct ChainImpl<U, TAKEN> {
   __device__ void load(int, int, int, const Ctx&, SIdx) {}
   __device__ void advance() {}
   __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
-  __device__ void finish(int, int, const Ctx&, double&, double) {}
+  __device__ void finish(int, int, const Ctx&, double&, double, int) {}
   __device__ void accumulate(int, int, const Ctx&, double) {}
   __device__ void rescale(double) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
@@ -1015,12 +1083,12 @@ struct ChainImpl<U, TAKEN, K, Rest...> {
       return l + rest.eval(u, ti + 1, c, lin);
     }
   }
-  // the deferred term: lin *= its density times exp(E)
-  __device__ void finish(int u, int ti, const Ctx& c, double& lin, double E) {
+  // the deferred term: lin *= its density times exp(E) 2^-nshift
+  __device__ void finish(int u, int ti, const Ctx& c, double& lin, double E, int nshift) {
     if constexpr (kDefer)
-      Term<K>::template eval_shifted<true>(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin, E);
+      Term<K>::template eval_shifted<true>(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin, E, nshift);
     else
-      rest.finish(u, ti + 1, c, lin, E);
+      rest.finish(u, ti + 1, c, lin, E, nshift);
   }
   __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
     Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
@@ -1034,6 +1102,90 @@ struct ChainImpl<U, TAKEN, K, Rest...> {
     Term<K>::collect(c.a->terms[ti], acc, vals, th);
     rest.collect(ti + 1, c, vals + Term<K>::kNumAcc, th + Term<K>::kNumAcc);
   }
+};
+
+// ---- the generic chain (kind sequence {0}): term kinds read from the argument block at RUN time, for products of
+//      densities that have no compiled chain (the reference's user model multiplies any densities:
+//      tests/inference_test.py:256-260, examples/simple_bspline_example.py:58-71).  Nothing is held per term: a sample's
+//      terms are evaluated once for the value (columns loaded on the spot, no prefetch) and once more for the gradient,
+//      whose every entry -- scalar parameters included -- goes through the workgroup's LDS rows like the spline
+//      coefficients of the compiled chains (kSpline = true selects that mode of scan_kernel).  No register state indexed by
+//      a run-time term number, hence no scratch; several times slower than a compiled chain, which
+//      `python -m gwinferno_amd.add_variant` builds when it matters.
+constexpr int kGenericChain = 0;
+#define GWI_FOR_EACH_KIND(X)                                                                                             \
+  X(GWI_TERM_POWERLAW) X(GWI_TERM_PLPEAK) X(GWI_TERM_POWERLAW_RATIO) X(GWI_TERM_BETA) X(GWI_TERM_TILT_MIXTURE)           \
+  X(GWI_TERM_POWERLAW_REDSHIFT) X(GWI_TERM_EXP_SPLINE) X(GWI_TERM_TRUNCNORM) X(GWI_TERM_LINEAR_SPLINE) X(GWI_TERM_TILT_JOINT) \
+  X(GWI_TERM_SMOOTH) X(GWI_TERM_PLPEAK_SMOOTH) X(GWI_TERM_POWERLAW_BOUNDS) X(GWI_TERM_EXP_SPLINE_LERP)
+template <int K>
+__device__ __forceinline__ double generic_value(const TermD& t, const double* d, const Ctx& c, const double* const* tc, SIdx idx, double& lin) {
+  typename Term<K>::In in;
+  typename Term<K>::State st;
+  Term<K>::load(tc, idx, in);
+  return Term<K>::eval(t, d, c, in, st, lin);
+}
+template <int K>
+__device__ __forceinline__ void generic_gradient(const TermD& t, const double* d, const Ctx& c, const double* const* tc, SIdx idx, double w) {
+  typename Term<K>::In in;
+  typename Term<K>::State st;
+  typename Term<K>::Acc acc;
+  Term<K>::load(tc, idx, in);
+  double lin = 1.0;
+  Term<K>::eval(t, d, c, in, st, lin);
+  Term<K>::init(acc);
+  Term<K>::accumulate(t, c, w, st, acc);  // spline kinds scatter into the rows themselves; the others leave w dl/dtheta in acc
+  constexpr int kN = Term<K>::kNumAcc;
+  if constexpr (kN > 0) {
+    double vals[kN];
+    int th[kN];
+    Term<K>::collect(t, acc, vals, th);
+#pragma unroll
+    for (int j = 0; j < kN; ++j)
+      if (vals[j] != 0.0) unsafeAtomicAdd(c.gacc + (th[j] << c.rep_shift), vals[j]);
+  }
+}
+template <int U>
+struct ChainImpl<U, false, kGenericChain> {
+  static constexpr bool kSpline = true;
+  static constexpr bool kAbsorb = false;
+  static constexpr int kNumAcc = 0;
+  SIdx idx[2][U];
+  __device__ void init() {}
+  __device__ void load(int buf, int u, int, const Ctx&, SIdx i) { idx[buf][u] = i; }
+  __device__ void advance() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx[0][u] = idx[1][u];
+  }
+  __device__ double eval(int u, int, const Ctx& c, double& lin) {
+    double l = 0.0;
+    for (int t = 0; t < c.a->n_terms; ++t) {
+      const TermD& td = c.a->terms[t];
+      switch (td.kind) {
+#define GWI_X(K) \
+  case K: l += generic_value<K>(td, c.derived[t], c, c.tcols[t], idx[0][u], lin); break;
+        GWI_FOR_EACH_KIND(GWI_X)
+#undef GWI_X
+        default: lin = 0.0;
+      }
+    }
+    return l;
+  }
+  __device__ void finish(int, int, const Ctx&, double&, double, int) {}
+  __device__ void accumulate(int u, int, const Ctx& c, double w) {
+    if (w == 0.0) return;
+    for (int t = 0; t < c.a->n_terms; ++t) {
+      const TermD& td = c.a->terms[t];
+      switch (td.kind) {
+#define GWI_X(K) \
+  case K: generic_gradient<K>(td, c.derived[t], c, c.tcols[t], idx[0][u], w); break;
+        GWI_FOR_EACH_KIND(GWI_X)
+#undef GWI_X
+        default: break;
+      }
+    }
+  }
+  __device__ void rescale(double) {}
+  __device__ void collect(int, const Ctx&, double*, int*) {}
 };
 
 template <int U, int... Ks>
@@ -1384,8 +1536,8 @@ constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular 
 #ifndef GWI_SCAN_WAVES_PER_EU
 #define GWI_SCAN_WAVES_PER_EU 1
 #endif
-// SAFE (spline models only): the fallback instantiation with the two-pass sweep and the replay (deterministic) mode as
-// run-time options -- and the batch index as one too, so that there is ONE such kernel per term sequence.  Carrying these
+// SAFE (spline models only): the fallback instantiation with the two-pass sweep (last resort: a repeat that still misses)
+// and the replay (deterministic) mode as run-time options -- and the batch index as one too, so that there is ONE such kernel per term sequence.  Carrying these
 // options in the regular kernel cost it 50-90 VGPRs (config 5: 125 -> 213), i.e. one or two resident waves per SIMD.
 template <bool WRITE_LOGW, bool BATCH, bool SAFE, int U, int... Ks>
 __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(const KArgs a) {
@@ -1393,12 +1545,11 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   constexpr int kU = U;
   // Models with spline terms ("shared" mode): the workgroup keeps ONE set of gradient rows in LDS ([coefficient][replica],
   // see spline_scatter) that all four waves add into, so every wave must weigh its samples against the SAME reference
-  // exponent.  That reference is fixed when the workgroup first sees a live sample (one barrier, in the first trip) and
-  // never moves: no per-trip wave maximum, no rescaling of running sums or rows.  Any reference within ~150 of the
-  // tile's true maximum is exact to rounding (the sums hold e^{l-ref} and e^{2(l-ref)}, far from fp64's range); if a
-  // later sample exceeds the reference by more than that, the workgroup says so (redo_host) and the host repeats the
-  // evaluation in two-pass mode, where a first sweep over the tile finds the exact maximum.  Parametric models keep the
-  // per-wave online maximum (registers only, no barrier in the loop).
+  // exponent, known before the first sample is weighed.  It is the tile's exact maximum at the previous evaluation
+  // (KArgs::tile_nref; a scalar load, no barrier, no wave maximum in the loop) applied as an exact power of two, and the
+  // record is normalised so that its bits do not depend on it; the tile's true maximum is tracked on the side and, should
+  // it lie outside the safe range around the reference, the host repeats the evaluation, which then finds the exact
+  // reference in place (see n_ref below).  Parametric models keep the per-wave online maximum (registers only).
   constexpr bool kShared = ChainT::kSpline && !WRITE_LOGW;
   extern __shared__ double s_gacc[];
   __shared__ double s_theta[GWI_MAX_THETA];
@@ -1504,14 +1655,25 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   const int i0 = tid;
   GWI_STAMP(1);
 
-  // shared mode: the workgroup-wide reference exponent and whether it has been fixed yet.  Both are workgroup-uniform
-  // and kept in SCALAR registers (uniform()): the branches on them are scalar branches, which a barrier inside needs.
-  double m_ref = GWI_NEG_INF;
-  int ref_set = 0;
-  int over = 0;                    // some live sample exceeded the reference by more than kRefSlack (wave-uniform)
-  double lane_max = GWI_NEG_INF;   // two-pass mode, pass 0 only: this lane's largest live exponent
-  constexpr double kRefSlack = 150.0;
-  // two-pass mode (shared only): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
+  // shared mode: the reference exponent of this tile, in binades, workgroup-uniform and in a SCALAR register: the tile's
+  // exact maximum at the previous evaluation of this (handle, point) -- a sampler moves theta by a leapfrog step between
+  // two evaluations, log-weights by a few units -- or 0 where there is none yet.  Weights are exp(l) 2^-n_ref with the
+  // shift applied to the exponent field (fast_exp_shift), so every sum scales EXACTLY with the choice and the record below
+  // is normalised to the tile's own S1: results do not depend, to the bit, on which reference was used.  What the choice
+  // must guarantee is the range: the tile's true maximum (tracked per lane, one v_max per sample) has to lie within
+  // kRefSlack binades of n_ref, else sums may have over- or underflowed and the workgroup asks for a repeat (redo_host),
+  // which finds the exact maximum of THIS evaluation in tile_nref already: the repeat cannot miss.
+  int n_ref = 0;
+  int* nref_slot = nullptr;
+  if (kShared) {
+    nref_slot = a.tile_nref + ((long long)(a.nref_row0 + kb) * a.nref_stride + b);
+    const int prev = *nref_slot;
+    n_ref = __builtin_amdgcn_readfirstlane(prev == kNoRef ? 0 : prev);
+  }
+  double lane_max = GWI_NEG_INF;   // shared mode: this lane's largest live exponent
+  // S2 holds w^2 (w^4 in a squared pass): 2 x 430 (4 x 215) binades stay inside fp64's +-1022 with room for the sum
+  const int ref_slack = a.square ? 215 : 430;
+  // two-pass mode (SAFE, shared only; the last resort): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
   const int first_pass = (SAFE && kShared && a.two_pass) ? 0 : 1;
   if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns, in flight before theta is waited for
   if (ChainT::kSpline) {
@@ -1524,9 +1686,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the first trip's load latency
     GWI_STAMP(2);
 #endif
-    int trip = 0;
-    // shared mode iterates whole-workgroup trips (a barrier may sit inside); otherwise a wave stops with its samples
-    for (int i = i0; kShared ? (i - tid < n_tile) : (i - lane < n_tile); i += kU * kBlock, ++trip) {
+    // shared mode iterates whole-workgroup trips in replay mode only (a barrier sits inside); otherwise a wave stops with its samples
+    const bool wg_trips = SAFE && kShared && a.deterministic;
+    for (int i = i0; wg_trips ? (i - tid < n_tile) : (i - lane < n_tile); i += kU * kBlock) {
       // loop-invariant mode flags, laundered so that the compiler keeps ONE copy of the loop body instead of one per
       // combination (unswitching): the branches on them are scalar and cost nothing next to the body
       int pass = pass_, det = (SAFE && kShared) ? a.deterministic : 0;
@@ -1550,7 +1712,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         const bool valid = iu < n_tile;
         lin[u] = 1.0;
         ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
-        if constexpr (WRITE_LOGW && ChainT::kAbsorb) chain.finish(u, 0, ctx, lin[u], 0.0);  // the log-weight wants the plain density
+        if constexpr (WRITE_LOGW && ChainT::kAbsorb) chain.finish(u, 0, ctx, lin[u], 0.0, 0);  // the log-weight wants the plain density
         // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
         live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
         if (!live[u]) ell[u] = GWI_NEG_INF;
@@ -1559,58 +1721,53 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         }
         mx_lane = fmax(mx_lane, ell[u]);
       }
-      // the weight of sample u against the reference exponent: L exp(l - ref), the exponential folded into the chain's
-      // absorbing term where it has one (which is evaluated here, last); a zero, overflowing or NaN density counts as 0
-      auto weight = [&](int u, double ref) -> double {
-        if constexpr (ChainT::kAbsorb && !WRITE_LOGW) {
-          double f = lin[u];
-          chain.finish(u, 0, ctx, f, ell[u] - ref);
-          return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
-        } else {
-          return live[u] ? lin[u] * fast_exp(ell[u] - ref) : 0.0;
-        }
-      };
       if (kShared) {
-        if (SAFE && pass == 0) {
-          lane_max = fmax(lane_max, mx_lane);
-        } else {
-          if (!ref_set) {  // workgroup-uniform: nothing live seen so far -- agree on the reference exponent
-            const double mx = wave_max(mx_lane);
-            if (lane == 0) s_wrec[wave][trip & 1] = mx;  // slot by trip parity: a fast wave's next trip cannot overwrite what a slow one still reads
-            __syncthreads();
-            const int q = trip & 1;
-            const double mm = uniform(fmax(fmax(s_wrec[0][q], s_wrec[1][q]), fmax(s_wrec[2][q], s_wrec[3][q])));
-            if (mm != GWI_NEG_INF) {
-              m_ref = mm;
-              ref_set = 1;
+        lane_max = fmax(lane_max, mx_lane);
+        if (!(SAFE && pass == 0)) {
+          // the weight of sample u: L exp(l) 2^-n_ref, the exponential folded into the chain's absorbing term where it has
+          // one (which is evaluated here, last); a zero, overflowing or NaN density counts as 0
+          auto weight = [&](int u) -> double {
+            if constexpr (ChainT::kAbsorb) {
+              double f = lin[u];
+              chain.finish(u, 0, ctx, f, ell[u], n_ref);
+              return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+            } else {
+              return live[u] ? lin[u] * fast_exp_shift(ell[u], n_ref) : 0.0;
             }
-          } else if (__builtin_amdgcn_ballot_w64(mx_lane > m_ref + kRefSlack) != 0) {
-            over = 1;
-          }
-          if (ref_set) {
-            // replay mode (det): the waves take turns, so every row slot receives its additions in one fixed order
-            // (with rep = 64 a wave instruction never has two lanes on one address)
-            const int n_turns = (SAFE && det) ? kWaves : 1;
-            for (int turn = 0; turn < n_turns; ++turn) {
-              if (wave_has && (!det || turn == wave)) {
+          };
+          // replay mode (det): the waves take turns, so every row slot receives its additions in one fixed order
+          // (with rep = 64 a wave instruction never has two lanes on one address)
+          const int n_turns = (SAFE && det) ? kWaves : 1;
+          for (int turn = 0; turn < n_turns; ++turn) {
+            if (wave_has && (!det || turn == wave)) {
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                  if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
-                  double w = weight(u, m_ref);
-                  if (a.square) w *= w;
-                  s1 += w;
-                  s2 += w * w;
-                  chain.accumulate(u, 0, ctx, w);
-                }
+              for (int u = 0; u < kU; ++u) {
+                if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
+                double w = weight(u);
+                if (a.square) w *= w;
+                s1 += w;
+                s2 += w * w;
+                chain.accumulate(u, 0, ctx, w);
               }
-              if (SAFE && det) __syncthreads();
             }
+            if (SAFE && det) __syncthreads();
           }
         }
       } else if (!WRITE_LOGW) {
+        // the weight of sample u against the wave's reference exponent: L exp(l - ref)
+        auto weight = [&](int u, double ref) -> double {
+          if constexpr (ChainT::kAbsorb) {
+            double f = lin[u];
+            chain.finish(u, 0, ctx, f, ell[u] - ref, 0);
+            return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+          } else {
+            return live[u] ? lin[u] * fast_exp(ell[u] - ref) : 0.0;
+          }
+        };
         // The wave's reference exponent m is set by the first trip that holds a live sample and moves only when a later
-        // sample outruns it by more than kRefSlack (any reference within that distance is exact to rounding, see above):
+        // sample outruns it by more than kRefSlack (any reference within that distance is exact to rounding):
         // the other trips pay one compare + ballot instead of the 20-instruction DPP maximum.
+        constexpr double kRefSlack = 150.0;
         if (m == GWI_NEG_INF || __builtin_amdgcn_ballot_w64(mx_lane > m + kRefSlack) != 0) {  // wave-uniform
           const double mx = wave_max(mx_lane);
           if (mx > m) {  // move every running sum to the new reference exponent
@@ -1645,27 +1802,19 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       if (lane == 0) s_wrec[wave][2] = mx;
       __syncthreads();
       const double mm = uniform(fmax(fmax(s_wrec[0][2], s_wrec[1][2]), fmax(s_wrec[2][2], s_wrec[3][2])));
-      if (mm != GWI_NEG_INF) {
-        m_ref = mm;
-        ref_set = 1;
-      }
+      if (mm != GWI_NEG_INF) n_ref = __builtin_amdgcn_readfirstlane((int)__builtin_rint(fmin(fmax(mm, -7.0e5), 7.0e5) * kLog2e));
+      __syncthreads();  // s_wrec[.][2] is used again below
     }
   }
   if (WRITE_LOGW) return;
   GWI_STAMP(3);
 
   // ---- workgroup record: common exponent M, then a transposed LDS reduction of every scalar sum
-  double M, f;
+  double M = GWI_NEG_INF, f = 1.0;
   if (kShared) {
-    // every wave already used the workgroup's reference; if a live sample outran it by more than the slack, ask the host
-    // for the two-pass repeat (any wave that saw one says so; the stores carry the same value)
-    if (over && lane == 0) {
-      __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    M = m_ref;
-    f = 1.0;
+    // every wave used the tile's reference n_ref; the tile's true maximum decides below whether that was good enough
+    const double mx = wave_max(lane_max);
+    if (lane == 0) s_wrec[wave][2] = mx;
   } else {
     if (lane == 0) s_wrec[wave][0] = m;
     __syncthreads();
@@ -1679,6 +1828,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
   int th[kNV];
+#ifdef GWI_ABL_SCATTER_TO_REG
+  s1 += 1e-300 * ctx.sink;
+#endif
   vals[0] = s1 * f;
   vals[1] = s2 * f * f;
   th[0] = th[1] = -1;
@@ -1699,17 +1851,42 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       const double* row = s_red[v - v0];
       const double r = wave_sum((row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]));
       if (lane == 0) {
-        if (v == 0)
-          out[1] = r;
-        else if (v == 1)
-          out[2] = r;
-        else
+        if (v < 2) {
+          if (kShared)
+            s_wrec[v][3] = r;  // S1 / S2 against n_ref: normalised below, once the whole workgroup can see S1
+          else
+            out[1 + v] = r;
+        } else {
           unsafeAtomicAdd(&s_out[th[v]], r);  // several accumulators may feed one theta slot
+        }
       }
     }
   }
-  if (tid == 0) out[0] = a.square ? 2.0 * M : M;
+  if (!kShared && tid == 0) out[0] = a.square ? 2.0 * M : M;
   __syncthreads();
+  // Shared mode: the record is normalised to the tile's own S1 -- S1 in [1, 2), everything else scaled by the same exact
+  // power of two, the exponent M a whole number of binades -- so that it is, to the bit, the record any other reference
+  // n_ref would have produced (see n_ref above).
+  int e_norm = 0;
+  if (kShared) {
+    const double S1 = s_wrec[0][3], S2 = s_wrec[1][3];
+    const bool has_sum = S1 > 0.0 && S1 < GWI_POS_INF;
+    if (has_sum) e_norm = ilogb(S1);
+    if (tid == 0) {
+      const double mm = fmax(fmax(s_wrec[0][2], s_wrec[1][2]), fmax(s_wrec[2][2], s_wrec[3][2]));
+      const int n_max = (mm == GWI_NEG_INF) ? kNoRef : (int)__builtin_rint(fmin(fmax(mm, -7.0e5), 7.0e5) * kLog2e);
+      *nref_slot = n_max;  // the next evaluation's reference (and, if this one has to be repeated, the repeat's: exact)
+      const int dist = n_max - n_ref;
+      if (n_max != kNoRef && (dist > ref_slack || dist < -ref_slack)) {
+        __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int n_tot = (a.square ? 2 * n_ref : n_ref) + e_norm;
+      out[0] = has_sum ? (double)n_tot * kLn2 : GWI_NEG_INF;
+      out[1] = has_sum ? ldexp(S1, -e_norm) : 0.0;
+      out[2] = has_sum ? ldexp(S2, -2 * e_norm) : 0.0;
+    }
+  }
   // gradient numerators: scalar sums from s_out, spline-coefficient sums from the shared rows (replicas in fixed order)
   for (int p = tid; p < a.n_theta; p += kBlock) {
     double g = s_out[p];
@@ -1717,7 +1894,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       const double* rows = s_gacc + ((long)p << rep_shift);
       double gw = 0.0;
       for (int r = 0; r < rep; ++r) gw += rows[(r + p) & (rep - 1)];  // rotated start: the threads of a wave read different banks
-      g += gw;
+      g = ldexp(g + gw, -e_norm);
     }
     out[kRecHeader + p] = g;
   }

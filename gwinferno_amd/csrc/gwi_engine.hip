@@ -160,6 +160,12 @@ const Variant kVariants[] = {
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+// The fallback for every other product of terms: the generic chain (gwi_device.h, kGenericChain), whose term kinds are read
+// from the argument block at run time.  One kernel plays every role (single / batched / two-pass / replay: the SAFE
+// instantiation takes those as run-time options) plus the log-weight variant.
+const Variant kGenericVariant = {"generic (run-time term loop)", 0, {0}, 1, &scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<true, false, false, 1, kGenericChain>,
+                                 &scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<false, false, true, 1, kGenericChain>};
+
 // ---- batched launches of spline models on the matrix cores (gwi_mfma.h): term sequences with the number of 16-basis
 // gradient tiles of every spline term fixed at compile time.  A model qualifies when its kinds match and every spline
 // term has n_basis <= 16 * tiles; the first qualifying entry is used (entries with fewer tiles first).
@@ -339,7 +345,6 @@ struct gwi_engine {
   double *h_ev = nullptr, *h_ev_dev = nullptr;
   // host-final mode: per-group result rows + normaliser values in pinned host memory
   bool host_final = false;
-  int two_pass_streak = 0;  // evaluations that still go straight to the two-pass kernel (run_pipeline)
   // launch geometry of batched launches (K >= 4, device-final) where it differs from the single evaluation's: two trips
   // per workgroup instead of one (gwi_create)
   struct BatchGeometry {
@@ -358,6 +363,7 @@ struct gwi_engine {
   int gacc_rep = 1;
   bool deterministic = false;   // GWI_DETERMINISTIC=1: replay mode of the shared gradient rows (scan_kernel)
   unsigned long long* d_seq = nullptr;                              // device words: [0] sequence number of the evaluation in flight, [1] redo request
+  int* d_tile_nref = nullptr;   // spline models: every tile's reference exponent = its exact maximum at the previous evaluation (KArgs::tile_nref)
   unsigned long long *h_redo = nullptr, *h_redo_dev = nullptr;      // pinned: a scan workgroup asks for the two-pass repeat
   long redo_count = 0;          // evaluations repeated in two-pass mode so far
   unsigned long long seq = 0;
@@ -392,6 +398,7 @@ struct gwi_engine {
   bool scan_is_batch = false;
   int aql_tail_variant = 0;        // 0: single evaluation, 1 / 2: batched without / with the per-event sites
   bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
+  bool generic = false;       // no compiled chain for this model: the generic scan kernel (kGenericVariant)
   bool combine_acquire = false;  // the combine packet carries an acquire fence after all (A/B only)
   bool aql_tail_only = true;  // scan launches rewrite only the per-evaluation tail of their argument block (GWI_AQL_TAIL=0: the whole block)
   unsigned tail_parity = 0; // which of the two persistent scan-argument slots the next launch rewrites (aql::dispatch_tail)
@@ -609,7 +616,7 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   const int grid = (h->use_bgeo && !logw ? h->bgeo.n_scan_blocks : h->n_scan_blocks) + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   // two-pass repeats and the replay mode run the SAFE instantiation (spline models; it takes single and batched launches)
   // ... and so does any replica count other than the 16 the regular kernels are built for (GWI_GACC_REP)
-  const bool safe = !logw && h->variant->scan_safe && (h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
+  const bool safe = !logw && h->variant->scan_safe && (h->generic || h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
   ScanFn fn = logw ? h->variant->logw : (safe ? h->variant->scan_safe : (batch ? h->variant->scan_batch : h->variant->scan));
   h->scan_is_safe = safe;
   h->kargs.k_batch = batch ? K : 1;
@@ -705,6 +712,7 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
 #endif
   const int n_theta = h->spec.n_theta;
   h->kargs.square = square ? 1 : 0;
+  h->kargs.nref_row0 = batch ? 1 : 0;  // tile references: row 0 belongs to single evaluations, rows 1..K to the points of a batch
   // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
   // (batched theta uploads, the sharded path's exchange behind record_dev) stays on the stream, and so does everything
   // after gwi_set_timing(h, 2)
@@ -781,34 +789,27 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
   return wait_for_norms(h, h->h_record, K);
 }
 
-// A scan workgroup whose fixed reference exponent turned out too low for a later sample (models with spline terms:
+// A scan workgroup whose reference exponent turned out too far from its tile's true maximum (models with spline terms:
 // scan_kernel, shared mode) has stored this evaluation's sequence number in the pinned redo word.
 bool redo_requested(const gwi_engine* h) { return *reinterpret_cast<volatile unsigned long long*>(h->h_redo) == h->seq; }
 
-// launches scan -> combine [-> final]; with `wait`, repeats the evaluation in two-pass mode (exact tile maxima) when a
-// workgroup asked for it.  Callers that pass wait = false check redo_requested() themselves once their results are in.
-// A chain that has reached such a region (warm-up under a wide prior: spline coefficients whose weights span hundreds of
-// e-folds inside a tile) needs the repeat for most of its evaluations, each of which then costs a wasted single-pass attempt
-// on top of the two-pass run.  So a repeat puts the handle into two-pass mode for the next kTwoPassStreak evaluations
-// (they go straight to the two-pass kernel), after which the single-pass kernel is tried again.
-constexpr int kTwoPassStreak = 16;
+// launches scan -> combine [-> final]; with `wait`, repeats the evaluation when a workgroup asked for it.  The failed attempt
+// has left every tile's exact maximum in tile_nref, so the repeat is the same (fast) kernel with exact references and cannot
+// miss; should it ever ask again (it never has) the two-pass instantiation finds the maxima in a sweep of its own.
+// Callers that pass wait = false check redo_requested() themselves once their results are in (repeat_after_redo).
+gwi_status repeat_after_redo(gwi_handle h, const double* theta, double* record_dev, int K, bool batch, bool square) {
+  ++h->redo_count;
+  gwi_status st = run_pipeline_once(h, theta, record_dev, true, K, batch, square);
+  if (st == GWI_OK && redo_requested(h) && h->variant->scan_safe) {
+    h->kargs.two_pass = 1;
+    st = run_pipeline_once(h, theta, record_dev, true, K, batch, square);
+    h->kargs.two_pass = 0;
+  }
+  return st;
+}
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
-  if (wait && h->two_pass_streak > 0 && h->variant->scan_safe && !h->kargs.two_pass) {
-    --h->two_pass_streak;
-    ++h->redo_count;
-    h->kargs.two_pass = 1;
-    const gwi_status st2 = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
-    h->kargs.two_pass = 0;
-    return st2;
-  }
   gwi_status st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
-  if (st == GWI_OK && wait && redo_requested(h)) {
-    ++h->redo_count;
-    h->two_pass_streak = kTwoPassStreak;
-    h->kargs.two_pass = 1;
-    st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
-    h->kargs.two_pass = 0;
-  }
+  if (st == GWI_OK && wait && redo_requested(h)) st = repeat_after_redo(h, theta, record_dev, K, batch, square);
   return st;
 }
 
@@ -1041,14 +1042,17 @@ void assemble(const gwi_engine* h, const double* records, int n_ranks, const gwi
       std::vector<double> H(n_theta, 0.0);
       for (int r = 0; r < n_ranks; ++r) {
         const double* rec = records_sq + (size_t)r * len;
-        const double f2 = (rec[4] == -INFINITY) ? 0.0 : std::exp(rec[4] - M2);  // M2 = 2 M
+        const double f2 = (rec[4] == -INFINITY) ? 0.0 : std::exp(rec[4] - M2);
         const double* gi = rec + kRecNormOff + n_norms + n_theta;
         for (int p = 0; p < n_theta; ++p) H[p] += f2 * gi[p];
       }
+      // S1, S2 and g_inj are in units of e^M (e^2M for S2), H in units of e^M2: each pass reports the exponent its own records
+      // were brought to, and nothing makes M2 equal 2 M (the two passes normalise their tile records independently)
+      const double h_scale = (M2 == -INFINITY || M == -INFINITY) ? 0.0 : std::exp(M2 - 2.0 * M);
       const double V = S2 - S1 * S1 / n_tot;
       const double c_over_neff = (3.0 + n_obs) / (2.0 * std::exp(log_neff_inj));
       for (int p = 0; p < n_theta; ++p) {
-        const double dlog_neff = 2.0 * g_inj[p] / S1 - (2.0 * H[p] - 2.0 * S1 * g_inj[p] / n_tot) / V;
+        const double dlog_neff = 2.0 * g_inj[p] / S1 - (2.0 * h_scale * H[p] - 2.0 * S1 * g_inj[p] / n_tot) / V;
         grad[p] -= n_obs * c_over_neff * dlog_neff;
       }
     }
@@ -1192,6 +1196,7 @@ void destroy_impl(gwi_engine* h) {
     if (e) (void)hipEventDestroy(e);
   (void)hipFree(h->d_tblocks);
   (void)hipFree(h->d_seq);
+  (void)hipFree(h->d_tile_nref);
   if (h->h_redo) (void)hipHostFree(h->h_redo);
   if (h->h_tblocks) (void)hipHostFree(h->h_tblocks);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1225,6 +1230,7 @@ extern "C" {
 int32_t gwi_abi_version(void) { return GWI_ABI_VERSION; }
 int32_t gwi_kernel_variants(void) { return kNumVariants; }
 const char* gwi_kernel_variant_name(int32_t i) { return (i >= 0 && i < kNumVariants) ? kVariants[i].name : nullptr; }
+const char* gwi_scan_kernel_name(gwi_handle h) { return (h && h->variant) ? h->variant->name : "none"; }
 
 const char* gwi_last_error(gwi_handle h) {
   static const char* none = "";
@@ -1317,14 +1323,21 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     return GWI_OK;
   }
   h->variant = find_variant(*spec);
+  if (const char* env = std::getenv("GWI_FORCE_GENERIC"))  // tests: run models that do have a compiled chain through the generic kernel
+    if (std::atoi(env) != 0) h->variant = nullptr;
   if (!h->variant) {
-    std::string seq;
-    for (int t = 0; t < spec->n_terms; ++t) seq += (t ? "," : "") + std::to_string(spec->terms[t].kind);
-    std::string cmd = seq;
-    for (char& ch : cmd)
-      if (ch == ',') ch = ' ';
-    return fail(h, GWI_ERR_UNSUPPORTED, "no compiled kernel for term-kind sequence [" + seq + "]: add it with `python -m gwinferno_amd.add_variant " + cmd +
-                                            "` (appends to gwinferno_amd/csrc/gwi_user_variants.inc and rebuilds the library; ~1 min), then restart the process");
+    // no compiled chain for this product of terms: the generic scan kernel evaluates it (term kinds read at run time)
+    h->variant = &kGenericVariant;
+    h->generic = true;
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true) && !std::getenv("GWI_QUIET")) {
+      std::string cmd;
+      for (int t = 0; t < spec->n_terms; ++t) cmd += (t ? " " : "") + std::to_string(spec->terms[t].kind);
+      std::fprintf(stderr,
+                   "gwi: term-kind sequence [%s] has no compiled scan kernel: using the generic one (run-time term loop, several times slower).  "
+                   "`python -m gwinferno_amd.add_variant %s` builds a compiled chain for it (~1 min, then restart the process).\n",
+                   cmd.c_str(), cmd.c_str());
+    }
   }
   if (device < 0) {
     GWI_HIP(hipGetDevice(&h->device));
@@ -1400,6 +1413,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   bool has_spline = false;
   for (int t = 0; t < spec->n_terms; ++t)
     has_spline = has_spline || spec->terms[t].kind == GWI_TERM_EXP_SPLINE || spec->terms[t].kind == GWI_TERM_LINEAR_SPLINE || spec->terms[t].kind == GWI_TERM_EXP_SPLINE_LERP;
+  has_spline = has_spline || h->generic;  // the generic chain keeps every gradient sum in the LDS rows
   if (const char* env = std::getenv("GWI_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
   size_t scan_lds = 0;
   int rep = 1;
@@ -1553,6 +1567,12 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipHostMalloc((void**)&h->h_fin, sizeof(double) * KB * h->final_groups * record_len(h), hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_fin_dev, h->h_fin, 0));
   std::memset(h->h_fin, 0, sizeof(double) * KB * h->final_groups * record_len(h));
+  {  // tile references of spline models (scan_kernel, shared mode): none yet
+    const size_t n = (size_t)(1 + h->max_batch) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1);
+    std::vector<int> none(n, kNoRef);
+    GWI_HIP(hipMalloc(&h->d_tile_nref, sizeof(int) * n));
+    GWI_HIP(hipMemcpy(h->d_tile_nref, none.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  }
   GWI_HIP(hipMalloc(&h->d_seq, 2 * sizeof(unsigned long long)));
   GWI_HIP(hipMemset(h->d_seq, 0, 2 * sizeof(unsigned long long)));
   GWI_HIP(hipHostMalloc((void**)&h->h_redo, sizeof(unsigned long long), hipHostMallocMapped));
@@ -1612,6 +1632,8 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   k.gacc_rep = rep;
   k.gacc_shift = __builtin_ctz((unsigned)rep);
   k.seq_dev = h->d_seq;
+  k.tile_nref = h->d_tile_nref;
+  k.nref_stride = h->n_scan_blocks ? h->n_scan_blocks : 1;
   k.redo_host = h->h_redo_dev;
   k.redo_dev = h->d_seq + 1;
   k.two_pass = 0;
@@ -1620,8 +1642,6 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     const gwi_term& tm = spec->terms[t];
     TermD& d = k.terms[t];
     d.kind = tm.kind;
-    d.col0 = tm.cols[0];
-    d.col1 = tm.cols[1];
     d.n_basis = tm.n_basis;
     d.th0 = tm.theta[0];
     d.th1 = tm.theta[1];
@@ -1636,6 +1656,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE || tm.kind == GWI_TERM_EXP_SPLINE_LERP) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
+      d.p3 = -tm.p[0] * d.p2;
     }
   }
   h->combine_threads = spec->n_theta + 4 <= 64 ? 64 : kBlock;
@@ -1850,12 +1871,9 @@ gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double
     if (st == GWI_OK) st = wait_for_norms(h, h->h_record, 1);
   }
   if (st != GWI_OK) return st;
-  if (redo_requested(h)) {  // repeat in two-pass mode, blocking (the squared-weight pass, if any, ran through run_pipeline and is exact already)
+  if (redo_requested(h)) {  // repeat, blocking (the squared-weight pass, if any, ran through run_pipeline already)
     const std::vector<double> th(h->kargs.theta, h->kargs.theta + h->spec.n_theta);
-    ++h->redo_count;
-    h->kargs.two_pass = 1;
-    st = run_pipeline_once(h, th.data(), nullptr, true, 1, false, false);
-    h->kargs.two_pass = 0;
+    st = repeat_after_redo(h, th.data(), nullptr, 1, false, false);
     if (st != GWI_OK) return st;
   }
   gwi_summary s;
@@ -2045,7 +2063,13 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
     bool redo = false;
     for (int r = 0; r < h->comm_world; ++r) redo = redo || h->h_gather[(size_t)r * len + 7] < 0.0;
     if (!redo) return GWI_OK;
+    // every rank repeats the exchange (the ranks whose tiles were fine find their references exact as well)
     ++h->redo_count;
+    st_ = run(square);
+    if (st_ != GWI_OK) return st_;
+    redo = false;
+    for (int r = 0; r < h->comm_world; ++r) redo = redo || h->h_gather[(size_t)r * len + 7] < 0.0;
+    if (!redo || !h->variant->scan_safe) return GWI_OK;
     h->kargs.two_pass = 1;
     st_ = run(square);
     h->kargs.two_pass = 0;

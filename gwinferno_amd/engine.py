@@ -601,8 +601,13 @@ class NativePopulationLikelihood:
         """"mfma" or "taps": the kernel a batched launch of ``k_batch`` points uses (``gwi_batch_path``)."""
         return self.lib.gwi_batch_path(self.handle, int(k_batch)).decode()
 
+    def scan_kernel_name(self):
+        """The compiled term chain this engine's scan runs, or "generic (run-time term loop)" (``gwi_scan_kernel_name``)."""
+        return self.lib.gwi_scan_kernel_name(self.handle).decode()
+
     def two_pass_repeats(self):
-        """Evaluations this engine had to repeat with the two-pass scan (``gwi_two_pass_repeats``; 0 in ordinary runs)."""
+        """Evaluations this engine had to repeat because a tile's weights lay outside the safe range around its reference
+        exponent (``gwi_two_pass_repeats``; at most the first evaluation in ordinary runs)."""
         return int(self.lib.gwi_two_pass_repeats(self.handle))
 
     def set_timing(self, on=True):

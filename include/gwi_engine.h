@@ -48,7 +48,7 @@ enum {
   GWI_ERR_INVALID = -1,     /* malformed spec / argument */
   GWI_ERR_NO_DEVICE = -2,   /* no usable gfx950 device: the engine never falls back to the CPU */
   GWI_ERR_HIP = -3,         /* a HIP runtime call failed; see gwi_last_error() */
-  GWI_ERR_UNSUPPORTED = -4, /* term sequence has no compiled kernel; gradient of marginalize_selection via gwi_combine */
+  GWI_ERR_UNSUPPORTED = -4, /* gradient of marginalize_selection via gwi_combine; host placement unknown */
   GWI_ERR_TIMEOUT = -5
 };
 
@@ -307,12 +307,13 @@ gwi_status gwi_eval_sequence(gwi_handle h, const double* thetas, int32_t n, cons
  * seconds[n]: the latency distribution (median, p5/p95) of SURVEY.md section 8(d). */
 gwi_status gwi_eval_latencies(gwi_handle h, const double* thetas, int32_t n, const gwi_options* opt, double* seconds);
 
-/* Models with spline terms: the scan weighs a tile's samples against a reference exponent fixed at the tile's first live
- * sample (so that the four wavefronts of a workgroup can share one set of gradient rows); when a later sample of the tile
- * exceeds it by more than e^150 the evaluation is repeated with a two-pass kernel that finds each tile's exact maximum
- * first.  Results are identical to rounding either way.  After a repeat the next 16 evaluations of the handle go straight
- * to the two-pass kernel (a chain that has wandered into such a region would otherwise pay a wasted attempt every time).
- * This counts the evaluations that ran in two-pass mode (0 in any ordinary run). */
+/* Models with spline terms: the scan weighs a tile's samples against a reference exponent known before the tile's first
+ * sample -- the tile's exact maximum at the previous evaluation of the handle (of the same point of a batch), applied as an
+ * exact power of two so that results do not depend on it to the bit.  When the tile's true maximum turns out more than
+ * 2^430 (2^215 in a squared-weight pass) away from it -- the first evaluation of a handle whose log-weights lie that far
+ * from 0, or a jump in theta that moves a tile's weights by ~300 e-folds -- the evaluation is repeated once; the failed
+ * attempt has left the exact maxima behind, so the repeat cannot miss.  This counts the repeated evaluations (a sampler
+ * moves theta by a leapfrog step between two evaluations: 0 in any ordinary run, whatever the prior width). */
 int64_t gwi_two_pass_repeats(gwi_handle h);
 
 /* Host tuning: restrict the CALLING thread to the CPUs next to the engine's GPU (the local_cpulist of its PCI function,
@@ -333,6 +334,13 @@ gwi_status gwi_hbm_bandwidth(int32_t device, int64_t n_doubles, int32_t iters, d
 /* How plain evaluations are dispatched: "aql: active" (AQL packets into a user-mode queue of the engine's own,
  * gwinferno_amd/csrc/gwi_aql.h: 0.4 us of host time per launch instead of 3.5) or the reason the HIP stream is used. */
 const char* gwi_dispatch_info(gwi_handle h);
+
+/* Name of the scan kernel this engine runs: the compiled term chain ("plq+plz+spline5", ...; gwi_kernel_variant_name) or
+ * "generic (run-time term loop)" -- any product of <= GWI_MAX_TERMS terms has a kernel (the reference's model function
+ * multiplies whatever densities the user picks: tests/inference_test.py:256-260, examples/simple_bspline_example.py:58-71);
+ * products outside the compiled set run the generic kernel, several times slower, and `python -m gwinferno_amd.add_variant`
+ * adds a compiled chain where that matters. */
+const char* gwi_scan_kernel_name(gwi_handle h);
 
 const char* gwi_last_error(gwi_handle h);
 void gwi_destroy(gwi_handle h);

@@ -28,13 +28,15 @@
 
 typedef struct {
   double m, s1, s2;
-  double g[GWI_MAX_THETA];
+  double g[GWI_MAX_THETA]; /* sum w dl/dtheta, in units of e^m */
+  double h[GWI_MAX_THETA]; /* sum w^2 dl/dtheta, in units of e^2m: the gradient of n_eff needs it (analysis.py:270-271) */
 } acc_t;
 
 static void acc_init(acc_t* a) {
   a->m = -INFINITY;
   a->s1 = a->s2 = 0.0;
   memset(a->g, 0, sizeof(a->g));
+  memset(a->h, 0, sizeof(a->h));
 }
 
 static void acc_rescale(acc_t* a, double new_m, int n_theta) {
@@ -46,6 +48,7 @@ static void acc_rescale(acc_t* a, double new_m, int n_theta) {
   a->s1 *= sc;
   a->s2 *= sc * sc;
   for (int p = 0; p < n_theta; ++p) a->g[p] *= sc;
+  for (int p = 0; p < n_theta; ++p) a->h[p] *= sc * sc;
   a->m = new_m;
 }
 
@@ -56,6 +59,7 @@ static void acc_merge(acc_t* dst, const acc_t* src, int n_theta) {
   dst->s1 += f * src->s1;
   dst->s2 += f * f * src->s2;
   for (int p = 0; p < n_theta; ++p) dst->g[p] += f * src->g[p];
+  for (int p = 0; p < n_theta; ++p) dst->h[p] += f * f * src->h[p];
 }
 
 static void pl_lognorm(double alpha, double lo, double hi, double* la, double* dla) {
@@ -270,6 +274,7 @@ static void scan_range(const gwi_spec* sp, const double* const* cols, int64_t lo
     out->s1 += w;
     out->s2 += w * w;
     for (int p = 0; p < n_theta; ++p) out->g[p] += w * d[p];
+    for (int p = 0; p < n_theta; ++p) out->h[p] += w * w * d[p];
   }
 }
 
@@ -425,6 +430,13 @@ int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int
       double g = 0.0;
       for (int64_t e = 0; e < n_ev; ++e) g += ev[e * (3 + n_theta) + 3 + p];
       grad[p] = cut ? 0.0 : g - n_obs * (inj.s1 > 0.0 ? inj.g[p] / inj.s1 : 0.0);
+      if (opt->marginalize_selection && !cut && inj.s1 > 0.0) {
+        /* lde = log mu - c / n_eff, c = (3 + N_obs) / 2 (analysis.py:271); log n_eff = 2 log S1 - log V, V = S2 - S1^2 / N_tot;
+         * dS1 = G = sum w dl, dS2 = 2 H, H = sum w^2 dl  =>  d(-N_obs lde) carries  -N_obs (c / n_eff) dlog n_eff */
+        const double V = inj.s2 - inj.s1 * inj.s1 / n_tot;
+        const double dlog_neff = 2.0 * inj.g[p] / inj.s1 - (2.0 * inj.h[p] - 2.0 * inj.s1 * inj.g[p] / n_tot) / V;
+        grad[p] -= n_obs * (3.0 + n_obs) / (2.0 * exp(log_neff_inj)) * dlog_neff;
+      }
     }
   }
   free(ev);

@@ -965,6 +965,30 @@ def make_pipeline_fixture():
     print("wrote pipeline.npz", {k: float(v) for k, v in out.items() if k.startswith("factor/")})
 
 
+def make_margsel_fixture():
+    """Finite-difference gradients of the reference's `log_likelihood` with marginalize_selection=True (analysis.py:270-271),
+    same extrapolated stencil as the other gradient goldens, for one parametric and two B-spline compositions: pins the
+    extra term -N_obs d[(3 + N_obs) / (2 n_eff)] / d theta of the C oracle and of the engine."""
+    out = {}
+    cases = [("plpeak", (8, 64, 512, BASE_SEED + 11), 2), ("bspline_iid", (6, 96, 768, BASE_SEED + 12), 5), ("bspline_test", (8, 64, 512, BASE_SEED + 11), 4)]
+    for comp_name, cat, seed in cases:
+        pe, inj, tot = make_catalog(*cat)
+        cls = COMPOSITIONS[comp_name]
+        comp = cls({k: jnp.asarray(v) for k, v in pe.items()}, {k: jnp.asarray(v) for k, v in inj.items()})
+        nobs = next(iter(pe.values())).shape[0]
+        pt = cls.draw(np.random.default_rng(seed))
+        for name in cls.params:
+            out[f"{comp_name}/theta/{name}"] = np.asarray(pt[name], dtype=np.float64)
+        sites, _, _ = run_likelihood(comp, pt, nobs, tot, FLAGSETS["lin_marg"])
+        out[f"{comp_name}/log_likelihood"] = np.asarray(sites["log_likelihood"], dtype=np.float64)
+        for name, arr in fd_gradient(comp, pt, nobs, tot, FLAGSETS["lin_marg"]).items():
+            out[f"{comp_name}/fdgrad/{name}"] = arr
+        out[f"{comp_name}/catalog"] = np.asarray(cat, dtype=np.int64)
+        out[f"{comp_name}/total_inj"] = np.asarray(float(tot))
+    np.savez_compressed(os.path.join(HERE, "margsel_grad.npz"), **out)
+    print("wrote margsel_grad.npz", sorted(k for k in out if k.endswith("log_likelihood")))
+
+
 def load_gwtc3(n_samples=64):
     """The reference's own PE tensor (tests/data/..., NetCDF-3 classic): 69 events x 9 params x
     1000 samples, big-endian float32 -> float64; first n_samples per event."""
@@ -978,9 +1002,11 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel"]
     if "ppd" in todo:
         make_ppd_fixture()
+    if "margsel" in todo:
+        make_margsel_fixture()
     if "pipeline" in todo:
         make_pipeline_fixture()
     if "catalog" in todo:

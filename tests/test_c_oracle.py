@@ -47,3 +47,38 @@ def test_thread_count_does_not_change_values():
     th = bm.theta_of(comp.weights(p0, True))
     a, b = orc.evaluate(th, case.total_inj, min_neff_cut=False, n_threads=1), orc.evaluate(th, case.total_inj, min_neff_cut=False, n_threads=4)
     assert a["log_likelihood"] == b["log_likelihood"] and np.array_equal(a["grad"], b["grad"])
+
+
+@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_iid", "bspline_test"])
+def test_c_oracle_marginalised_selection_gradient(comp_name):
+    """The gradient with marginalize_selection=True (analysis.py:270-271: the selection term becomes
+    log mu - (3 + N_obs) / (2 n_eff)) against finite differences of the unmodified reference's log_likelihood under that
+    flag (tests/golden/margsel_grad.npz, written by make_golden.py margsel: extrapolated five-point stencil)."""
+    import os
+
+    from golden_util import GOLDEN_DIR
+
+    from gwinferno_amd.synthetic import make_catalog
+
+    z = np.load(os.path.join(GOLDEN_DIR, "margsel_grad.npz"))
+    pe, inj, total = make_catalog(*[int(v) for v in z[f"{comp_name}/catalog"]])
+    assert total == float(z[f"{comp_name}/total_inj"])
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    pre = f"{comp_name}/theta/"
+    p = {k[len(pre):]: (z[k] if z[k].ndim else float(z[k])) for k in z.files if k.startswith(pre)}
+    bm = bind(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p))
+    comp._engine = type("E", (), {"bound": bm})()
+    got = COracle(bm).evaluate(bm.theta_of(comp.weights(p, True)), total, min_neff_cut=False, marginalize_selection=True)
+    assert rel_err(got["log_likelihood"], float(z[f"{comp_name}/log_likelihood"])) < 1e-9
+    g = comp.named_gradient(got["grad"], p=p)
+    pre = f"{comp_name}/fdgrad/"
+    plain = comp.named_gradient(COracle(bm).evaluate(bm.theta_of(comp.weights(p, True)), total, min_neff_cut=False)["grad"], p=p)
+    differs = 0.0
+    for k in z.files:
+        if not k.startswith(pre):
+            continue
+        ref = z[k]
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        assert np.max(np.abs(np.asarray(g[k[len(pre):]]) - ref)) < fd_gradient_tolerance(comp_name, k[len(pre):]) * scale, (comp_name, k)
+        differs = max(differs, float(np.max(np.abs(np.asarray(plain[k[len(pre):]]) - ref))) / scale)
+    assert differs > 1e-6  # the extra term is visible at this catalog size: the test would notice its absence

@@ -96,24 +96,10 @@ def test_randomised_parity_against_c_oracle(name):
             assert gm.log_likelihood == rms.log_likelihood or rel_err(gm.log_likelihood, rms.log_likelihood) < 1e-9, (name, i, flags, gm.log_likelihood, rms.log_likelihood)
             if abs(rms.log_likelihood) < 1e300:
                 assert np.all(np.isfinite(gm.grad)), (name, i, flags)
-                if not flags.get("marginalize_selection"):  # the C oracle applies the marginalisation to the value only
-                    sc = max(1.0, float(np.max(np.abs(rm["grad"]))))
-                    assert float(np.max(np.abs(gm.grad - rm["grad"]))) / sc < 1e-8, (name, i, flags)
-                elif name in ("pl_test", "plpeak") and i % 64 == 3 and i < N_POINTS // 3:
-                    # ... so the marginalised gradient is held against 4th-order central differences of the engine's own
-                    # value (few parameters; benchmark-prior draws, where the differences are well conditioned).  Not for
-                    # plpeak_smooth: the reference's `smooth` (distributions.py:16-21) jumps from 1 to 0 where m = mmin + delta,
-                    # so the value is discontinuous in delta wherever a sample sits there and its differences mean nothing
-                    # (the analytic gradient is the derivative of the smooth part, pinned by the golden case)
-                    fd = np.zeros_like(th)
-                    for q in range(len(th)):
-                        hq = 1e-3 * max(1.0, abs(th[q]))
-                        eq = np.zeros_like(th)
-                        eq[q] = hq
-                        v = [eng.evaluate(th + c * eq, total, want_grad=False, **flags).log_likelihood for c in (1, -1, 2, -2)]
-                        fd[q] = (8 * (v[0] - v[1]) - (v[2] - v[3])) / (12 * hq)
-                    if np.all(np.isfinite(fd)):
-                        assert np.max(np.abs(gm.grad - fd)) < 2e-6 * max(1.0, float(np.max(np.abs(fd)))), (name, i, gm.grad, fd)
+                # value AND gradient: the C oracle carries the gradient of the marginalised selection term too (pinned to the
+                # reference's finite differences by tests/test_c_oracle.py)
+                sc = max(1.0, float(np.max(np.abs(rm["grad"]))))
+                assert float(np.max(np.abs(gm.grad - rm["grad"]))) / sc < 1e-8, (name, i, flags)
         # the same points eight at a time through the batched launch (its own kernel instantiation and tail): equal to the
         # single evaluations up to summation-order rounding
         pending.append((th, got))

@@ -1,0 +1,200 @@
+"""GPU: the generic scan kernel (run-time term loop) behind the same C ABI.
+
+The reference's user model multiplies whatever densities the user picks (tests/inference_test.py:256-260,
+examples/simple_bspline_example.py:58-71).  Products whose sorted term-kind sequence has a compiled chain run that chain;
+every other product of <= GWI_MAX_TERMS terms runs the generic kernel -- `gwi_create` never refuses a model for lack of a
+kernel.  Held against the C oracle (values 1e-9, analytic gradients 1e-8) on three products written with
+the drop-in model API that have no compiled chain, and against the compiled chains on models that do (GWI_FORCE_GENERIC=1).
+"""
+import numpy as np
+import pytest
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+VALUE_RTOL = 1e-9
+
+
+def _compositions():
+    from gwinferno_amd import models as M
+    from gwinferno_amd.compositions import Composition
+    from gwinferno_amd.interpolation import LogXLogYBSpline, LogYBSpline
+    from gwinferno_amd.lazy import where_finite
+
+    class PLPeakBetaMagSplineTilt(Composition):
+        """PL+Peak m1 x PL q x independent Beta spin magnitudes (parametric.py:71-81) x IID B-spline tilts
+        (separable.py:156-218) x PL z: kinds 2,3,4,4,6,7,7."""
+
+        NT = 10
+        PARAMS = {"alpha": (), "beta": (), "mpp": (), "sigpp": (), "lam": (), "alpha_a1": (), "beta_a1": (), "alpha_a2": (), "beta_a2": (), "t_coefs": (NT,), "lamb": ()}
+
+        def __init__(self, pe, inj, **kw):
+            super().__init__(pe, inj, **kw)
+            self.tilt_model = M.BSplineIIDSpinTilts(self.NT, self.pe["cos_tilt_1"], self.pe["cos_tilt_2"], self.inj["cos_tilt_1"], self.inj["cos_tilt_2"], normalize=True)
+            self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+        def placeholder(self):
+            q = super().placeholder()
+            q.update(mpp=30.0, sigpp=5.0, lam=0.1, alpha_a1=2.0, beta_a1=3.0, alpha_a2=2.0, beta_a2=3.0)
+            return q
+
+        def weights(self, p, pe_samples):
+            d = self.data(pe_samples)
+            mass = M.plpeak_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], p["alpha"], p["beta"], self.mmin, self.mmax, p["mpp"], p["sigpp"], p["lam"])
+            p_a = M.independent_spin_magnitude_beta_dist(d["a_1"], d["a_2"], p["alpha_a1"], p["beta_a1"], p["alpha_a2"], p["beta_a2"])
+            return where_finite(mass * p_a * self.tilt_model(p["t_coefs"], pe_samples=pe_samples) * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+        def hypervolume(self, p):
+            return self.z_model.normalization(p["lamb"])
+
+        @staticmethod
+        def draw(rng):
+            return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "mpp": rng.uniform(20.0, 50.0), "sigpp": rng.uniform(1.0, 10.0), "lam": rng.uniform(0.0, 0.2),
+                    "alpha_a1": rng.uniform(1.0, 3.0), "beta_a1": rng.uniform(1.0, 5.0), "alpha_a2": rng.uniform(1.0, 3.0), "beta_a2": rng.uniform(1.0, 5.0),
+                    "t_coefs": rng.normal(size=10), "lamb": rng.normal(2.7, 1.0)}
+
+    class SplineMassMixtureTilt(Composition):
+        """BSplinePrimaryBSplineRatio (separable.py:446-530) x independent iso+aligned tilt mixtures (parametric.py:93-94) x
+        PL z: kinds 5,5,6,7,7."""
+
+        NM, NQ = 12, 7
+        PARAMS = {"m1_coefs": (NM,), "q_coefs": (NQ,), "xi1": (), "xi2": (), "sig_t1": (), "sig_t2": (), "lamb": ()}
+
+        def __init__(self, pe, inj, **kw):
+            super().__init__(pe, inj, **kw)
+            self.mass_model = M.BSplinePrimaryBSplineRatio(self.NM, self.NQ, self.pe["mass_1"], self.inj["mass_1"], self.pe["mass_ratio"], self.inj["mass_ratio"],
+                                                           m1min=self.mmin, m2min=self.mmin, mmax=self.mmax, kwargs_m={"basis": LogXLogYBSpline}, kwargs_q={"basis": LogYBSpline})
+            self.z_model = M.PowerlawRedshiftModel(self.pe["redshift"], self.inj["redshift"])
+
+        def placeholder(self):
+            q = super().placeholder()
+            q.update(xi1=0.5, xi2=0.5, sig_t1=1.0, sig_t2=1.0)
+            return q
+
+        def weights(self, p, pe_samples):
+            d = self.data(pe_samples)
+            p_ct = M.independent_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi1"], p["xi2"], p["sig_t1"], p["sig_t2"])
+            return where_finite(self.mass_model(p["m1_coefs"], p["q_coefs"], pe_samples=pe_samples) * p_ct * self.z_model(d["redshift"], p["lamb"]) / d["prior"])
+
+        def hypervolume(self, p):
+            return self.z_model.normalization(p["lamb"])
+
+        @staticmethod
+        def draw(rng):
+            return {"m1_coefs": rng.normal(size=12), "q_coefs": rng.normal(size=7), "xi1": rng.uniform(0.0, 1.0), "xi2": rng.uniform(0.0, 1.0), "sig_t1": rng.uniform(0.3, 4.0),
+                    "sig_t2": rng.uniform(0.3, 4.0), "lamb": rng.normal(2.7, 1.0)}
+
+    class PowerlawJointTiltSplineSpinsSplineZ(Composition):
+        """powerlaw_primary_ratio_pdf (parametric.py:27-30) x default_spin_tilt (:97-102) x independent B-spline spin magnitudes
+        (separable.py:82-153) x PowerlawSplineRedshiftModel (spline_perturbation.py:304-372): kinds 1,3,6,7,7,7,10."""
+
+        NA, NZ = 9, 6
+        PARAMS = {"alpha": (), "beta": (), "xi": (), "sig_t": (), "a1_coefs": (NA,), "a2_coefs": (NA,), "z_coefs": (NZ,), "lamb": ()}
+
+        def __init__(self, pe, inj, **kw):
+            super().__init__(pe, inj, **kw)
+            self.mag_model = M.BSplineIndependentSpinMagnitudes(self.NA, self.NA, self.pe["a_1"], self.pe["a_2"], self.inj["a_1"], self.inj["a_2"], normalize=True)
+            self.z_model = M.PowerlawSplineRedshiftModel(self.NZ, self.pe["redshift"], self.inj["redshift"])
+
+        def placeholder(self):
+            q = super().placeholder()
+            q.update(xi=0.5, sig_t=1.0)
+            return q
+
+        def weights(self, p, pe_samples):
+            d = self.data(pe_samples)
+            mass = M.powerlaw_primary_ratio_pdf(d["mass_1"], d["mass_ratio"], alpha=p["alpha"], beta=p["beta"], mmin=self.mmin, mmax=self.mmax)
+            p_ct = M.default_spin_tilt(d["cos_tilt_1"], d["cos_tilt_2"], p["xi"], p["sig_t"])
+            p_a = self.mag_model(p["a1_coefs"], p["a2_coefs"], pe_samples=pe_samples)
+            return where_finite(mass * p_ct * p_a * self.z_model(d["redshift"], p["lamb"], p["z_coefs"]) / d["prior"])
+
+        def hypervolume(self, p):
+            return self.z_model.normalization(p["lamb"], p["z_coefs"])
+
+        @staticmethod
+        def draw(rng):
+            zc = rng.normal(size=6)
+            zc[0] = 0.0
+            return {"alpha": rng.normal(-2.5, 1.0), "beta": rng.normal(1.0, 1.0), "xi": rng.uniform(0.0, 1.0), "sig_t": rng.uniform(0.3, 4.0), "a1_coefs": rng.normal(size=9),
+                    "a2_coefs": rng.normal(size=9), "z_coefs": zc, "lamb": rng.normal(2.7, 1.0)}
+
+    return [PLPeakBetaMagSplineTilt, SplineMassMixtureTilt, PowerlawJointTiltSplineSpinsSplineZ]
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_products_without_a_compiled_chain_match_the_c_oracle(which):
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(11, 1300, 9000, seed=31 + which)
+    cls = _compositions()[which]
+    comp = cls(pe, inj)
+    eng = comp.engine()
+    assert eng.scan_kernel_name().startswith("generic"), eng.scan_kernel_name()
+    orc = COracle(eng.bound)
+    rng = np.random.default_rng(5 + which)
+    thetas = np.stack([comp.theta(cls.draw(rng)) for _ in range(4)])
+    singles = []
+    for th in thetas:
+        got = eng.evaluate(th, total, min_neff_cut=False)
+        ref = orc.evaluate(th, total, min_neff_cut=False)
+        assert rel_err(got.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        assert rel_err(got.log_bfs, ref["logBFs"]) < VALUE_RTOL
+        assert rel_err(got.log_neffs, ref["log_nEffs"]) < 1e-8
+        assert rel_err(got.summary.log_det_eff, ref["summary"].log_det_eff) < VALUE_RTOL
+        assert rel_err(got.norms, ref["norms"]) < VALUE_RTOL
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+        singles.append(got)
+    # flag sets: cuts on; selection marginalised (squared-weight pass through the same kernel)
+    for flags in (dict(min_neff_cut=True), dict(min_neff_cut=False, marginalize_selection=True), dict(min_neff_cut=False, max_variance_cut=True)):
+        got = eng.evaluate(thetas[0], total, **flags)
+        ref = orc.evaluate(thetas[0], total, **flags)
+        assert got.log_likelihood == ref["log_likelihood"] or rel_err(got.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    # batched launches and the begin / end pair run the same kernel
+    batch = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+    begin, end = eng.configure_async(total, min_neff_cut=False)
+    for k, one in enumerate(singles):
+        assert rel_err(batch[k].log_likelihood, one.log_likelihood) < 1e-12
+        assert np.allclose(batch[k].grad, one.grad, rtol=1e-10, atol=1e-11)
+        begin(thetas[k])
+        ll, g = end()
+        assert rel_err(ll, one.log_likelihood) < 1e-12 and np.allclose(g, one.grad, rtol=1e-10, atol=1e-11)
+    eng.close()
+
+
+@pytest.mark.parametrize("comp_name", ["plpeak_full", "bspline_full", "bspline_chieff", "chm_powerlaw", "chm_bspline", "plpeak_smooth", "bspline_misc", "plpeak_default_tilt"])
+def test_generic_kernel_equals_the_compiled_chain(comp_name, monkeypatch):
+    """Every term kind through the generic kernel: models that DO have a compiled chain, forced onto the generic one
+    (GWI_FORCE_GENERIC=1), give the compiled chain's value, sites, per-sample log-weights and gradient."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(7, 900, 5000, seed=17)
+    rng = np.random.default_rng(3)
+    fast = COMPOSITIONS[comp_name](pe, inj)
+    ef = fast.engine()
+    assert not ef.scan_kernel_name().startswith("generic")
+    monkeypatch.setenv("GWI_FORCE_GENERIC", "1")
+    slow = COMPOSITIONS[comp_name](pe, inj)
+    es = slow.engine()
+    assert es.scan_kernel_name().startswith("generic")
+    for _ in range(3):
+        p = draw_params(comp_name, rng)
+        if comp_name == "chm_powerlaw":
+            p["mmin"], p["mmax"] = 4.0, 110.0
+        th = fast.theta(p)
+        a, b = ef.evaluate(th, total, min_neff_cut=False), es.evaluate(th, total, min_neff_cut=False)
+        assert rel_err(b.log_likelihood, a.log_likelihood) < 1e-12
+        assert rel_err(b.log_bfs, a.log_bfs) < 1e-12 and rel_err(b.log_neffs, a.log_neffs) < 1e-10
+        scale = max(1.0, float(np.max(np.abs(a.grad))))
+        assert float(np.max(np.abs(b.grad - a.grad))) / scale < 1e-11
+        wa, wb = ef.log_weights(th), es.log_weights(th)
+        for x, y in zip(wa, wb):
+            assert np.array_equal(np.isneginf(x), np.isneginf(y))
+            ok = ~np.isneginf(x)
+            assert np.max(np.abs(x[ok] - y[ok])) < 1e-11
+    ef.close()
+    es.close()
