@@ -309,7 +309,7 @@ class Run:
         return box
 
 
-def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4):
+def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4, nuts_chains=0):
     """One configuration: W warm-up + exactly K timed steps (barrier + synchronise on both sides, max over ranks), then
     the latency distribution of >= 1000 further evaluations, kernel durations of >= 20 timed launches, and the secondary
     throughput figures.  Returns the dict that goes into the JSON line (rank 0) or None."""
@@ -555,7 +555,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             "two_pass_repeats": eng.two_pass_repeats(),
         }
         if dist is not None:
-            out["multi_gpu"] = {"ranks": world, "rccl_ranks": world if run.backend == "nccl" else 0, "rendezvous_backend": run.backend, "exchange": exchange,
+            key = "shm" if exchange.startswith("host shared-memory") else ("rccl_allgather" if exchange.startswith("ncclAllGather") else "torch_all_gather")
+            rccl_ranks = world if (key == "rccl_allgather" or (key == "torch_all_gather" and run.backend == "nccl")) else 0
+            out["multi_gpu"] = {"ranks": world, "rccl_ranks": rccl_ranks, "headline_exchange_key": key, "rendezvous_backend": run.backend, "exchange": exchange,
                                 "devices_shared_between_ranks": run.shared_devices, "per_rank": per_rank, "sharded_vs_single_gpu": sharded_check,
                                 "independent_chains": replicas}
         else:
@@ -575,6 +577,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
             # the same batch on the matrix cores where the model has an MFMA instantiation (spline models; opt-in path)
+            prev_mfma = os.environ.get("GWI_BATCH_MFMA")
             os.environ["GWI_BATCH_MFMA"] = "1"
             try:
                 alt = COMPOSITIONS[comp_name](pe, inj).engine(device=dev)
@@ -590,9 +593,19 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                                            "what": "spline-coefficient gradient as v_mfma_f64_16x16x4 GEMM, 16 points per wavefront (gwi_mfma.h)"}
                 alt.close()
             finally:
-                del os.environ["GWI_BATCH_MFMA"]
+                if prev_mfma is None:
+                    del os.environ["GWI_BATCH_MFMA"]
+                else:
+                    os.environ["GWI_BATCH_MFMA"] = prev_mfma
         if dist is None and headline and chains > 1:
-            out.update(multi_chain(eng, comp_name, pe, inj, total, thetas, chains, steps, dev))
+            out.update(multi_chain(eng, comp, comp_name, pe, inj, total, thetas, chains, steps, dev))
+        elif dist is None and nuts_chains > 1:
+            # configs 3 / 5: the sampler figure under the reference's priors, on engines of its own
+            comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
+            engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
+            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas)
+            for e in engs[1:]:
+                e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
             out["cpu_baseline"] = cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0 if headline else 5.0, numpy_reference=cfg != "c5")
     if dist is not None:
@@ -601,12 +614,11 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
     return out
 
 
-def multi_chain(eng, comp_name, pe, inj, total, thetas, C, steps, dev):
+def multi_chain(eng, eng_comp, comp_name, pe, inj, total, thetas, C, steps, dev):
     """Secondary numbers (N = 1): C independent chains on the one GPU, each with its own engine."""
     import threading
 
     from gwinferno_amd.compositions import COMPOSITIONS
-    from gwinferno_amd.sampling import GaussianSmoothingPrior, nuts_engine
 
     out = {}
     extra = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C - 1)]
@@ -647,91 +659,164 @@ def multi_chain(eng, comp_name, pe, inj, total, thetas, C, steps, dev):
     for w in workers:
         w.join()
     out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
-    # (c) the same engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain per
-    # engine and host thread, flat priors wide enough not to matter; trees capped at 2^6 leapfrogs so that the line stays
-    # within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second as a sampler sees them
-    # Spline models: the reference's own coefficient prior scale, N(0, 1) (tests/inference_test.py:228-229) -- under a 10 times
-    # wider one the warm-up wanders to coefficient vectors whose weights span hundreds of e-folds inside a tile, where most
-    # evaluations are repeated in two-pass mode (three launches of the scan each) and the trajectories diverge: that measures
-    # the repeat path, not the sampler (config 3: 78 us per leapfrog with 83 % repeats against 27 us with none)
-    sigma = 1.0 if comp_name.startswith("bspline") else 10.0
-    prior = GaussianSmoothingPrior(eng.n_theta).normal(slice(0, eng.n_theta), sigma)
-    starts = np.stack(thetas[:C])
-    repeats0 = sum(e.two_pass_repeats() for e in all_engines)
-    kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
-    nuts_engine(all_engines, total, prior, None, starts, n_warmup=5, n_samples=5, **kw)
-    t0 = time.perf_counter()
-    res = nuts_engine(all_engines, total, prior, None, starts, n_warmup=60, n_samples=60, **kw)
-    dt = time.perf_counter() - t0
-    n_lf = sum(r["n_evals"] for r in res)
-    out["native_nuts"] = {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf,
-                          "prior_sigma": sigma, "two_pass_repeats": sum(e.two_pass_repeats() for e in all_engines) - repeats0}
+    out["native_nuts"] = native_nuts(all_engines, comp_name, eng_comp, total, thetas)
     for c in extra:
         c.engine().close()
     return out
 
 
-def rccl_variant(run, cfg, steps, out):
-    """N > 1 on one GPU per rank, last thing before the line is printed: the same sharded evaluation with the records
-    exchanged by ONE ncclAllGather (RCCL over xGMI) on the engine's own stream instead of the host shared-memory segment.
-    The in-engine communicator has never run across several GPUs in the build environment (1-GPU boxes), so it runs under
-    a watchdog: if it does not come back within the time limit every rank leaves -- rank 0 after printing the line, whose
-    main results are complete by then -- instead of hanging the run."""
-    import threading
+def param_slices(comp):
+    """{parameter name: slice of the flat theta} of a composition (contiguous by construction of the layout)."""
+    idx = {}
+    for slot, (name, _) in enumerate(comp._theta_map()):
+        if name is not None:
+            idx.setdefault(name, []).append(slot)
+    return {name: slice(min(v), max(v) + 1) for name, v in idx.items()}
+
+
+def reference_priors(comp_name, comp, n_theta):
+    """The priors a reference run puts on this composition's hyper-parameters, for the library's sampler
+    (``GaussianSmoothingPrior`` + ``Bijector``).  B-spline models: Normal(0, 15) on the mass coefficients, Normal(0, 5) on
+    mass-ratio and spin coefficients, Normal(0, 1) on the redshift coefficients (the first pinned to 0), each with its
+    P-spline difference penalty (pipeline/utils.py:163-216 with the tau of examples/simple_bspline_example.py:47-56:
+    m 1, q 1, spins 25, z 1), lamb ~ Normal(0, 3) (:56); beta ~ Normal(0, 5) (examples/simple_powerlaw_peak_example.py:52).
+    Parametric models: wide Normals (the bounded sites of that example need its bijectors; flat enough not to matter)."""
+    from gwinferno_amd.pipeline_utils import bspline_example_prior
+    from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior
+
+    sl = param_slices(comp)
+    if comp_name in ("bspline_full", "bspline_defaults"):
+        prior, bij = bspline_example_prior({"m1": sl["m1_coefs"], "q": sl["q_coefs"], "a1": sl["a1_coefs"], "a2": sl["a2_coefs"], "tilt1": sl["t1_coefs"], "tilt2": sl["t2_coefs"],
+                                            "redshift": sl["z_coefs"], "lamb": sl["lamb"]})
+        return prior, bij, "pipeline/utils.py:163-216 as used at examples/simple_bspline_example.py:47-56: N(0,15) m1, N(0,5) q / spins, N(0,1) z, P-spline penalties tau 1/1/25/25/1, lamb N(0,3)"
+    if comp_name == "bspline_iid":
+        prior, bij = GaussianSmoothingPrior(n_theta), Bijector(n_theta)
+        prior.normal(sl["m1_coefs"], 15.0).smoothing(sl["m1_coefs"], 1.0, 1)   # bspline_mass_prior(m_nsplines, m_tau=1)
+        for key in ("a_coefs", "t_coefs"):                                       # bspline_spin_prior(IID=True, a_tau=25, ct_tau=25)
+            prior.normal(sl[key], 5.0).smoothing(sl[key], 25.0, 2)
+        prior.normal(sl["beta"], 5.0).normal(sl["lamb"], 3.0)
+        return prior, bij, "pipeline/utils.py:163-208 (IID spins): N(0,15) m1 tau 1, N(0,5) spins tau 25 degree 2; beta N(0,5), lamb N(0,3)"
+    return GaussianSmoothingPrior(n_theta).normal(slice(0, n_theta), 10.0), None, "Normal(0, 10) on every parameter"
+
+
+def native_nuts(engines, comp_name, comp, total, thetas):
+    """The engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain per engine
+    and host thread, under the priors a reference run uses (reference_priors); trees capped at 2^6 leapfrogs so that the
+    line stays within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second as a sampler
+    sees them, and how many of them the engine had to repeat (gwi_two_pass_repeats: a tile whose weights left the range
+    around the previous evaluation's maximum)."""
+    from gwinferno_amd.sampling import nuts_engine
+
+    C = len(engines)
+    prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
+    starts = np.stack(thetas[:C])
+    if bij is not None:
+        for k in np.flatnonzero(bij.kind == 3):  # pinned entries take their fixed value
+            starts[:, k] = bij.lo[k]
+    kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
+    nuts_engine(engines, total, prior, bij, starts, n_warmup=5, n_samples=5, **kw)
+    repeats0 = sum(e.two_pass_repeats() for e in engines)
+    t0 = time.perf_counter()
+    res = nuts_engine(engines, total, prior, bij, starts, n_warmup=60, n_samples=60, **kw)
+    dt = time.perf_counter() - t0
+    n_lf = sum(r["n_evals"] for r in res)
+    reps = sum(e.two_pass_repeats() for e in engines) - repeats0
+    return {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf, "priors": what,
+            "two_pass_repeats": reps, "repeat_fraction": reps / max(n_lf, 1), "mean_tree_depth": float(np.mean([np.mean(r["tree_depth"]) for r in res]))}
+
+
+RCCL_LEG_FLAG = "--rccl-leg"
+
+
+def rccl_leg_main(argv):
+    """Child process of one rank (`bench.py --rccl-leg ...`): the headline configuration sharded over the ranks with the
+    partial records exchanged by ONE ncclAllGather (RCCL over xGMI) on each engine's own stream -- the exchange
+    BASELINE.json's north_star names.  A process of its own, started by the rank before that touches a GPU, because this
+    communicator has only ever run with one rank in the build environment (1-GPU boxes): if it hangs, the rank kills this
+    child after a time limit and reports a non-zero exit code; the main measurement (shared-memory exchange) is unaffected."""
+    import torch
+    import torch.distributed as dist
 
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.distributed import init_engine_communicator
     from gwinferno_amd.synthetic import make_config_catalog
 
-    limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", "90"))
+    ap = argparse.ArgumentParser()
+    ap.add_argument(RCCL_LEG_FLAG, action="store_true")
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--steps", type=int, default=400)
+    args = ap.parse_args(argv)
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    comp_name, cat_name, _, desc = CONFIGS[args.config]
+    pe, inj, total = make_config_catalog(cat_name)
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    eng = comp.engine(device=local, rank=rank, world=world)
+    init_engine_communicator(eng)  # ncclCommInitRank; the unique id travels through torch.distributed
+    rng = np.random.default_rng(1234)
+    thetas = [comp.theta(draw_params(comp_name, rng)) for _ in range(64)]
+    n = max(200, args.steps)
+    blk = np.stack([thetas[i % len(thetas)] for i in range(n)])
+    eng.evaluate_sequence(blk[:100], total, min_neff_cut=False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ll, _ = eng.evaluate_sequence(blk, total, min_neff_cut=False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lls = torch.tensor([float(ll[-1])], dtype=torch.float64, device="cuda")
+    box = [torch.zeros_like(lls) for _ in range(world)]
+    dist.all_gather(box, lls)
+    same = all(float(b.item()) == float(lls.item()) for b in box)
+    if rank == 0:
+        print(json.dumps({"evals_per_s": n / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / n, "steps": n, "rccl_ranks": world, "workload": desc,
+                          "exchange": "one ncclAllGather of the ~1 KiB partial records per evaluation, on the engine's own stream (gwi_eval_sharded)",
+                          "last_log_likelihood": float(ll[-1]), "identical_on_all_ranks": bool(same), "two_pass_repeats": eng.two_pass_repeats()}), flush=True)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
-    def bail():
-        if run.rank == 0:
-            out["multi_gpu"]["rccl_allgather_variant"] = {"error": f"did not finish within {limit:.0f} s; abandoned"}
-            sys.stdout.flush()
-            print(json.dumps(out), flush=True)
-        os._exit(0)
 
-    dog = threading.Timer(limit, bail)
-    dog.daemon = True
-    dog.start()
-    res = None
+def run_rccl_leg(args):
+    """Called by every rank BEFORE it touches a GPU: start this rank's `--rccl-leg` child (same RANK / WORLD_SIZE /
+    LOCAL_RANK, rendezvous on the port after the run's own), wait for it with a time limit, and return rank 0's parsed line
+    plus the child's exit code.  A child that does not finish is killed by its PID and reported with exit code 124."""
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29517")) + 1)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)  # the child makes a plain env:// rendezvous of its own (rank 0 hosts the store)
+    limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", "150"))
+    cmd = [sys.executable, os.path.abspath(__file__), RCCL_LEG_FLAG, "--config", args.config, "--steps", str(max(200, min(args.steps, 2000)))]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        comp_name, cat_name, _, _ = CONFIGS[cfg]
-        pe, inj, total = make_config_catalog(cat_name)
-        comp = COMPOSITIONS[comp_name](pe, inj)
-        eng = comp.engine(device=run.local_rank, rank=run.rank, world=run.world)
+        out, err = child.communicate(timeout=limit)
+        code = child.returncode
+    except subprocess.TimeoutExpired:
+        child.kill()  # this exact PID
+        out, err = child.communicate()
+        code = 124
+    res = {"child_exit_code": code}
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if lines and code == 0:
         try:
-            init_engine_communicator(eng)
-            ok = True
-        except Exception as exc:
-            print(f"[rank {run.rank}] in-engine RCCL communicator unavailable ({exc})", file=sys.stderr)
-            ok = False
-        if run.all_agree(ok):
-            rng = np.random.default_rng(1234)
-            thetas = [comp.theta(draw_params(comp_name, rng)) for _ in range(64)]
-            n_alt = max(200, steps // 2)
-            blk = np.stack([thetas[i % len(thetas)] for i in range(n_alt)])
-            eng.evaluate_sequence(blk[:50], total, min_neff_cut=False)
-            run.fence()
-            t0 = time.perf_counter()
-            eng.evaluate_sequence(blk, total, min_neff_cut=False)
-            run.fence()
-            ta = run.max_over_ranks(time.perf_counter() - t0)
-            res = {"evals_per_s": n_alt / ta, "ms_per_step": 1e3 * ta / n_alt, "rccl_ranks": run.world,
-                   "what": "same sharded evaluation, records exchanged by one ncclAllGather on the engine's stream"}
-        else:
-            res = {"error": "ncclCommInitRank failed on some rank"}
-        eng.close()
-    except Exception as exc:  # the headline results are complete: report the variant's failure instead of losing the line
-        res = {"error": f"{type(exc).__name__}: {exc}"}
-    finally:
-        dog.cancel()
-    if run.rank == 0:
-        out["multi_gpu"]["rccl_allgather_variant"] = res
+            res.update(json.loads(lines[-1]))
+        except ValueError:
+            res["error"] = "unparsable line from the RCCL leg"
+    elif code == 124:
+        res["error"] = f"the RCCL leg did not finish within {limit:.0f} s; its process was killed"
+    elif code != 0:
+        res["error"] = "the RCCL leg failed: " + (err or "").strip().splitlines()[-1][:300] if (err or "").strip() else "the RCCL leg failed"
+    return res
 
 
 def main():
+    if RCCL_LEG_FLAG in sys.argv[1:]:
+        sys.exit(rccl_leg_main(sys.argv[1:]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -748,6 +833,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and os.environ.get("GWI_FORCE_SHARDED") != "1":
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # N > 1 on one GPU per rank: the in-engine RCCL exchange runs FIRST, in a child process of every rank, before this
+    # process touches a GPU (run_rccl_leg); the main measurement below uses the shared-memory exchange unless told otherwise
+    rccl_leg = None
+    if (args.gpus > 1 and "RANK" in os.environ and os.environ.get("GWI_BENCH_BACKEND", "nccl") == "nccl" and "GWI_BENCH_DEVICE" not in os.environ
+            and "GWI_BENCH_SHARE_DEVICES" not in os.environ and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0"):
+        rccl_leg = run_rccl_leg(args)
+
     run = Run(args)
     if run.world != args.gpus and not (run.world == 1 and os.environ.get("GWI_FORCE_SHARDED") == "1"):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={run.world}")
@@ -763,7 +855,8 @@ def main():
         # the other BASELINE configurations with the same procedure (their own warm-up, K and latency blocks: sized so that
         # the default run stays within minutes)
         k = {"c5": 300, "c3": 600}.get(cfg, 600)
-        blocks[cfg] = measure(run, cfg, k, 50, args.timing_every, spin_s=min(args.spin, 0.3), headline=False, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch, chains=0)
+        blocks[cfg] = measure(run, cfg, k, 50, args.timing_every, spin_s=min(args.spin, 0.3), headline=False, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch, chains=0,
+                              nuts_chains=args.chains)
 
     if run.rank == 0:
         out = {
@@ -784,8 +877,16 @@ def main():
             out.setdefault(k, v)
         if blocks:
             out["configs"] = blocks
-    if run.dist is not None and run.backend == "nccl" and run.shared_devices is None and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0":
-        rccl_variant(run, args.config, args.steps, out if run.rank == 0 else {"multi_gpu": {}})
+    if run.rank == 0 and run.dist is not None:
+        # the exchanges side by side; `rccl_ranks` says how many ranks the communicator that carried the HEADLINE's records had
+        mg = out["multi_gpu"]
+        mg["exchanges"] = {mg.pop("headline_exchange_key"): {"ms_per_step": out["ms_per_step"], "evals_per_s": out["value"], "headline": True}}
+        if rccl_leg is not None:
+            mg["exchanges"]["rccl_allgather"] = rccl_leg
+        for blk in out.get("configs", {}).values():
+            bm = blk.get("multi_gpu")
+            if bm:
+                bm["exchanges"] = {bm.pop("headline_exchange_key"): {"ms_per_step": blk["ms_per_step"], "evals_per_s": blk["value"]}}
     if run.rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last
         import ctypes
@@ -801,7 +902,7 @@ def main():
         # hold the run
         import threading
 
-        dog = threading.Timer(60.0, lambda: os._exit(0))
+        dog = threading.Timer(60.0, lambda: os._exit(3))  # the line is out; a shutdown that hangs is still a failure of this rank
         dog.daemon = True
         dog.start()
         run.dist.barrier()
