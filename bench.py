@@ -576,27 +576,34 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
-            # the same batch on the matrix cores where the model has an MFMA instantiation (spline models; opt-in path)
-            prev_mfma = os.environ.get("GWI_BATCH_MFMA")
-            os.environ["GWI_BATCH_MFMA"] = "1"
-            try:
-                alt = COMPOSITIONS[comp_name](pe, inj).engine(device=dev)
-                if alt.batch_path(K) == "mfma":
-                    vgm = alt.configure_batch(K, total, min_neff_cut=False)
-                    for _ in range(10):
-                        vgm(tb)
-                    t0 = time.perf_counter()
-                    for _ in range(n_b):
-                        vgm(tb)
-                    dtm = time.perf_counter() - t0
-                    out["batched_mfma"] = {"k_batch": K, "evals_per_s": n_b * K / dtm, "us_per_eval": 1e6 * dtm / (n_b * K), "launch_sets": n_b, "path": "mfma",
-                                           "what": "spline-coefficient gradient as v_mfma_f64_16x16x4 GEMM, 16 points per wavefront (gwi_mfma.h)"}
-                alt.close()
-            finally:
-                if prev_mfma is None:
-                    del os.environ["GWI_BATCH_MFMA"]
-                else:
-                    os.environ["GWI_BATCH_MFMA"] = prev_mfma
+            # the other batched kernels on the same batch, where the model has them (spline models): the 4-tap kernel (one
+            # grid row per point, LDS atomics) and the LDS-row variant of the 16-points-per-wavefront kernel
+            alts = {}
+            for alt_name, env_kv in (("taps", {"GWI_BATCH_MFMA": "0"}), ("mfma", {"GWI_BATCH_MFMA": "1"}), ("rows", {"GWI_BATCH_ROWS": "1"})):
+                saved = {k_: os.environ.get(k_) for k_ in env_kv}
+                os.environ.update(env_kv)
+                try:
+                    alt = COMPOSITIONS[comp_name](pe, inj).engine(device=dev)
+                    if alt.batch_path(K) == alt_name and alt_name != out["batched"]["path"]:
+                        vgm = alt.configure_batch(K, total, min_neff_cut=False)
+                        for _ in range(10):
+                            vgm(tb)
+                        t0 = time.perf_counter()
+                        for _ in range(n_b):
+                            vgm(tb)
+                        dtm = time.perf_counter() - t0
+                        alts[alt_name] = {"evals_per_s": n_b * K / dtm, "us_per_eval": 1e6 * dtm / (n_b * K)}
+                    alt.close()
+                finally:
+                    for k_, v_ in saved.items():
+                        if v_ is None:
+                            os.environ.pop(k_, None)
+                        else:
+                            os.environ[k_] = v_
+            if alts:
+                out["batched"]["other_paths"] = alts
+                out["batched"]["paths"] = ("taps: one grid row per point, 4-tap gradient into LDS rows (scan_kernel BATCH); mfma: 16 points per wavefront, gradient as "
+                                           "v_mfma_f64_16x16x4 tiles (gwi_mfma.h); rows: the same kernel with the gradient in conflict-free LDS rows")
         if dist is None and headline and chains > 1:
             out.update(multi_chain(eng, comp, comp_name, pe, inj, total, thetas, chains, steps, dev))
         elif dist is None and nuts_chains > 1:
@@ -788,6 +795,8 @@ def run_rccl_leg(args):
     env = dict(os.environ)
     env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29517")) + 1)
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+        env.setdefault(k, v)
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)  # the child makes a plain env:// rendezvous of its own (rank 0 hosts the store)
     limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", "150"))
@@ -836,7 +845,8 @@ def main():
     # N > 1 on one GPU per rank: the in-engine RCCL exchange runs FIRST, in a child process of every rank, before this
     # process touches a GPU (run_rccl_leg); the main measurement below uses the shared-memory exchange unless told otherwise
     rccl_leg = None
-    if (args.gpus > 1 and "RANK" in os.environ and os.environ.get("GWI_BENCH_BACKEND", "nccl") == "nccl" and "GWI_BENCH_DEVICE" not in os.environ
+    forced = os.environ.get("GWI_FORCE_SHARDED") == "1"  # the N > 1 code path with a world of one rank (tests)
+    if (((args.gpus > 1 and "RANK" in os.environ) or forced) and os.environ.get("GWI_BENCH_BACKEND", "nccl") == "nccl" and "GWI_BENCH_DEVICE" not in os.environ
             and "GWI_BENCH_SHARE_DEVICES" not in os.environ and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0"):
         rccl_leg = run_rccl_leg(args)
 

@@ -89,8 +89,9 @@ def _shape(L, space):
     return tuple(int(d) for d in dims[:nd])
 
 
-def _read(L, obj, ftype, shape, reader):
-    """Read a dataset / attribute `obj` of file type `ftype` into NumPy (numbers) or a list of str (strings)."""
+def _read(L, obj, ftype, shape, reader, space=None):
+    """Read a dataset / attribute `obj` of file type `ftype` into NumPy (numbers) or a list of str (strings).  `space`
+    (the object's dataspace) lets variable-length string reads hand the library's buffers back (H5Dvlen_reclaim)."""
     cls = L.H5Tget_class(ftype)
     n = int(np.prod(shape)) if shape else 1
     if cls == H5T_STRING:
@@ -99,7 +100,9 @@ def _read(L, obj, ftype, shape, reader):
             L.H5Tset_size(mtype, H5T_VARIABLE)
             buf = (C.c_char_p * n)()
             _check(reader(mtype, buf), "read (variable-length strings)")
-            out = [b.decode() if b is not None else "" for b in buf]
+            out = [b.decode() if b is not None else "" for b in buf]  # copies: the pointers below still belong to the library
+            if space is not None:
+                L.H5Dvlen_reclaim(mtype, space, H5P_DEFAULT, C.cast(buf, C.c_void_p))
             L.H5Tclose(mtype)
         else:
             size = L.H5Tget_size(ftype)
@@ -123,6 +126,7 @@ class File:
     def __init__(self, path):
         self.L = lib()
         self.fid = _check(self.L.H5Fopen(os.fsencode(path), H5F_ACC_RDONLY, H5P_DEFAULT), f"H5Fopen({path})")
+        self.skipped_attributes = []  # attributes attrs() could not decode (unsupported datatype classes)
 
     def close(self):
         if self.fid:
@@ -148,7 +152,7 @@ class File:
         d = _check(L.H5Dopen2(self.fid, path.encode(), H5P_DEFAULT), f"H5Dopen2({path})")
         space, ftype = L.H5Dget_space(d), L.H5Dget_type(d)
         try:
-            return _read(L, d, ftype, _shape(L, space), lambda mt, buf: L.H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf))
+            return _read(L, d, ftype, _shape(L, space), lambda mt, buf: L.H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf), space)
         finally:
             L.H5Tclose(ftype), L.H5Sclose(space), L.H5Dclose(d)
 
@@ -195,10 +199,12 @@ class File:
                 L.H5Aget_name(a, n + 1, buf)
                 space, ftype = L.H5Aget_space(a), L.H5Aget_type(a)
                 try:
-                    v = _read(L, a, ftype, _shape(L, space), lambda mt, b_: L.H5Aread(a, mt, b_))
+                    v = _read(L, a, ftype, _shape(L, space), lambda mt, b_: L.H5Aread(a, mt, b_), space)
                     out[buf.value.decode()] = v[0] if isinstance(v, np.ndarray) and v.size == 1 else v
                 except OSError:
-                    pass  # a datatype this reader does not cover (references, compounds): skipped
+                    # a datatype this reader does not cover (references, compounds: netCDF-4's dimension bookkeeping): not in
+                    # the dict; attr(path, name) on such an attribute raises with the datatype class
+                    self.skipped_attributes.append(f"{path}@{buf.value.decode()}")
                 finally:
                     L.H5Tclose(ftype), L.H5Sclose(space), L.H5Aclose(a)
             return out
@@ -216,7 +222,7 @@ class File:
             a = _check(L.H5Aopen(g, name.encode(), H5P_DEFAULT), "H5Aopen")
             space, ftype = L.H5Aget_space(a), L.H5Aget_type(a)
             try:
-                v = _read(L, a, ftype, _shape(L, space), lambda mt, buf: L.H5Aread(a, mt, buf))
+                v = _read(L, a, ftype, _shape(L, space), lambda mt, buf: L.H5Aread(a, mt, buf), space)
                 return v[0] if isinstance(v, np.ndarray) and v.size == 1 else v  # netCDF stores scalars as 1-element arrays
             finally:
                 L.H5Tclose(ftype), L.H5Sclose(space), L.H5Aclose(a)

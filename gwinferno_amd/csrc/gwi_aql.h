@@ -407,6 +407,16 @@ inline bool timed_collect(Queue& q, int n, float* ms) {
   return true;
 }
 
+// An engine whose evaluation timed out with work possibly in flight gives its place on the shared queue back without
+// freeing anything a kernel may still touch (the kernel-argument allocation stays).
+inline void abandon_queue(Queue& q) {
+  if (q.sq && q.dev) {
+    std::lock_guard<std::mutex> lock(q.dev->mu);
+    --q.sq->users;
+  }
+  q.sq = nullptr;
+}
+
 inline void close_queue(Queue& q) {
   if (q.have_signals)
     for (auto& sg : q.done)

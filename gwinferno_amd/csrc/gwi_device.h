@@ -106,7 +106,8 @@ struct KArgs {
   // exact maximum at the PREVIOUS evaluation of this handle, [1 + max_batch][nref_stride] (row 0: single evaluations,
   // rows 1..K: the points of a batched launch); kNoRef where there is none yet
   int* tile_nref;
-  int nref_stride, pad0;
+  int nref_stride;
+  int rows_rep;  // scan_rows_kernel (gwi_mfma.h): sample-slot replicas of its gradient rows (4, 2 or 1)
   TermD terms[GWI_MAX_TERMS];
   // ---- everything ABOVE is fixed at gwi_create; what follows changes from one evaluation to the next.  On the AQL path the
   //      block lives in a persistent kernel-argument slot in device memory and only this tail is rewritten through the PCIe
@@ -299,7 +300,11 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
 }
 // knot coordinate of a term's sample in one fma: u = x / dx - lo / dx (p2, p3 of the term)
 __device__ __forceinline__ void spline_locate_term(double x, const TermD& td, int& k, double& t) {
-  const double u = fma(x, td.p2, td.p3);
+#ifdef GWI_LOCATE_FMA
+  const double u = fma(x, td.p2, td.p3);  // one instruction less per term, two scalar registers more: the config-5 kernel spills scalars with it
+#else
+  const double u = (x - td.p0) * td.p2;
+#endif
   const int last = td.n_basis - 4;
   int kk = (int)u;
   kk = max(0, min(kk, last));

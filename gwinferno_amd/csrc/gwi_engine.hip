@@ -174,13 +174,15 @@ struct MfmaVariant {
   int n;
   int kinds[GWI_MAX_TERMS];
   int tiles[GWI_MAX_TERMS];
-  ScanFn fn;
+  ScanFn fn;        // gradient tiles on the matrix cores (scan_mfma_kernel)
+  ScanFn rows_fn;   // gradient rows in LDS (scan_rows_kernel)
+  int row_doubles;  // doubles a staged sample occupies (gwi_mfma.h: MChain::kRowDoubles)
 };
 #define T1(K) (100 + (K))
 #define T2(K) (200 + (K))
 #define T4(K) (400 + (K))
 #define GWI_MFMA(NAME, U, ...) \
-  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, {0}, &scan_mfma_kernel<U, __VA_ARGS__> }
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, {0}, &scan_mfma_kernel<U, __VA_ARGS__>, &scan_rows_kernel<U, __VA_ARGS__>, MChain<false, __VA_ARGS__>::kRowDoubles }
 MfmaVariant kMfmaVariants[] = {
     // tests/inference_test.py:244-285 model and the mass-only models
     GWI_MFMA("plz+spline3 (16,16,16)", 1, K_PZ, T1(K_SP), T1(K_SP), T1(K_SP)),
@@ -192,9 +194,10 @@ MfmaVariant kMfmaVariants[] = {
     GWI_MFMA("plz+spline7 (32,16,16,16,16,16,16)", 1, K_PZ, T2(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP)),
     // the reference's default spline counts (pipeline/utils.py:29-33): m1 50, q 30, spins 16, z 20
     GWI_MFMA("plz+spline7 (64,32,16,16,16,16,32)", 1, K_PZ, T4(K_SP), T2(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP), T2(K_SP)),
-    // linear (chi_eff / chi_p) splines and the grid-interpolated BSplineDistribution
+    // linear (chi_eff / chi_p) splines
     GWI_MFMA("plz+spline2+lspline2 (16,16,16,16)", 1, K_PZ, T1(K_SP), T1(K_SP), T1(K_LS), T1(K_LS)),
-    GWI_MFMA("plz+lerp2 (16,16)", 1, K_PZ, T1(K_SL), T1(K_SL)),
+    // parametric masses with B-spline spins
+    GWI_MFMA("plpeak+plq+plz+spline4 (16,16,16,16)", 1, K_PP, K_PQ, K_PZ, T1(K_SP), T1(K_SP), T1(K_SP), T1(K_SP)),
 };
 constexpr int kNumMfmaVariants = (int)(sizeof(kMfmaVariants) / sizeof(kMfmaVariants[0]));
 struct MfmaTableInit {
@@ -321,7 +324,9 @@ bool load_nccl(const char* path, std::string* err) {
 struct gwi_engine {
   gwi_spec spec;
   const Variant* variant = nullptr;
-  const MfmaVariant* mfma = nullptr;  // batched launches on the matrix cores, when the model qualifies
+  const MfmaVariant* mfma = nullptr;  // batched launches with 16 points per wavefront (gwi_mfma.h), when the model qualifies
+  bool batch_rows = false;            // ... with the gradient in LDS rows (scan_rows_kernel) instead of MFMA tiles
+  int rows_rep = 4;
   int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
   size_t mfma_lds_bytes = 0;
   bool batch_used_mfma = false;       // path of the most recent batched launch
@@ -623,7 +628,7 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (batch && !safe && !logw) {
     h->batch_used_mfma = h->mfma && K >= h->mfma_min_batch;
     if (h->batch_used_mfma) {  // 16 points per wavefront: the grid's second dimension counts groups of 16
-      launch_timed(h, 0, h->mfma->fn, dim3(grid, (K + kPts - 1) / kPts), dim3(kBlock), h->mfma_lds_bytes, h->kargs, offsetof(KArgs, theta));
+      launch_timed(h, 0, h->batch_rows ? h->mfma->rows_fn : h->mfma->fn, dim3(grid, (K + kPts - 1) / kPts), dim3(kBlock), h->mfma_lds_bytes, h->kargs, offsetof(KArgs, theta));
       GWI_HIP(hipGetLastError());
       return GWI_OK;
     }
@@ -1165,6 +1170,7 @@ void destroy_impl(gwi_engine* h) {
   if (h->shm_base) munmap(h->shm_base, h->shm_bytes);
   if (h->poisoned && !aql::drain(h->aq, 2.0)) {
     // a kernel of the timed-out evaluation may still be running: leak the device buffers rather than free them under it
+    aql::abandon_queue(h->aq);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return;
@@ -1444,17 +1450,31 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   }
   h->gacc_rep = rep;
   if (has_spline) {
-    // Opt-in (GWI_BATCH_MFMA=1; =2: for every batch size, not only >= 9 points): measured against the 4-tap batched kernel
-    // on the BASELINE catalogs at K = 16 it loses (config 5: 57.0 vs 44.6 us per evaluation, config 3: 14.6 vs 11.6) --
-    // the 16 point-lanes of a sample repeat its knot lookup and taps, and forming the A operand costs more vector
-    // instructions than the four atomics it replaces now that those are conflict-free.
+    // Batched launches of >= 9 points take the 16-points-per-wavefront kernel (gwi_mfma.h) where the model has an
+    // instantiation: at K = 16 it measures 3-4 % ahead of the 4-tap kernel on the BASELINE catalogs (config 5: 39.8 vs 41.5 us
+    // per evaluation, config 3: 9.7 vs 10.0) and its gradient is bit-reproducible.  GWI_BATCH_MFMA=0 keeps the 4-tap kernel,
+    // =2 uses the matrix-core kernel for every batch size; GWI_BATCH_ROWS=1 selects the LDS-row variant of the same kernel.
+    h->mfma = find_mfma_variant(*spec);
     if (const char* env = std::getenv("GWI_BATCH_MFMA")) {
-      if (std::atoi(env) >= 1) h->mfma = find_mfma_variant(*spec);
+      if (std::atoi(env) == 0) h->mfma = nullptr;
       if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
-    if (h->mfma) {
-      const size_t th_pad = (size_t)spec->n_theta | 1, der_pad = (size_t)(spec->n_terms * kMaxDerived) | 1;
-      h->mfma_lds_bytes = sizeof(double) * (kPts * th_pad + kPts * der_pad + (size_t)kPts * spec->n_theta + kWaves * 256);
+    if (const char* env = std::getenv("GWI_BATCH_ROWS")) {
+      if (std::atoi(env) >= 1) {
+        h->mfma = find_mfma_variant(*spec);
+        h->batch_rows = h->mfma != nullptr;
+      }
+      if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
+    }
+    if (h->mfma && h->batch_rows) {
+      // sample-slot replicas of the gradient rows: as many (4, 2, 1) as leave two workgroups per CU their LDS
+      h->rows_rep = 4;
+      while (h->rows_rep > 1 && sizeof(double) * mfma_lds_doubles(spec->n_theta, spec->n_terms, h->mfma->row_doubles, h->rows_rep) + 4608 > 80 * 1024) h->rows_rep >>= 1;
+      if (const char* env = std::getenv("GWI_ROWS_REP")) h->rows_rep = std::max(1, std::min(4, std::atoi(env)));
+      h->mfma_lds_bytes = sizeof(double) * mfma_lds_doubles(spec->n_theta, spec->n_terms, h->mfma->row_doubles, h->rows_rep);
+      if (h->mfma_lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->mfma->rows_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mfma_lds_bytes);
+    } else if (h->mfma) {
+      h->mfma_lds_bytes = sizeof(double) * mfma_lds_doubles(spec->n_theta, spec->n_terms, h->mfma->row_doubles, 0);
       if (h->mfma_lds_bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->mfma->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mfma_lds_bytes);
     }
   }
@@ -1634,6 +1654,7 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   k.seq_dev = h->d_seq;
   k.tile_nref = h->d_tile_nref;
   k.nref_stride = h->n_scan_blocks ? h->n_scan_blocks : 1;
+  k.rows_rep = h->rows_rep;
   k.redo_host = h->h_redo_dev;
   k.redo_dev = h->d_seq + 1;
   k.two_pass = 0;
@@ -1799,7 +1820,7 @@ int64_t gwi_two_pass_repeats(gwi_handle h) { return h ? h->redo_count : 0; }
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   if (!h || h->host_only) return "none";
   const bool safe = h->variant && h->variant->scan_safe && h->kargs.deterministic;
-  return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? "mfma" : "taps";
+  return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";
 }
 
 gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {

@@ -10,17 +10,26 @@
 // and this kernel runs it on the matrix cores: v_mfma_f64_16x16x4_f64 with A = a 16-basis x 4-sample slab of the design
 // matrix formed IN REGISTERS from the sample's four taps (never stored anywhere), B = the 4-sample x 16-point block of
 // importance weights, D = the 16 x 16 gradient tile, which stays in registers for the whole tile of the catalog.  No LDS
-// atomics, a fixed summation order (bit-reproducible), and the matrix pipe runs beside the vector pipe that evaluates the
-// densities.  The forward half stays in the 4-tap form: as a dense product it would spend one MFMA (32 cycles) per 4 basis
-// functions per 16 samples where the taps need 4 FMAs per sample (measured: tools/microbench/mfma_f64_layout.hip gives the
-// instruction's rate; DESIGN.md section 4 has the arithmetic and the measurement of this kernel against the tap kernel).
+// atomics, a fixed summation order (bit-reproducible), and the matrix pipe runs beside the vector pipe.
 //
-// Layout: a wavefront holds 4 samples x 16 hyper-parameter points: lane l = (q = l / 16: sample slot, j = l % 16: point).
-//   B operand  lane (q, j) holds w[sample q, point j]                      -- the lane's own weight
-//   A operand  lane (q, i) holds B_{16 tile + i}(x_{sample q})             -- the lane's own sample, basis = its j index
-//   D          lane (q, j), register r holds G[16 tile + q + 4 r][point j]
-// (layout confirmed on the hardware by tools/microbench/mfma_f64_layout.hip).  Per-sample work that does not depend on
-// the hyper-parameters (column loads, knot interval, taps) is replicated across the 16 point-lanes of a sample.
+// Two phases per trip of a wavefront (64 samples), so that the memory traffic and the knot lookup are paid once per sample
+// and not once per (sample, point):
+//   phase A   lane = sample: column loads (coalesced, register-prefetched one trip ahead), knot interval k and fraction t of
+//             every spline term, outside-domain flag -> a wavefront-private staging row in LDS (per spline term: k | flag, t;
+//             per other term: its one or two column values; kappa first)
+//   phase B   lane = (q = sample slot 0..3, j = point 0..15), sixteen rounds: read the sample's staged row (broadcast reads:
+//             16 bytes per spline term), the four taps from t, dot with point j's coefficients (LDS), the parametric terms
+//             with point j's scalars, exponential, running sums; then per 16-basis tile one MFMA: A = the lane's tap for
+//             basis 16 tile + j (select on basis - k), B = the lane's weight.
+// The staging carries (k, t) and not the taps: the kernel is bound by the LDS pipe the four SIMDs of a CU share (every
+// wave instruction moves 64 lanes' worth of bytes, broadcast or not), and the coefficient gather alone is 32 bytes per lane,
+// term and sample-point; recomputing the taps costs 11 vector instructions per term where reading them costs two more
+// 16-byte reads (measured: taps staged 44.3 us per evaluation at config 5, K = 16).
+// Operand / result layout of v_mfma_f64_16x16x4_f64 (confirmed on the hardware by tools/microbench/mfma_f64_layout.hip):
+//   A  lane l holds A[i = l % 16][k = l / 16];  B  lane l holds B[k = l / 16][j = l % 16];
+//   D  lane l, register r holds D[row = l / 16 + 4 r][col = l % 16].
+// Reference exponents: one per (tile, point), the tile's exact maximum at the previous batched launch of the handle
+// (KArgs::tile_nref rows 1..K), applied as an exact power of two; records normalised per point exactly as scan_kernel's.
 #pragma once
 #include "gwi_device.h"
 
@@ -28,7 +37,7 @@ namespace gwi {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int kPts = 16;  // hyper-parameter points per wavefront (the N of the MFMA tile)
+constexpr int kPts = 16;      // hyper-parameter points per wavefront (the N of the MFMA tile)
 
 // the tap of basis function `first + d` for a sample whose non-zero bases start at `first`: b_d for d in 0..3, else 0
 __device__ __forceinline__ double tap_select(const Taps& b, int d) {
@@ -40,103 +49,196 @@ __device__ __forceinline__ double tap_select(const Taps& b, int d) {
   return v;
 }
 
-// ---- per-kind MFMA operands: one row slab of the (implicit) design matrix and the weight that multiplies it ----------
+// ---- per-kind staging.  kDoubles = doubles a sample occupies in the staging row for this term.  Phase B runs in three
+//      passes over the chain -- b_rows (every term's staged words requested), b_coefs (every spline term's four
+//      coefficients requested, which needs k), b_value (the arithmetic) -- so that a round of the loop waits for the LDS
+//      twice, not once or twice per term: with two resident waves per SIMD (the gradient tiles take 64 registers) there is
+//      nothing to hide twenty LDS round trips per round behind (measured: 21 s_waitcnt per round, 2770 cycles per
+//      64 sample-points whatever the vector instruction count).
 template <int K>
-struct SplineOperands;
-template <>
-struct SplineOperands<GWI_TERM_EXP_SPLINE> {
-  struct Prep {
-    Taps b;
-    int k;
+struct Stage {  // every kind without spline coefficients: the term's column values travel as they are
+  static constexpr bool kSpline = false;
+  static constexpr int kDoubles = (int)(sizeof(typename Term<K>::In) / sizeof(double));
+  struct Keep {
+    typename Term<K>::In in;
+    typename Term<K>::State st;
   };
-  __device__ static Prep prepare(const typename Term<GWI_TERM_EXP_SPLINE>::State& s) { return {cubic_taps(s.t), s.k}; }
-  __device__ static double a(const Prep& p, int basis) { return p.k >= 0 ? tap_select(p.b, basis - p.k) : 0.0; }
-  __device__ static double b(const typename Term<GWI_TERM_EXP_SPLINE>::State&, double w) { return w; }
-};
-template <>
-struct SplineOperands<GWI_TERM_LINEAR_SPLINE> {
-  struct Prep {
-    Taps b;
-    int k;
-  };
-  __device__ static Prep prepare(const typename Term<GWI_TERM_LINEAR_SPLINE>::State& s) { return {cubic_taps(s.t), s.k}; }
-  __device__ static double a(const Prep& p, int basis) { return tap_select(p.b, basis - p.k); }
-  __device__ static double b(const typename Term<GWI_TERM_LINEAR_SPLINE>::State& s, double w) { return w * s.inv_f; }  // dl/dc_k = B_k / f
-};
-template <>
-struct SplineOperands<GWI_TERM_EXP_SPLINE_LERP> {
-  struct Prep {
-    Taps b0, b1;
-    int k0, k1;
-    double f;
-  };
-  __device__ static Prep prepare(const typename Term<GWI_TERM_EXP_SPLINE_LERP>::State& s) { return {cubic_taps(s.t0), cubic_taps(s.t1), s.k0, s.k1, s.f}; }
-  __device__ static double a(const Prep& p, int basis) {
-    const double a0 = p.k0 >= 0 ? tap_select(p.b0, basis - p.k0) : 0.0;
-    const double a1 = p.k1 >= 0 ? tap_select(p.b1, basis - p.k1) : 0.0;
-    return fma(p.f, a1 - a0, a0);  // the same blend of the two grid nodes as the value
+  __device__ static void phase_a(const TermD&, const typename Term<K>::In& in, double* row) {
+    const double* src = reinterpret_cast<const double*>(&in);
+#pragma unroll
+    for (int i = 0; i < kDoubles; ++i) row[i] = src[i];
   }
-  __device__ static double b(const typename Term<GWI_TERM_EXP_SPLINE_LERP>::State&, double w) { return w; }
+  __device__ static void b_rows(const double* row, Keep& kp) {
+    double* dst = reinterpret_cast<double*>(&kp.in);
+#pragma unroll
+    for (int i = 0; i < kDoubles; ++i) dst[i] = row[i];
+  }
+  __device__ static void b_coefs(const TermD&, const Ctx&, Keep&) {}
+  __device__ static double b_value(const TermD& t, const double* d, const Ctx& c, Keep& kp, double& lin) { return Term<K>::eval(t, d, c, kp.in, kp.st, lin); }
+};
+struct SplineKeep {
+  Taps b;
+  double cf[4];
+  int k;
+  double scale;  // what multiplies the weight in the B operand (1, or 1 / f for the linear spline; 0 outside the domain)
+};
+// staged: [0] = k in the low word, outside-domain flag in the high word; [1..4] = the four taps
+__device__ __forceinline__ void stage_spline(const TermD& t, double x, bool zero_outside, double* row) {
+  int k;
+  double tt;
+  spline_locate_term(x, t, k, tt);
+  const int out = (zero_outside && !((x >= t.p0) && (x <= t.p1))) ? 1 : 0;  // bases are 0 out there (interpolation.py:175)
+  const Taps b = cubic_taps(tt);
+  row[0] = __hiloint2double(out, k);
+  row[1] = b.b0;
+  row[2] = b.b1;
+  row[3] = b.b2;
+  row[4] = b.b3;
+}
+__device__ __forceinline__ void spline_rows(const double* row, SplineKeep& kp) {
+  const double w0 = row[0];
+  kp.b.b0 = row[1];
+  kp.b.b1 = row[2];
+  kp.b.b2 = row[3];
+  kp.b.b3 = row[4];
+  kp.k = __double2loint(w0);
+  kp.scale = __double2hiint(w0) != 0 ? 0.0 : 1.0;
+}
+__device__ __forceinline__ void spline_coefs(const TermD& t, const Ctx& c, SplineKeep& kp) {
+  const double* cf = c.coefs + t.th0 + kp.k;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kp.cf[i] = cf[i];
+}
+__device__ __forceinline__ double spline_value(SplineKeep& kp) {
+  return kp.cf[0] * kp.b.b0 + kp.cf[1] * kp.b.b1 + kp.cf[2] * kp.b.b2 + kp.cf[3] * kp.b.b3;
+}
+template <>
+struct Stage<GWI_TERM_EXP_SPLINE> {
+  static constexpr bool kSpline = true;
+  static constexpr int kDoubles = 5;
+  using Keep = SplineKeep;
+  __device__ static void phase_a(const TermD& t, const typename Term<GWI_TERM_EXP_SPLINE>::In& in, double* row) {
+    // LogY bases exclude outside samples through kappa (decided when the catalog was bound); zero-outside bases give exp(0)
+    stage_spline(t, in.x0, (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0, row);
+  }
+  __device__ static void b_rows(const double* row, Keep& kp) { spline_rows(row, kp); }
+  __device__ static void b_coefs(const TermD& t, const Ctx& c, Keep& kp) { spline_coefs(t, c, kp); }
+  __device__ static double b_value(const TermD& t, const double*, const Ctx&, Keep& kp, double&) {
+    double v = spline_value(kp);
+    if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {  // wave-uniform; kept a scalar branch (cf. Term<GWI_TERM_EXP_SPLINE>::eval)
+      asm volatile("");
+      v *= kp.scale;
+    }
+    return v;
+  }
+};
+template <>
+struct Stage<GWI_TERM_LINEAR_SPLINE> {
+  static constexpr bool kSpline = true;
+  static constexpr int kDoubles = 5;
+  using Keep = SplineKeep;
+  __device__ static void phase_a(const TermD& t, const typename Term<GWI_TERM_LINEAR_SPLINE>::In& in, double* row) { stage_spline(t, in.x0, true, row); }
+  __device__ static void b_rows(const double* row, Keep& kp) { spline_rows(row, kp); }
+  __device__ static void b_coefs(const TermD& t, const Ctx& c, Keep& kp) { spline_coefs(t, c, kp); }
+  __device__ static double b_value(const TermD&, const double*, const Ctx&, Keep& kp, double& lin) {
+    const double f = spline_value(kp) * kp.scale;
+    kp.scale = f > 0.0 ? fast_rcp(f) : 0.0;  // dl / dc_k = B_k / f; f <= 0 (outside the domain too) makes the sample dead (lin > 0 test)
+    lin *= f;
+    return 0.0;
+  }
 };
 
 // ---- compile-time chain.  Every entry is  kind + 100 * tiles:  tiles = 16-basis gradient tiles of a spline term
 //      (n_basis <= 16 tiles, checked by the host), 0 for the other kinds. ------------------------------------------------
-template <int U, int... KTs>
+// ROWS: the gradient of the spline coefficients goes into LDS rows (scan_rows_kernel) instead of MFMA tiles.
+template <bool ROWS, int... KTs>
 struct MChain;
-template <int U>
-struct MChain<U> {
-  static constexpr int kNumAcc = 0, kTiles = 0;
+template <bool ROWS>
+struct MChain<ROWS> {
+  static constexpr int kNumAcc = 0, kTiles = 0, kRowDoubles = 0;
   __device__ void init() {}
-  __device__ void load(int, int, int, const Ctx&, SIdx) {}
+  __device__ void load(int, const Ctx&, SIdx) {}
   __device__ void advance() {}
-  __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
-  __device__ void accumulate(int, int, const Ctx&, double, int) {}
+  __device__ void phase_a(int, const Ctx&, double*) {}
+  __device__ void b_rows(const double*) {}
+  __device__ void b_coefs(int, const Ctx&) {}
+  __device__ double b_value(int, const Ctx&, double&) { return 0.0; }
+  __device__ void accumulate(int, const Ctx&, double, int, double*) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
   template <class F>
   __device__ void for_each_tile(int, const Ctx&, F&&) {}
 };
-template <int U, int KT, int... Rest>
-struct MChain<U, KT, Rest...> {
-  static constexpr int K = KT % 100, NT = KT / 100;
-  static constexpr bool kIsSpline = Term<K>::kSpline;
-  static_assert(kIsSpline == (NT > 0), "spline kinds carry their tile count (kind + 100 * tiles), the others none");
-  static constexpr int kNumAcc = Term<K>::kNumAcc + MChain<U, Rest...>::kNumAcc;
-  static constexpr int kTiles = NT + MChain<U, Rest...>::kTiles;
-  typename Term<K>::In in[2][U];
-  typename Term<K>::State st[U];
+template <bool ROWS, int KT, int... Rest>
+struct MChain<ROWS, KT, Rest...> {
+  static constexpr int K = KT % 100, NT = ROWS ? 0 : KT / 100;
+  using S = Stage<K>;
+  using RestT = MChain<ROWS, Rest...>;
+  static_assert(S::kSpline == (KT / 100 > 0), "spline kinds carry their tile count (kind + 100 * tiles), the others none");
+  static constexpr int kNumAcc = Term<K>::kNumAcc + RestT::kNumAcc;
+  static constexpr int kTiles = NT + RestT::kTiles;
+  static constexpr int kRowDoubles = S::kDoubles + RestT::kRowDoubles;
+  typename Term<K>::In in[2];  // phase A lanes: this trip's and the next trip's column values
+  typename S::Keep keep;       // phase B lanes: what the accumulation needs from the evaluation
   typename Term<K>::Acc acc;
   v4d tile[NT > 0 ? NT : 1];
-  MChain<U, Rest...> rest;
+  RestT rest;
   __device__ void init() {
     Term<K>::init(acc);
 #pragma unroll
     for (int t = 0; t < NT; ++t) tile[t] = v4d{0.0, 0.0, 0.0, 0.0};
     rest.init();
   }
-  __device__ void load(int buf, int u, int ti, const Ctx& c, SIdx idx) {
-    Term<K>::load(c.tcols[ti], idx, in[buf][u]);
-    rest.load(buf, u, ti + 1, c, idx);
+  __device__ void load(int ti, const Ctx& c, SIdx idx) {
+    Term<K>::load(c.tcols[ti], idx, in[1]);
+    rest.load(ti + 1, c, idx);
   }
   __device__ void advance() {
-#pragma unroll
-    for (int u = 0; u < U; ++u) in[0][u] = in[1][u];
+    in[0] = in[1];
     rest.advance();
   }
-  __device__ double eval(int u, int ti, const Ctx& c, double& lin) {
-    const double l = Term<K>::eval(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin);
-    return l + rest.eval(u, ti + 1, c, lin);
+  __device__ void phase_a(int ti, const Ctx& c, double* row) {
+    S::phase_a(c.a->terms[ti], in[0], row);
+    rest.phase_a(ti + 1, c, row + S::kDoubles);
   }
-  // w = this lane's weight w[sample, point]; basis_lane = lane & 15 (the lane's row inside a gradient tile)
-  __device__ void accumulate(int u, int ti, const Ctx& c, double w, int basis_lane) {
-    if constexpr (kIsSpline) {
-      const auto prep = SplineOperands<K>::prepare(st[u]);
-      const double bw = SplineOperands<K>::b(st[u], w);
+  __device__ void b_rows(const double* row) {
+    S::b_rows(row, keep);
+    rest.b_rows(row + S::kDoubles);
+  }
+  __device__ void b_coefs(int ti, const Ctx& c) {
+    S::b_coefs(c.a->terms[ti], c, keep);
+    rest.b_coefs(ti + 1, c);
+  }
+  __device__ double b_value(int ti, const Ctx& c, double& lin) {
+    const double l = S::b_value(c.a->terms[ti], c.derived[ti], c, keep, lin);
+    return l + rest.b_value(ti + 1, c, lin);
+  }
+  // w = this lane's weight w[sample, point]; basis_lane = lane & 15 (the lane's row inside a gradient tile); grow = this
+  // lane's gradient row in LDS (ROWS)
+  __device__ void accumulate(int ti, const Ctx& c, double w, int basis_lane, double* grow) {
+    if constexpr (S::kSpline && ROWS) {
+      const double bw = w * keep.scale;
+      double* g = grow + c.a->terms[ti].th0 + keep.k;
+      unsafeAtomicAdd(g, bw * keep.b.b0);
+      unsafeAtomicAdd(g + 1, bw * keep.b.b1);
+      unsafeAtomicAdd(g + 2, bw * keep.b.b2);
+      unsafeAtomicAdd(g + 3, bw * keep.b.b3);
+    } else if constexpr (S::kSpline) {
+      const double bw = w * keep.scale;
+      const int d0 = basis_lane - keep.k;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(SplineOperands<K>::a(prep, 16 * t + basis_lane), bw, tile[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+#if defined(GWI_ABL_NO_MFMA)  // timing-only ablations (results wrong): the A operand still formed, no matrix instruction
+        tile[t][0] += tap_select(keep.b, 16 * t + d0) * bw;
+#elif defined(GWI_ABL_NO_AFORM)  // ... the matrix instruction with an operand that costs nothing to form
+        tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(keep.b.b0, bw, tile[t], 0, 0, 0);
+#else
+        tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tap_select(keep.b, 16 * t + d0), bw, tile[t], 0, 0, 0);
+#endif
+      }
     } else {
-      Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
+      Term<K>::accumulate(c.a->terms[ti], c, w, keep.st, acc);
     }
-    rest.accumulate(u, ti + 1, c, w, basis_lane);
+    rest.accumulate(ti + 1, c, w, basis_lane, grow);
   }
   __device__ void collect(int ti, const Ctx& c, double* vals, int* th) {
     Term<K>::collect(c.a->terms[ti], acc, vals, th);
@@ -145,7 +247,7 @@ struct MChain<U, KT, Rest...> {
   // f(theta offset of the tile's first coefficient, number of valid rows, the tile)
   template <class F>
   __device__ void for_each_tile(int ti, const Ctx& c, F&& f) {
-    if constexpr (kIsSpline) {
+    if constexpr (S::kSpline && !ROWS) {
       const TermD& t = c.a->terms[ti];
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) f(t.th0 + 16 * tl, t.n_basis - 16 * tl, tile[tl]);
@@ -154,17 +256,29 @@ struct MChain<U, KT, Rest...> {
   }
 };
 
-// ---- the kernel.  grid = (scan blocks [+ normaliser blocks], groups of 16 hyper-parameter points) x 256 threads.
-//      Dynamic LDS: theta and derived scalars of the group's 16 points ([16][n_theta | 1] + [16][n_terms * kMaxDerived | 1]
-//      doubles), then the per-point output rows [16][n_theta] and a 16 x 16 x 4-wave staging tile. ------------------------
-template <int U, int... KTs>
-// two wavefronts per SIMD: left alone the compiler takes 284 registers for the config-5 sequence (one wave per SIMD, nothing to
-// hide a dependent fp64 chain behind); bounded to 256 it needs 217 and spills nothing
-__global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
-  using ChainT = MChain<U, KTs...>;
-  constexpr int kU = U;
+// dynamic LDS of the two kernels in doubles (the host sizes the launch with it).  rows_rep = 0: scan_mfma_kernel; else the
+// sample-slot replicas (4, 2 or 1) of scan_rows_kernel's gradient rows
+__host__ __device__ inline size_t mfma_lds_doubles(int n_theta, int n_terms, int row_doubles, int rows_rep) {
+  const size_t th_pad = (size_t)n_theta | 1, der_pad = (size_t)(n_terms * kMaxDerived) | 1;
+  const size_t S = rows_rep ? 16 : 32;
+  size_t stage = (size_t)kWaves * S * (size_t)((row_doubles + 1) | 1);  // + kappa; odd stride
+  if (rows_rep) {
+    if (stage < 256) stage = 256;  // the scalar-sum staging of the epilogue aliases the rows
+    return kPts * th_pad + kPts * der_pad + stage + (size_t)rows_rep * kPts * th_pad;
+  }
+  const size_t epilogue = (size_t)kPts * th_pad + (size_t)kWaves * 256;  // per-point output rows + the D staging: aliases the staging rows
+  return kPts * th_pad + kPts * der_pad + (stage > epilogue ? stage : epilogue);
+}
+
+// ---- the kernel.  grid = (scan blocks [+ normaliser blocks], groups of 16 hyper-parameter points) x 256 threads. ------
+template <bool ROWS, int... KTs>
+__device__ __forceinline__ void scan_points_body(const KArgs& a) {
+  using ChainT = MChain<ROWS, KTs...>;
+  constexpr int kRow = ((ChainT::kRowDoubles + 1) | 1);  // doubles per staged sample (kappa first), odd
+  constexpr int kStageS = ROWS ? 16 : 32;                // samples per wavefront and trip (phase A lanes)
   extern __shared__ double s_dyn[];
   __shared__ double s_mx[kWaves][64];
+  __shared__ int s_enorm[kPts];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & (kPts - 1);
   const int group = blockIdx.y;
@@ -173,8 +287,19 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
   const int th_pad = a.n_theta | 1, der_pad = (a.n_terms * kMaxDerived) | 1;
   double* const s_thetaK = s_dyn;                       // [16][th_pad]
   double* const s_derK = s_thetaK + kPts * th_pad;      // [16][der_pad]
-  double* const s_outK = s_derK + kPts * der_pad;       // [16][n_theta]: gradient numerators per point
-  double* const s_stage = s_outK + kPts * a.n_theta;    // [kWaves][16][16] (also the scalar-sum staging [vals][256])
+  double* const s_rows = s_derK + kPts * der_pad;       // main loop: [kWaves][kStageS][kRow] staging rows
+  // MFMA: the epilogue's [16][th_pad] gradient numerators per point and its [kWaves][16][16] D staging (also the scalar-sum
+  // staging [256]) alias the staging rows.  ROWS: the gradient rows [rep][16][th_pad] follow the staging rows -- one row
+  // per (sample slot q & (rep - 1), point j): the 16 lanes of a sample add to the same coefficient of 16 different rows
+  // (odd stride: 16 different banks), the four samples of a wave instruction to different replicas, so the atomics never
+  // meet on an address inside an instruction whatever the data; replica 0 becomes the output rows in the epilogue
+  const int rows_rep = ROWS ? a.rows_rep : 0;
+  const size_t stage_doubles = (size_t)kWaves * kStageS * kRow;
+  double* const s_grad = s_rows + (stage_doubles < 256 ? 256 : stage_doubles);
+  double* const s_outK = ROWS ? s_grad : s_rows;
+  double* const s_stage = ROWS ? s_rows : s_outK + kPts * th_pad;
+  if (ROWS)
+    for (int p = tid; p < rows_rep * kPts * th_pad; p += kBlock) s_grad[p] = 0.0;
 
   if (blockIdx.x == 0 && group == 0 && tid == 0) *a.seq_dev = a.norm_seq;
   if ((int)blockIdx.x < a.n_norms) {  // grid normalisers of the group's points, one after the other
@@ -202,8 +327,6 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
     const int k = group * kPts + pt;
     s_derK[pt * der_pad + idx] = (&a.tblocks[k < a.k_batch ? k : a.k_batch - 1].derived[0][0])[idx];
   }
-  for (int p = tid; p < kPts * a.n_theta; p += kBlock) s_outK[p] = 0.0;
-  __syncthreads();
 
   long long start, end, base;
   Ctx ctx;
@@ -228,78 +351,95 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
     ctx.tcols = a.inj_tcols;
   }
   const double* kappa_col = b < n_pe_blocks ? a.kappa_pe : a.kappa_inj;
+  const int n_tile = (int)(end - start);
+
+  // the reference exponent of (this tile, this lane's point), in binades: the tile's maximum at the previous batched launch
+  int* const nref_slot = a.tile_nref + ((long long)(a.nref_row0 + kb) * a.nref_stride + b);
+  int n_ref = *nref_slot;
+  n_ref = n_ref == kNoRef ? 0 : n_ref;
+  const int ref_slack = a.square ? 215 : 430;
 
   ChainT chain;
   chain.init();
-  double s1 = 0.0, s2 = 0.0;
-  double m_ref = GWI_NEG_INF;  // reference exponent of (this tile, this lane's point): fixed at the first live trip
-  int all_set = 0, over = 0;   // workgroup-uniform: every point has its reference; some sample outran one by > slack
-  constexpr double kRefSlack = 150.0;
+  double s1 = 0.0, s2 = 0.0, lane_max = GWI_NEG_INF;
+  double* const my_rows = s_rows + (size_t)wave * kStageS * kRow;
+  double* const grow = ROWS ? s_grad + (size_t)((q & (rows_rep - 1)) * kPts + j) * th_pad : nullptr;
 
-  // a trip of the workgroup covers 16 U samples: wave w, slot q, unroll u -> sample  first + 16 u + 4 w + q
-  double kap[2][kU];
-  auto issue_loads = [&](int buf, long long first) {
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const long long s = first + 16 * u + 4 * wave + q;
-      const SIdx idx{base + start, (unsigned)((s < end ? s : end - 1) - start) << 3};
-      kap[buf][u] = gload(kappa_col, idx);
-      chain.load(buf, u, 0, ctx, idx);
-    }
+  // a trip of the workgroup covers 256 samples: wave w, phase-A lane a -> sample  i + 64 w + a
+  double kap[2];
+  auto issue_loads = [&](int i) {
+    const int s = i + kStageS * wave + lane;
+    const SIdx idx{base + start, (unsigned)(s < n_tile ? s : n_tile - 1) << 3};
+    kap[1] = gload(kappa_col, idx);
+    chain.load(0, ctx, idx);
   };
-  issue_loads(0, start);
-  int trip = 0;
-  for (long long first = start; first < end; first += 16 * kU, ++trip) {  // workgroup-uniform
-    const long long next = first + 16 * kU;
-    if (next < end) issue_loads(1, next);
-    double ell[kU], lin[kU];
-    bool live[kU];
-    double mx_lane = GWI_NEG_INF;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const bool valid = first + 16 * u + 4 * wave + q < end;
-      lin[u] = 1.0;
-      ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
-      live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
-      if (!live[u]) ell[u] = GWI_NEG_INF;
-      mx_lane = fmax(mx_lane, ell[u]);
+  const bool a_lane = lane < kStageS;
+  if (a_lane && kStageS * wave < n_tile) issue_loads(0);  // this wave's first 64 samples
+  __syncthreads();  // theta / derived staged
+  for (int i = 0; i + kStageS * wave < n_tile; i += kWaves * kStageS) {  // wave-uniform: a wave stops with its samples
+    // ---- phase A
+    if (a_lane) {
+      chain.advance();
+      kap[0] = kap[1];
+      const int i_next = i + kWaves * kStageS;
+      if (i_next + kStageS * wave < n_tile) issue_loads(i_next);
+      double* row = my_rows + lane * kRow;
+      const bool valid = i + kStageS * wave + lane < n_tile;
+      row[0] = valid ? kap[0] : GWI_NEG_INF;
+      chain.phase_a(0, ctx, row + 1);
     }
-    if (!all_set) {  // workgroup-uniform: some point of the group has not seen a live sample yet
-      double* mx_slot = &s_mx[0][0];  // single buffer: two barriers bracket its use (only while references are being fixed)
-      mx_slot[wave * 64 + lane] = mx_lane;
-      __syncthreads();
-      double mm = GWI_NEG_INF;
-#pragma unroll
-      for (int w_ = 0; w_ < kWaves; ++w_)
-#pragma unroll
-        for (int q_ = 0; q_ < 4; ++q_) mm = fmax(mm, mx_slot[w_ * 64 + q_ * 16 + j]);
-      if (m_ref == GWI_NEG_INF) m_ref = mm;  // per point; never moves once set
-      all_set = __builtin_amdgcn_ballot_w64(m_ref == GWI_NEG_INF) == 0;  // the same in every wave: all read the same 16 maxima
-      __syncthreads();
-    } else if (__builtin_amdgcn_ballot_w64(mx_lane > m_ref + kRefSlack) != 0) {
-      over = 1;
-    }
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      double w = (live[u] && m_ref != GWI_NEG_INF) ? lin[u] * fast_exp(ell[u] - m_ref) : 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS traffic is processed in order: the rows are there
+    // ---- phase B: sixteen rounds of (4 samples x 16 points)
+#pragma unroll 1
+    for (int g = 0; g < kStageS / 4; ++g) {
+      const double* row = my_rows + (4 * g + q) * kRow;
+      const double kappa = row[0];
+      chain.b_rows(row + 1);
+      chain.b_coefs(0, ctx);
+      double lin = 1.0;
+      double ell = kappa + chain.b_value(0, ctx, lin);
+      const bool live = (ell < GWI_POS_INF) && (ell > GWI_NEG_INF) && (lin > 0.0) && (lin < GWI_POS_INF);
+      if (!live) ell = GWI_NEG_INF;
+      lane_max = fmax(lane_max, ell);
+      double w = live ? lin * fast_exp_shift(ell, n_ref) : 0.0;
       if (a.square) w *= w;
       s1 += w;
       s2 += w * w;
-      chain.accumulate(u, 0, ctx, w, j);
+      chain.accumulate(0, ctx, w, j, grow);
     }
-    if (next < end) {
-      chain.advance();
-#pragma unroll
-      for (int u = 0; u < kU; ++u) kap[0][u] = kap[1][u];
-    }
-  }
-  if (over && lane == 0) {
-    __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read before the next trip overwrites them
   }
 
-  // ---- epilogue.  Scalar sums: lanes (w, q, j) -> point j, fixed order over the 16 (w, q) partials.
+  // ---- epilogue.  Tile maxima and reference check per point: lanes (w, q, j) -> point j
+  s_mx[wave][lane] = lane_max;
+  __syncthreads();  // also: every wave is done with the staging rows, which s_outK / s_stage alias
+  if (tid < kPts) {
+    double mm = GWI_NEG_INF;
+#pragma unroll
+    for (int w_ = 0; w_ < kWaves; ++w_)
+#pragma unroll
+      for (int q_ = 0; q_ < 4; ++q_) mm = fmax(mm, s_mx[w_][q_ * 16 + tid]);
+    const int n_max = (mm == GWI_NEG_INF) ? kNoRef : (int)__builtin_rint(fmin(fmax(mm, -7.0e5), 7.0e5) * kLog2e);
+    if (kb_raw < a.k_batch) {
+      *nref_slot = n_max;
+      const int dist = n_max - n_ref;
+      if (n_max != kNoRef && (dist > ref_slack || dist < -ref_slack)) {
+        __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (ROWS) {  // fold the sample-slot replicas into replica 0 (fixed order)
+    for (int p = tid; p < kPts * th_pad; p += kBlock) {
+      double g = s_grad[p];
+      for (int r = 1; r < rows_rep; ++r) g += s_grad[(size_t)r * kPts * th_pad + p];
+      s_grad[p] = g;
+    }
+  } else {
+    for (int p = tid; p < kPts * th_pad; p += kBlock) s_outK[p] = 0.0;
+  }
+
+  // scalar sums: lanes (w, q, j) -> point j, fixed order over the 16 (w, q) partials
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
   int th[kNV];
@@ -309,6 +449,7 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
   chain.collect(0, ctx, vals + 2, th + 2);
   const long long n_blocks = n_pe_blocks + a.n_inj_tiles;
   double* const out_j = a.partials + ((long long)kb_raw * n_blocks + b) * a.rec_stride;  // record of point j (valid iff kb_raw < k_batch)
+  int e_norm = 0;  // threads 0..15: the point's normalisation exponent (record normalised to S1 in [1, 2), as scan_kernel's)
 #pragma unroll
   for (int v = 0; v < kNV; ++v) {
     __syncthreads();
@@ -320,12 +461,19 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
       for (int w_ = 0; w_ < kWaves; ++w_)
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_) r += s_stage[w_ * 64 + q_ * 16 + tid];
-      if (v == 0 && kb_raw < a.k_batch) out_j[1] = r;
-      if (v == 1 && kb_raw < a.k_batch) out_j[2] = r;
-      if (v >= 2) s_outK[tid * a.n_theta + th[v]] += r;  // tid == j here; several accumulators may feed one slot (in order)
+      if (v == 0) {
+        const bool has_sum = r > 0.0 && r < GWI_POS_INF;
+        e_norm = has_sum ? ilogb(r) : 0;
+        s_enorm[tid] = e_norm;
+        if (kb_raw < a.k_batch) {
+          out_j[0] = has_sum ? (double)((a.square ? 2 * n_ref : n_ref) + e_norm) * kLn2 : GWI_NEG_INF;
+          out_j[1] = has_sum ? ldexp(r, -e_norm) : 0.0;
+        }
+      }
+      if (v == 1 && kb_raw < a.k_batch) out_j[2] = (r > 0.0 && r < GWI_POS_INF) ? ldexp(r, -2 * e_norm) : 0.0;
+      if (v >= 2) s_outK[tid * th_pad + th[v]] += r;  // tid == j here; several accumulators may feed one slot (in order)
     }
   }
-  if (tid < kPts && kb_raw < a.k_batch) out_j[0] = a.square ? 2.0 * m_ref : m_ref;
   // gradient tiles: D of wave w -> staging [w][row][point]; thread (row, point) sums the four waves in order
   chain.for_each_tile(0, ctx, [&](int th0, int rows, const v4d& d) {
     __syncthreads();
@@ -335,15 +483,25 @@ __global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
     const int row = tid >> 4, pt = tid & (kPts - 1);
     if (row < rows) {
       const double g = (s_stage[row * kPts + pt] + s_stage[256 + row * kPts + pt]) + (s_stage[512 + row * kPts + pt] + s_stage[768 + row * kPts + pt]);
-      s_outK[pt * a.n_theta + th0 + row] += g;  // shared coefficient blocks (IID models) accumulate; one thread per slot per tile
+      s_outK[pt * th_pad + th0 + row] += g;  // shared coefficient blocks (IID models) accumulate; one thread per slot per tile
     }
   });
   __syncthreads();
   for (int p = tid; p < kPts * a.n_theta; p += kBlock) {
     const int pt = p / a.n_theta, idx = p - pt * a.n_theta;
     const int k = group * kPts + pt;
-    if (k < a.k_batch) a.partials[((long long)k * n_blocks + b) * a.rec_stride + kRecHeader + idx] = s_outK[p];
+    if (k < a.k_batch) a.partials[((long long)k * n_blocks + b) * a.rec_stride + kRecHeader + idx] = ldexp(s_outK[pt * th_pad + idx], -s_enorm[pt]);
   }
+}
+
+// the two instantiations of the body: gradient tiles on the matrix cores / gradient rows in LDS
+template <int U_UNUSED, int... KTs>
+__global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
+  scan_points_body<false, KTs...>(a);
+}
+template <int U_UNUSED, int... KTs>
+__global__ __launch_bounds__(kBlock, 2) void scan_rows_kernel(const KArgs a) {
+  scan_points_body<true, KTs...>(a);
 }
 
 }  // namespace gwi

@@ -989,6 +989,51 @@ def make_margsel_fixture():
     print("wrote margsel_grad.npz", sorted(k for k in out if k.endswith("log_likelihood")))
 
 
+def make_formats_fixture():
+    """f4 on the GPU: what the reference computes from the two catalog FILES the product readers
+    load.  (a) tests/golden/idata_small.h5 (InferenceData layout; its arrays are in idata_small.npz, written together by
+    make_idata_fixture.py): sites of hierarchical_likelihood for two compositions at two hyper-points each, with the
+    file's own total_generated / analysis_time.  (b) tests/golden/gwtc3_first64.nc: the first 64 samples per event of the
+    reference's GWTC-3 PE tensor (tests/data/xarray_GWTC3_BBH_69evs_downsampled_1000samps_nospin.h5) re-written in the same
+    NetCDF-3 layout (char `param` coordinate, one big-endian float32 (param, sample) variable per event) -- a data file of
+    the reference's own tests, truncated; the sites for it are those of case_gwtc3_pl_test.npz."""
+    from scipy.io import netcdf_file
+
+    z = np.load(os.path.join(HERE, "idata_small.npz"))
+    params = [str(p) for p in z["params"]]
+    pe = {k: np.ascontiguousarray(z["posteriors"][:, i, :]) for i, k in enumerate(params)}
+    inj = {k: np.ascontiguousarray(z["injections"][i]) for i, k in enumerate(params)}
+    total, tobs = float(z["total_generated"]), float(z["analysis_time"])
+    out = {}
+    for comp_name, seed in (("plpeak_full", 31), ("bspline_test", 32)):
+        cls = COMPOSITIONS[comp_name]
+        comp = cls({k: jnp.asarray(v) for k, v in pe.items()}, {k: jnp.asarray(v) for k, v in inj.items()})
+        rng = np.random.default_rng(seed)
+        pts = [cls.draw(rng) for _ in range(2)]
+        for name in cls.params:
+            out[f"{comp_name}/theta/{name}"] = np.stack([np.asarray(pt[name], dtype=np.float64) for pt in pts])
+        per = {}
+        for pt in pts:
+            sites, _, _ = run_likelihood(comp, pt, 5, total, FLAGSETS["lin"])
+            for k in ("log_likelihood", "log_l", "logBFs", "log_nEffs", "log_nEff_inj", "detection_efficiency", "surveyed_hypervolume"):
+                per.setdefault(k, []).append(sites[k])
+        for k, v in per.items():
+            out[f"{comp_name}/sites/{k}"] = np.stack(v)
+    out["tobs_used_by_generator"] = np.asarray(TOBS)
+    np.savez_compressed(os.path.join(HERE, "idata_golden.npz"), **out)
+    src = netcdf_file(os.path.join(REFERENCE_ROOT, "tests/data/xarray_GWTC3_BBH_69evs_downsampled_1000samps_nospin.h5"), mmap=False)
+    with netcdf_file(os.path.join(HERE, "gwtc3_first64.nc"), "w") as f:
+        f.createDimension("param", 9)
+        f.createDimension("sample", 64)
+        f.createDimension("string10", 10)
+        f.createVariable("param", "S1", ("param", "string10"))[:] = src.variables["param"].data
+        f.createVariable("sample", ">i4", ("sample",))[:] = np.arange(64)
+        for name, v in src.variables.items():
+            if name not in ("param", "sample"):
+                f.createVariable(name, ">f4", ("param", "sample"))[:] = v.data[:, :64]
+    print("wrote idata_golden.npz, gwtc3_first64.nc")
+
+
 def load_gwtc3(n_samples=64):
     """The reference's own PE tensor (tests/data/..., NetCDF-3 classic): 69 events x 9 params x
     1000 samples, big-endian float32 -> float64; first n_samples per event."""
@@ -1002,11 +1047,13 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel", "formats"]
     if "ppd" in todo:
         make_ppd_fixture()
     if "margsel" in todo:
         make_margsel_fixture()
+    if "formats" in todo:
+        make_formats_fixture()
     if "pipeline" in todo:
         make_pipeline_fixture()
     if "catalog" in todo:

@@ -73,14 +73,34 @@ def test_three_ranks_torch_collective_fallback():
 
 
 def test_forced_sharded_world1_runs_the_rccl_variant():
-    """GWI_FORCE_SHARDED=1: one process, one GPU, the N > 1 code path with a nccl (RCCL) process group of one rank --
-    shared-memory exchange for the headline, then the in-engine ncclAllGather variant under its watchdog."""
+    """GWI_FORCE_SHARDED=1: one GPU, the N > 1 code path with a nccl (RCCL) process group of one rank -- the in-engine
+    ncclAllGather exchange measured first, in a child process started before the parent touches the GPU, then the
+    shared-memory exchange for the headline; the two are reported as peers and `rccl_ranks` counts the ranks of the
+    communicator that carried the HEADLINE's records (0 for shared memory)."""
     env = dict(os.environ, GWI_FORCE_SHARDED="1", MASTER_PORT=str(29800 + os.getpid() % 90))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--config", "c1", "--spin", "0.05", "--also", "none"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     mg = d["multi_gpu"]
-    assert mg["exchange"].startswith("host shared-memory") and mg["rccl_ranks"] == 1
-    assert mg["rccl_allgather_variant"]["evals_per_s"] > 0 and mg["rccl_allgather_variant"]["rccl_ranks"] == 1
+    assert mg["exchange"].startswith("host shared-memory") and mg["rccl_ranks"] == 0
+    ex = mg["exchanges"]
+    assert ex["shm"]["headline"] and ex["shm"]["ms_per_step"] == d["ms_per_step"]
+    leg = ex["rccl_allgather"]
+    assert leg["child_exit_code"] == 0 and leg["evals_per_s"] > 0 and leg["rccl_ranks"] == 1 and leg["identical_on_all_ranks"]
+    assert abs(leg["last_log_likelihood"]) > 0
     assert mg["sharded_vs_single_gpu"]["log_likelihood_rel_err"] < 1e-12
+
+
+def test_rccl_leg_that_does_not_finish_is_killed_and_reported():
+    """A hung RCCL exchange is a time-out of the CHILD: it is killed by its PID, reported with a non-zero exit code, and the
+    main measurement (started only afterwards) is complete."""
+    env = dict(os.environ, GWI_FORCE_SHARDED="1", GWI_BENCH_RCCL_TIMEOUT="0.05", MASTER_PORT=str(29700 + os.getpid() % 90))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--config", "c1", "--spin", "0.05", "--also", "none",
+           "--k-batch", "0", "--chains", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    leg = d["multi_gpu"]["exchanges"]["rccl_allgather"]
+    assert leg["child_exit_code"] == 124 and "killed" in leg["error"] and "evals_per_s" not in leg
+    assert d["value"] > 0 and d["multi_gpu"]["exchanges"]["shm"]["headline"]

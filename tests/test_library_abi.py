@@ -103,8 +103,12 @@ def test_raw_code_object_for_the_aql_path(lib):
     n_variants = lib.gwi_kernel_variants()
     scans = [n for n in names if "scan_kernel" in n]
     safe = [n for n in scans if "scan_kernelILb0ELb0ELb1E" in n]  # the two-pass / replay instantiation of the spline term sequences
-    assert len(scans) == 3 * n_variants + len(safe)  # value / log-weight / batched instantiation per variant
-    assert 0 < len(safe) < n_variants
+    # value / log-weight / batched instantiation per compiled term sequence, + the SAFE instantiation of the spline sequences,
+    # + the generic (run-time term loop) chain: one SAFE instantiation for every role and its log-weight variant
+    generic = [n for n in scans if n.endswith("JLi0EEEEvNS_5KArgsE")]
+    assert len(generic) == 2 and sum(n in safe for n in generic) == 1
+    assert len(scans) == 3 * n_variants + (len(safe) - 1) + 2
+    assert 0 < len(safe) - 1 < n_variants
     assert any("combine_kernel" in n for n in names) and any("final_kernel" in n for n in names)
     assert "hidden_" not in notes  # no implicit kernel arguments anywhere
     # no scratch in anything the AQL path dispatches: the value-and-gradient scan of every variant and the tail kernels

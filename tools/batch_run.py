@@ -17,9 +17,12 @@ ap.add_argument("--config", default="c5")
 ap.add_argument("--k", type=int, default=16)
 ap.add_argument("--n", type=int, default=40)
 ap.add_argument("--mfma", action="store_true")
+ap.add_argument("--rows", action="store_true")
 args = ap.parse_args()
 if args.mfma:
     os.environ["GWI_BATCH_MFMA"] = "1"
+if args.rows:
+    os.environ["GWI_BATCH_ROWS"] = "1"
 from gwinferno_amd.compositions import COMPOSITIONS, draw_params  # noqa: E402
 from gwinferno_amd.synthetic import make_config_catalog  # noqa: E402
 
