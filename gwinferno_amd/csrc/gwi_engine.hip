@@ -1455,8 +1455,16 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
     // per evaluation, config 3: 9.7 vs 10.0) and its gradient is bit-reproducible.  GWI_BATCH_MFMA=0 keeps the 4-tap kernel,
     // =2 uses the matrix-core kernel for every batch size; GWI_BATCH_ROWS=1 selects the LDS-row variant of the same kernel.
     h->mfma = find_mfma_variant(*spec);
+    if (h->mfma) {
+      // more than 8 gradient tiles (64 registers) do not fit the matrix-core kernel's register budget (the reference's default
+      // spline counts need 11: 256 registers and spills): such models take the LDS-row variant of the same kernel
+      int tiles = 0;
+      for (int t = 0; t < h->mfma->n; ++t) tiles += h->mfma->tiles[t];
+      h->batch_rows = tiles > 8;
+    }
     if (const char* env = std::getenv("GWI_BATCH_MFMA")) {
       if (std::atoi(env) == 0) h->mfma = nullptr;
+      if (std::atoi(env) == 1) h->batch_rows = false;
       if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
     if (const char* env = std::getenv("GWI_BATCH_ROWS")) {

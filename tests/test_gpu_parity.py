@@ -503,6 +503,7 @@ def test_batched_launch_on_the_matrix_cores(comp_name, path, monkeypatch):
     comp = COMPOSITIONS[comp_name](pe, inj)
     eng = comp.engine()
     assert eng.batch_path(16) == path and eng.batch_path(4) == "taps"
+    # (the default, with neither variable set: "mfma", or "rows" for models with more than 8 gradient tiles -- bspline_defaults)
     thetas = np.stack([comp.theta(draw_params(comp_name, rng)) for _ in range(35)])
     orc = COracle(eng.bound)
     refs = [orc.evaluate(t, total, min_neff_cut=False) for t in thetas[:6]]

@@ -22,19 +22,20 @@ for c in $CONFIGS; do
   python3 $R/bench.py --config $c --steps 2000 --warmup 200 --also none > $out/bench.json 2> /dev/null
 done
 for c in c3 c5; do
-  for path in taps mfma; do
+  for path in taps mfma rows; do
     out=$R/gpurun_out/prof/batch_${c}_$path
     mkdir -p $out
-    flag=""; [ $path = mfma ] && flag="--mfma"
+    flag=""; [ $path = mfma ] && flag="--mfma"; [ $path = rows ] && flag="--rows"; [ $path = taps ] && export GWI_BATCH_MFMA=0 || unset GWI_BATCH_MFMA
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/batch_run.py --config $c --k 16 --n 40 $flag > $out/run_under_trace.json 2> /dev/null
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d $out/mfma -- python3 $R/tools/batch_run.py --config $c --k 16 --n 10 $flag > /dev/null 2>&1
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d $out/mfma -- python3 $R/tools/batch_run.py --config $c --k 16 --n 10 $flag > /dev/null 2>&1
     python3 $R/tools/batch_run.py --config $c --k 16 --n 100 $flag > $out/run.json 2> /dev/null
   done
 done
 # the driver's own command, for the record
 cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_form.json 2> /dev/null
 # summarise on the box (the raw traces exceed what gpurun carries back) and keep only the summary
-python3 tools/summarize_profiles.py ${ROUND:-round2} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
+unset GWI_BATCH_MFMA
+python3 tools/summarize_profiles.py ${ROUND:-round3} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
 cp gpurun_out/prof/bench_driver_form.json gpurun_out/profile_summary/ 2>/dev/null
 rm -rf $R/gpurun_out/prof
 ls -la $R/gpurun_out/profile_summary

@@ -84,8 +84,8 @@ def main(round_name, dst=None):
         if cfg in traffic:
             traffic[cfg].update(lds_addr_conflict_share=ac / ia, lds_bank_conflict_share=bc / ia, wait_inst_lds_share=wl / wc)
     # ---- batched kernels (K = 16 points per launch): 4-tap gradient vs the MFMA gradient GEMM
-    b_lines = ["| config | path | kernel | calls | avg us (rocprofv3) | us per evaluation (untraced loop) | MFMA instr / launch | fp64 MFMA GFLOP / launch | MFMA TFLOP/s | of the 78.6 TFLOP/s matrix peak | SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES |",
-               "|---|---|---|---|---|---|---|---|---|---|---|"]
+    b_lines = ["| config | path | kernel | calls | avg us (rocprofv3) | us per evaluation (untraced loop) | MFMA instr / launch | fp64 MFMA GFLOP / launch | MFMA TFLOP/s | of the 78.6 TFLOP/s matrix peak | VALU instr / launch | LDS instr / launch |",
+               "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     batched = {}
     for name in sorted(c for c in os.listdir(src) if c.startswith("batch_")):
         _, cfg, path = name.split("_")
@@ -102,22 +102,22 @@ def main(round_name, dst=None):
             if "gwi::scan_" not in r["Name"]:
                 continue
             short = r["Name"].split("(")[0].replace("void ", "")
-            key = "scan_mfma_kernel" if "scan_mfma_kernel" in short else "scan_kernel"
+            key = "scan_mfma_kernel" if "scan_mfma_kernel" in short else ("scan_rows_kernel" if "scan_rows_kernel" in short else "scan_kernel")
             def c(cn):
                 return mean_counter(os.path.join(src, name, "mfma", "*", "*_counter_collection.csv"), key, cn)
             n_mfma, mops = c("SQ_INSTS_MFMA"), c("SQ_INSTS_VALU_MFMA_MOPS_F64")
-            busy, tot = c("SQ_VALU_MFMA_BUSY_CYCLES"), c("SQ_BUSY_CYCLES")
+            n_valu, n_lds = c("SQ_INSTS_VALU"), c("SQ_INSTS_LDS")
             t_us = float(r["AverageNs"]) / 1e3
             flop = 2048.0 * n_mfma if n_mfma else 0.0  # v_mfma_f64_16x16x4: 16 x 16 x 4 x 2 flop per wave instruction
             tf = flop / (t_us * 1e-6) / 1e12 if flop else 0.0
             b_lines.append(f"| {cfg} | {path} | {short[:60]} | {r['Calls']} | {t_us:.1f} | {run.get('us_per_eval', float('nan')):.2f} | {n_mfma or 0:.0f} | {flop / 1e9:.2f} | {tf:.2f} | {tf / 78.6:.1%} | "
-                           f"{(busy / tot if busy and tot else 0):.1%} |")
+                           f"{n_valu or 0:.0f} | {n_lds or 0:.0f} |")
             batched[f"{cfg}_{path}"] = {"scan_avg_us_rocprof": t_us, "us_per_eval": run.get("us_per_eval"), "mfma_instructions_per_launch": n_mfma, "mfma_mops_f64_counter": mops,
-                                        "mfma_tflops": tf, "mfma_utilisation_of_78.6": tf / 78.6, "mfma_busy_share": (busy / tot if busy and tot else None)}
+                                        "mfma_tflops": tf, "mfma_utilisation_of_78.6": tf / 78.6, "valu_instructions_per_launch": n_valu, "lds_instructions_per_launch": n_lds}
     if batched:
         traffic["batched_k16"] = batched
     lines += ["", "LDS pipe of the scan kernel (`--pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES`):", ""] + lds_lines
-    lines += ["", "Batched launches, K = 16 hyper-parameter points (tools/batch_run.py; `--mfma` = GWI_BATCH_MFMA=1, gwi_mfma.h). MFMA FLOP = 2048 x SQ_INSTS_MFMA:", ""] + b_lines
+    lines += ["", "Batched launches, K = 16 hyper-parameter points (tools/batch_run.py; paths: `mfma` = the default for spline models, gwi_mfma.h; `taps` = GWI_BATCH_MFMA=0; `rows` = GWI_BATCH_ROWS=1). MFMA FLOP = 2048 x SQ_INSTS_MFMA; utilisation = that rate over the 78.6 TFLOP/s fp64 matrix peak (SQ_INSTS_VALU includes the matrix instructions):", ""] + b_lines
     lines += ["", "Scan-kernel SQ counters (separate `--pmc` passes; fp64 FLOP = 64 x (ADD + MUL + 2 FMA + TRANS) wave-instructions):", ""] + sq_lines
     with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
         fh.write(f"# rocprofv3 summary, {round_name}\n\nCommands: tools/profile_round.sh (kernel trace: `rocprofv3 --kernel-trace --stats`; counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  The traced launches are AQL dispatches from the engine's own queues (gwinferno_amd/csrc/gwi_aql.h); `<config>_bench.json` holds the untraced run of the same command, whose live kernel durations come from the same dispatch timestamps.\n\n")
