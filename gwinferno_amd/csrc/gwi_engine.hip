@@ -404,6 +404,7 @@ struct gwi_engine {
   int aql_tail_variant = 0;        // 0: single evaluation, 1 / 2: batched without / with the per-event sites
   bool scan_is_safe = false;  // the scan launch being issued is the SAFE instantiation
   bool generic = false;       // no compiled chain for this model: the generic scan kernel (kGenericVariant)
+  bool small_geometry = false;  // small catalog of a spline model: the one-sample-per-lane sibling on many small workgroups (gwi_create)
   bool combine_acquire = false;  // the combine packet carries an acquire fence after all (A/B only)
   bool aql_tail_only = true;  // scan launches rewrite only the per-evaluation tail of their argument block (GWI_AQL_TAIL=0: the whole block)
   unsigned tail_parity = 0; // which of the two persistent scan-argument slots the next launch rewrites (aql::dispatch_tail)
@@ -1356,6 +1357,27 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   GWI_HIP(hipGetDeviceProperties(&prop, h->device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
+  // Small catalogs of spline models (fewer than ~11 trips of 256 samples per CU: BASELINE config 3) are a chain of latencies, not
+  // a throughput problem: more and smaller workgroups of the one-sample-per-lane sibling -- four per CU, equal tiles inside an
+  // event -- measured 12.5-12.9 us for the config-3 scan against 13.4-14.3 for 443 workgroups of two samples per lane and two trips
+  // (tools/geometry_sweep.py; profiles/round3/EXPERIMENTS.md).  Explicit geometry knobs switch the rule off.
+  h->small_geometry = false;
+  if (h->variant->samples_per_lane == 2 && h->variant->scan_safe && !h->generic && !std::getenv("GWI_SAMPLES_PER_LANE") && !std::getenv("GWI_SAMPLES_PER_BLOCK") &&
+      !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK") && !(std::getenv("GWI_SMALL_GEOMETRY") && std::atoi(std::getenv("GWI_SMALL_GEOMETRY")) == 0)) {
+    const Variant* sib = nullptr;
+    for (int v = 0; v < kNumVariants; ++v) {
+      const Variant& c = kVariants[v];
+      if (c.samples_per_lane != 1 || c.n != h->variant->n) continue;
+      bool same = true;
+      for (int t = 0; t < c.n; ++t) same = same && c.kinds[t] == h->variant->kinds[t];
+      if (same) sib = &c;
+    }
+    const long long total = n_ev * n_pe + n_inj;
+    if (sib && total < 2816LL * prop.multiProcessorCount && total >= 64LL * prop.multiProcessorCount) {
+      h->variant = sib;
+      h->small_geometry = true;
+    }
+  }
   GWI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   if (const char* env = std::getenv("GWI_SPIN_WAIT")) h->spin_wait = std::atoi(env) != 0;
   for (auto& e : h->ev) GWI_HIP(hipEventCreate(&e));
@@ -1527,6 +1549,16 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   const long long n_pe_pad = ((n_pe + gran - 1) / gran) * gran;
   h->chunk_pe = (int)(spb < n_pe_pad ? spb : n_pe_pad);
   h->chunk_inj = (int)spb;
+  if (h->small_geometry) {
+    const long long total = n_ev * n_pe + n_inj;
+    double per_cu = 4.0;  // one round of resident workgroups at four waves per SIMD; 2.0 / 2.75 / 3.4 / 4.0 / 5.5 / 7.0 measured 15.4 / 13.8 / 13.7 / 13.1 / 16.2 / 14.7 us on one box
+    if (const char* env = std::getenv("GWI_SMALL_WGS_PER_CU")) per_cu = std::max(0.5, std::atof(env));
+    const long long target = std::max<long long>(64, (long long)((double)total / (per_cu * prop.multiProcessorCount) + 0.5));
+    const long long tiles_pe = std::max<long long>(1, (n_pe + target / 2) / target);
+    h->chunk_pe = (int)((n_pe + tiles_pe - 1) / tiles_pe);  // equal tiles inside an event
+    h->chunk_inj = (int)target;
+    spb_batch = 0;
+  }
   // experiment knobs: exact tile sizes (the kernel takes any size; a trip covers samples_per_lane * 256 samples)
   if (const char* env = std::getenv("GWI_PE_CHUNK")) h->chunk_pe = std::max(1, std::atoi(env));
   if (const char* env = std::getenv("GWI_INJ_CHUNK")) h->chunk_inj = std::max(1, std::atoi(env));
