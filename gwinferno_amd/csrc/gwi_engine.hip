@@ -1473,20 +1473,19 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->gacc_rep = rep;
   if (has_spline) {
     // Batched launches of >= 9 points take the 16-points-per-wavefront kernel (gwi_mfma.h) where the model has an
-    // instantiation: at K = 16 it measures 3-4 % ahead of the 4-tap kernel on the BASELINE catalogs (config 5: 39.8 vs 41.5 us
-    // per evaluation, config 3: 9.7 vs 10.0) and its gradient is bit-reproducible.  GWI_BATCH_MFMA=0 keeps the 4-tap kernel,
+    // instantiation: at K = 16 it measures 15 % ahead of the 4-tap kernel on the BASELINE catalogs (config 5: 34.9 vs 41.0 us
+    // per evaluation, config 3: 8.7 vs 10.5) and its gradient is bit-reproducible.  GWI_BATCH_MFMA=0 keeps the 4-tap kernel,
     // =2 uses the matrix-core kernel for every batch size; GWI_BATCH_ROWS=1 selects the LDS-row variant of the same kernel.
     h->mfma = find_mfma_variant(*spec);
-    if (h->mfma) {
-      // more than 8 gradient tiles (64 registers) do not fit the matrix-core kernel's register budget (the reference's default
-      // spline counts need 11: 256 registers and spills): such models take the LDS-row variant of the same kernel
+    if (h->mfma && !std::getenv("GWI_BATCH_MFMA") && !std::getenv("GWI_BATCH_ROWS")) {
+      // more than 8 gradient tiles: the 4-tap kernel is faster (the reference's default spline counts, 11 tiles / 165
+      // hyper-parameters, on the config-3 catalog: 11.7 us per evaluation against 14.4 on the matrix cores and 14.5 with LDS rows)
       int tiles = 0;
       for (int t = 0; t < h->mfma->n; ++t) tiles += h->mfma->tiles[t];
-      h->batch_rows = tiles > 8;
+      if (tiles > 8) h->mfma = nullptr;
     }
     if (const char* env = std::getenv("GWI_BATCH_MFMA")) {
       if (std::atoi(env) == 0) h->mfma = nullptr;
-      if (std::atoi(env) == 1) h->batch_rows = false;
       if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
     if (const char* env = std::getenv("GWI_BATCH_ROWS")) {

@@ -61,7 +61,9 @@ struct Stage {  // every kind without spline coefficients: the term's column val
   static constexpr int kDoubles = (int)(sizeof(typename Term<K>::In) / sizeof(double));
   struct Keep {
     typename Term<K>::In in;
-    typename Term<K>::State st;
+    typename Term<K>::State st;      // of the round being evaluated (stage 1)
+    typename Term<K>::State st_cur;  // of the round being accumulated (stage 2)
+    __device__ void commit() { st_cur = st; }
   };
   __device__ static void phase_a(const TermD&, const typename Term<K>::In& in, double* row) {
     const double* src = reinterpret_cast<const double*>(&in);
@@ -77,37 +79,58 @@ struct Stage {  // every kind without spline coefficients: the term's column val
   __device__ static double b_value(const TermD& t, const double* d, const Ctx& c, Keep& kp, double& lin) { return Term<K>::eval(t, d, c, kp.in, kp.st, lin); }
 };
 struct SplineKeep {
-  Taps b;
-  double cf[4];
+  Taps b;        // (forward passes only: dead after b_value; accumulate gathers its operand from the staging row)
+  double cf[4];  // (forward passes only)
   int k;
-  double scale;  // what multiplies the weight in the B operand (1, or 1 / f for the linear spline; 0 outside the domain)
+  double scale;  // what multiplies the weight in the B operand (1, or 1 / f for the linear spline)
+  int k_cur;     // the same two of the round being accumulated (stage 2 of the software pipeline in scan_points_body)
+  double scale_cur;
+  __device__ void commit() {
+    k_cur = k;
+    scale_cur = scale;
+  }
 };
-// staged: [0] = k in the low word, outside-domain flag in the high word; [1..4] = the four taps
+// staged per spline term: [0] = k, [1] = 0, [2..5] = the four taps (all 0 outside a zero-outside basis), [6] = 0.
+// The zeros on both sides let the matrix-core path GATHER its A operand: the tap of basis 16 tile + j for a sample whose
+// non-zero bases start at k is  row[2 + clamp(16 tile + j - k, -1, 4)]  -- one v_med3, one address add and one 8-byte LDS read
+// per tile instead of four compares and eight selects on registers (96 of ~400 vector quad-cycles per 64 sample-points at
+// config 5; the LDS pipe has the room: 19 % busy).
+constexpr int kSplineStage = 7;
 __device__ __forceinline__ void stage_spline(const TermD& t, double x, bool zero_outside, double* row) {
   int k;
   double tt;
   spline_locate_term(x, t, k, tt);
-  const int out = (zero_outside && !((x >= t.p0) && (x <= t.p1))) ? 1 : 0;  // bases are 0 out there (interpolation.py:175)
-  const Taps b = cubic_taps(tt);
-  row[0] = __hiloint2double(out, k);
-  row[1] = b.b0;
-  row[2] = b.b1;
-  row[3] = b.b2;
-  row[4] = b.b3;
+  Taps b = cubic_taps(tt);
+  if (zero_outside && !((x >= t.p0) && (x <= t.p1))) b.b0 = b.b1 = b.b2 = b.b3 = 0.0;  // bases are 0 out there (interpolation.py:175)
+  row[0] = __hiloint2double(0, k);
+  row[1] = 0.0;
+  row[2] = b.b0;
+  row[3] = b.b1;
+  row[4] = b.b2;
+  row[5] = b.b3;
+  row[6] = 0.0;
 }
 __device__ __forceinline__ void spline_rows(const double* row, SplineKeep& kp) {
-  const double w0 = row[0];
-  kp.b.b0 = row[1];
-  kp.b.b1 = row[2];
-  kp.b.b2 = row[3];
-  kp.b.b3 = row[4];
-  kp.k = __double2loint(w0);
-  kp.scale = __double2hiint(w0) != 0 ? 0.0 : 1.0;
+  kp.k = __double2loint(row[0]);
+#ifdef GWI_ABL_NO_TAPREAD  // timing-only ablation: the taps not read from the staging row
+  kp.b.b0 = kp.b.b1 = kp.b.b2 = kp.b.b3 = 0.25;
+#else
+  kp.b.b0 = row[2];
+  kp.b.b1 = row[3];
+  kp.b.b2 = row[4];
+  kp.b.b3 = row[5];
+#endif
+  kp.scale = 1.0;
 }
 __device__ __forceinline__ void spline_coefs(const TermD& t, const Ctx& c, SplineKeep& kp) {
+#ifdef GWI_ABL_NO_COEF  // timing-only ablation: no coefficient gather
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kp.cf[i] = 1.0 + kp.k;
+#else
   const double* cf = c.coefs + t.th0 + kp.k;
 #pragma unroll
   for (int i = 0; i < 4; ++i) kp.cf[i] = cf[i];
+#endif
 }
 __device__ __forceinline__ double spline_value(SplineKeep& kp) {
   return kp.cf[0] * kp.b.b0 + kp.cf[1] * kp.b.b1 + kp.cf[2] * kp.b.b2 + kp.cf[3] * kp.b.b3;
@@ -115,7 +138,7 @@ __device__ __forceinline__ double spline_value(SplineKeep& kp) {
 template <>
 struct Stage<GWI_TERM_EXP_SPLINE> {
   static constexpr bool kSpline = true;
-  static constexpr int kDoubles = 5;
+  static constexpr int kDoubles = kSplineStage;
   using Keep = SplineKeep;
   __device__ static void phase_a(const TermD& t, const typename Term<GWI_TERM_EXP_SPLINE>::In& in, double* row) {
     // LogY bases exclude outside samples through kappa (decided when the catalog was bound); zero-outside bases give exp(0)
@@ -123,25 +146,18 @@ struct Stage<GWI_TERM_EXP_SPLINE> {
   }
   __device__ static void b_rows(const double* row, Keep& kp) { spline_rows(row, kp); }
   __device__ static void b_coefs(const TermD& t, const Ctx& c, Keep& kp) { spline_coefs(t, c, kp); }
-  __device__ static double b_value(const TermD& t, const double*, const Ctx&, Keep& kp, double&) {
-    double v = spline_value(kp);
-    if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {  // wave-uniform; kept a scalar branch (cf. Term<GWI_TERM_EXP_SPLINE>::eval)
-      asm volatile("");
-      v *= kp.scale;
-    }
-    return v;
-  }
+  __device__ static double b_value(const TermD&, const double*, const Ctx&, Keep& kp, double&) { return spline_value(kp); }  // taps are 0 outside
 };
 template <>
 struct Stage<GWI_TERM_LINEAR_SPLINE> {
   static constexpr bool kSpline = true;
-  static constexpr int kDoubles = 5;
+  static constexpr int kDoubles = kSplineStage;
   using Keep = SplineKeep;
   __device__ static void phase_a(const TermD& t, const typename Term<GWI_TERM_LINEAR_SPLINE>::In& in, double* row) { stage_spline(t, in.x0, true, row); }
   __device__ static void b_rows(const double* row, Keep& kp) { spline_rows(row, kp); }
   __device__ static void b_coefs(const TermD& t, const Ctx& c, Keep& kp) { spline_coefs(t, c, kp); }
   __device__ static double b_value(const TermD&, const double*, const Ctx&, Keep& kp, double& lin) {
-    const double f = spline_value(kp) * kp.scale;
+    const double f = spline_value(kp);
     kp.scale = f > 0.0 ? fast_rcp(f) : 0.0;  // dl / dc_k = B_k / f; f <= 0 (outside the domain too) makes the sample dead (lin > 0 test)
     lin *= f;
     return 0.0;
@@ -158,12 +174,19 @@ struct MChain<ROWS> {
   static constexpr int kNumAcc = 0, kTiles = 0, kRowDoubles = 0;
   __device__ void init() {}
   __device__ void load(int, const Ctx&, SIdx) {}
-  __device__ void advance() {}
   __device__ void phase_a(int, const Ctx&, double*) {}
-  __device__ void b_rows(const double*) {}
-  __device__ void b_coefs(int, const Ctx&) {}
-  __device__ double b_value(int, const Ctx&, double&) { return 0.0; }
-  __device__ void accumulate(int, const Ctx&, double, int, double*) {}
+  __device__ void commit() {}
+  template <int N>
+  __device__ void g_rows(const double*) {}
+  template <int N>
+  __device__ void g_coefs(int, const Ctx&) {}
+  template <int N>
+  __device__ double g_value(int, const Ctx&, double&) { return 0.0; }
+  template <int N>
+  __device__ double forward_after(int, const Ctx&, const double*, double&) { return 0.0; }
+  __device__ double forward(int, const Ctx&, const double*, double&) { return 0.0; }
+  __device__ void gather(int, const double*) {}
+  __device__ void accumulate(int, const Ctx&, double, int, double*, const double*) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
   template <class F>
   __device__ void for_each_tile(int, const Ctx&, F&&) {}
@@ -177,10 +200,11 @@ struct MChain<ROWS, KT, Rest...> {
   static constexpr int kNumAcc = Term<K>::kNumAcc + RestT::kNumAcc;
   static constexpr int kTiles = NT + RestT::kTiles;
   static constexpr int kRowDoubles = S::kDoubles + RestT::kRowDoubles;
-  typename Term<K>::In in[2];  // phase A lanes: this trip's and the next trip's column values
+  typename Term<K>::In in;     // phase A lanes: the column values of the trip about to be staged (loaded one trip ahead)
   typename S::Keep keep;       // phase B lanes: what the accumulation needs from the evaluation
   typename Term<K>::Acc acc;
   v4d tile[NT > 0 ? NT : 1];
+  double aval[NT > 0 ? NT : 1];  // the A operands of the round being accumulated, gathered ahead of its matrix instructions
   RestT rest;
   __device__ void init() {
     Term<K>::init(acc);
@@ -189,56 +213,94 @@ struct MChain<ROWS, KT, Rest...> {
     rest.init();
   }
   __device__ void load(int ti, const Ctx& c, SIdx idx) {
-    Term<K>::load(c.tcols[ti], idx, in[1]);
+    Term<K>::load(c.tcols[ti], idx, in);
     rest.load(ti + 1, c, idx);
   }
-  __device__ void advance() {
-    in[0] = in[1];
-    rest.advance();
-  }
   __device__ void phase_a(int ti, const Ctx& c, double* row) {
-    S::phase_a(c.a->terms[ti], in[0], row);
+    S::phase_a(c.a->terms[ti], in, row);
     rest.phase_a(ti + 1, c, row + S::kDoubles);
   }
-  __device__ void b_rows(const double* row) {
-    S::b_rows(row, keep);
-    rest.b_rows(row + S::kDoubles);
+  __device__ void commit() {
+    keep.commit();
+    rest.commit();
   }
-  __device__ void b_coefs(int ti, const Ctx& c) {
-    S::b_coefs(c.a->terms[ti], c, keep);
-    rest.b_coefs(ti + 1, c);
+  // The forward half of a round, kFwdGroup terms at a time: every term of the group requests its staged words, then every
+  // spline term of the group its four coefficients (which needs k), then the arithmetic -- the LDS round trips of a group
+  // overlap, and only one group's operands (16 registers per spline term) are live at a time (all seven terms of config 5 at
+  // once: 256 registers and spills)
+  static constexpr int kFwdGroup = 4;
+  template <int N>
+  __device__ void g_rows(const double* row) {
+    if constexpr (N > 0) {
+      S::b_rows(row, keep);
+      rest.template g_rows<N - 1>(row + S::kDoubles);
+    }
   }
-  __device__ double b_value(int ti, const Ctx& c, double& lin) {
-    const double l = S::b_value(c.a->terms[ti], c.derived[ti], c, keep, lin);
-    return l + rest.b_value(ti + 1, c, lin);
+  template <int N>
+  __device__ void g_coefs(int ti, const Ctx& c) {
+    if constexpr (N > 0) {
+      S::b_coefs(c.a->terms[ti], c, keep);
+      rest.template g_coefs<N - 1>(ti + 1, c);
+    }
   }
-  // w = this lane's weight w[sample, point]; basis_lane = lane & 15 (the lane's row inside a gradient tile); grow = this
-  // lane's gradient row in LDS (ROWS)
-  __device__ void accumulate(int ti, const Ctx& c, double w, int basis_lane, double* grow) {
-    if constexpr (S::kSpline && ROWS) {
-      const double bw = w * keep.scale;
-      double* g = grow + c.a->terms[ti].th0 + keep.k;
-      unsafeAtomicAdd(g, bw * keep.b.b0);
-      unsafeAtomicAdd(g + 1, bw * keep.b.b1);
-      unsafeAtomicAdd(g + 2, bw * keep.b.b2);
-      unsafeAtomicAdd(g + 3, bw * keep.b.b3);
-    } else if constexpr (S::kSpline) {
-      const double bw = w * keep.scale;
-      const int d0 = basis_lane - keep.k;
+  template <int N>
+  __device__ double g_value(int ti, const Ctx& c, double& lin) {
+    if constexpr (N > 0) {
+      const double l = S::b_value(c.a->terms[ti], c.derived[ti], c, keep, lin);
+      return l + rest.template g_value<N - 1>(ti + 1, c, lin);
+    } else {
+      return 0.0;
+    }
+  }
+  template <int N>
+  __device__ double forward_after(int ti, const Ctx& c, const double* row, double& lin) {  // skip N terms, then go on
+    if constexpr (N > 0)
+      return rest.template forward_after<N - 1>(ti + 1, c, row + S::kDoubles, lin);
+    else
+      return forward(ti, c, row, lin);
+  }
+  __device__ double forward(int ti, const Ctx& c, const double* row, double& lin) {
+    g_rows<kFwdGroup>(row);
+    g_coefs<kFwdGroup>(ti, c);
+    const double l = g_value<kFwdGroup>(ti, c, lin);
+    return l + forward_after<kFwdGroup>(ti, c, row, lin);
+  }
+  // The A operands of the current round's matrix instructions, requested from the staging rows as soon as k is known (the
+  // caller fences the instruction scheduler behind this pass: left to itself it sinks every read to its matrix
+  // instruction -- read, full LDS round trip, MFMA, eight times per round)
+  __device__ void gather(int basis_lane, const double* row) {
+    if constexpr (S::kSpline && !ROWS) {
+      const int d0 = basis_lane - keep.k_cur;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#if defined(GWI_ABL_NO_MFMA)  // timing-only ablations (results wrong): the A operand still formed, no matrix instruction
-        tile[t][0] += tap_select(keep.b, 16 * t + d0) * bw;
-#elif defined(GWI_ABL_NO_AFORM)  // ... the matrix instruction with an operand that costs nothing to form
-        tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(keep.b.b0, bw, tile[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) aval[t] = row[2 + max(-1, min(16 * t + d0, 4))];  // v_med3_i32; row[1] and row[6] are 0
+    }
+    rest.gather(basis_lane, row + S::kDoubles);
+  }
+  // w = this lane's weight w[sample, point]; grow = this lane's gradient row in LDS (ROWS); row = the sample's staged words
+  // for this term and the ones after it
+  __device__ void accumulate(int ti, const Ctx& c, double w, int basis_lane, double* grow, const double* row) {
+    if constexpr (S::kSpline) {
+      const double bw = w * keep.scale_cur;
+      if constexpr (ROWS) {
+        double* g = grow + c.a->terms[ti].th0 + keep.k_cur;
+        unsafeAtomicAdd(g, bw * row[2]);
+        unsafeAtomicAdd(g + 1, bw * row[3]);
+        unsafeAtomicAdd(g + 2, bw * row[4]);
+        unsafeAtomicAdd(g + 3, bw * row[5]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#if defined(GWI_ABL_NO_MFMA)  // timing-only ablation (results wrong): the A operand still fetched, no matrix instruction
+          tile[t][0] += aval[t] * bw;
 #else
-        tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tap_select(keep.b, 16 * t + d0), bw, tile[t], 0, 0, 0);
+          tile[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[t], bw, tile[t], 0, 0, 0);
 #endif
+        }
       }
     } else {
-      Term<K>::accumulate(c.a->terms[ti], c, w, keep.st, acc);
+      Term<K>::accumulate(c.a->terms[ti], c, w, keep.st_cur, acc);
     }
-    rest.accumulate(ti + 1, c, w, basis_lane, grow);
+    rest.accumulate(ti + 1, c, w, basis_lane, grow, row + S::kDoubles);
   }
   __device__ void collect(int ti, const Ctx& c, double* vals, int* th) {
     Term<K>::collect(c.a->terms[ti], acc, vals, th);
@@ -366,38 +428,50 @@ __device__ __forceinline__ void scan_points_body(const KArgs& a) {
   double* const grow = ROWS ? s_grad + (size_t)((q & (rows_rep - 1)) * kPts + j) * th_pad : nullptr;
 
   // a trip of the workgroup covers 256 samples: wave w, phase-A lane a -> sample  i + 64 w + a
-  double kap[2];
+  double kap = 0.0;
   auto issue_loads = [&](int i) {
     const int s = i + kStageS * wave + lane;
     const SIdx idx{base + start, (unsigned)(s < n_tile ? s : n_tile - 1) << 3};
-    kap[1] = gload(kappa_col, idx);
+    kap = gload(kappa_col, idx);
     chain.load(0, ctx, idx);
   };
   const bool a_lane = lane < kStageS;
-  if (a_lane && kStageS * wave < n_tile) issue_loads(0);  // this wave's first 64 samples
+  if (a_lane && kStageS * wave < n_tile) issue_loads(0);  // this wave's first samples
   __syncthreads();  // theta / derived staged
   for (int i = 0; i + kStageS * wave < n_tile; i += kWaves * kStageS) {  // wave-uniform: a wave stops with its samples
-    // ---- phase A
+    // ---- phase A: stage the trip whose columns were loaded one trip ago, then request the next trip's
     if (a_lane) {
-      chain.advance();
-      kap[0] = kap[1];
-      const int i_next = i + kWaves * kStageS;
-      if (i_next + kStageS * wave < n_tile) issue_loads(i_next);
       double* row = my_rows + lane * kRow;
       const bool valid = i + kStageS * wave + lane < n_tile;
-      row[0] = valid ? kap[0] : GWI_NEG_INF;
+      row[0] = valid ? kap : GWI_NEG_INF;
       chain.phase_a(0, ctx, row + 1);
+      const int i_next = i + kWaves * kStageS;
+      if (i_next + kStageS * wave < n_tile) issue_loads(i_next);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS traffic is processed in order: the rows are there
-    // ---- phase B: sixteen rounds of (4 samples x 16 points)
+    // ---- phase B: rounds of (4 samples x 16 points).  The A operands of the round's matrix instructions are requested as
+    //      soon as the forward half has read k -- ahead of the exponential -- and the instruction scheduler is fenced there:
+    //      left to itself it sinks every gather to its matrix instruction (read, full LDS round trip, MFMA, eight times a
+    //      round).  A two-stage software pipeline over rounds on top of this measured the same (36.6 vs 36.4 us per evaluation
+    //      at config 5) and is not kept.
+#ifdef GWI_ABL_B_NONE  // timing-only ablation: phase A and the staging only
+    constexpr int kRounds = 0;
+#else
+    constexpr int kRounds = kStageS / 4;
+#endif
 #pragma unroll 1
-    for (int g = 0; g < kStageS / 4; ++g) {
+    for (int g = 0; g < kRounds; ++g) {
       const double* row = my_rows + (4 * g + q) * kRow;
       const double kappa = row[0];
-      chain.b_rows(row + 1);
-      chain.b_coefs(0, ctx);
       double lin = 1.0;
-      double ell = kappa + chain.b_value(0, ctx, lin);
+#ifdef GWI_ABL_NO_FWD  // timing-only ablation: no forward half
+      double ell = kappa;
+#else
+      double ell = kappa + chain.forward(0, ctx, row + 1, lin);
+#endif
+      chain.commit();
+      chain.gather(j, row + 1);
+      __builtin_amdgcn_sched_barrier(0);
       const bool live = (ell < GWI_POS_INF) && (ell > GWI_NEG_INF) && (lin > 0.0) && (lin < GWI_POS_INF);
       if (!live) ell = GWI_NEG_INF;
       lane_max = fmax(lane_max, ell);
@@ -405,7 +479,8 @@ __device__ __forceinline__ void scan_points_body(const KArgs& a) {
       if (a.square) w *= w;
       s1 += w;
       s2 += w * w;
-      chain.accumulate(0, ctx, w, j, grow);
+      __builtin_amdgcn_sched_barrier(0);
+      chain.accumulate(0, ctx, w, j, grow, row + 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read before the next trip overwrites them
   }
