@@ -146,3 +146,42 @@ def test_inference_data_file_loads_like_the_reference_loader():
 
     comp = COMPOSITIONS["plpeak"](pedict, injdict)
     assert comp.pe["mass_1"].shape == (5, 40)
+
+
+@pytest.mark.parametrize("comp_name", ["plpeak_full", "bspline_test"])
+def test_inference_data_file_through_the_oracle(comp_name):
+    """CPU half of tests/test_gpu_formats.py: the catalog read from tests/golden/idata_small.h5 by the product reader, bound
+    by the product binder and evaluated by the C oracle reproduces the sites the unmodified reference computed from the same
+    arrays (tests/golden/idata_golden.npz, written by make_golden.py formats)."""
+    _hdf5_or_skip()
+    from golden_util import GOLDEN_DIR, rel_err
+
+    from gwinferno_amd.catalog import load_pe_and_injections_as_dict
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from gwinferno_amd.engine import bind
+    from oracle.c_oracle import COracle
+
+    gold = np.load(os.path.join(GOLDEN_DIR, "idata_golden.npz"))
+    pedict, injdict, constants, _ = load_pe_and_injections_as_dict(os.path.join(GOLDEN_DIR, "idata_small.h5"))
+    comp = COMPOSITIONS[comp_name](pedict, injdict)
+    pre = f"{comp_name}/theta/"
+    thetas = {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)}
+    for i in range(2):
+        p = {k: (v[i] if v.ndim > 1 else float(v[i])) for k, v in thetas.items()}
+        bm = bind(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p))
+        got = COracle(bm).evaluate(bm.theta_of(comp.weights(p, True)), constants["total_inj"], nobs=constants["nObs"], min_neff_cut=False)
+        assert rel_err(got["log_likelihood"], gold[f"{comp_name}/sites/log_likelihood"][i]) < 1e-9
+        assert rel_err(got["logBFs"], gold[f"{comp_name}/sites/logBFs"][i]) < 1e-9
+        assert rel_err(got["log_nEffs"], gold[f"{comp_name}/sites/log_nEffs"][i]) < 1e-9
+
+
+def test_truncated_reference_pe_tensor_equals_the_golden_arrays():
+    """tests/golden/gwtc3_first64.nc (the reference's own GWTC-3 PE tensor, first 64 samples per event, NetCDF-3) read by the
+    product reader == the PE arrays of the committed GWTC-3 golden case."""
+    from golden_util import GOLDEN_DIR, GoldenCase
+
+    pe, events = cat.read_pe_netcdf3(os.path.join(GOLDEN_DIR, "gwtc3_first64.nc"))
+    case = GoldenCase("gwtc3_pl_test")
+    assert len(events) == 69
+    for k, v in case.pe.items():
+        assert np.array_equal(pe[k], v), k
