@@ -3,7 +3,9 @@
  * 4 "events" x 1000 posterior samples and 3000 found injections, evaluated by gwi_eval and checked against
  * a plain double loop in this file (value of log_l, per-event log Bayes factors, d log_l / d alpha); then the
  * library's NUTS (gwi_nuts_engine) samples alpha under a Normal(0, 5) prior and its posterior mean and width are
- * checked against quadrature of the same posterior on a grid.
+ * checked against quadrature of the same posterior on a grid.  A second engine is built from the RAW x and prior
+ * arrays with gwi_create_ingest (logarithm, truncation mask and -log prior computed by the library's setup kernel on
+ * the device) and must give the same likelihood.
  *   gcc -O2 -Iinclude examples/c_abi_example.c -o c_abi_example -Lgwinferno_amd/_lib -lgwi_engine \
  *       -Wl,-rpath,$PWD/gwinferno_amd/_lib -lm && ./c_abi_example                                        */
 #include <math.h>
@@ -28,14 +30,19 @@ static double urand(unsigned long long* s) { /* xorshift64*, [0, 1) */
 int main(void) {
   const double lo = 5.0, hi = 100.0, alpha = -2.3, total_inj = 60000.0;
   static double logx_pe[N_EV * N_PE], kap_pe[N_EV * N_PE], logx_inj[N_INJ], kap_inj[N_INJ];
+  static double x_pe[N_EV * N_PE], prior_pe[N_EV * N_PE], x_inj[N_INJ], prior_inj[N_INJ]; /* the raw catalog, for gwi_create_ingest */
   unsigned long long seed = 88172645463325252ULL;
   for (int i = 0; i < N_EV * N_PE; ++i) {
     const double x = 4.0 + 110.0 * urand(&seed); /* some samples fall outside [lo, hi] */
+    x_pe[i] = x;
+    prior_pe[i] = 0.01 * x;
     logx_pe[i] = log(x);
     kap_pe[i] = (x < lo || x > hi) ? -INFINITY : -log(0.01 * x); /* kappa = -log prior, -inf = excluded */
   }
   for (int i = 0; i < N_INJ; ++i) {
     const double x = lo + (hi - lo) * urand(&seed);
+    x_inj[i] = x;
+    prior_inj[i] = 1.0 / (hi - lo);
     logx_inj[i] = log(x);
     kap_inj[i] = -log(1.0 / (hi - lo));
   }
@@ -73,6 +80,44 @@ int main(void) {
     fprintf(stderr, "gwi_eval failed (%d): %s\n", (int)st, gwi_last_error(h));
     return 2;
   }
+
+  /* the same engine from the raw columns: the setup program below is what a binding emits for
+   *   col0 = log x;   kappa = where((x < lo) | (x > hi), -inf, -log prior)                                   */
+  const gwi_ingest_op prog[] = {
+      {GWI_ING_LOAD, 0, 0, 0, 0, 0, 0.0},  /* r0 = x */
+      {GWI_ING_LOG, 1, 0, 0, 0, 0, 0.0},   /* r1 = log x */
+      {GWI_ING_LOAD, 2, 1, 0, 0, 0, 0.0},  /* r2 = prior */
+      {GWI_ING_LOG, 2, 2, 0, 0, 0, 0.0},
+      {GWI_ING_NEG, 2, 2, 0, 0, 0, 0.0},   /* r2 = -log prior */
+      {GWI_ING_CONST, 3, 0, 0, 0, 0, lo},
+      {GWI_ING_LT, 3, 0, 3, 0, 0, 0.0},    /* r3 = x < lo */
+      {GWI_ING_CONST, 4, 0, 0, 0, 0, hi},
+      {GWI_ING_GT, 4, 0, 4, 0, 0, 0.0},    /* r4 = x > hi */
+      {GWI_ING_OR, 3, 3, 4, 0, 0, 0.0},
+      {GWI_ING_CONST, 4, 0, 0, 0, 0, -INFINITY},
+      {GWI_ING_WHERE, 2, 3, 4, 2, 0, 0.0}, /* r2 = r3 ? -inf : r2 */
+      {GWI_ING_STORE, 0, 1, 0, 0, 0, 0.0},
+      {GWI_ING_STORE, 1, 2, 0, 0, 0, 0.0},
+  };
+  const int32_t f64x2[2] = {GWI_DTYPE_F64, GWI_DTYPE_F64};
+  const void* src_pe[2] = {x_pe, prior_pe};
+  const void* src_inj[2] = {x_inj, prior_inj};
+  const gwi_ingest_program ing_pe = {(int32_t)(sizeof(prog) / sizeof(prog[0])), 5, 2, 0, prog, src_pe, f64x2, NULL, NULL};
+  const gwi_ingest_program ing_inj = {(int32_t)(sizeof(prog) / sizeof(prog[0])), 5, 2, 0, prog, src_inj, f64x2, NULL, NULL};
+  gwi_handle h2 = NULL;
+  st = gwi_create_ingest(&spec, &ing_pe, N_EV, N_PE, &ing_inj, N_INJ, GWI_DEVICE_CURRENT, &h2);
+  if (st != GWI_OK) {
+    fprintf(stderr, "gwi_create_ingest failed (%d): %s\n", (int)st, h2 ? gwi_last_error(h2) : "no device");
+    return 2;
+  }
+  gwi_summary s2;
+  static double kap_back[N_EV * N_PE];
+  if (gwi_eval(h2, &alpha, &opt, &s2, NULL, NULL, NULL, NULL, NULL) != GWI_OK || gwi_read_column(h2, 1, 1, kap_back) != GWI_OK) return 2;
+  int same_mask = 1;
+  for (int i = 0; i < N_EV * N_PE; ++i) same_mask = same_mask && ((kap_back[i] == -INFINITY) == (kap_pe[i] == -INFINITY));
+  const double e_ingest = fabs(s2.log_likelihood - s.log_likelihood) / fabs(s.log_likelihood);
+  printf("device setup (gwi_create_ingest): log_l %.12f, rel. diff to the host-prepared engine %.2e, masks %s\n", s2.log_likelihood, e_ingest, same_mask ? "equal" : "DIFFER");
+  gwi_destroy(h2);
 
   /* the same, written out: log_l = sum_i log(mean_j w_ij) - N_ev log(sum_j w_j / N_tot) */
   const double b1 = 1.0 + alpha, den = pow(hi, b1) - pow(lo, b1);
@@ -139,7 +184,7 @@ int main(void) {
          nres.accept_rate, (int)nres.n_divergent);
   const int nuts_ok = fabs(m1 - q_mean) < 0.2 * q_sd && fabs(sqrt(m2) / q_sd - 1.0) < 0.2;
   gwi_destroy(h);
-  if (e_val < 1e-11 && e_grad < 1e-10 && worst_bf < 1e-11 && nuts_ok) {
+  if (e_val < 1e-11 && e_grad < 1e-10 && worst_bf < 1e-11 && nuts_ok && e_ingest < 1e-13 && same_mask) {
     printf("OK\n");
     return 0;
   }

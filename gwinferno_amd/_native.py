@@ -121,6 +121,59 @@ class GwiSummary(C.Structure):
     ]
 
 
+class GwiIngestOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("reserved", C.c_int32), ("k", C.c_double)]
+
+
+class GwiIngestProgram(C.Structure):
+    _fields_ = [
+        ("n_ops", C.c_int32),
+        ("n_regs", C.c_int32),
+        ("n_sources", C.c_int32),
+        ("n_tables", C.c_int32),
+        ("ops", C.POINTER(GwiIngestOp)),
+        ("sources", C.POINTER(C.c_void_p)),
+        ("source_dtype", C.POINTER(C.c_int32)),
+        ("tables", C.POINTER(C.POINTER(C.c_double))),
+        ("table_len", C.POINTER(C.c_int64)),
+    ]
+
+
+GWI_INGEST_MAX_REGS, GWI_INGEST_MAX_SOURCES, GWI_INGEST_MAX_TABLES = 64, 32, 16
+GWI_DTYPE_F64, GWI_DTYPE_F32 = 0, 1
+
+
+def ingest_program(prog):
+    """``gwi_ingest_program`` of a compiled :class:`gwinferno_amd.expr.Program`.  Returns ``(struct, keep)``: ``keep`` holds
+    every buffer the struct points to (sources that had to be made contiguous / converted included) and must outlive the call."""
+    if len(prog.sources) > GWI_INGEST_MAX_SOURCES or len(prog.tables) > GWI_INGEST_MAX_TABLES or prog.n_regs > GWI_INGEST_MAX_REGS:
+        raise ValueError(f"setup program too large for the device evaluator ({len(prog.sources)} sources, {len(prog.tables)} tables, {prog.n_regs} registers)")
+    ops = (GwiIngestOp * max(len(prog.ops), 1))()
+    for i, (op, dst, a, b, c, k) in enumerate(prog.ops):
+        o = ops[i]
+        o.op, o.dst, o.a, o.b, o.c, o.k = op, dst, a, b, c, k
+    srcs, dtypes = [], []
+    for a in prog.sources:
+        a = np.asarray(a)
+        if a.dtype not in (np.float64, np.float32):  # bool masks, integer columns: converted once
+            a = a.astype(np.float64)
+        srcs.append(np.ascontiguousarray(a))
+        dtypes.append(GWI_DTYPE_F32 if a.dtype == np.float32 else GWI_DTYPE_F64)
+    tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in prog.tables]
+    src_ptrs = (C.c_void_p * max(len(srcs), 1))(*[a.ctypes.data for a in srcs])
+    dt = (C.c_int32 * max(len(srcs), 1))(*dtypes)
+    tab_ptrs = (_DP * max(len(tabs), 1))(*[as_dp(t) for t in tabs])
+    tab_len = (C.c_int64 * max(len(tabs), 1))(*[t.size for t in tabs])
+    st = GwiIngestProgram()
+    st.n_ops, st.n_regs, st.n_sources, st.n_tables = len(prog.ops), prog.n_regs, len(srcs), len(tabs)
+    st.ops = ops
+    st.sources = src_ptrs
+    st.source_dtype = dt
+    st.tables = tab_ptrs
+    st.table_len = tab_len
+    return st, (ops, srcs, tabs, src_ptrs, dt, tab_ptrs, tab_len)
+
+
 class GwiNutsOptions(C.Structure):
     _fields_ = [
         ("n_warmup", C.c_int32),
@@ -158,6 +211,9 @@ LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.p
 # every symbol include/gwi_engine.h declares
 EXPORTED_SYMBOLS = [
     "gwi_create",
+    "gwi_create_ingest",
+    "gwi_ingest_columns",
+    "gwi_read_column",
     "gwi_eval",
     "gwi_eval_begin",
     "gwi_eval_end",
@@ -226,6 +282,13 @@ def load_library():
     vp = C.c_void_p
     lib.gwi_create.restype = C.c_int32
     lib.gwi_create.argtypes = [C.POINTER(GwiSpec), C.POINTER(_DP), C.c_int64, C.c_int64, C.POINTER(_DP), C.c_int64, C.c_int32, C.POINTER(vp)]
+    if hasattr(lib, "gwi_create_ingest"):  # absent from older builds loaded through GWI_ENGINE_LIB for A/B timing
+        lib.gwi_create_ingest.restype = C.c_int32
+        lib.gwi_create_ingest.argtypes = [C.POINTER(GwiSpec), C.POINTER(GwiIngestProgram), C.c_int64, C.c_int64, C.POINTER(GwiIngestProgram), C.c_int64, C.c_int32, C.POINTER(vp)]
+        lib.gwi_ingest_columns.restype = C.c_int32
+        lib.gwi_ingest_columns.argtypes = [C.POINTER(GwiIngestProgram), C.c_int64, C.c_int32, C.POINTER(_DP), C.c_int32]
+        lib.gwi_read_column.restype = C.c_int32
+        lib.gwi_read_column.argtypes = [vp, C.c_int32, C.c_int32, _DP]
     lib.gwi_eval.restype = C.c_int32
     lib.gwi_eval.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_eval_begin.restype = C.c_int32

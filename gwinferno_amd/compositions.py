@@ -34,10 +34,11 @@ class Composition:
         """Any parameter point (used only to establish the model structure)."""
         return {k: (np.zeros(s) if s else 1.0) for k, s in self.PARAMS.items()}
 
-    def engine(self, device=-1, rank=0, world=1):
+    def engine(self, device=-1, rank=0, world=1, device_setup=None):
         if self._engine is None:
             p = self.placeholder()
-            self._engine = NativePopulationLikelihood(self.weights(p, True), self.weights(p, False), self.hypervolume(p), device=device, rank=rank, world=world)
+            self._engine = NativePopulationLikelihood(self.weights(p, True), self.weights(p, False), self.hypervolume(p), device=device, rank=rank, world=world,
+                                                      device_setup=device_setup)
         return self._engine
 
     def _theta_map(self):

@@ -65,6 +65,21 @@ class FlatLambdaCDM:
         z = np.asarray(z, dtype=np.float64)
         return 4 * np.pi * self.z_to_Dc(z) ** 2 * self.dDc_dz(z)
 
+    def dVc_dz_expr(self, z, max_z=None):
+        """``dVc_dz`` of a per-sample setup expression ``z`` (gwinferno_amd.expr): the same operation sequence as
+        :meth:`dVc_dz` -- linear interpolation into the comoving-distance table, ``4 pi Dc^2 (c/H0)/E(z)`` -- with the
+        integer powers of ``1 + z`` written as products, evaluated on the device when a catalog is ingested.  ``max_z``:
+        the largest redshift the expression will see (the table is extended to it first, as :meth:`z_to_Dc` does)."""
+        from . import expr as E
+
+        if max_z is not None and max_z > self.z[-1]:
+            self._tabulate(float(max_z), self.z[1] - self.z[0])
+        opz = 1.0 + z
+        opz2 = opz * opz
+        e2 = self.omega_lambda + self.omega_kappa * opz2 + self.omega_matter * (opz2 * opz) + self.omega_radiation * (opz2 * opz2)
+        dc = E.interp(z, self.z, self.Dc)
+        return 4 * np.pi * (dc * dc) * (self.c_over_H0 / E.sqrt(e2))
+
     def log_dVc_dz(self, z):
         z = np.asarray(z, dtype=np.float64)
         return np.log(4 * np.pi) + 2 * np.log(self.z_to_Dc(z)) + np.log(self.dDc_dz(z))

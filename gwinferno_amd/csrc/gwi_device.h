@@ -1579,6 +1579,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   } while (0)
 #endif
   GWI_STAMP(0);
+#ifdef GWI_STAMPS
+  {  // where the wave runs: HW_ID (wave slot, SIMD, CU, shader array / engine) and the XCD, for the placement report of tools/stamp_phases.py
+    unsigned hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    if (lane == 0) stamp_row[5] = ((unsigned long long)xcc_id << 32) | hw_id;
+  }
+#endif
   // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
   const bool batch = BATCH || (SAFE && a.tblocks != nullptr);
   const int kb = batch ? (int)blockIdx.y : 0;

@@ -3,6 +3,7 @@
 #include "gwi_device.h"
 #include "gwi_mfma.h"
 #include "gwi_aql.h"
+#include "gwi_ingest.h"
 
 #include <hip/hip_ext.h>
 
@@ -1307,11 +1308,15 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
   h->aql_note = "active";
 }
 
-gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
-                      int32_t device, gwi_handle* out) {
+// gwi_create / gwi_create_ingest: the columns either come from the host ready-made (pe_cols / inj_cols) or are computed
+// on the device from raw sources by the two setup programs (gwi_ingest.h)
+static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
+                              int32_t device, gwi_handle* out, const gwi_ingest_program* ing_pe, const gwi_ingest_program* ing_inj) {
   if (!out) return GWI_ERR_INVALID;
   *out = nullptr;
-  if (!spec || !pe_cols || !inj_cols || n_ev < 0 || n_pe < 1 || n_inj < 0) return GWI_ERR_INVALID;
+  const bool ingest = ing_pe != nullptr;
+  if (!spec || n_ev < 0 || n_pe < 1 || n_inj < 0) return GWI_ERR_INVALID;
+  if (ingest ? !ing_inj : (!pe_cols || !inj_cols)) return GWI_ERR_INVALID;
   int n_dev = 0;
   if (device != GWI_DEVICE_HOST_ONLY && (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)) return GWI_ERR_NO_DEVICE;
   gwi_engine* h = new (std::nothrow) gwi_engine();
@@ -1390,12 +1395,27 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
 
   // ---- columns -> HBM (struct-of-arrays: one contiguous fp64 array per column and sample set)
   std::vector<const double*> tab_pe(spec->n_cols), tab_inj(spec->n_cols);
-  for (int c = 0; c < spec->n_cols; ++c) {
-    double* d;
-    if ((st = upload(h, pe_cols[c], (size_t)(n_ev * n_pe), &d, &h->d_cols_pe)) != GWI_OK) return st;
-    tab_pe[c] = d;
-    if ((st = upload(h, inj_cols[c], (size_t)n_inj, &d, &h->d_cols_inj)) != GWI_OK) return st;
-    tab_inj[c] = d;
+  if (ingest) {
+    // setup on the device: raw catalog columns up, one kernel per sample set writes the engine's columns (gwi_ingest.h)
+    for (int c = 0; c < spec->n_cols; ++c) {
+      double* d = nullptr;
+      GWI_HIP(hipMalloc(&d, sizeof(double) * (size_t)(n_ev * n_pe ? n_ev * n_pe : 1)));
+      h->d_cols_pe.push_back(d);
+      tab_pe[c] = d;
+      GWI_HIP(hipMalloc(&d, sizeof(double) * (size_t)(n_inj ? n_inj : 1)));
+      h->d_cols_inj.push_back(d);
+      tab_inj[c] = d;
+    }
+    if ((st = ingest_run(h->err, ing_pe, n_ev * n_pe, spec->n_cols, h->d_cols_pe.data(), h->stream)) != GWI_OK) return st;
+    if ((st = ingest_run(h->err, ing_inj, n_inj, spec->n_cols, h->d_cols_inj.data(), h->stream)) != GWI_OK) return st;
+  } else {
+    for (int c = 0; c < spec->n_cols; ++c) {
+      double* d;
+      if ((st = upload(h, pe_cols[c], (size_t)(n_ev * n_pe), &d, &h->d_cols_pe)) != GWI_OK) return st;
+      tab_pe[c] = d;
+      if ((st = upload(h, inj_cols[c], (size_t)n_inj, &d, &h->d_cols_inj)) != GWI_OK) return st;
+      tab_inj[c] = d;
+    }
   }
 
   // ---- normaliser grids
@@ -1722,6 +1742,47 @@ gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_
   h->combine_threads = spec->n_theta + 4 <= 64 ? 64 : kBlock;
   if (const char* env = std::getenv("GWI_COMBINE_THREADS")) h->combine_threads = std::atoi(env) == 64 ? 64 : kBlock;
   setup_aql(h, prop);
+  return GWI_OK;
+}
+
+gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
+                      int32_t device, gwi_handle* out) {
+  return create_impl(spec, pe_cols, n_ev, n_pe, inj_cols, n_inj, device, out, nullptr, nullptr);
+}
+
+gwi_status gwi_create_ingest(const gwi_spec* spec, const gwi_ingest_program* pe, int64_t n_ev, int64_t n_pe, const gwi_ingest_program* inj, int64_t n_inj,
+                             int32_t device, gwi_handle* out) {
+  if (!pe || !inj) return GWI_ERR_INVALID;
+  if (device == GWI_DEVICE_HOST_ONLY) return GWI_ERR_INVALID;  // a host-only handle owns no columns: use gwi_create
+  return create_impl(spec, nullptr, n_ev, n_pe, nullptr, n_inj, device, out, pe, inj);
+}
+
+gwi_status gwi_ingest_columns(const gwi_ingest_program* prog, int64_t n, int32_t n_cols, double* const* cols, int32_t device) {
+  if (!prog || !cols || n < 0 || n_cols < 1 || n_cols > GWI_MAX_COLS) return GWI_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return GWI_ERR_NO_DEVICE;
+  if (device >= n_dev) return GWI_ERR_NO_DEVICE;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GWI_ERR_HIP;
+  std::string err;
+  std::vector<double*> d(n_cols, nullptr);
+  gwi_status st = GWI_OK;
+  for (int c = 0; c < n_cols && st == GWI_OK; ++c)
+    if (hipMalloc(&d[c], sizeof(double) * (size_t)(n ? n : 1)) != hipSuccess) st = GWI_ERR_HIP;
+  if (st == GWI_OK) st = ingest_run(err, prog, n, n_cols, d.data(), nullptr);
+  for (int c = 0; c < n_cols && st == GWI_OK; ++c)
+    if (n && hipMemcpy(cols[c], d[c], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) st = GWI_ERR_HIP;
+  for (double* q : d) (void)hipFree(q);
+  if (st != GWI_OK && !err.empty()) std::fprintf(stderr, "gwi_ingest_columns: %s\n", err.c_str());
+  return st;
+}
+
+gwi_status gwi_read_column(gwi_handle h, int32_t pe_side, int32_t col, double* out) {
+  if (!h || !out || h->host_only) return GWI_ERR_INVALID;
+  const std::vector<double*>& cols = pe_side ? h->d_cols_pe : h->d_cols_inj;
+  if (col < 0 || col >= (int)cols.size()) return fail(h, GWI_ERR_INVALID, "gwi_read_column: column out of range");
+  const size_t n = pe_side ? (size_t)(h->n_ev * h->n_pe) : (size_t)h->n_inj;
+  GWI_HIP(hipSetDevice(h->device));
+  if (n) GWI_HIP(hipMemcpy(out, cols[col], sizeof(double) * n, hipMemcpyDeviceToHost));
   return GWI_OK;
 }
 

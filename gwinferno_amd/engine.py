@@ -6,11 +6,13 @@ owns the resulting engine handle and exposes value-and-gradient evaluations.  Th
 bookkeeping only -- every per-sample operation runs in gwinferno_amd/csrc (HIP, gfx950).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _native as N
-from .lazy import INJ, PE, Density, LazyNorm, static_key, static_log_values
+from . import expr as E
+from .lazy import INJ, PE, Density, LazyNorm, static_key, static_log_expr
 
 NEG_BIG = float(np.nan_to_num(-np.inf))
 
@@ -20,8 +22,9 @@ class BoundModel:
 
     def __init__(self):
         self.col_keys = []      # dedup keys
-        self.pe_cols = []       # list of (N_ev, N_pe) arrays
-        self.inj_cols = []      # list of (N_inj,) arrays
+        self.pe_exprs = []      # one setup expression (gwinferno_amd.expr) per column, kappa last: (N_ev, N_pe)
+        self.inj_exprs = []     # ... and for the injection set: (N_inj,)
+        self._cols = {}         # host evaluation of the expressions, on first use
         self.terms = []         # dicts mirroring gwi_term
         self.norms = []         # (GridNorm, expo_theta, coef_off)
         self.norm_keys = []
@@ -31,6 +34,32 @@ class BoundModel:
         self.vt_norm = -1
         self.n_ev = self.n_pe = self.n_inj = 0
         self.log_const = 0.0    # log of scalar multipliers common to both sides
+
+    def _host_columns(self, side):
+        if side not in self._cols:
+            exprs, shape = (self.pe_exprs, (self.n_ev, self.n_pe)) if side == PE else (self.inj_exprs, (self.n_inj,))
+            self._cols[side] = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), shape)) for v in E.evaluate(exprs)]
+        return self._cols[side]
+
+    @property
+    def pe_cols(self):
+        """The PE columns as ``(N_ev, N_pe)`` arrays, evaluated on the HOST (NumPy) on first use: engines without a
+        device, the oracles, and the parity test of the device ingest kernel read them."""
+        return self._host_columns(PE)
+
+    @property
+    def inj_cols(self):
+        return self._host_columns(INJ)
+
+    def program(self, side, events=None, samples=None):
+        """The compiled setup program of one side (``gwi_ingest_program``): ``events`` = (e0, e1) restricts the PE
+        sources to a block of events, ``samples`` = (j0, j1) the injection sources to a slice (sharded engines)."""
+        exprs = self.pe_exprs if side == PE else self.inj_exprs
+        prog = E.compile_program(exprs)
+        sl = events if side == PE else samples
+        if sl is not None:
+            prog.sources = [np.asarray(a)[sl[0]:sl[1]] for a in prog.sources]
+        return prog
 
     def theta_of(self, density):
         """Current hyper-parameter values of ``density`` in this model's theta layout."""
@@ -77,21 +106,29 @@ def bind(pe, inj, hypervolume=None):
     bm.log_const = pe.log_const
 
     # ---- shapes from the first column
-    first_pe = pe.factors[0].columns[0].values()
-    first_inj = inj.factors[0].columns[0].values()
-    bm.n_ev, bm.n_pe = first_pe.shape
-    bm.n_inj = first_inj.shape[0]
+    first_pe = pe.factors[0].columns[0].expr().shape
+    first_inj = inj.factors[0].columns[0].expr().shape
+    if len(first_pe) != 2 or len(first_inj) != 1:
+        raise ValueError("all PE arrays must share one (N_ev, N_pe) shape and all injection arrays one (N_inj,) shape")
+    bm.n_ev, bm.n_pe = first_pe
+    bm.n_inj = first_inj[0]
+    shapes = {PE: (bm.n_ev, bm.n_pe), INJ: (bm.n_inj,)}
+
+    def check_shape(e, side):
+        if e.shape not in ((), shapes[side]):
+            raise ValueError("all PE arrays must share one (N_ev, N_pe) shape and all injection arrays one (N_inj,) shape")
+        return e
 
     def add_column(cpe, cinj):
         key = (cpe.key(), cinj.key())
         if key in bm.col_keys:
             return bm.col_keys.index(key)
-        vpe, vinj = cpe.values(), cinj.values()
-        if vpe.shape != (bm.n_ev, bm.n_pe) or vinj.shape != (bm.n_inj,):
+        epe, einj = cpe.expr(), cinj.expr()
+        if epe.shape != shapes[PE] or einj.shape != shapes[INJ]:
             raise ValueError("all PE arrays must share one (N_ev, N_pe) shape and all injection arrays one (N_inj,) shape")
         bm.col_keys.append(key)
-        bm.pe_cols.append(vpe)
-        bm.inj_cols.append(vinj)
+        bm.pe_exprs.append(epe)
+        bm.inj_exprs.append(einj)
         return len(bm.col_keys) - 1
 
     # ---- theta layout (shared coefficient vectors -- the IID models -- get one block)
@@ -127,23 +164,23 @@ def bind(pe, inj, hypervolume=None):
     factor_index = {id(f): i for i, f in enumerate(pe.factors)}
     factor_index.update({id(f): i for i, f in enumerate(inj.factors)})
 
-    # ---- kappa = sum of theta-independent log factors, -inf where any static truncation excludes
-    kap_pe = np.zeros((bm.n_ev, bm.n_pe))
-    kap_inj = np.zeros(bm.n_inj)
-    with np.errstate(all="ignore"):
-        for d, kap in ((pe, kap_pe), (inj, kap_inj)):
-            kap += d.log_const  # plain scalar multipliers (e.g. the 0.5 of a symmetrised density)
-            for sgn, arr in d.log_static:
-                kap += sgn * static_log_values(arr)
-            for f in d.factors:
-                if f.static_log is not None:
-                    kap += f.static_log
-            for f in d.factors:
-                if f.mask is not None:
-                    kap[~f.mask] = -np.inf
-            # NaN or +inf weights count as zero (tests/inference_test.py:172); a NaN / +inf kappa can
-            # only ever produce those
-            kap[~(kap < np.inf)] = -np.inf
+    # ---- kappa = sum of theta-independent log factors, -inf where any static truncation excludes: a setup expression
+    # per side (evaluated with the columns, on the device where the engine has one)
+    kappa = {}
+    for d, side in ((pe, PE), (inj, INJ)):
+        kap = E.Sym.const(d.log_const)  # plain scalar multipliers (e.g. the 0.5 of a symmetrised density)
+        for sgn, arr in d.log_static:
+            e = check_shape(static_log_expr(arr), side)
+            kap = kap + e if sgn > 0 else kap - e
+        for f in d.factors:
+            if f.static_log_expr() is not None:
+                kap = kap + check_shape(f.static_log_expr(), side)
+        for f in d.factors:
+            if f.mask_expr() is not None:
+                kap = E.where(check_shape(f.mask_expr(), side), kap, -np.inf)
+        # NaN or +inf weights count as zero (tests/inference_test.py:172); a NaN / +inf kappa can
+        # only ever produce those
+        kappa[side] = E.where(kap < np.inf, kap, -np.inf)
 
     # ---- terms
     for fi in order:
@@ -182,17 +219,16 @@ def bind(pe, inj, hypervolume=None):
     # A non-finite column entry (log of a non-positive number, NaN in the data) can only produce a NaN / Inf
     # weight, which counts as zero (tests/inference_test.py:172): exclude the sample and park a finite value
     # in its place, so that the per-sample gradient state the kernel carries stays finite (0 x NaN = NaN).
-    for cols, kap in ((bm.pe_cols, kap_pe), (bm.inj_cols, kap_inj)):
-        for ci, col in enumerate(cols):
-            bad = ~np.isfinite(col)
-            if bad.any():
-                kap[bad] = -np.inf
-                cols[ci] = np.where(bad, 0.0, col)
-    bm.kappa_col = len(bm.pe_cols)
-    bm.pe_cols.append(kap_pe)
-    bm.inj_cols.append(kap_inj)
-    if len(bm.pe_cols) > N.GWI_MAX_COLS:
-        raise ValueError(f"{len(bm.pe_cols)} columns exceed GWI_MAX_COLS={N.GWI_MAX_COLS}")
+    for exprs, side in ((bm.pe_exprs, PE), (bm.inj_exprs, INJ)):
+        kap = kappa[side]
+        for ci, col in enumerate(exprs):
+            ok = E.isfinite(col)
+            kap = E.where(ok, kap, -np.inf)
+            exprs[ci] = E.where(ok, col, 0.0)
+        exprs.append(kap)
+    bm.kappa_col = len(bm.pe_exprs) - 1
+    if len(bm.pe_exprs) > N.GWI_MAX_COLS:
+        raise ValueError(f"{len(bm.pe_exprs)} columns exceed GWI_MAX_COLS={N.GWI_MAX_COLS}")
 
     # ---- which normaliser is the surveyed hypervolume (analysis.py:267)
     if hypervolume is not None:
@@ -204,6 +240,23 @@ def bind(pe, inj, hypervolume=None):
         if bm.vt_norm < 0:
             raise ValueError("surveyed_hypervolume refers to a model that is not part of the weights")
     return bm
+
+
+def ingest_columns(outputs, device=-1):
+    """Evaluate setup expressions (gwinferno_amd.expr) with the device's ingest kernel (``gwi_ingest_columns``) and
+    return them as host arrays: the device twin of :func:`gwinferno_amd.expr.evaluate`."""
+    lib = N.load_library()
+    prog = E.compile_program(list(outputs))
+    shape = next((o.shape for o in outputs if o.shape != ()), ())
+    n = int(np.prod(shape)) if shape != () else 1
+    st, keep = N.ingest_program(prog)
+    cols = [np.empty(n) for _ in outputs]
+    ptrs = (N._DP * len(cols))(*[N.as_dp(c) for c in cols])
+    rc = lib.gwi_ingest_columns(C.byref(st), n, len(cols), ptrs, int(device))
+    del keep
+    if rc != 0:
+        raise N.NativeEngineError(f"gwi_ingest_columns: {N.STATUS_NAMES.get(rc, rc)}")
+    return [c.reshape(shape) for c in cols]
 
 
 def pin_thread_to_device(device=-1):
@@ -247,7 +300,11 @@ class NativePopulationLikelihood:
     SURVEY.md section 8e); the model objects must have been built from the GLOBAL arrays.
     """
 
-    def __init__(self, pe_density, inj_density, hypervolume=None, device=-1, rank=0, world=1):
+    def __init__(self, pe_density, inj_density, hypervolume=None, device=-1, rank=0, world=1, device_setup=None):
+        """``device_setup``: compute the columns (transforms, masks, dVc/dz, kappa) on the GPU from the raw catalog arrays
+        (``gwi_create_ingest``; the default wherever the engine has a device) or on the host with NumPy and upload them
+        (``gwi_create``; ``GWI_HOST_SETUP=1`` in the environment selects it too -- the two agree to the last bit except
+        for the <= 1 ulp of the logarithms)."""
         self.lib = N.load_library()
         self.bound = bm = bind(pe_density, inj_density, hypervolume)
         self.n_theta = bm.n_theta
@@ -257,12 +314,19 @@ class NativePopulationLikelihood:
         j0, j1 = shard_bounds(bm.n_inj, rank, world)
         self.event_range, self.inj_range = (e0, e1), (j0, j1)
         self.n_ev, self.n_pe, self.n_inj = e1 - e0, bm.n_pe, j1 - j0
-        pe_cols = [N.f64(c[e0:e1]) for c in bm.pe_cols]
-        inj_cols = [N.f64(c[j0:j1]) for c in bm.inj_cols]
+        if device_setup is None:
+            device_setup = device != N.DEVICE_HOST_ONLY and os.environ.get("GWI_HOST_SETUP", "0") in ("", "0")
+        if device_setup and device == N.DEVICE_HOST_ONLY:
+            raise ValueError("a host-only handle has no device to set the catalog up on")
+        self.device_setup = bool(device_setup)
+        pe_cols = inj_cols = ()
+        if not device_setup and device != N.DEVICE_HOST_ONLY:
+            pe_cols = [N.f64(c[e0:e1]) for c in bm.pe_cols]
+            inj_cols = [N.f64(c[j0:j1]) for c in bm.inj_cols]
 
         spec = N.GwiSpec()
         spec.abi_version = N.GWI_ABI_VERSION
-        spec.n_cols = len(pe_cols)
+        spec.n_cols = len(bm.pe_exprs)
         spec.kappa_col = bm.kappa_col
         spec.n_theta = bm.n_theta
         spec.n_terms = len(bm.terms)
@@ -295,10 +359,18 @@ class NativePopulationLikelihood:
             nm.lb = N.as_dp(g.lb)
             nm.l1 = N.as_dp(g.l1)
             nm.us = N.as_dp(g.us)
-        pe_ptrs = (N._DP * len(pe_cols))(*[N.as_dp(c) for c in pe_cols])
-        inj_ptrs = (N._DP * len(inj_cols))(*[N.as_dp(c) for c in inj_cols])
         handle = C.c_void_p()
-        st = self.lib.gwi_create(C.byref(spec), pe_ptrs, self.n_ev, self.n_pe, inj_ptrs, self.n_inj, device, C.byref(handle))
+        if device_setup:
+            prog_pe, keep_pe = N.ingest_program(bm.program(PE, events=(e0, e1)))
+            prog_inj, keep_inj = N.ingest_program(bm.program(INJ, samples=(j0, j1)))
+            self._keep.append((keep_pe, keep_inj))
+            st = self.lib.gwi_create_ingest(C.byref(spec), C.byref(prog_pe), self.n_ev, self.n_pe, C.byref(prog_inj), self.n_inj, device, C.byref(handle))
+        else:
+            # a host-only handle owns no columns: it gets placeholders it never reads
+            dummy = np.zeros(1)
+            pe_ptrs = (N._DP * spec.n_cols)(*[N.as_dp(c) for c in (pe_cols or [dummy] * spec.n_cols)])
+            inj_ptrs = (N._DP * spec.n_cols)(*[N.as_dp(c) for c in (inj_cols or [dummy] * spec.n_cols)])
+            st = self.lib.gwi_create(C.byref(spec), pe_ptrs, self.n_ev, self.n_pe, inj_ptrs, self.n_inj, device, C.byref(handle))
         self.handle = handle
         if st != 0:
             msg = self.lib.gwi_last_error(handle).decode() if handle else "no HIP device visible (gwi_create returned before allocating an engine)"
@@ -307,7 +379,7 @@ class NativePopulationLikelihood:
                 self.handle = None
             raise N.NativeEngineError(f"gwi_create failed: {N.STATUS_NAMES.get(st, st)}: {msg}")
         self._keep = None  # the engine copied everything it needs
-        self.bytes_per_sample = 8 * len(pe_cols)
+        self.bytes_per_sample = 8 * spec.n_cols
         self.partial_len = int(self.lib.gwi_partial_len(self.handle))
 
     # ---------------------------------------------------------------------------------------------
@@ -580,6 +652,13 @@ class NativePopulationLikelihood:
         norms = np.zeros(max(len(self.bound.norms), 1))
         self._check(self.lib.gwi_combine(self.handle, N.as_dp(records), records.shape[0], C.byref(opt), C.byref(summ), N.as_dp(grad), N.as_dp(norms)))
         return EvalResult(log_likelihood=summ.log_likelihood, grad=grad, summary=summ, log_bfs=None, log_neffs=None, variances=None, norms=norms[: len(self.bound.norms)])
+
+    def read_column(self, side, col):
+        """Column ``col`` of the engine's resident catalog (``gwi_read_column``): ``(n_ev, n_pe)`` for ``side == "pe"``, else
+        ``(n_inj,)`` -- what the setup path (host or device) left in HBM."""
+        out = np.empty((self.n_ev, self.n_pe) if side == PE else (self.n_inj,))
+        self._check(self.lib.gwi_read_column(self.handle, 1 if side == PE else 0, int(col), N.as_dp(out)))
+        return out
 
     def log_weights(self, theta):
         """Per-sample log importance weights (diagnostic; parity with the arrays the reference's

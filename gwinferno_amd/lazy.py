@@ -14,13 +14,15 @@ products to the HIP engine, which evaluates value, gradient and diagnostics in o
 """
 import numpy as np
 
+from . import expr as E
+
 PE, INJ = "pe", "inj"
 
 
 def side_of(arr):
     """The reference tells PE from injection data by array rank (parametric.py:130-131,
     spline_perturbation.py:351-352): 2-D -> PE samples, 1-D -> injections."""
-    nd = np.ndim(arr)
+    nd = arr.ndim if isinstance(arr, E.Sym) else np.ndim(arr)
     if nd == 2:
         return PE
     if nd == 1:
@@ -29,58 +31,59 @@ def side_of(arr):
 
 
 class Column:
-    """One per-sample fp64 column for one side: a transform of a user array."""
+    """One per-sample fp64 column for one side: a transform of a user array, or a whole setup expression."""
 
-    __slots__ = ("transform", "source", "const", "aux", "_cache")
+    __slots__ = ("transform", "source", "const", "aux", "_cache", "_expr")
 
     def __init__(self, transform, source, const=0.0, aux=None):
-        """``source``: the user's array, or a tuple of two for the product transform; ``const``: the
-        subtrahend of "sub" / "prod_sub"; ``aux``: the grid of "gridindex".  Identity of the SOURCE (and
-        aux) arrays keys the engine cache."""
-        self.transform, self.source, self.const, self.aux, self._cache = transform, source, float(const), aux, None
+        """``source``: the user's array (or a :class:`~gwinferno_amd.expr.Sym` over user arrays), or a tuple of two for
+        the product transform; ``const``: the subtrahend of "sub" / "prod_sub"; ``aux``: the grid of "gridindex".
+        Identity of the SOURCE (and aux) arrays keys the engine cache."""
+        self.transform, self.source, self.const, self.aux, self._cache, self._expr = transform, source, float(const), aux, None, None
 
     def key(self):
-        ids = tuple(id(a) for a in self.source) if isinstance(self.source, tuple) else (id(self.source),)
+        """Cache identity without building the expression (a model function makes its columns on every call)."""
+        src = self.source
+        ids = tuple(a.key if isinstance(a, E.Sym) else id(a) for a in src) if isinstance(src, tuple) else (src.key if isinstance(src, E.Sym) else id(src),)
         return (self.transform, self.const) + ids + ((id(self.aux),) if self.aux is not None else ())
+
+    def expr(self):
+        """The column as a setup expression (gwinferno_amd.expr): what the device ingest kernel and :meth:`values` evaluate."""
+        if self._expr is None:
+            t = self.transform
+            if t == "prod_sub":  # a * b - const  (e.g. m2 - mmin = q m1 - mmin)
+                a, b = (E.Sym.of(v) for v in self.source)
+                e = a * b - self.const
+            else:
+                x = E.Sym.of(self.source)
+                if t == "gridindex":
+                    e = E.gridindex(x, self.aux)
+                elif t == "sub":
+                    e = x - self.const
+                elif t == "logdiv":    # log(x / const)
+                    e = E.log(x / self.const)
+                elif t == "log1mdiv":  # log(1 - x / const)
+                    e = E.log(1.0 - x / self.const)
+                elif t == "id":
+                    e = x
+                elif t == "log":
+                    e = E.log(x)
+                elif t == "neglog":
+                    e = -E.log(x)
+                elif t == "log1m":
+                    e = E.log(1.0 - x)
+                elif t == "log1p":
+                    e = E.log(1.0 + x)
+                elif t == "abs":
+                    e = abs(x)
+                else:
+                    raise ValueError(t)
+            self._expr = e
+        return self._expr
 
     def values(self):
         if self._cache is None:
-            if self.transform == "prod_sub":  # a * b - const  (e.g. m2 - mmin = q m1 - mmin)
-                a, b = (np.asarray(v, dtype=np.float64) for v in self.source)
-                self._cache = np.ascontiguousarray(a * b - self.const)
-                return self._cache
-            x = np.asarray(self.source, dtype=np.float64)
-            if self.transform == "gridindex":
-                # fractional index j + f of x in the grid, exactly the piece and weight np.interp uses
-                # (end values held outside the grid); NaN stays NaN (excluded at bind)
-                g = np.asarray(self.aux, dtype=np.float64)
-                j = np.clip(np.searchsorted(g, x, side="right") - 1, 0, g.size - 2)
-                with np.errstate(all="ignore"):
-                    f = np.clip((x - g[j]) / (g[j + 1] - g[j]), 0.0, 1.0)
-                self._cache = np.ascontiguousarray(j + f)
-                return self._cache
-            with np.errstate(all="ignore"):
-                if self.transform == "sub":
-                    v = x - self.const
-                elif self.transform == "logdiv":    # log(x / const)
-                    v = np.log(x / self.const)
-                elif self.transform == "log1mdiv":  # log(1 - x / const)
-                    v = np.log(1.0 - x / self.const)
-                elif self.transform == "id":
-                    v = x
-                elif self.transform == "log":
-                    v = np.log(x)
-                elif self.transform == "neglog":
-                    v = -np.log(x)
-                elif self.transform == "log1m":
-                    v = np.log(1.0 - x)
-                elif self.transform == "log1p":
-                    v = np.log(1.0 + x)
-                elif self.transform == "abs":
-                    v = np.abs(x)
-                else:
-                    raise ValueError(self.transform)
-            self._cache = np.ascontiguousarray(v, dtype=np.float64)
+            self._cache = np.ascontiguousarray(np.broadcast_to(self.expr().numpy(), self.expr().shape), dtype=np.float64)
         return self._cache
 
 
@@ -107,11 +110,13 @@ class LogValues:
     then only computed when an engine is bound), or a content hash (blake2b over the bytes) for an anonymous array (a model function
     recomputes ``log(prior)`` on every call)."""
 
-    __slots__ = ("_values", "key", "_source")
+    __slots__ = ("_values", "key", "_source", "_expr")
 
-    def __init__(self, values=None, source=None):
-        self._values, self._source = values, source
-        if source is not None:
+    def __init__(self, values=None, source=None, expr=None):
+        self._values, self._source, self._expr = values, source, expr
+        if expr is not None:      # a setup expression that IS the logarithm
+            self.key = ("log-expr",) + expr.key
+        elif source is not None:
             self.key = ("log-of", id(source))
         else:
             import hashlib
@@ -124,13 +129,18 @@ class LogValues:
     @property
     def values(self):
         if self._values is None:
-            with np.errstate(all="ignore"):
-                self._values = np.log(np.asarray(self._source, dtype=np.float64))
+            if self._expr is not None:
+                self._values = np.broadcast_to(np.asarray(self._expr.numpy(), dtype=np.float64), self._expr.shape)
+            else:
+                with np.errstate(all="ignore"):
+                    self._values = np.log(np.asarray(self._source, dtype=np.float64))
         return self._values
 
     @property
     def shape_source(self):
         """An array with the shape of the values, without computing them."""
+        if self._expr is not None:
+            return self._expr
         return self._source if self._values is None else self._values
 
 
@@ -143,7 +153,16 @@ def log(x):
 
 def static_key(a):
     """Cache identity of one ``log_static`` entry."""
-    return a.key if isinstance(a, LogValues) else id(a)
+    return a.key if isinstance(a, (LogValues, E.Sym)) else id(a)
+
+
+def static_log_expr(a):
+    """log of one ``log_static`` entry as a setup expression."""
+    if isinstance(a, LogValues):
+        if a._expr is not None:
+            return a._expr
+        return E.log(E.Sym.src(a._source)) if a._values is None else E.Sym.src(a._values)
+    return E.log(E.Sym.of(a))
 
 
 def static_log_values(a):
@@ -167,9 +186,11 @@ class Factor:
         self.consts = tuple(float(c) for c in consts)  # p[] of gwi_term
         self.n_basis = int(n_basis)
         self.flags = int(flags)
-        # bool array (False -> sample excluded, weight 0) and theta-independent per-sample log factor (e.g. log dVc/dz):
-        # either the arrays or zero-argument callables producing them.  Only bind() reads them, once per engine, while
-        # a model function builds its factors on EVERY call: comparisons over the whole catalog must not run per call.
+        # Setup expressions (gwinferno_amd.expr) over the caller's arrays, or zero-argument callables returning them:
+        # ``mask`` (False -> sample excluded, weight 0) and ``static_log`` (theta-independent per-sample log factor, e.g.
+        # log dVc/dz).  Only bind() looks at them, once per engine, and evaluates them on the device where there is one; a
+        # model function builds its factors on EVERY call, so even assembling the expression is deferred (the callable).
+        # Plain arrays are accepted and become sources of the expression.
         self._mask = mask
         self._static_log = static_log
         self.norm = norm                      # GridNorm dividing this factor, or None
@@ -177,19 +198,31 @@ class Factor:
         self.norm_owner = norm_owner if norm_owner is not None else owner  # normalisers are shared per owner
         self.tag = tag
 
+    def mask_expr(self):
+        """The validity mask as a boolean setup expression, or None."""
+        if callable(self._mask):
+            self._mask = self._mask()
+        if self._mask is not None and not isinstance(self._mask, E.Sym):
+            self._mask = E.Sym.src(np.ascontiguousarray(self._mask))
+        return self._mask
+
+    def static_log_expr(self):
+        if callable(self._static_log):
+            self._static_log = self._static_log()
+        if self._static_log is not None and not isinstance(self._static_log, E.Sym):
+            self._static_log = E.Sym.src(np.ascontiguousarray(self._static_log, dtype=np.float64))
+        return self._static_log
+
     @property
     def mask(self):
-        if callable(self._mask):
-            with np.errstate(all="ignore"):
-                self._mask = self._mask()
-        return self._mask
+        """The mask as a bool array (host evaluation of :meth:`mask_expr`)."""
+        e = self.mask_expr()
+        return None if e is None else np.broadcast_to(E._as_bool(e.numpy()), e.shape)
 
     @property
     def static_log(self):
-        if callable(self._static_log):
-            with np.errstate(all="ignore"):
-                self._static_log = self._static_log()
-        return self._static_log
+        e = self.static_log_expr()
+        return None if e is None else np.broadcast_to(np.asarray(e.numpy(), dtype=np.float64), e.shape)
 
     def structure(self):
         return (self.kind, self.consts, self.n_basis, self.flags, id(self.owner) if self.owner is not None else None, self.tag)
@@ -214,7 +247,7 @@ class Density:
     def __mul__(self, other):
         if isinstance(other, Density):
             return Density(self.factors + other.factors, self._merge_side(other.side), self.log_static + other.log_static, self.log_const + other.log_const)
-        if np.ndim(other) == 0:
+        if not isinstance(other, E.Sym) and np.ndim(other) == 0:
             with np.errstate(all="ignore"):
                 return Density(self.factors, self.side, self.log_static, self.log_const + np.log(float(other)))
         return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(1.0, other)], self.log_const)
@@ -224,7 +257,7 @@ class Density:
     def __truediv__(self, other):
         if isinstance(other, Density):
             raise TypeError("division by a lazy density is not supported")
-        if np.ndim(other) == 0:
+        if not isinstance(other, E.Sym) and np.ndim(other) == 0:
             return Density(self.factors, self.side, self.log_static, self.log_const - np.log(float(other)))
         return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(-1.0, other)], self.log_const)
 

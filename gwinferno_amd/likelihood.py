@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from .engine import NEG_BIG, NativePopulationLikelihood, structure_key
-from .lazy import INJ, PE, Column, Density, Factor, LazyNorm, LogValues, side_of, static_key
+from .lazy import INJ, PE, Column, Density, Factor, LazyNorm, LogValues, side_of, static_key, static_log_expr
 
 _ENGINES = {}
 _LAST_SITES = {}
@@ -394,18 +394,20 @@ def _mirror(density, side):
     always scans a PE tensor and an injection set together; for the one-sided reference functions
     below the mirrored side is ballast (a few hundred samples) whose results are discarded."""
     other = INJ if side == PE else PE
+    memo = {}
+    cut = lambda e: None if e is None else e.substitute(lambda a: _cut(a, side), memo)  # noqa: E731 -- shared sources stay shared
     factors = []
     for f in density.factors:
-        factors.append(Factor(f.kind, other, [Column(c.transform, tuple(_cut(a, side) for a in c.source) if isinstance(c.source, tuple) else _cut(c.source, side), c.const, c.aux) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
-                              n_basis=f.n_basis, flags=f.flags, mask=None if f.mask is None else _cut(f.mask, side),
-                              static_log=None if f.static_log is None else _cut(f.static_log, side), norm=f.norm, owner=f.owner, norm_owner=f.norm_owner, tag=f.tag))
-    return Density(factors, other, [(sgn, LogValues(_cut(a.values, side)) if isinstance(a, LogValues) else _cut(a, side)) for sgn, a in density.log_static], density.log_const)
+        factors.append(Factor(f.kind, other, [Column("id", cut(c.expr())) for c in f.columns], scalars=f.scalars, coefs=f.coefs, consts=f.consts,
+                              n_basis=f.n_basis, flags=f.flags, mask=cut(f.mask_expr()), static_log=cut(f.static_log_expr()), norm=f.norm, owner=f.owner,
+                              norm_owner=f.norm_owner, tag=f.tag))
+    return Density(factors, other, [(sgn, LogValues(expr=cut(static_log_expr(a)))) for sgn, a in density.log_static], density.log_const)
 
 
 def _one_sided(weights):
     if not isinstance(weights, Density) or not weights.factors:
         raise TypeError("weights must be a lazy density from gwinferno_amd.models")
-    side = weights.side if weights.side is not None else side_of(weights.factors[0].columns[0].source)
+    side = weights.side if weights.side is not None else side_of(weights.factors[0].columns[0].expr())
     key = (side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in weights.factors), tuple((sgn, static_key(a)) for sgn, a in weights.log_static))
     hit = _ONE_SIDED.get(key)
     if hit is None:

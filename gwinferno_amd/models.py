@@ -8,14 +8,17 @@ Mirrors (paths relative to the reference root):
   gwinferno/models/bsplines/separable.py          products of 1-D models
   gwinferno/models/spline_perturbation.py         PowerlawSplineRedshiftModel
 
-Construction does the reference's one-time work (masks, zmin/zmax, dVc/dz per sample, grids) in
-NumPy; the per-step arithmetic happens in the HIP engine.
+Construction records the reference's one-time per-sample work (masks, coordinate transforms, dVc/dz per sample) as
+setup expressions (gwinferno_amd.expr) which the engine evaluates once, on the device, when it ingests the catalog;
+only the small tables (grids, zmin/zmax) are made here in NumPy.  The per-step arithmetic happens in the HIP engine.
 """
 import numpy as np
 
 from . import _native as N
 from .cosmology import planck15_lvk
 from .interpolation import BSpline, LogXBSpline, LogXLogYBSpline, LogYBSpline, trapezoid_weights
+from . import expr as E
+from .expr import Sym
 from .lazy import INJ, PE, Column, Density, Factor, GridNorm, LazyNorm, side_of
 
 __all__ = [
@@ -38,9 +41,10 @@ _CONVERTED = {}  # id(original) -> (original, float64 ndarray)
 def _f(x):
     """The caller's array as a float64 ndarray WITHOUT losing its identity across calls: engines are cached on the
     identity of the data arrays, and a model function hands the same objects in on every evaluation.  A plain float64
-    ndarray is returned as is; anything else (float32 catalogs, memmaps and other ndarray subclasses, lists) is converted
-    once and the conversion remembered for as long as the original lives here."""
-    if type(x) is np.ndarray and x.dtype == np.float64:
+    ndarray is returned as is, and so is a float32 one (the reference's GWTC-3 tensors: the setup expressions read it as
+    fp64, on the device where the engine has one); anything else (memmaps and other ndarray subclasses, lists) is
+    converted once and the conversion remembered for as long as the original lives here.  A setup expression passes through."""
+    if isinstance(x, Sym) or (type(x) is np.ndarray and x.dtype in (np.float64, np.float32)):
         return x
     if np.ndim(x) == 0:
         return np.asarray(x, dtype=np.float64)
@@ -64,24 +68,22 @@ def powerlaw_pdf(xx, alpha, low, high, floor=0.0):
         raise NotImplementedError("floor != 0 is not used by any reference model")
     xx = _f(xx)
     side = side_of(xx)
-    with np.errstate(all="ignore"):
-        if np.ndim(low) == 0:
-            mask = lambda: ~((xx < low) | (xx > high))  # noqa: E731 -- evaluated at bind time only
-            return Density([Factor(N.TERM_POWERLAW, side, [Column("log", xx)], [alpha], consts=(low, high), mask=mask)], side)
-        if float(high) != 1.0:
-            raise NotImplementedError("per-sample lower bound is implemented for high == 1 (the reference's only use)")
-        low = _f(low)
-        mask = lambda: ~((xx < low) | (xx > high))  # noqa: E731
-        # log r = 0 - (-log low)
-        return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", xx), Column("neglog", low)], [alpha], consts=(0.0,), mask=mask)], side)
+    if not isinstance(low, Sym) and np.ndim(low) == 0:
+        mask = lambda: ~((Sym.src(xx) < low) | (Sym.src(xx) > high))  # noqa: E731 -- a setup expression, built and evaluated when an engine is bound
+        return Density([Factor(N.TERM_POWERLAW, side, [Column("log", xx)], [alpha], consts=(low, high), mask=mask)], side)
+    if float(high) != 1.0:
+        raise NotImplementedError("per-sample lower bound is implemented for high == 1 (the reference's only use)")
+    low = _f(low)
+    mask = lambda: ~((Sym.src(xx) < Sym.src(low)) | (Sym.src(xx) > high))  # noqa: E731
+    # log r = 0 - (-log low)
+    return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", xx), Column("neglog", low)], [alpha], consts=(0.0,), mask=mask)], side)
 
 
 def _powerlaw_ratio(q, m1, beta, mmin):
     """powerlaw_pdf(q, beta, mmin/m1, 1) sharing the log m1 column (parametric.py:28, :40; separable.py:364)."""
     q, m1 = _f(q), _f(m1)
     side = side_of(q)
-    with np.errstate(all="ignore"):
-        mask = lambda: ~((q < mmin / m1) | (q > 1))  # noqa: E731 -- evaluated at bind time only
+    mask = lambda: ~((Sym.src(q) < mmin / Sym.src(m1)) | (Sym.src(q) > 1))  # noqa: E731 -- built when an engine is bound
     return Density([Factor(N.TERM_POWERLAW_RATIO, side, [Column("log", q), Column("log", m1)], [beta], consts=(np.log(mmin),), mask=mask)], side)
 
 
@@ -90,10 +92,11 @@ def truncnorm_pdf(xx, mu, sig, low, high, log=False):
     [log low, log high] times the Jacobian 1/x (:129-134)."""
     xx = _f(xx)
     side = side_of(xx)
-    with np.errstate(all="ignore"):
-        mask = lambda: ~((xx > high) | (xx < low))  # noqa: E731
-        if log:
-            return Density([Factor(N.TERM_TRUNCNORM, side, [Column("log", xx)], [mu, sig], consts=(np.log(low), np.log(high)), mask=mask, static_log=lambda: -np.log(xx))], side)
+    mask = lambda: ~((Sym.src(xx) > high) | (Sym.src(xx) < low))  # noqa: E731
+    if log:
+        with np.errstate(all="ignore"):
+            return Density([Factor(N.TERM_TRUNCNORM, side, [Column("log", xx)], [mu, sig], consts=(np.log(low), np.log(high)), mask=mask,
+                                   static_log=lambda: -E.log(Sym.src(xx)))], side)
     return Density([Factor(N.TERM_TRUNCNORM, side, [Column("id", xx)], [mu, sig], consts=(low, high), mask=mask)], side)
 
 
@@ -104,8 +107,7 @@ def betadist(xx, alpha, beta, scale=1.0, floor=0.0):
     xx = _f(xx)
     side = side_of(xx)
     scale = float(scale)
-    with np.errstate(all="ignore"):
-        mask = lambda: (xx <= scale) & (xx >= 0)  # noqa: E731
+    mask = lambda: (Sym.src(xx) <= scale) & (Sym.src(xx) >= 0)  # noqa: E731
     if scale == 1.0:
         return Density([Factor(N.TERM_BETA, side, [Column("log", xx), Column("log1m", xx)], [alpha, beta], mask=mask)], side)
     return Density([Factor(N.TERM_BETA, side, [Column("logdiv", xx, scale), Column("log1mdiv", xx, scale)], [alpha, beta], mask=mask)], side, log_const=-np.log(scale))
@@ -127,8 +129,7 @@ def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
     """parametric.py:49-53; with ``delta`` the power-law component carries the taper ``smooth(delta, m1, mmin)``."""
     m1 = _f(m1)
     side = side_of(m1)
-    with np.errstate(all="ignore"):
-        mask = lambda: ~((m1 < mmin) | (m1 > mmax))  # noqa: E731 -- evaluated at bind time only
+    mask = lambda: ~((Sym.src(m1) < mmin) | (Sym.src(m1) > mmax))  # noqa: E731 -- built when an engine is bound
     cols = [Column("id", m1), Column("log", m1)]
     if delta is None:
         return Density([Factor(N.TERM_PLPEAK, side, cols, [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
@@ -165,8 +166,7 @@ def mixture_isoalign_spin_tilt(ct, xi_tilt, sigma_tilt):
     """parametric.py:84-86."""
     ct = _f(ct)
     side = side_of(ct)
-    with np.errstate(all="ignore"):
-        mask = lambda: ~((ct > 1) | (ct < -1))  # noqa: E731
+    mask = lambda: ~((Sym.src(ct) > 1) | (Sym.src(ct) < -1))  # noqa: E731
     return Density([Factor(N.TERM_TILT_MIXTURE, side, [Column("id", ct)], [xi_tilt, sigma_tilt], mask=mask)], side)
 
 
@@ -182,8 +182,7 @@ def default_spin_tilt(ct1, ct2, xi_tilt, sigma_tilt):
     """parametric.py:97-102: (1-xi) iso(ct1) iso(ct2) + xi TN(ct1) TN(ct2), one mixing fraction."""
     ct1, ct2 = _f(ct1), _f(ct2)
     side = side_of(ct1)
-    with np.errstate(all="ignore"):
-        mask = lambda: ~((ct1 > 1) | (ct1 < -1)) & ~((ct2 > 1) | (ct2 < -1))  # noqa: E731
+    mask = lambda: ~((Sym.src(ct1) > 1) | (Sym.src(ct1) < -1)) & ~((Sym.src(ct2) > 1) | (Sym.src(ct2) < -1))  # noqa: E731
     return Density([Factor(N.TERM_TILT_JOINT, side, [Column("id", ct1), Column("id", ct2)], [xi_tilt, sigma_tilt], mask=mask)], side)
 
 
@@ -194,17 +193,26 @@ class PowerlawRedshiftModel(object):
     def __init__(self, z_pe, z_inj):
         cosmo = planck15_lvk()
         z_pe, z_inj = _f(z_pe), _f(z_inj)
-        self.zmin = max(np.min(z_pe), np.min(z_inj))
-        self.zmax = min(np.max(z_pe), np.max(z_inj))
+        lo_pe, hi_pe, lo_inj, hi_inj = float(np.min(z_pe)), float(np.max(z_pe)), float(np.min(z_inj)), float(np.max(z_inj))
+        self.zmin = max(lo_pe, lo_inj)
+        self.zmax = min(hi_pe, hi_inj)
         self.zs = np.linspace(self.zmin, self.zmax, 1000)
         self.dVdz_ = cosmo.dVc_dz(self.zs)
         self._z = {PE: z_pe, INJ: z_inj}
-        self.dVdzs = [cosmo.dVc_dz(z_inj), cosmo.dVc_dz(z_pe)]
+        # dVc/dz at every sample (:116): a setup expression -- table interpolation + E(z), evaluated when the catalog is ingested
+        self._dVdz = {side: cosmo.dVc_dz_expr(Sym.src(z), max_z=max(hi_pe, hi_inj)) for side, z in self._z.items()}
+        self._log_dVdz = {side: E.log(e) for side, e in self._dVdz.items()}
         with np.errstate(all="ignore"):
-            self._log_dVdz = {PE: np.log(self.dVdzs[1]), INJ: np.log(self.dVdzs[0])}
             self._grid_lb = np.log(self.dVdz_)
             self._grid_l1 = np.log(1.0 + self.zs)
         self._grid_tw = trapezoid_weights(self.zs)
+
+    @property
+    def dVdzs(self):
+        """``[dVc/dz(z_inj), dVc/dz(z_pe)]`` as arrays (parametric.py:116), computed on first use."""
+        if getattr(self, "_dVdzs", None) is None:
+            self._dVdzs = [np.asarray(self._dVdz[INJ].numpy()), np.asarray(self._dVdz[PE].numpy())]
+        return self._dVdzs
 
     def _side_data(self, z):
         side = side_of(z)
@@ -215,8 +223,7 @@ class PowerlawRedshiftModel(object):
 
     def _powerlaw_factor(self, z, lamb):
         side, zz = self._side_data(z)
-        with np.errstate(all="ignore"):
-            mask = lambda: zz <= self.zmax  # noqa: E731
+        mask = lambda: Sym.src(zz) <= self.zmax  # noqa: E731
         return Factor(N.TERM_POWERLAW_REDSHIFT, side, [Column("log1p", zz)], [lamb], mask=mask, static_log=self._log_dVdz[side], owner=self, tag="plz")
 
     def normalization(self, lamb):
@@ -276,13 +283,13 @@ class Base1DBSplineModel(object):
         self._mask = {}
         self._coord = {}
         for side, x in self._x.items():
-            with np.errstate(all="ignore"):
-                valid = (x >= self.xmin) & (x <= self.xmax)  # single.py:54-55
-                coord = it.coordinate(x)
-                valid = valid & ~it.outside(coord)           # -inf columns of the log-Y bases (:407, :449)
+            X = Sym.src(x)
+            valid = (X >= self.xmin) & (X <= self.xmax)  # single.py:54-55
+            coord = E.log(X) if it.log_x else X
+            valid = valid & ~((coord < it.lo) | (coord > it.hi))  # -inf columns of the log-Y bases (:407, :449)
             self._mask[side] = valid
             # excluded samples never reach the spline (kappa = -inf); park them inside the domain
-            self._coord[side] = np.ascontiguousarray(np.where(valid, coord, it.lo))
+            self._coord[side] = E.where(valid, coord, it.lo)
         self._norm = None
         if it.normalize:
             tw, us = it.grid_tables()
@@ -322,7 +329,7 @@ class BSplineChiEffective(Base1DBSplineModel):
 class BSplineSymmetricChiEffective(Base1DBSplineModel):
     def __init__(self, n_splines, chieff, chieff_inj, basis=BSpline, **kwargs):  # single.py:233-284
         xrange = kwargs.pop("xrange", (0.0, 1.0))
-        super().__init__(n_splines, np.abs(_f(chieff)), np.abs(_f(chieff_inj)), basis=basis, xrange=xrange, **kwargs)
+        super().__init__(n_splines, abs(Sym.src(_f(chieff))), abs(Sym.src(_f(chieff_inj))), basis=basis, xrange=xrange, **kwargs)
         self.scale = 0.5  # :284
 
 
@@ -370,12 +377,12 @@ class BSplineRedshift(object):
         self.interpolator = it = LogXBSpline(self.n_splines, xrange=xrange, k=4, **kwargs)
         z, z_inj = _f(z), _f(z_inj)
         self._z = {PE: z, INJ: z_inj}
-        self.zmin = max(np.min(z), np.min(z_inj))
-        self.zmax = min(np.max(z), np.max(z_inj))
+        self.zmin = max(float(np.min(z)), float(np.min(z_inj)))
+        self.zmax = min(float(np.max(z)), float(np.max(z_inj)))
         self.zgrid = np.linspace(self.zmin, self.zmax, 1000)
         self.dVcdzgrid = planck15_lvk().dVc_dz(self.zgrid)
+        self._static = {PE: E.log(Sym.src(_f(dVdc))) - E.log1p(Sym.src(z)), INJ: E.log(Sym.src(_f(dVdc_inj))) - E.log1p(Sym.src(z_inj))}
         with np.errstate(all="ignore"):
-            self._static = {PE: np.log(_f(dVdc)) - np.log1p(z), INJ: np.log(_f(dVdc_inj)) - np.log1p(z_inj)}
             self._grid_lb = np.log(self.dVcdzgrid) - np.log1p(self.zgrid)
         self._grid_tw = trapezoid_weights(self.zgrid)
         self._grid_us = it.coordinate(self.zgrid)
@@ -461,16 +468,21 @@ class _ComponentMasses(object):
     mask_ratio = False
 
     def _setup(self, m1, m2, m1_inj, m2_inj):
-        with np.errstate(all="ignore"):
-            self.qs = [_f(m2_inj) / _f(m1_inj), _f(m2) / _f(m1)]  # :585, :679
+        self._q = [Sym.src(_f(m2_inj)) / Sym.src(_f(m1_inj)), Sym.src(_f(m2)) / Sym.src(_f(m1))]  # :585, :679
+
+    @property
+    def qs(self):
+        """``[m2_inj / m1_inj, m2 / m1]`` as arrays, computed on first use."""
+        if getattr(self, "_qs", None) is None:
+            self._qs = [np.asarray(q.numpy()) for q in self._q]
+        return self._qs
 
     def _pairing(self, beta, pe_samples):
-        q = self.qs[1 if pe_samples else 0]
+        q = self._q[1 if pe_samples else 0]
         side = PE if pe_samples else INJ
         mask = None
         if self.mask_ratio:
-            with np.errstate(all="ignore"):
-                mask = lambda: ~((q < 0) | (q > 1))  # noqa: E731  (:609-613)
+            mask = lambda: ~((q < 0) | (q > 1))  # noqa: E731  (:609-613)
         return Density([Factor(N.TERM_POWERLAW, side, [Column("log", q)], [beta], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, mask=mask, owner=self, tag="pairing")], side)
 
 

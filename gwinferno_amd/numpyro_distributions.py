@@ -13,6 +13,7 @@ the caller passes in (kept constant across calls, as ``prior_dict`` constants ar
 import numpy as np
 
 from . import _native as N
+from . import expr as E
 from .interpolation import DesignMatrix, trapezoid_weights
 from .lazy import Column, Factor, GridNorm, LazyNorm, LogDensity, side_of
 from .models import _f
@@ -66,7 +67,7 @@ class PowerlawRedshift:
         self._owner = _token("PowerlawRedshift", (zgrid, dVcdz), (self.maximum,))
         if not isinstance(self._owner.keep, dict):
             with np.errstate(all="ignore"):
-                self._owner.keep = dict(arrays=self._owner.keep, tw=trapezoid_weights(self.zs), lb=np.log(self.dVdc_), l1=np.log(1.0 + self.zs), logdv={})
+                self._owner.keep = dict(arrays=self._owner.keep, tw=trapezoid_weights(self.zs), lb=np.log(self.dVdc_), l1=np.log(1.0 + self.zs), zs=np.ascontiguousarray(self.zs), dv=np.ascontiguousarray(self.dVdc_))
 
     @property
     def norm(self):
@@ -74,19 +75,14 @@ class PowerlawRedshift:
         return LazyNorm(self._owner, [self.lamb])
 
     def log_prob(self, value, dVdc=None):
-        value = src = _f(value)
+        value = _f(value)
         side = side_of(value)
         t = self._owner.keep
-        if dVdc is None:
-            hit = t["logdv"].get(id(src))
-            if hit is None:  # per-sample table, once per data array
-                with np.errstate(all="ignore"):
-                    hit = t["logdv"][id(src)] = (src, np.log(np.interp(value, self.zs, self.dVdc_)), value <= self.maximum)
-            _, logdv, mask = hit
-        else:
-            with np.errstate(all="ignore"):
-                logdv, mask = np.log(np.asarray(dVdc, dtype=np.float64)), value <= self.maximum
-        f = Factor(N.TERM_POWERLAW_REDSHIFT, side, [Column("log1p", src if isinstance(src, np.ndarray) else value)], [self.lamb], mask=mask, static_log=logdv, owner=self._owner, tag="plz")
+        Z = E.Sym.src(value)
+        mask = Z <= self.maximum
+        # per-sample dVc/dz: a setup expression (table interpolation), evaluated once when the catalog is ingested
+        logdv = E.log(E.interp(Z, t["zs"], t["dv"])) if dVdc is None else E.log(E.Sym.src(_f(dVdc)))
+        f = Factor(N.TERM_POWERLAW_REDSHIFT, side, [Column("log1p", value)], [self.lamb], mask=mask, static_log=logdv, owner=self._owner, tag="plz")
         f.norm = GridNorm(t["tw"], lb=t["lb"], l1=t["l1"], expo_param=(f, 0), expo_add=-1.0)
         return LogDensity([f], side)
 
@@ -125,10 +121,10 @@ class BSplineDistribution:
 
     def _factor(self, src):
         basis, t = self.basis, self._owner.keep
-        value = src = _f(src)
+        value = _f(src)
         side = side_of(value)
         flags = 0 if basis.log_y else N.SPLINE_OUTSIDE_ZERO_EXPONENT
-        f = Factor(N.TERM_EXP_SPLINE_LERP, side, [Column("gridindex", src if isinstance(src, np.ndarray) else value, aux=t["grid"])], coefs=self.cs, consts=(basis.lo, basis.hi), n_basis=basis.N,
+        f = Factor(N.TERM_EXP_SPLINE_LERP, side, [Column("gridindex", value, aux=t["grid"])], coefs=self.cs, consts=(basis.lo, basis.hi), n_basis=basis.N,
                    flags=flags, owner=self._owner, tag="lerp")
         f.norm = GridNorm(t["tw"], us=t["us"], n_basis=basis.N, lo=basis.lo, hi=basis.hi, spline_flags=flags)
         return f, side

@@ -205,6 +205,65 @@ typedef struct gwi_engine* gwi_handle;
 gwi_status gwi_create(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe,
                       const double* const* inj_cols, int64_t n_inj, int32_t device, gwi_handle* out);
 
+/* ---- setup on the device ---------------------------------------------------------
+ * The reference prepares its per-sample, hyper-parameter-independent quantities eagerly on the host when the model
+ * objects are constructed: validity masks (models/bsplines/single.py:54-55, distributions.py:119,143,162,
+ * parametric.py:141-145), logarithms of the mass / ratio / redshift columns (interpolation.py:357,447), dVc/dz per
+ * sample by linear interpolation into the comoving-distance table (cosmology.py:95-120, parametric.py:116) and the
+ * division by the sampling prior (examples/simple_bspline_example.py:58-71).  gwi_create_ingest() takes the RAW catalog
+ * columns (the arrays of pedict / injdict, float64 or float32) and a small register program per sample set that
+ * describes those operations; one HIP kernel evaluates the program for every sample and writes the engine's columns
+ * (kappa included) straight into HBM.  The program is straight-line code over `n_regs` fp64 registers (booleans are
+ * 0.0 / 1.0), the same for every sample:
+ *
+ *   LOAD  dst <- sources[a][i]           CONST dst <- k
+ *   LOG LOG1P NEG ABS NOT SQRT ISFINITE  dst <- f(r[a])
+ *   ADD SUB MUL DIV LT GT LE GE AND OR   dst <- r[a] (op) r[b]         (IEEE fp64, never fused)
+ *   WHERE dst <- r[a] != 0 ? r[b] : r[c]
+ *   INTERP dst <- linear interpolation of r[a] in (tables[b], tables[c]), end values held outside (numpy.interp /
+ *                 jnp.interp as used at cosmology.py:111-120); NaN in, NaN out
+ *   GRIDINDEX dst <- j + f, the piece j and weight f numpy.interp would use on tables[b]
+ *   STORE  column dst <- r[a]
+ *
+ * Every step except LOG / LOG1P reproduces the host (NumPy) evaluation of the same program to the bit. */
+enum {
+  GWI_ING_LOAD = 0, GWI_ING_CONST = 1,
+  GWI_ING_LOG = 2, GWI_ING_LOG1P = 3, GWI_ING_NEG = 4, GWI_ING_ABS = 5, GWI_ING_NOT = 6, GWI_ING_SQRT = 7, GWI_ING_ISFINITE = 8,
+  GWI_ING_ADD = 10, GWI_ING_SUB = 11, GWI_ING_MUL = 12, GWI_ING_DIV = 13, GWI_ING_LT = 14, GWI_ING_GT = 15, GWI_ING_LE = 16,
+  GWI_ING_GE = 17, GWI_ING_AND = 18, GWI_ING_OR = 19,
+  GWI_ING_WHERE = 20, GWI_ING_INTERP = 21, GWI_ING_GRIDINDEX = 22, GWI_ING_STORE = 23
+};
+#define GWI_INGEST_MAX_REGS 64
+#define GWI_INGEST_MAX_SOURCES 32
+#define GWI_INGEST_MAX_TABLES 16
+enum { GWI_DTYPE_F64 = 0, GWI_DTYPE_F32 = 1 };
+
+typedef struct gwi_ingest_op {
+  int32_t op, dst, a, b, c, reserved;
+  double k;
+} gwi_ingest_op;
+
+typedef struct gwi_ingest_program {
+  int32_t n_ops, n_regs, n_sources, n_tables;
+  const gwi_ingest_op* ops;
+  const void* const* sources;      /* host arrays, one value per sample of the set, in sample order */
+  const int32_t* source_dtype;     /* GWI_DTYPE_F64 | GWI_DTYPE_F32 per source */
+  const double* const* tables;     /* host arrays */
+  const int64_t* table_len;
+} gwi_ingest_program;
+
+/* gwi_create() with the columns computed on the device: `pe` / `inj` must STORE every column 0 .. spec->n_cols-1 of
+ * their sample set.  Raw sources are uploaded once (float32 ones as float32) and released after the kernel ran. */
+gwi_status gwi_create_ingest(const gwi_spec* spec, const gwi_ingest_program* pe, int64_t n_ev, int64_t n_pe,
+                             const gwi_ingest_program* inj, int64_t n_inj, int32_t device, gwi_handle* out);
+
+/* The ingest kernel on its own: run `prog` over n samples on `device` and copy the n_cols columns it stores back to
+ * the host (cols[c] has n entries).  What the parity test of the setup path compares with the host evaluation. */
+gwi_status gwi_ingest_columns(const gwi_ingest_program* prog, int64_t n, int32_t n_cols, double* const* cols, int32_t device);
+
+/* Copy column `col` of an engine's resident catalog back to the host (`pe_side` != 0: n_ev * n_pe entries, else n_inj). */
+gwi_status gwi_read_column(gwi_handle h, int32_t pe_side, int32_t col, double* out);
+
 /* One value-and-gradient evaluation == one execution of the user's NumPyro model body ending in
  * hierarchical_likelihood(...) (analysis.py:139-319) under jit(value_and_grad)
  * (tests/inference_test.py:320-326).  theta has spec.n_theta entries.  Nullable outputs:

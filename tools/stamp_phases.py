@@ -28,10 +28,12 @@ n_words = 1 << 22
 buf = (C.c_uint64 * n_words)()
 eng.lib.gwi_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
 assert eng.lib.gwi_debug_stamps(eng.handle, buf, n_words) == 0
-st_all = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:, :5].astype(np.int64)
+raw = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)
+st_all = raw[:, :5].astype(np.int64)
+hw_all = raw[:, 5].copy()
 blk = np.arange(len(st_all)) // 4
 ok = (st_all[:, 0] > 0) & (st_all[:, 4] > 0)
-st, blk = st_all[ok], blk[ok]
+st, blk, hw = st_all[ok], blk[ok], hw_all[ok]
 # blocks are dealt round-robin over the 8 XCDs (block b and b+8 share one); each XCD has its own
 # realtime counter phase, so the origin is taken per XCD group
 xcd = blk % 8
@@ -47,3 +49,29 @@ prev = np.zeros(len(us))
 for k in range(5):
     d = us[:, k] - (us[:, k - 1] if k else 0.0)
     print(f"  {names[k]:26s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us   (absolute median end {np.median(us[:, k]):6.2f})")
+
+# ---- placement: which SIMD of which CU every wave ran on (HW_ID: SIMD_ID bits 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13; XCC_ID low bits)
+simd = (hw >> np.uint64(4)) & np.uint64(3)
+cu = (hw >> np.uint64(8)) & np.uint64(15)
+sh = (hw >> np.uint64(12)) & np.uint64(1)
+se = (hw >> np.uint64(13)) & np.uint64(7)
+xcc = (hw >> np.uint64(32)) & np.uint64(15)
+cu_key = (((xcc * np.uint64(8) + se) * np.uint64(2) + sh) * np.uint64(16) + cu).astype(np.int64)
+simd_key = cu_key * 4 + simd.astype(np.int64)
+wave_in_wg = np.arange(len(st_all))[ok] % 4
+dur = us[:, 3] - us[:, 2]  # evaluate + accumulate
+print(f"placement: {len(np.unique(cu_key))} CUs, {len(np.unique(simd_key))} SIMDs hold waves; xcc values {sorted(set(xcc.tolist()))}")
+cnt = np.bincount(np.unique(simd_key, return_inverse=True)[1])
+print("  waves per SIMD: " + ", ".join(f"{k}: {int((cnt == k).sum())} SIMDs" for k in sorted(set(cnt.tolist()))))
+for w in range(4):
+    sel = wave_in_wg == w
+    print(f"  wave {w} of its workgroup: SIMD histogram {np.bincount(simd[sel].astype(np.int64), minlength=4).tolist()}, evaluate median {np.median(dur[sel]):.2f} us")
+blocks_of_cu = {}
+for b_, c_ in zip(blk, cu_key):
+    blocks_of_cu.setdefault(int(c_), set()).add(int(b_))
+some = sorted(blocks_of_cu.items())[:6]
+for c_, bs in some:
+    print(f"  CU {c_}: workgroups {sorted(bs)}")
+load = np.zeros(simd_key.max() + 1)
+np.add.at(load, simd_key, dur)
+print(f"  sum of evaluate time per SIMD: median {np.median(load[load > 0]):.2f}, max {load.max():.2f} us")
