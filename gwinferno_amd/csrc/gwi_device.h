@@ -298,6 +298,21 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
   r.b3 = t2 * (t * w6);
   return r;
 }
+// The spline VALUE in the local power basis: on knot interval k the uniform cubic B-spline sum is one cubic in t,
+//   sum_i c_{k+i} b_i(t) = A + B t + C t^2 + D t^3,   A = (c0 + 4 c1 + c2)/6, B = (c2 - c0)/2, C = (c0 - 2 c1 + c2)/2, D = (c3 - c0)/6 + (c1 - c2)/2,
+// tabulated per workgroup when theta is staged: four arrays A[], B[], C[], D[] indexed like the coefficients (position
+// th0 + k), kPolyStride doubles apart -- each array is read exactly as the coefficient array was (neighbouring lanes on the
+// same or neighbouring 8-byte words: broadcast, no bank conflicts; interleaved 32-byte rows per interval measured 7 % SLOWER
+// than the taps, profiles/round3/EXPERIMENTS.md section 8), and the constant stride lets one ds_read2st64_b64 fetch two of them.
+// A sample's value is then 3 FMAs instead of the four taps + dot product (15 vector instructions); the taps are only formed
+// once per sample, weighted, for the gradient rows.
+constexpr int kPolyStride = GWI_MAX_THETA;
+__device__ __forceinline__ void spline_poly(double c0, double c1, double c2, double c3, double* out) {
+  out[0] = (c0 + 4.0 * c1 + c2) * (1.0 / 6.0);
+  out[kPolyStride] = (c2 - c0) * 0.5;
+  out[2 * kPolyStride] = (c0 - 2.0 * c1 + c2) * 0.5;
+  out[3 * kPolyStride] = (c3 - c0) * (1.0 / 6.0) + (c1 - c2) * 0.5;
+}
 // knot coordinate of a term's sample in one fma: u = x / dx - lo / dx (p2, p3 of the term)
 __device__ __forceinline__ void spline_locate_term(double x, const TermD& td, int& k, double& t) {
 #ifdef GWI_LOCATE_FMA
@@ -340,6 +355,7 @@ struct Ctx {
   const double* theta;          // scalar hyper-parameters: uniform index -> scalar loads, never LDS
   const double (*derived)[kMaxDerived];  // host-precomputed theta-only scalars per term
   const double* coefs;          // LDS copy of theta for the lane-varying spline coefficient reads
+  const double* poly;           // LDS: the cubic of every knot interval in the local power basis, four arrays kPolyStride apart (spline_poly)
   double* gacc;                 // LDS gradient numerators [n_theta][rep] + this lane's replica: coefficient p lives at gacc[p << rep_shift]
   int rep_shift;
   const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
@@ -347,6 +363,17 @@ struct Ctx {
   mutable double sink = 0.0;  // timing-only ablation: the weighted taps end up here instead of in the LDS rows
 #endif
 };
+
+__device__ __forceinline__ double spline_value(const Ctx& c, int first, double t) {
+#ifdef GWI_SPLINE_TAPS_VALUE  // A/B: the four-tap form
+  const double* cf = c.coefs + first;
+  const Taps b = cubic_taps(t);
+  return cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+#else
+  const double* q = c.poly + first;
+  return fma(fma(fma(q[3 * kPolyStride], t, q[2 * kPolyStride]), t, q[kPolyStride]), t, q[0]);
+#endif
+}
 
 // ---- spline-coefficient gradient numerators ------------------------------------------------------
 // G_p += w B_p(x) for the four non-zero bases of a sample: ds_add_f64 into the workgroup's rows in LDS.  Layout
@@ -703,9 +730,7 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     int k;
     double tt;
     spline_locate_term(x, t, k, tt);
-    const double* cf = c.coefs + t.th0 + k;
-    const Taps b = cubic_taps(tt);
-    double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+    double v = spline_value(c, t.th0 + k, tt);
     // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175); LogY bases exclude the sample
     // (kappa = -inf, decided when the catalog was bound).  The flag is wave-uniform and the block behind it is kept a real
     // scalar branch (the empty asm cannot be speculated, so the compiler does not turn it into selects): terms without the
@@ -756,9 +781,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
     int k;
     double tt;
     spline_locate_term(x, t, k, tt);
-    const double* cf = c.coefs + t.th0 + k;
-    const Taps b = cubic_taps(tt);
-    double f = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+    double f = spline_value(c, t.th0 + k, tt);
     if (!((x >= t.p0) && (x <= t.p1))) f = 0.0;  // bases are 0 outside the closed domain (:175)
     s.t = tt;
     s.k = k;
@@ -999,9 +1022,7 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   struct Acc {};
   __device__ static double node(const TermD& t, const Ctx& c, double sx, double wt, int& k, double& tt, double& lin) {
     spline_locate_term(sx, t, k, tt);
-    const double* cf = c.coefs + t.th0 + k;
-    const Taps b = cubic_taps(tt);
-    double v = cf[0] * b.b0 + cf[1] * b.b1 + cf[2] * b.b2 + cf[3] * b.b3;
+    double v = spline_value(c, t.th0 + k, tt);
     if (!((sx >= t.p0) && (sx <= t.p1))) {
       k = -1;
       v = 0.0;
@@ -1606,8 +1627,13 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // memory round trips of a workgroup's start -- theta out of the argument block, then the columns -- overlap instead of
   // queueing at the barrier (the caches were invalidated when the launch started: both come from memory)
   static_assert(GWI_MAX_THETA <= kBlock, "one hyper-parameter per thread in the theta staging");
-  double theta_mine = 0.0;
-  if (ChainT::kSpline) theta_mine = theta_src[tid < a.n_theta ? tid : a.n_theta - 1];  // unconditional (clamped index): no control flow between this load and the columns', so the wait below can count
+  double theta_mine = 0.0, theta_next[3] = {0.0, 0.0, 0.0};  // theta[tid .. tid + 3]: this thread's entries of the power-basis table (spline_poly)
+  if (ChainT::kSpline) {
+    const int last = a.n_theta - 1;
+    theta_mine = theta_src[tid < last ? tid : last];  // unconditional (clamped index): no control flow between these loads and the columns', so the wait below can count
+#pragma unroll
+    for (int j = 0; j < 3; ++j) theta_next[j] = theta_src[tid + 1 + j < last ? tid + 1 + j : last];
+  }
   // Replicas per coefficient: the regular kernels are built for 16 (the four rows of a sample then sit at immediate
   // offsets of one LDS address: three address adds per spline term and sample less); the SAFE instantiation takes the
   // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
@@ -1624,6 +1650,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   ctx.theta = theta_src;
   ctx.derived = batch ? a.tblocks[kb].derived : a.derived;
   ctx.coefs = s_theta;
+  double* const s_poly = s_gacc + (kShared ? n_rows : 0);  // behind the gradient rows in the dynamic LDS (log-weight launches keep no rows)
+  ctx.poly = s_poly;
   ctx.gacc = s_gacc + (lane & (rep - 1));
   ctx.rep_shift = rep_shift;
   double* logw;
@@ -1690,7 +1718,10 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   const int first_pass = (SAFE && kShared && a.two_pass) ? 0 : 1;
   if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns, in flight before theta is waited for
   if (ChainT::kSpline) {
-    if (tid < a.n_theta) s_theta[tid] = theta_mine;
+    if (tid < a.n_theta) {
+      s_theta[tid] = theta_mine;
+      spline_poly(theta_mine, theta_next[0], theta_next[1], theta_next[2], s_poly + tid);
+    }
     __syncthreads();  // also covers the zeroing of the rows and of s_out above
   }
   for (int pass_ = first_pass; pass_ < 2; ++pass_) {

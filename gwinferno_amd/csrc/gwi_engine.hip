@@ -1482,7 +1482,9 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     if (rep > 64) rep = 64;
     while (rep & (rep - 1)) rep &= rep - 1;  // power of two
     while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + static_lds > lds_per_cu) rep >>= 1;
-    scan_lds = sizeof(double) * (size_t)spec->n_theta * rep;
+    const size_t poly_lds = 4 * sizeof(double) * (size_t)kPolyStride;  // the power-basis table of the spline values (gwi_device.h: spline_poly), behind the rows
+    while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + poly_lds + static_lds > lds_per_cu) rep >>= 1;
+    scan_lds = sizeof(double) * (size_t)spec->n_theta * rep + poly_lds;
     if (scan_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a HIP launch (the AQL packets carry any size)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
