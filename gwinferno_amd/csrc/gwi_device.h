@@ -28,7 +28,7 @@ struct TermD {
   int th0, th1, th2, th3;  // EXP_SPLINE: th0 = coef_off
   int flags, th4;     // th4: fifth hyper-parameter (PLPEAK_SMOOTH: delta)
   double p0, p1, p2;  // spline kinds: lo, hi, 1/dx of the spline coordinate
-  double p3;          // spline kinds: -lo/dx, so that the knot coordinate is one fma
+  double p3;          // spline kinds: number of knot intervals, n_basis - 3 (the closed domain in knot coordinates is [0, p3])
 };
 static_assert(sizeof(TermD) == 64, "twelve of these sit in the 4 KiB kernel-argument block");
 
@@ -313,18 +313,28 @@ __device__ __forceinline__ void spline_poly(double c0, double c1, double c2, dou
   out[2 * kPolyStride] = (c0 - 2.0 * c1 + c2) * 0.5;
   out[3 * kPolyStride] = (c3 - c0) * (1.0 / 6.0) + (c1 - c2) * 0.5;
 }
-// knot coordinate of a term's sample in one fma: u = x / dx - lo / dx (p2, p3 of the term)
-__device__ __forceinline__ void spline_locate_term(double x, const TermD& td, int& k, double& t) {
-#ifdef GWI_LOCATE_FMA
-  const double u = fma(x, td.p2, td.p3);  // one instruction less per term, two scalar registers more: the config-5 kernel spills scalars with it
-#else
-  const double u = (x - td.p0) * td.p2;
-#endif
+// The columns of EXP_SPLINE / LINEAR_SPLINE terms hold the KNOT COORDINATE u = (x - lo) / dx of the sample, not x: the engine
+// converts them once when the catalog becomes resident (gwi_engine.hip: spline_knot_kernel), so the scan never spends the
+// subtract and multiply -- nor the scalar registers of lo and 1/dx -- per sample and term.
+//   * exponentiated splines without the zero-outside flag (the LogY bases of every mass / ratio / spin model): the
+//     conversion also clamps u into [0, n_int): interval and fraction are two instructions, (int)u and fract(u).  (x = hi
+//     lands one ulp below n_int: t = 1 - 2^-52 n_int instead of 1, taps within 1e-15 of the reference's (1/6, 2/3, 1/6).)
+//   * zero-outside and linear splines keep the unclamped coordinate (samples outside the domain are alive there): clamp here.
+__device__ __forceinline__ void spline_locate_knot(double u, int& k, double& t) {
+  k = (int)u;
+  t = __builtin_amdgcn_fract(u);
+}
+__device__ __forceinline__ void spline_locate_term(double u, const TermD& td, int& k, double& t) {
   const int last = td.n_basis - 4;
-  int kk = (int)u;
+  int kk = (int)u;  // truncation == floor wherever the clamp below does not decide anyway (u < 0 -> 0; overflow saturates)
   kk = max(0, min(kk, last));
   k = kk;
   t = u - (double)kk;
+}
+__device__ __forceinline__ bool spline_outside(double u, const TermD& td) { return !((u >= 0.0) && (u <= td.p3)); }
+// the same from a spline coordinate x (grid nodes of the LERP term, computed in the kernel)
+__device__ __forceinline__ void spline_locate_x(double x, const TermD& td, int& k, double& t) {
+  spline_locate_term((x - td.p0) * td.p2, td, k, t);
 }
 __device__ __forceinline__ void spline_locate(double x, double lo, double inv_dx, int n_basis, int& k, double& t) {
   const double u = (x - lo) * inv_dx;
@@ -726,29 +736,25 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   };
   struct Acc {};
   __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double&) {
-    const double x = in.x0;
+    const double u = in.x0;  // knot coordinate (see spline_locate_knot)
     int k;
-    double tt;
-    spline_locate_term(x, t, k, tt);
-    double v = spline_value(c, t.th0 + k, tt);
+    double tt, v;
     // BSpline / LogXBSpline bases are 0 outside the closed domain (interpolation.py:175); LogY bases exclude the sample
-    // (kappa = -inf, decided when the catalog was bound).  The flag is wave-uniform and the block behind it is kept a real
-    // scalar branch (the empty asm cannot be speculated, so the compiler does not turn it into selects): terms without the
-    // flag -- six of config 5's seven, all five of config 3's -- skip two compares and three selects per sample
-#ifdef GWI_OUTSIDE_SELECT
-    const bool chk = (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) != 0;
-    const double lo_eff = chk ? t.p0 : GWI_NEG_INF, hi_eff = chk ? t.p1 : GWI_POS_INF;
-    const bool outside = !((x >= lo_eff) && (x <= hi_eff));
-    k = outside ? -1 : k;
-    v = outside ? 0.0 : v;
-#else
+    // (kappa = -inf, decided when the catalog was bound) and their coordinate was clamped into the domain.  The flag is
+    // wave-uniform and the two forms sit behind a real scalar branch (the empty asm cannot be speculated, so the compiler does
+    // not turn it into selects): terms without the flag -- six of config 5's seven, all five of config 3's -- pay neither
+    // the clamps nor the two compares and three selects of the domain check
     if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) {
       asm volatile("");
-      const bool outside = !((x >= t.p0) && (x <= t.p1));
+      spline_locate_term(u, t, k, tt);
+      v = spline_value(c, t.th0 + k, tt);
+      const bool outside = spline_outside(u, t);
       k = outside ? -1 : k;
       v = outside ? 0.0 : v;
+    } else {
+      spline_locate_knot(u, k, tt);
+      v = spline_value(c, t.th0 + k, tt);
     }
-#endif
     s.t = tt;
     s.k = k;
     return v;
@@ -777,12 +783,12 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
   };
   struct Acc {};
   __device__ static double eval(const TermD& t, const double*, const Ctx& c, const In& in, State& s, double& lin) {
-    const double x = in.x0;
+    const double u = in.x0;  // knot coordinate, unclamped (see spline_locate_knot)
     int k;
     double tt;
-    spline_locate_term(x, t, k, tt);
+    spline_locate_term(u, t, k, tt);
     double f = spline_value(c, t.th0 + k, tt);
-    if (!((x >= t.p0) && (x <= t.p1))) f = 0.0;  // bases are 0 outside the closed domain (:175)
+    if (spline_outside(u, t)) f = 0.0;  // bases are 0 outside the closed domain (:175)
     s.t = tt;
     s.k = k;
     s.inv_f = f > 0.0 ? fast_rcp(f) : 0.0;
@@ -1021,7 +1027,7 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   };
   struct Acc {};
   __device__ static double node(const TermD& t, const Ctx& c, double sx, double wt, int& k, double& tt, double& lin) {
-    spline_locate_term(sx, t, k, tt);
+    spline_locate_x(sx, t, k, tt);
     double v = spline_value(c, t.th0 + k, tt);
     if (!((sx >= t.p0) && (sx <= t.p1))) {
       k = -1;

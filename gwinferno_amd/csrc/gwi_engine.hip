@@ -1418,6 +1418,70 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     }
   }
 
+  // ---- spline terms read the KNOT coordinate of their column (gwi_device.h: spline_locate_knot): convert x -> u once, here.
+  // A column that several spline terms read with different knots, or that another kind of term (or kappa) reads too, is
+  // copied for each distinct use; otherwise it is converted in place.
+  std::vector<const double*> over_pe(spec->n_terms, nullptr), over_inj(spec->n_terms, nullptr);
+  {
+    struct Use {
+      double lo, inv_dx, top;
+      const double *pe, *inj;
+    };
+    std::vector<std::vector<Use>> uses(spec->n_cols);
+    std::vector<char> plain(spec->n_cols, 0);  // read as it is by some term or as kappa
+    auto is_knot_term = [](const gwi_term& tm) { return tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE; };
+    plain[spec->kappa_col] = 1;
+    for (int t = 0; t < spec->n_terms; ++t) {
+      const gwi_term& tm = spec->terms[t];
+      for (int j = 0; j < 2; ++j) {
+        const int c = tm.cols[j];
+        if (c < 0 || c >= spec->n_cols) continue;
+        if (!(is_knot_term(tm) && j == 0)) plain[c] = 1;
+      }
+    }
+    for (int t = 0; t < spec->n_terms; ++t) {
+      const gwi_term& tm = spec->terms[t];
+      if (!is_knot_term(tm)) continue;
+      const int c = tm.cols[0];
+      const int n_int = tm.n_basis - 3;
+      const double inv_dx = (double)n_int / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
+      const bool clamp = tm.kind == GWI_TERM_EXP_SPLINE && !(tm.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT);
+      const double top = clamp ? std::nextafter((double)n_int, 0.0) : -1.0;
+      const Use* hit = nullptr;
+      for (const Use& u : uses[c])
+        if (u.lo == tm.p[0] && u.inv_dx == inv_dx && u.top == top) hit = &u;
+      if (!hit) {
+        Use u{tm.p[0], inv_dx, top, nullptr, nullptr};
+        // in place when every knot term of this column wants the same conversion and nobody reads the column as it is;
+        // else every distinct use gets a copy and the column itself stays what the caller handed over
+        bool all_agree = !plain[c];
+        for (int t2 = 0; t2 < spec->n_terms && all_agree; ++t2) {
+          const gwi_term& o = spec->terms[t2];
+          if (!is_knot_term(o) || o.cols[0] != c) continue;
+          const bool oclamp = o.kind == GWI_TERM_EXP_SPLINE && !(o.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT);
+          const double otop = oclamp ? std::nextafter((double)(o.n_basis - 3), 0.0) : -1.0;
+          all_agree = o.p[0] == u.lo && (double)(o.n_basis - 3) / (o.p[1] - o.p[0]) == u.inv_dx && otop == u.top;
+        }
+        double *dpe = h->d_cols_pe[c], *dinj = h->d_cols_inj[c];
+        if (!all_agree) {  // a private copy for this use
+          GWI_HIP(hipMalloc(&dpe, sizeof(double) * (size_t)(n_ev * n_pe ? n_ev * n_pe : 1)));
+          h->d_cols_pe.push_back(dpe);
+          GWI_HIP(hipMalloc(&dinj, sizeof(double) * (size_t)(n_inj ? n_inj : 1)));
+          h->d_cols_inj.push_back(dinj);
+        }
+        GWI_HIP(spline_knot_run(tab_pe[c], dpe, n_ev * n_pe, u.lo, u.inv_dx, u.top, h->stream));
+        GWI_HIP(spline_knot_run(tab_inj[c], dinj, n_inj, u.lo, u.inv_dx, u.top, h->stream));
+        u.pe = dpe;
+        u.inj = dinj;
+        uses[c].push_back(u);
+        hit = &uses[c].back();
+      }
+      over_pe[t] = hit->pe;
+      over_inj[t] = hit->inj;
+    }
+    GWI_HIP(hipStreamSynchronize(h->stream));
+  }
+
   // ---- normaliser grids
   std::vector<NormD> nd(spec->n_norms ? spec->n_norms : 1);
   for (int j = 0; j < spec->n_norms; ++j) {
@@ -1685,8 +1749,8 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   for (int t = 0; t < spec->n_terms; ++t)
     for (int j = 0; j < 2; ++j) {
       const int c = spec->terms[t].cols[j] >= 0 && spec->terms[t].cols[j] < spec->n_cols ? spec->terms[t].cols[j] : spec->terms[t].cols[0];
-      k.pe_tcols[t][j] = tab_pe[c];
-      k.inj_tcols[t][j] = tab_inj[c];
+      k.pe_tcols[t][j] = (j == 0 && over_pe[t]) ? over_pe[t] : tab_pe[c];
+      k.inj_tcols[t][j] = (j == 0 && over_inj[t]) ? over_inj[t] : tab_inj[c];
     }
   k.kappa_pe = tab_pe[spec->kappa_col];
   k.kappa_inj = tab_inj[spec->kappa_col];
@@ -1738,7 +1802,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE || tm.kind == GWI_TERM_EXP_SPLINE_LERP) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)
-      d.p3 = -tm.p[0] * d.p2;
+      d.p3 = (double)(tm.n_basis - 3);                          // the closed domain in knot coordinates: [0, p3]
     }
   }
   h->combine_threads = spec->n_theta + 4 <= 64 ? 64 : kBlock;

@@ -121,6 +121,33 @@ __global__ __launch_bounds__(256) void ingest_kernel(const IngestArgs a) {
   }
 }
 
+// Spline coordinate x -> knot coordinate u = (x - lo) / dx, once per catalog (gwi_device.h: spline_locate_knot): the scan
+// kernels read u.  `top` >= 0: clamp into [0, top] (exponentiated splines without the zero-outside flag: every live sample lies
+// in the closed domain already, x = hi lands one ulp below the number of intervals; NaN cannot occur -- non-finite column
+// entries were parked when the catalog was bound -- and would become 0).  Same arithmetic as the scan used to do per sample.
+struct KnotArgs {
+  const double* x;
+  double* u;
+  long long n, stride;
+  double lo, inv_dx, top;
+};
+__global__ __launch_bounds__(256) void spline_knot_kernel(const KnotArgs a) {
+#pragma clang fp contract(off)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += a.stride) {
+    double u = (a.x[i] - a.lo) * a.inv_dx;
+    if (a.top >= 0.0) u = fmin(fmax(u, 0.0), a.top);
+    a.u[i] = u;
+  }
+}
+inline hipError_t spline_knot_run(const double* x, double* u, long long n, double lo, double inv_dx, double top, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256LL * 16) blocks = 256LL * 16;
+  const KnotArgs a{x, u, n, blocks * 256, lo, inv_dx, top};
+  hipLaunchKernelGGL(spline_knot_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 // Host side: validate, upload sources / tables / ops, run, release.  `d_out[c]` are device arrays of n doubles the
 // caller owns.  Returns GWI_OK or a status with `err` filled in.
 inline gwi_status ingest_check(std::string& err, const gwi_ingest_program* p, int n_cols) {

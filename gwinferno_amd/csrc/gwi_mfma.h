@@ -99,9 +99,9 @@ constexpr int kSplineStage = 7;
 __device__ __forceinline__ void stage_spline(const TermD& t, double x, bool zero_outside, double* row) {
   int k;
   double tt;
-  spline_locate_term(x, t, k, tt);
+  spline_locate_term(x, t, k, tt);  // x: the knot coordinate the engine keeps for spline terms (gwi_device.h: spline_locate_knot)
   Taps b = cubic_taps(tt);
-  if (zero_outside && !((x >= t.p0) && (x <= t.p1))) b.b0 = b.b1 = b.b2 = b.b3 = 0.0;  // bases are 0 out there (interpolation.py:175)
+  if (zero_outside && spline_outside(x, t)) b.b0 = b.b1 = b.b2 = b.b3 = 0.0;  // bases are 0 out there (interpolation.py:175)
   row[0] = __hiloint2double(0, k);
   row[1] = 0.0;
   row[2] = b.b0;

@@ -51,6 +51,32 @@ class BoundModel:
     def inj_cols(self):
         return self._host_columns(INJ)
 
+    def resident_columns(self, side):
+        """What an engine keeps in HBM for this side (``gwi_read_column``): the columns, except that a column read only by
+        exponentiated / linear spline terms that agree on their knots holds the KNOT coordinate ``u = (x - lo) / dx`` -- clamped
+        into ``[0, n_intervals)`` for bases without the zero-outside flag -- which the engine computes once at creation
+        (gwi_engine.hip: spline_knot_kernel; the scan kernels then take interval and fraction from ``(int)u`` and ``fract(u)``)."""
+        cols = list(self._host_columns(side))
+        knot = (N.TERM_EXP_SPLINE, N.TERM_LINEAR_SPLINE)
+        plain = {self.kappa_col}
+        for t in self.terms:
+            for j, c in enumerate(t["cols"]):
+                if not (t["kind"] in knot and j == 0):
+                    plain.add(c)
+        uses = {}
+        for t in self.terms:
+            if t["kind"] in knot:
+                lo, hi = t["p"][0], t["p"][1]
+                n_int = t["n_basis"] - 3
+                clamp = t["kind"] == N.TERM_EXP_SPLINE and not (t["flags"] & N.SPLINE_OUTSIDE_ZERO_EXPONENT)
+                uses.setdefault(t["cols"][0], set()).add((lo, n_int / (hi - lo), float(np.nextafter(float(n_int), 0.0)) if clamp else -1.0))
+        for c, us in uses.items():
+            if len(us) == 1 and c not in plain:
+                lo, inv_dx, top = next(iter(us))
+                u = (cols[c] - lo) * inv_dx
+                cols[c] = np.minimum(np.maximum(u, 0.0), top) if top >= 0 else u
+        return cols
+
     def program(self, side, events=None, samples=None):
         """The compiled setup program of one side (``gwi_ingest_program``): ``events`` = (e0, e1) restricts the PE
         sources to a block of events, ``samples`` = (j0, j1) the injection sources to a slice (sharded engines)."""
