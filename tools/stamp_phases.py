@@ -75,3 +75,8 @@ for c_, bs in some:
 load = np.zeros(simd_key.max() + 1)
 np.add.at(load, simd_key, dur)
 print(f"  sum of evaluate time per SIMD: median {np.median(load[load > 0]):.2f}, max {load.max():.2f} us")
+# ---- evaluate time along the block index (PE tiles come first, event by event; the injection tiles are the last blocks).  Blocks
+# b, b + 256, b + 512, ... share a CU and a SIMD's arbiter prefers its oldest wave: the phase grows from one 256-block group to the next
+nb = int(blk.max()) + 1
+edges = np.linspace(0, nb, 11).astype(int)
+print("  evaluate median by block-index decile: " + " ".join(f"{np.median(dur[(blk >= a) & (blk < b)]):.1f}" for a, b in zip(edges[:-1], edges[1:])))
