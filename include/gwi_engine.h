@@ -261,7 +261,11 @@ gwi_status gwi_create_ingest(const gwi_spec* spec, const gwi_ingest_program* pe,
  * the host (cols[c] has n entries).  What the parity test of the setup path compares with the host evaluation. */
 gwi_status gwi_ingest_columns(const gwi_ingest_program* prog, int64_t n, int32_t n_cols, double* const* cols, int32_t device);
 
-/* Copy column `col` of an engine's resident catalog back to the host (`pe_side` != 0: n_ev * n_pe entries, else n_inj). */
+/* Copy column `col` of an engine's resident catalog back to the host (`pe_side` != 0: n_ev * n_pe entries, else n_inj).
+ * Resident means what the kernels read: a column that only GWI_TERM_EXP_SPLINE / GWI_TERM_LINEAR_SPLINE terms with one set of
+ * knots read holds the KNOT coordinate (x - p[0]) * (n_basis - 3) / (p[1] - p[0]) of the spline coordinate x the caller handed
+ * over (clamped into [0, n_basis - 3) for exponentiated splines without GWI_SPLINE_OUTSIDE_ZERO_EXPONENT), computed once at
+ * gwi_create / gwi_create_ingest; every other column is returned as it was handed over or ingested. */
 gwi_status gwi_read_column(gwi_handle h, int32_t pe_side, int32_t col, double* out);
 
 /* One value-and-gradient evaluation == one execution of the user's NumPyro model body ending in
