@@ -22,12 +22,22 @@ PE, INJ = "pe", "inj"
 def side_of(arr):
     """The reference tells PE from injection data by array rank (parametric.py:130-131,
     spline_perturbation.py:351-352): 2-D -> PE samples, 1-D -> injections."""
-    nd = arr.ndim if isinstance(arr, E.Sym) else np.ndim(arr)
+    nd = getattr(arr, "ndim", None)  # ndarray and Sym answer directly; np.ndim() is for lists
+    if nd is None:
+        nd = np.ndim(arr)
     if nd == 2:
         return PE
     if nd == 1:
         return INJ
     raise ValueError(f"expected a (N_ev, N_pe) or (N_inj,) array, got rank {nd}")
+
+
+def _is_number(x):
+    """A plain multiplier (Python or NumPy scalar, 0-d array) as opposed to per-sample data (array or setup expression)."""
+    nd = getattr(x, "ndim", None)  # ndarray, NumPy scalars and Sym answer directly; np.ndim() is for lists
+    if nd is None:
+        nd = np.ndim(x)
+    return nd == 0 and not isinstance(x, E.Sym)
 
 
 class Column:
@@ -178,12 +188,13 @@ class Factor:
 
     def __init__(self, kind, side, columns, scalars=(), coefs=None, consts=(), n_basis=0, flags=0, mask=None, static_log=None, norm=None,
                  owner=None, norm_owner=None, tag=""):
+        # (a model function builds its factors on every evaluation: no per-element conversions here)
         self.kind = kind
         self.side = side
-        self.columns = list(columns)          # list[Column], order = cols[] of gwi_term
-        self.scalars = list(scalars)          # hyper-parameter values, order = theta[] of gwi_term
+        self.columns = columns if type(columns) is list else list(columns)  # list[Column], order = cols[] of gwi_term
+        self.scalars = scalars if type(scalars) is list else list(scalars)  # hyper-parameter values, order = theta[] of gwi_term
         self.coefs = coefs                    # spline coefficient vector or None
-        self.consts = tuple(float(c) for c in consts)  # p[] of gwi_term
+        self.consts = tuple(map(float, consts)) if consts else ()  # p[] of gwi_term
         self.n_basis = int(n_basis)
         self.flags = int(flags)
         # Setup expressions (gwinferno_amd.expr) over the caller's arrays, or zero-argument callables returning them:
@@ -247,7 +258,7 @@ class Density:
     def __mul__(self, other):
         if isinstance(other, Density):
             return Density(self.factors + other.factors, self._merge_side(other.side), self.log_static + other.log_static, self.log_const + other.log_const)
-        if not isinstance(other, E.Sym) and np.ndim(other) == 0:
+        if _is_number(other):
             with np.errstate(all="ignore"):
                 return Density(self.factors, self.side, self.log_static, self.log_const + np.log(float(other)))
         return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(1.0, other)], self.log_const)
@@ -257,7 +268,7 @@ class Density:
     def __truediv__(self, other):
         if isinstance(other, Density):
             raise TypeError("division by a lazy density is not supported")
-        if not isinstance(other, E.Sym) and np.ndim(other) == 0:
+        if _is_number(other):
             return Density(self.factors, self.side, self.log_static, self.log_const - np.log(float(other)))
         return Density(self.factors, self._merge_side(side_of(other)), self.log_static + [(-1.0, other)], self.log_const)
 
