@@ -1644,6 +1644,22 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     h->chunk_inj = (int)target;
     spb_batch = 0;
   }
+  // The combine launch requests the records of up to 16 tiles of an event in its first memory round trip (kEarly in
+  // combine_group) and needs another dependent round per 16 more: a catalog of few events with many posterior samples each --
+  // one rank's share of config 5 on 8 GPUs: 25 events x 10 000 -- got 40 tiles of 256 per event and a 9.5 us combine behind a
+  // 10.7 us scan.  At most 16 tiles per event where that still leaves every CU a workgroup: 768-sample tiles there, scan
+  // 11.7 us, combine 4.1 us, 27.4 -> 21.3 us per local evaluation (tools/shard_time.py).
+  if (!std::getenv("GWI_SAMPLES_PER_BLOCK") && !(std::getenv("GWI_TILE_CAP") && std::atoi(std::getenv("GWI_TILE_CAP")) == 0)) {
+    const long long cap_chunk = (((n_pe + 15) / 16 + gran - 1) / gran) * gran;
+    if (h->chunk_pe < cap_chunk) {
+      const long long inj_chunk = h->chunk_inj < cap_chunk ? cap_chunk : h->chunk_inj;
+      const long long blocks = n_ev * ((n_pe + cap_chunk - 1) / cap_chunk) + (n_inj + inj_chunk - 1) / inj_chunk;
+      if (blocks >= (long long)prop.multiProcessorCount) {
+        h->chunk_pe = (int)cap_chunk;
+        h->chunk_inj = (int)inj_chunk;
+      }
+    }
+  }
   // experiment knobs: exact tile sizes (the kernel takes any size; a trip covers samples_per_lane * 256 samples)
   if (const char* env = std::getenv("GWI_PE_CHUNK")) h->chunk_pe = std::max(1, std::atoi(env));
   if (const char* env = std::getenv("GWI_INJ_CHUNK")) h->chunk_inj = std::max(1, std::atoi(env));
