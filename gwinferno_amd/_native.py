@@ -236,6 +236,7 @@ EXPORTED_SYMBOLS = [
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
+    "gwi_launch_geometry",
     "gwi_dispatch_info",
     "gwi_pin_thread_to_engine",
     "gwi_pin_thread_to_device",
@@ -331,6 +332,9 @@ def load_library():
     lib.gwi_selftime.argtypes = [vp, _DP, C.POINTER(GwiOptions), C.c_int32, _DP]
     lib.gwi_last_kernel_ms.restype = C.c_int32
     lib.gwi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if hasattr(lib, "gwi_launch_geometry"):
+        lib.gwi_launch_geometry.restype = C.c_int32
+        lib.gwi_launch_geometry.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.gwi_set_timing.restype = C.c_int32
     lib.gwi_set_timing.argtypes = [vp, C.c_int32]
     lib.gwi_pin_thread_to_engine.restype = C.c_int32

@@ -1984,6 +1984,17 @@ const char* gwi_dispatch_info(gwi_handle h) {
   return h->aql_active ? (h->aq.failed() ? h->aq.why().c_str() : "aql: active") : h->aql_note.c_str();
 }
 
+gwi_status gwi_launch_geometry(gwi_handle h, int32_t out[6]) {
+  if (!h || !out || h->host_only) return GWI_ERR_INVALID;
+  out[0] = h->chunk_pe;
+  out[1] = h->chunk_inj;
+  out[2] = h->tiles_per_event;
+  out[3] = h->n_inj_tiles;
+  out[4] = h->n_scan_blocks;
+  out[5] = h->n_inj_groups;
+  return GWI_OK;
+}
+
 gwi_status gwi_set_timing(gwi_handle h, int32_t enabled) {
   if (!h) return GWI_ERR_INVALID;
   h->timing = enabled != 0;

@@ -679,6 +679,12 @@ class NativePopulationLikelihood:
         self._check(self.lib.gwi_combine(self.handle, N.as_dp(records), records.shape[0], C.byref(opt), C.byref(summ), N.as_dp(grad), N.as_dp(norms)))
         return EvalResult(log_likelihood=summ.log_likelihood, grad=grad, summary=summ, log_bfs=None, log_neffs=None, variances=None, norms=norms[: len(self.bound.norms)])
 
+    def launch_geometry(self):
+        """``gwi_launch_geometry``: dict of the tile sizes and workgroup counts ``gwi_create`` chose."""
+        out = (C.c_int32 * 6)()
+        self._check(self.lib.gwi_launch_geometry(self.handle, out))
+        return dict(zip(("chunk_pe", "chunk_inj", "tiles_per_event", "n_inj_tiles", "n_scan_blocks", "n_inj_groups"), [int(v) for v in out]))
+
     def read_column(self, side, col):
         """Column ``col`` of the engine's resident catalog (``gwi_read_column``): ``(n_ev, n_pe)`` for ``side == "pe"``, else
         ``(n_inj,)`` -- what the setup path (host or device) left in HBM."""

@@ -345,6 +345,10 @@ gwi_status gwi_shm_comm_unlink(const char* name);
 /* publish `record` (gwi_partial_len() doubles) as this rank's, wait for every rank's, copy them to gathered[world][len] */
 gwi_status gwi_shm_exchange(gwi_handle h, const double* record, double* gathered);
 
+/* Diagnostic: the launch geometry gwi_create chose -- out = {PE tile size, injection tile size, tiles per event, injection
+ * tiles, scan workgroups per hyper-parameter point, injection groups of the combine launch} (samples / counts). */
+gwi_status gwi_launch_geometry(gwi_handle h, int32_t out[6]);
+
 /* Timing of the most recent gwi_eval*: milliseconds between the start/stop HIP events attached to each
  * launch on the engine's stream ([0]=scan kernel, [1]=per-event combine, [2]=final reduce; 0 when the
  * host does the final sum). */

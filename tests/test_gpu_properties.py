@@ -244,3 +244,28 @@ def test_batched_launch_at_full_size_equals_single_evaluations(env, monkeypatch)
             scale = max(1.0, float(np.max(np.abs(single[k].grad))))
             assert float(np.max(np.abs(batch[k].grad - single[k].grad))) / scale < 1e-12
     eng.close()
+
+
+def test_few_events_with_many_samples_get_at_most_16_tiles_per_event(monkeypatch):
+    """One rank's share of config 5 on 8 GPUs (25 events x 10 000 PE samples + 62 500 injections): the combine launch fetches 16
+    tile records per memory round trip, so the launch geometry gives an event at most 16 tiles where that leaves every CU a
+    workgroup -- and the likelihood does not depend on the tiling (same values with the rule switched off: 40 tiles of 256)."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_config_catalog
+
+    pe, inj, total = make_config_catalog("c5")
+    comp = COMPOSITIONS["bspline_full"](pe, inj)
+    eng = comp.engine(rank=0, world=8)
+    geo = eng.launch_geometry()
+    assert eng.n_ev == 25 and geo["tiles_per_event"] <= 16 and geo["n_scan_blocks"] >= 256, geo
+    monkeypatch.setenv("GWI_TILE_CAP", "0")
+    ref = COMPOSITIONS["bspline_full"](pe, inj).engine(rank=0, world=8)
+    assert ref.launch_geometry()["tiles_per_event"] > 16
+    rng = np.random.default_rng(8)
+    for _ in range(2):
+        th = eng.bound.theta_of(comp.weights(draw_params("bspline_full", rng), True))
+        a, b = eng.evaluate(th, total, min_neff_cut=False), ref.evaluate(th, total, min_neff_cut=False)
+        assert abs(a.log_likelihood - b.log_likelihood) <= 1e-12 * abs(b.log_likelihood)
+        assert np.allclose(a.log_bfs, b.log_bfs, rtol=0, atol=1e-11) and np.allclose(a.grad, b.grad, rtol=1e-10, atol=1e-10 * np.max(np.abs(b.grad)))
+    eng.close()
+    ref.close()
