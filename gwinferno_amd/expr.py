@@ -179,18 +179,19 @@ def _numpy_node(n, v):
         return np.asarray(n.k, dtype=np.float64)
     if op == "const":
         return n.k
-    if op == "log":
-        return np.log(v[0])
-    if op == "log1p":
-        return np.log1p(v[0])
-    if op == "neg":
-        return -np.asarray(v[0], dtype=np.float64)
-    if op == "abs":
-        return np.abs(v[0])
-    if op == "sqrt":
-        return np.sqrt(v[0])
-    if op == "isfinite":
-        return np.isfinite(v[0])
+    if op in ("log", "log1p", "neg", "abs", "sqrt", "isfinite"):
+        x = np.asarray(v[0], dtype=np.float64)  # booleans count as 0.0 / 1.0, as in the device registers (NumPy would take their logarithm in float16)
+        if op == "log":
+            return np.log(x)
+        if op == "log1p":
+            return np.log1p(x)
+        if op == "neg":
+            return -x
+        if op == "abs":
+            return np.abs(x)
+        if op == "sqrt":
+            return np.sqrt(x)
+        return np.isfinite(x)
     if op == "not":
         return ~_as_bool(v[0])
     if op in ("and", "or"):
@@ -205,7 +206,7 @@ def _numpy_node(n, v):
     if op == "where":
         return np.where(_as_bool(v[0]), np.asarray(v[1], dtype=np.float64), np.asarray(v[2], dtype=np.float64))
     if op == "interp":
-        return np.interp(v[0], n.k[0], n.k[1])
+        return np.interp(np.asarray(v[0], dtype=np.float64), n.k[0], n.k[1])
     if op == "gridindex":
         # fractional index j + f of x in the grid, exactly the piece and weight np.interp uses (end values held outside
         # the grid); NaN stays NaN (excluded at bind)

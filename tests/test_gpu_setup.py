@@ -189,3 +189,41 @@ def test_float32_catalog_and_sharded_engines_are_set_up_on_the_device():
         shard.close()
     full_dev.close()
     full_host.close()
+
+
+def test_random_expression_graphs_on_the_device():
+    """Random expression DAGs without logarithms (arithmetic, comparisons, logic, selection, sqrt, both table operations, a
+    float32 source, special values in the data): the ingest kernel against the NumPy evaluation, bit for bit."""
+    from gwinferno_amd import expr as E
+    from gwinferno_amd.engine import ingest_columns
+
+    rng = np.random.default_rng(21)
+    n = 3001
+    data = [rng.uniform(-2.0, 5.0, n), rng.lognormal(size=n), rng.uniform(0.0, 1.0, n).astype(np.float32)]
+    data[0][:6] = [np.nan, np.inf, -np.inf, 0.0, -0.0, 5.0]
+    data[1][:3] = [0.0, np.inf, 1e-310]
+    grid = np.linspace(-1.0, 4.0, 23)
+    vals = np.cos(grid)
+    unary = ["neg", "abs", "sqrt", "isfinite", "not"]
+    binary = ["add", "sub", "mul", "div", "lt", "gt", "le", "ge", "and", "or"]
+    for trial in range(60):
+        pool = [E.Sym.src(d) for d in data] + [E.Sym.const(rng.choice([0.0, 1.0, -1.5, 3.0, np.inf]))]
+        pick = lambda: pool[rng.integers(len(pool))]  # noqa: E731
+        for _ in range(rng.integers(3, 30)):
+            kind = rng.choice(["u", "b", "b", "w", "i", "g"])
+            if kind == "u":
+                pool.append(E.Sym(str(rng.choice(unary)), (pick(),)))
+            elif kind == "b":
+                pool.append(E.Sym(str(rng.choice(binary)), (pick(), pick())))
+            elif kind == "w":
+                pool.append(E.where(pick(), pick(), pick()))
+            elif kind == "i":
+                pool.append(E.interp(pick(), grid, vals))
+            else:
+                pool.append(E.gridindex(pick(), grid))
+        outs = [e for e in pool[-4:] if e.shape != ()] or [pool[0]]
+        host = [np.broadcast_to(np.asarray(h, dtype=np.float64), (n,)) for h in E.evaluate(outs)]
+        dev = ingest_columns(outs)
+        for j, (h, d) in enumerate(zip(host, dev)):
+            bad = np.flatnonzero(~((h == d) | (np.isnan(h) & np.isnan(d))))
+            assert bad.size == 0, (trial, j, outs[j].key[:3], bad[:5], h[bad[:5]], d[bad[:5]])
