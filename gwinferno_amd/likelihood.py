@@ -127,6 +127,36 @@ def _evaluate_numpy(eng, theta, total_inj, Nobs, flags, want_grad=True):
     return {"summary": {k: getattr(r.summary, k) for k in _SUMMARY_FIELDS}, "log_bfs": r.log_bfs, "log_neffs": r.log_neffs, "variances": r.variances, "grad": r.grad}
 
 
+def _host_callback(eng, total_inj, Nobs, flags):
+    """The host side of the JAX seam: ``theta -> (summary[n_sum], per_event[3, n_ev], grad[n_theta])`` as NumPy arrays.
+    ``theta`` may carry leading batch dimensions -- what ``jax.vmap`` of the model (NumPyro's ``chain_method="vectorized"``,
+    ``vmap`` over initial points) hands a ``pure_callback`` declared with ``vmap_method="broadcast_all"``: the points then go
+    through ``gwi_eval_batch`` (one set of launches per <= 16 points: the batched kernels) and every output gets the same
+    leading dimensions."""
+    n_ev, n_theta = eng.n_ev, eng.n_theta
+    kw = dict(nobs=Nobs, marginalize_selection=flags["marginalize_selection"], min_neff_cut=flags["min_neff_cut"], max_variance_cut=flags["max_variance_cut"])
+
+    def pack(r):
+        summ = np.array([getattr(r.summary, k) for k in _SUMMARY_FIELDS])
+        per_event = np.stack([r.log_bfs, r.log_neffs, r.variances])
+        return summ, per_event, (r.grad if r.grad is not None else np.zeros(n_theta))
+
+    def host(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 1:
+            return pack(eng.evaluate(theta, total_inj, want_grad=True, **kw))
+        lead = theta.shape[:-1]
+        flat = theta.reshape(-1, n_theta)
+        step = max(1, int(os.environ.get("GWI_MAX_BATCH", "16")))
+        rows = []
+        for i in range(0, flat.shape[0], step):
+            rows += [pack(r) for r in eng.evaluate_batch(flat[i : i + step], total_inj, want_grad=True, **kw)]
+        return (np.stack([r[0] for r in rows]).reshape(lead + (len(_SUMMARY_FIELDS),)), np.stack([r[1] for r in rows]).reshape(lead + (3, n_ev)),
+                np.stack([r[2] for r in rows]).reshape(lead + (n_theta,)))
+
+    return host
+
+
 def _evaluate_jax(eng, params, total_inj, Nobs, flags):
     """``jax.custom_vjp`` over ``jax.pure_callback``: value and every site from one engine call, the
     gradient handed to JAX's reverse mode.  (Exercised only where jax is installed.)"""
@@ -139,21 +169,21 @@ def _evaluate_jax(eng, params, total_inj, Nobs, flags):
         jax.ShapeDtypeStruct((3, n_ev), jnp.float64),
         jax.ShapeDtypeStruct((n_theta,), jnp.float64),
     )
+    host = _host_callback(eng, total_inj, Nobs, flags)
 
-    def host(theta):
-        r = _evaluate_numpy(eng, np.asarray(theta, dtype=np.float64), total_inj, Nobs, flags)
-        summ = np.array([r["summary"][k] for k in _SUMMARY_FIELDS])
-        per_event = np.stack([r["log_bfs"], r["log_neffs"], r["variances"]])
-        grad = r["grad"] if r["grad"] is not None else np.zeros(n_theta)
-        return summ, per_event, grad
+    def callback(theta):
+        try:  # batched under vmap (vectorised chains): one call with the batch in front, see _host_callback
+            return jax.pure_callback(host, shapes, theta, vmap_method="broadcast_all")
+        except TypeError:  # a JAX that predates vmap_method
+            return jax.pure_callback(host, shapes, theta)
 
     @jax.custom_vjp
     def f(theta):
-        summ, per_event, _ = jax.pure_callback(host, shapes, theta)
+        summ, per_event, _ = callback(theta)
         return summ, per_event
 
     def f_fwd(theta):
-        summ, per_event, grad = jax.pure_callback(host, shapes, theta)
+        summ, per_event, grad = callback(theta)
         return (summ, per_event), grad
 
     def f_bwd(grad, cts):

@@ -26,8 +26,9 @@ def _check(result, spec, where):
 CALLBACK_CALLS = []
 
 
-def pure_callback(host, result_shape_dtypes, *args):
-    """Calls ``host`` with concrete NumPy arrays and verifies the result against the declared structure."""
+def pure_callback(host, result_shape_dtypes, *args, vmap_method=None):
+    """Calls ``host`` with concrete NumPy arrays and verifies the result against the declared structure (``vmap_method`` is
+    what a batching rule would consult; nothing is batched here)."""
     out = host(*[_unwrap(a) for a in args])
     CALLBACK_CALLS.append(host)
     if isinstance(result_shape_dtypes, (tuple, list)):

@@ -35,6 +35,9 @@ class _OracleEngine:
         return EvalResult(log_likelihood=r["log_likelihood"], grad=r["grad"] if want_grad else None, summary=r["summary"], log_bfs=r["logBFs"], log_neffs=r["log_nEffs"],
                           variances=r["variance_log_BFs"], norms=r["norms"])
 
+    def evaluate_batch(self, thetas, total_inj, **kw):
+        return [self.evaluate(t, total_inj, **kw) for t in np.asarray(thetas)]
+
     def log_weights(self, theta):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from bound_eval import log_weights
@@ -200,3 +203,30 @@ def test_evicted_engines_stay_usable(monkeypatch):
     assert len(L._ENGINES) == 2 and not any(e.closed for e in held)
     L.clear_engine_cache()
     assert not any(e.closed for e in held)
+
+
+def test_host_callback_takes_batches_of_points():
+    """What a vmapped model (NumPyro's vectorised chains) hands the callback under ``vmap_method="broadcast_all"``: theta with
+    leading batch dimensions.  The host side answers with the same leading dimensions on every output, point for point what
+    single calls give."""
+    from gwinferno_amd import _native as N
+    from gwinferno_amd import likelihood as L
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import NativePopulationLikelihood
+
+    pe, inj, total = _model_pieces()
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    p = comp.placeholder()
+    eng = _OracleEngine(NativePopulationLikelihood(comp.weights(p, True), comp.weights(p, False), comp.hypervolume(p), device=N.DEVICE_HOST_ONLY))
+    flags = dict(marginalize_selection=False, min_neff_cut=False, max_variance_cut=False)
+    host = L._host_callback(eng, total, 6, flags)
+    rng = np.random.default_rng(4)
+    thetas = np.stack([eng.bound.theta_of(comp.weights(draw_params("plpeak", rng), True)) for _ in range(6)])
+    singles = [host(t) for t in thetas]
+    summ, per_event, grad = host(thetas)                      # one batch dimension
+    assert summ.shape == (6, len(L._SUMMARY_FIELDS)) and per_event.shape == (6, 3, 6) and grad.shape == (6, eng.n_theta)
+    for k in range(6):
+        assert all(np.array_equal(a, b) for a, b in zip(singles[k], (summ[k], per_event[k], grad[k])))
+    summ2, per_event2, grad2 = host(thetas.reshape(2, 3, -1))  # nested vmaps: two
+    assert summ2.shape == (2, 3, len(L._SUMMARY_FIELDS)) and np.array_equal(summ2.reshape(6, -1), summ) and np.array_equal(grad2.reshape(6, -1), grad)
+    assert per_event2.shape == (2, 3, 3, 6)
