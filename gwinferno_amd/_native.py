@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-GWI_ABI_VERSION = 1
+GWI_ABI_VERSION = 2
 GWI_MAX_TERMS = 12
 GWI_MAX_THETA = 256
 GWI_MAX_NORMS = 8

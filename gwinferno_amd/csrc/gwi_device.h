@@ -466,12 +466,9 @@ template <>
 struct Term<GWI_TERM_PLPEAK> {
   static constexpr bool kSpline = false;
   struct In {
-    double x0, x1;
+    double x1;  // log x: the one column of the term; x for the Gaussian component is exp(log x), formed in eval_shifted()
   };
-  __device__ static void load(const double* const* tc, SIdx idx, In& in) {
-    in.x0 = gload(tc[0], idx);
-    in.x1 = gload(tc[1], idx);
-  }
+  __device__ static void load(const double* const* tc, SIdx idx, In& in) { in.x1 = gload(tc[0], idx); }
   struct State {
     double da, dmu, dsg, dlam;
   };
@@ -484,8 +481,11 @@ struct Term<GWI_TERM_PLPEAK> {
   // SHIFT: the sample's closing factor folded in: both exponents take E, and the result is scaled by 2^-nshift (fast_exp_shift)
   template <bool SHIFT>
   __device__ static double eval_shifted(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin, double E, int nshift) {
-    const double x = in.x0;
+    // x = exp(log x): round 2 streamed x as a second column (config 2: 40 B per sample against 32 algorithmic, FETCH_SIZE
+    // 1.29 x the algorithmic bytes); the exponential costs the config-2 scan nothing measurable (7.88-8.05 vs 7.87-8.01 us
+    // over four interleaved rounds) and moves the peak's exponent by <= 1e-12
     const double lx = in.x1;
+    const double x = fast_exp(lx);
     const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
     const double dx = x - mu;
     const double dx2 = dx * dx;

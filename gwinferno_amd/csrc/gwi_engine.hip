@@ -457,7 +457,7 @@ gwi_status validate_spec(gwi_handle h, const gwi_spec* s) {
     int n_cols = 1, n_th = 1;
     switch (tm.kind) {
       case GWI_TERM_POWERLAW: break;
-      case GWI_TERM_PLPEAK: n_cols = 2; n_th = 4; break;
+      case GWI_TERM_PLPEAK: n_th = 4; break;  // one column: log x
       case GWI_TERM_POWERLAW_RATIO: n_cols = 2; break;
       case GWI_TERM_BETA: n_cols = 2; n_th = 2; break;
       case GWI_TERM_TILT_MIXTURE: n_th = 2; break;

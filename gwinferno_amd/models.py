@@ -130,9 +130,9 @@ def plpeak_primary_pdf(m1, alpha, mmin, mmax, mpp, sigpp, lam, delta=None):
     m1 = _f(m1)
     side = side_of(m1)
     mask = lambda: ~((Sym.src(m1) < mmin) | (Sym.src(m1) > mmax))  # noqa: E731 -- built when an engine is bound
+    if delta is None:  # one column, log m1: the kernel forms m1 = exp(log m1) for the peak (include/gwi_engine.h, GWI_TERM_PLPEAK)
+        return Density([Factor(N.TERM_PLPEAK, side, [Column("log", m1)], [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
     cols = [Column("id", m1), Column("log", m1)]
-    if delta is None:
-        return Density([Factor(N.TERM_PLPEAK, side, cols, [alpha, mpp, sigpp, lam], consts=(mmin, mmax), mask=mask)], side)
     return Density([Factor(N.TERM_PLPEAK_SMOOTH, side, cols, [alpha, mpp, sigpp, lam, delta], consts=(mmin, mmax), mask=mask)], side)
 
 

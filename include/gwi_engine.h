@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GWI_ABI_VERSION 1
+#define GWI_ABI_VERSION 2 /* 2: GWI_TERM_PLPEAK takes ONE column (log x) */
 #define GWI_MAX_TERMS 12
 #define GWI_MAX_THETA 256
 #define GWI_MAX_NORMS 8
@@ -59,7 +59,9 @@ enum {
    * cols[0]=log x; theta[0]=alpha; p[0]=lo, p[1]=hi */
   GWI_TERM_POWERLAW = 1,
   /* (1-lam) PL(x;alpha,lo,hi) + lam TN(x;mpp,sigpp,lo,hi)   parametric.py:49-53 (delta=None)
-   * cols[0]=x, cols[1]=log x; theta = alpha, mpp, sigpp, lam; p[0]=lo, p[1]=hi */
+   * cols[0]=log x (the kernels form x = exp(log x) for the Gaussian component themselves: one exponential per sample instead
+   * of a second 8-byte column -- config 2 then streams its algorithmic 32 B per sample, not 40); theta = alpha, mpp, sigpp, lam;
+   * p[0]=lo, p[1]=hi */
   GWI_TERM_PLPEAK = 2,
   /* q^beta on [mmin/m1, 1]: powerlaw_pdf(q, beta, mmin/m1, 1)   parametric.py:28,40; separable.py:364
    * cols[0]=log q, cols[1]=log m1; theta[0]=beta; p[0]=log(mmin) */

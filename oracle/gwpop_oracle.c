@@ -107,14 +107,15 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
   double ell = cols[sp->kappa_col][idx];
   for (int t = 0; t < sp->n_terms && ell > -INFINITY; ++t) {
     const gwi_term* tm = &sp->terms[t];
-    const double x0 = cols[tm->cols[0]][idx];
+    const double x0_raw = cols[tm->cols[0]][idx];
+    const double x0 = tm->kind == GWI_TERM_PLPEAK ? exp(x0_raw) : x0_raw;
     switch (tm->kind) {
       case GWI_TERM_POWERLAW:
         ell += th[tm->theta[0]] * x0;
         d[tm->theta[0]] += x0;
         break;
-      case GWI_TERM_PLPEAK: {
-        const double lx = cols[tm->cols[1]][idx];
+      case GWI_TERM_PLPEAK: { /* one column: log x (include/gwi_engine.h); x0 below is x = exp(log x) */
+        const double lx = x0_raw;
         const double al = th[tm->theta[0]], mu = th[tm->theta[1]], sg = th[tm->theta[2]], lam = th[tm->theta[3]];
         const double epl = exp(al * lx + der[t][0]), etn = exp(-0.5 * (x0 - mu) * (x0 - mu) / (sg * sg) + der[t][2]);
         const double P = (1.0 - lam) * epl, T = lam * etn, p = P + T;

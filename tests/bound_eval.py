@@ -84,8 +84,8 @@ def log_weights(bm, theta, include_consts=True):
                     ell = ell + th[0] * c[0] + k_const * _pl_lognorm(th[0], p[0], p[1])
                 elif k == N.TERM_PLPEAK:
                     alpha, mu, sg, lam = th
-                    pl = np.exp(alpha * c[1] + _pl_lognorm(alpha, p[0], p[1]))
-                    tn = np.exp(-0.5 * (c[0] - mu) ** 2 / sg**2 + _tn_lognorm(mu, sg, p[0], p[1]))
+                    pl = np.exp(alpha * c[0] + _pl_lognorm(alpha, p[0], p[1]))  # one column: log x
+                    tn = np.exp(-0.5 * (np.exp(c[0]) - mu) ** 2 / sg**2 + _tn_lognorm(mu, sg, p[0], p[1]))
                     ell = ell + np.log((1 - lam) * pl + lam * tn)
                 elif k == N.TERM_PLPEAK_SMOOTH:
                     alpha, mu, sg, lam, dl = th

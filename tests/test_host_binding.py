@@ -69,8 +69,9 @@ def test_theta_layout_and_shared_coefficients():
 def test_column_sharing_and_count():
     case = GoldenCase("plpeak")
     _, bm = _bound(case)
-    # m1, log m1 (shared by PL+Peak and the q power law), log q, log(1+z), kappa
-    assert len(bm.pe_cols) == 5
+    # log m1 (shared by PL+Peak and the q power law), log q, log(1+z), kappa: SURVEY.md 8(d): C = 4 for config 2 (the kernel
+    # forms m1 = exp(log m1) for the Gaussian peak itself)
+    assert len(bm.pe_cols) == 4
     case = GoldenCase("bspline_full")
     _, bm = _bound(case)
     assert len(bm.pe_cols) == 9  # C = 9 for config 5
