@@ -32,6 +32,7 @@ TERM_POWERLAW_BOUNDS = 13
 TERM_EXP_SPLINE_LERP = 14
 
 SPLINE_OUTSIDE_ZERO_EXPONENT = 1
+RATIO_LOGM_FROM_SPLINE = 8
 POWERLAW_UNNORMALISED = 2
 NORM_LINEAR_SPLINE = 4
 DEVICE_CURRENT = -1

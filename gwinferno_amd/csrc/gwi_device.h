@@ -543,7 +543,10 @@ struct Term<GWI_TERM_POWERLAW_RATIO> {
   };
   __device__ static double eval(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double& lin) {
     const double lq = in.x0;
-    const double lr = t.p0 - in.x1;  // log(mmin/m1) <= 0 for every non-excluded sample
+    // log m1: its own column, or the knot coordinate u of the model's m1 spline (log m1 = lo + u dx: one FMA instead of an
+    // 8-byte column per sample; include/gwi_engine.h GWI_RATIO_LOGM_FROM_SPLINE).  The flag is wave-uniform.
+    const double lm = (t.flags & GWI_RATIO_LOGM_FROM_SPLINE) ? fma(in.x1, t.p3, t.p1) : in.x1;
+    const double lr = t.p0 - lm;  // log(mmin/m1) <= 0 for every non-excluded sample
     const double beta = c.theta[t.th0];
     const double b1 = 1.0 + beta;
     if (b1 == 0.0) {  // alpha == -1 branch of the reference: 1/log(high/low)

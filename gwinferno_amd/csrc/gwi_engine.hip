@@ -1421,7 +1421,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   // ---- spline terms read the KNOT coordinate of their column (gwi_device.h: spline_locate_knot): convert x -> u once, here.
   // A column that several spline terms read with different knots, or that another kind of term (or kappa) reads too, is
   // copied for each distinct use; otherwise it is converted in place.
-  std::vector<const double*> over_pe(spec->n_terms, nullptr), over_inj(spec->n_terms, nullptr);
+  std::vector<const double*> over_pe(spec->n_terms, nullptr), over_inj(spec->n_terms, nullptr), over_pe1, over_inj1;
   {
     struct Use {
       double lo, inv_dx, top;
@@ -1431,12 +1431,15 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     std::vector<char> plain(spec->n_cols, 0);  // read as it is by some term or as kappa
     auto is_knot_term = [](const gwi_term& tm) { return tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE; };
     plain[spec->kappa_col] = 1;
+    // a mass-ratio power law that takes log m1 from the m1 spline's column (GWI_RATIO_LOGM_FROM_SPLINE) reads the knot
+    // coordinate too: it follows whatever conversion the spline term of the same knots asked for
+    auto follows_knots = [](const gwi_term& tm, int j) { return tm.kind == GWI_TERM_POWERLAW_RATIO && (tm.flags & GWI_RATIO_LOGM_FROM_SPLINE) && j == 1; };
     for (int t = 0; t < spec->n_terms; ++t) {
       const gwi_term& tm = spec->terms[t];
       for (int j = 0; j < 2; ++j) {
         const int c = tm.cols[j];
         if (c < 0 || c >= spec->n_cols) continue;
-        if (!(is_knot_term(tm) && j == 0)) plain[c] = 1;
+        if (!(is_knot_term(tm) && j == 0) && !follows_knots(tm, j)) plain[c] = 1;
       }
     }
     for (int t = 0; t < spec->n_terms; ++t) {
@@ -1478,6 +1481,20 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
       }
       over_pe[t] = hit->pe;
       over_inj[t] = hit->inj;
+    }
+    over_pe1.assign(spec->n_terms, nullptr);
+    over_inj1.assign(spec->n_terms, nullptr);
+    for (int t = 0; t < spec->n_terms; ++t) {
+      const gwi_term& tm = spec->terms[t];
+      if (!follows_knots(tm, 1)) continue;
+      const int c = tm.cols[1];
+      const Use* hit = nullptr;
+      if (c >= 0 && c < spec->n_cols)
+        for (const Use& u : uses[c])
+          if (u.lo == tm.p[1] && u.inv_dx == tm.p[2]) hit = &u;
+      if (!hit) return fail(h, GWI_ERR_INVALID, "GWI_RATIO_LOGM_FROM_SPLINE: cols[1] is not the coordinate column of a spline term with the knots given in p[1], p[2]");
+      over_pe1[t] = hit->pe;
+      over_inj1[t] = hit->inj;
     }
     GWI_HIP(hipStreamSynchronize(h->stream));
   }
@@ -1765,8 +1782,8 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   for (int t = 0; t < spec->n_terms; ++t)
     for (int j = 0; j < 2; ++j) {
       const int c = spec->terms[t].cols[j] >= 0 && spec->terms[t].cols[j] < spec->n_cols ? spec->terms[t].cols[j] : spec->terms[t].cols[0];
-      k.pe_tcols[t][j] = (j == 0 && over_pe[t]) ? over_pe[t] : tab_pe[c];
-      k.inj_tcols[t][j] = (j == 0 && over_inj[t]) ? over_inj[t] : tab_inj[c];
+      k.pe_tcols[t][j] = (j == 0 && over_pe[t]) ? over_pe[t] : (j == 1 && over_pe1[t]) ? over_pe1[t] : tab_pe[c];
+      k.inj_tcols[t][j] = (j == 0 && over_inj[t]) ? over_inj[t] : (j == 1 && over_inj1[t]) ? over_inj1[t] : tab_inj[c];
     }
   k.kappa_pe = tab_pe[spec->kappa_col];
   k.kappa_inj = tab_inj[spec->kappa_col];
@@ -1813,6 +1830,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     d.p0 = tm.p[0];
     d.p1 = tm.p[1];
     d.p2 = tm.p[2];
+    d.p3 = tm.p[3];
     d.th4 = tm.kind == GWI_TERM_PLPEAK_SMOOTH ? tm.coef_off : 0;
     if (tm.kind == GWI_TERM_EXP_SPLINE_LERP) d.th1 = tm.norm;  // the grid's spline coordinates live in that normaliser's `us`
     if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE || tm.kind == GWI_TERM_EXP_SPLINE_LERP) {

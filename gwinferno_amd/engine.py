@@ -61,7 +61,8 @@ class BoundModel:
         plain = {self.kappa_col}
         for t in self.terms:
             for j, c in enumerate(t["cols"]):
-                if not (t["kind"] in knot and j == 0):
+                follows = t["kind"] == N.TERM_POWERLAW_RATIO and (t["flags"] & N.RATIO_LOGM_FROM_SPLINE) and j == 1  # reads the spline's knot coordinate
+                if not (t["kind"] in knot and j == 0) and not follows:
                     plain.add(c)
         uses = {}
         for t in self.terms:
@@ -208,10 +209,44 @@ def bind(pe, inj, hypervolume=None):
         # only ever produce those
         kappa[side] = E.where(kap < np.inf, kap, -np.inf)
 
+    # ---- a mass-ratio power law next to a spline in log m1 (BSplinePrimaryPowerlawRatio, separable.py:295-365): its `log m1`
+    # is an affine map of that spline's knot coordinate, which the engine keeps anyway -- hand the term the spline's column
+    # instead of one of its own (include/gwi_engine.h, GWI_RATIO_LOGM_FROM_SPLINE: config 3 then streams 64 B per sample, not 72)
+    def logx_source(expr):
+        """The array S if ``expr`` is where(valid, log(S), lo) -- the parked coordinate of a log-X spline model -- else None."""
+        if expr.op == "where" and expr.args[1].op == "log" and expr.args[1].args[0].op == "src" and expr.args[2].op == "const":
+            return expr.args[1].args[0].k
+        return None
+
+    logx_splines = {}
+    for fi in order:
+        fp, fj = pe.factors[fi], inj.factors[fi]
+        if fp.kind in (N.TERM_EXP_SPLINE, N.TERM_LINEAR_SPLINE) and fp.mask_expr() is not None and fj.mask_expr() is not None:
+            sp, sj = logx_source(fp.columns[0].expr()), logx_source(fj.columns[0].expr())
+            if sp is not None and sj is not None:
+                logx_splines.setdefault((id(sp), id(sj)), fi)
+    folded = {}
+    if os.environ.get("GWI_FOLD_LOGM", "1") not in ("", "0"):
+        for fi in order:
+            fp, fj = pe.factors[fi], inj.factors[fi]
+            if fp.kind == N.TERM_POWERLAW_RATIO and len(fp.columns) == 2 and fp.columns[1].transform == "log" and fj.columns[1].transform == "log":
+                key = (id(fp.columns[1].source), id(fj.columns[1].source))
+                if key in logx_splines:
+                    folded[fi] = logx_splines[key]
+
     # ---- terms
     for fi in order:
         fp, fj = pe.factors[fi], inj.factors[fi]
-        cols = [add_column(cp, cj) for cp, cj in zip(fp.columns, fj.columns)]
+        extra_flags, extra_p = 0, ()
+        if fi in folded:
+            sf, sj_ = pe.factors[folded[fi]], inj.factors[folded[fi]]
+            lo, hi = sf.consts[0], sf.consts[1]
+            n_int = sf.n_basis - 3
+            cols = [add_column(fp.columns[0], fj.columns[0]), add_column(sf.columns[0], sj_.columns[0])]
+            extra_flags = N.RATIO_LOGM_FROM_SPLINE
+            extra_p = (lo, n_int / (hi - lo), (hi - lo) / n_int)
+        else:
+            cols = [add_column(cp, cj) for cp, cj in zip(fp.columns, fj.columns)]
         slots, coef_off = factor_theta[fi]
         norm_idx = -1
         if fp.norm is not None:
@@ -238,7 +273,8 @@ def bind(pe, inj, hypervolume=None):
                 norm_idx = len(bm.norms) - 1
         if fp.kind == N.TERM_PLPEAK_SMOOTH:  # five scalars: gwi_term.theta holds four, coef_off carries the index of delta
             coef_off = slots[4]
-        bm.terms.append(dict(kind=fp.kind, cols=cols, theta=slots, n_basis=fp.n_basis, coef_off=max(coef_off, 0), flags=fp.flags, norm=norm_idx, p=fp.consts,
+        bm.terms.append(dict(kind=fp.kind, cols=cols, theta=slots, n_basis=fp.n_basis, coef_off=max(coef_off, 0), flags=fp.flags | extra_flags, norm=norm_idx,
+                             p=tuple(fp.consts) + extra_p,
                              owner=fp.norm_owner))
     if len(bm.norms) > N.GWI_MAX_NORMS:
         raise ValueError(f"{len(bm.norms)} normalisers exceed GWI_MAX_NORMS={N.GWI_MAX_NORMS}")

@@ -64,7 +64,12 @@ enum {
    * p[0]=lo, p[1]=hi */
   GWI_TERM_PLPEAK = 2,
   /* q^beta on [mmin/m1, 1]: powerlaw_pdf(q, beta, mmin/m1, 1)   parametric.py:28,40; separable.py:364
-   * cols[0]=log q, cols[1]=log m1; theta[0]=beta; p[0]=log(mmin) */
+   * cols[0]=log q, cols[1]=log m1; theta[0]=beta; p[0]=log(mmin).
+   * With GWI_RATIO_LOGM_FROM_SPLINE in flags, cols[1] is the coordinate column of a spline term in log m1 of the same model
+   * (BSplinePrimaryPowerlawRatio, separable.py:295-365: the LogXLogYBSpline of m1) and p[1], p[2], p[3] = that spline's lo,
+   * (n_basis - 3) / (hi - lo), (hi - lo) / (n_basis - 3): the engine keeps that column as the knot coordinate u and this term
+   * forms log m1 = lo + u dx itself -- one column per sample less (config 3: 64 B per sample, the algorithmic figure, not 72).
+   * The caller guarantees that every sample alive for this term lies inside that spline's domain (the spline's own mask). */
   GWI_TERM_POWERLAW_RATIO = 3,
   /* Beta(a; alpha, beta) on [0, 1]                  distributions.py:146-162, parametric.py:63-81
    * cols[0]=log a, cols[1]=log(1-a); theta = alpha, beta */
@@ -114,6 +119,7 @@ enum {
 /* POWERLAW flag: bare x^alpha with no normaliser and no truncation (the (m2/m1)^beta pairing factor,
  * models/bsplines/separable.py:609-613, :703). */
 #define GWI_POWERLAW_UNNORMALISED 2
+#define GWI_RATIO_LOGM_FROM_SPLINE 8 /* GWI_TERM_POWERLAW_RATIO: see there */
 /* gwi_norm.spline_flags bit: the integrand is the linear spline itself, Z = sum_g tw_g sum_k c_k B_k
  * (BSpline.norm, interpolation.py:280-291), not exp(...) of it. */
 #define GWI_NORM_LINEAR_SPLINE 4

@@ -227,3 +227,26 @@ def test_random_expression_graphs_on_the_device():
         for j, (h, d) in enumerate(zip(host, dev)):
             bad = np.flatnonzero(~((h == d) | (np.isnan(h) & np.isnan(d))))
             assert bad.size == 0, (trial, j, outs[j].key[:3], bad[:5], h[bad[:5]], d[bad[:5]])
+
+
+def test_log_m1_from_the_mass_spline_column(monkeypatch):
+    """Config 3's model with and without the fold of the ratio term's log m1 into the m1 spline's knot-coordinate column
+    (GWI_RATIO_LOGM_FROM_SPLINE): one column less in HBM, the same likelihood, sites and gradient."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 500, 8000, seed=5)
+    pe["mass_1"][1, :3] = [5.0, 100.0, 4.9]  # on the edges of the spline's domain and just outside
+    folded = COMPOSITIONS["bspline_iid"](pe, inj).engine()
+    monkeypatch.setenv("GWI_FOLD_LOGM", "0")
+    plain_comp = COMPOSITIONS["bspline_iid"](pe, inj)
+    plain = plain_comp.engine()
+    assert len(folded.bound.pe_exprs) == 8 and len(plain.bound.pe_exprs) == 9 and folded.bytes_per_sample == 64
+    rng = np.random.default_rng(12)
+    for _ in range(3):
+        th = plain.bound.theta_of(plain_comp.weights(draw_params("bspline_iid", rng), True))
+        a, b = folded.evaluate(th, total, min_neff_cut=False), plain.evaluate(th, total, min_neff_cut=False)
+        assert abs(a.log_likelihood - b.log_likelihood) <= 1e-12 * abs(b.log_likelihood)
+        assert np.allclose(a.log_bfs, b.log_bfs, rtol=0, atol=1e-11) and np.allclose(a.grad, b.grad, rtol=1e-10, atol=1e-10 * np.max(np.abs(b.grad)))
+    folded.close()
+    plain.close()

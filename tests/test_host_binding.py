@@ -171,3 +171,24 @@ def test_add_variant_line_for_an_unsupported_sequence():
     assert "GWI_VARIANT" in inc.split("\n")[0] or inc.startswith("//")  # the include file exists and is part of kVariants
     src = open(os.path.join(os.path.dirname(A.INC), "gwi_engine.hip")).read()
     assert '#include "gwi_user_variants.inc"' in src
+
+
+def test_ratio_term_takes_log_m1_from_the_mass_spline(monkeypatch):
+    """BSplinePrimaryPowerlawRatio (config 3): the mass-ratio power law needs log m1, the m1 spline's coordinate IS log m1 (parked
+    at the domain's lower edge for excluded samples): the binder hands the ratio term the spline's column with the knots as
+    constants (GWI_RATIO_LOGM_FROM_SPLINE) -- 8 columns = SURVEY 8(d)'s C for configs 3/4 -- and the flat description still
+    reproduces the reference's weights; GWI_FOLD_LOGM=0 keeps the separate column."""
+    case = GoldenCase("bspline_iid")
+    comp, bm = _bound(case)
+    (ratio,) = [t for t in bm.terms if t["kind"] == N.TERM_POWERLAW_RATIO]
+    m1_spline = [t for t in bm.terms if t["kind"] == N.TERM_EXP_SPLINE][0]
+    assert ratio["flags"] & N.RATIO_LOGM_FROM_SPLINE and ratio["cols"][1] == m1_spline["cols"][0] and len(bm.pe_cols) == 8
+    lo, hi, n_int = m1_spline["p"][0], m1_spline["p"][1], m1_spline["n_basis"] - 3
+    assert ratio["p"][1:] == (lo, n_int / (hi - lo), (hi - lo) / n_int)
+    theta = bm.theta_of(comp.weights(case.point(0), True))
+    lpe, linj, _ = log_weights(bm, theta)
+    monkeypatch.setenv("GWI_FOLD_LOGM", "0")
+    _, bm0 = _bound(case)
+    assert len(bm0.pe_cols) == 9 and not any(t["flags"] & N.RATIO_LOGM_FROM_SPLINE for t in bm0.terms if t["kind"] == N.TERM_POWERLAW_RATIO)
+    lpe0, linj0, _ = log_weights(bm0, theta)
+    assert np.array_equal(lpe, lpe0) and np.array_equal(linj, linj0)
