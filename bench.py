@@ -266,6 +266,12 @@ class Run:
             elif "GWI_BENCH_SHARE_DEVICES" in os.environ:
                 self.shared_devices = int(os.environ["GWI_BENCH_SHARE_DEVICES"])
                 self.local_rank = self.local_rank % self.shared_devices
+            elif torch.cuda.is_available() and 0 < torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", self.world)):
+                # more ranks than GPUs on this node (a launcher asked for N ranks on a smaller box): share the devices round robin
+                # with a CPU-side rendezvous instead of failing on an invalid device ordinal -- a logic run, reported as such
+                self.shared_devices = torch.cuda.device_count()
+                self.local_rank = self.local_rank % self.shared_devices
+                backend = "gloo"
             torch.cuda.set_device(self.local_rank)
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
