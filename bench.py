@@ -866,7 +866,12 @@ def main():
     forced = os.environ.get("GWI_FORCE_SHARDED") == "1"  # the N > 1 code path with a world of one rank (tests)
     if (((args.gpus > 1 and "RANK" in os.environ) or forced) and os.environ.get("GWI_BENCH_BACKEND", "nccl") == "nccl" and "GWI_BENCH_DEVICE" not in os.environ
             and "GWI_BENCH_SHARE_DEVICES" not in os.environ and os.environ.get("GWI_BENCH_RCCL_VARIANT", "1") != "0"):
-        rccl_leg = run_rccl_leg(args)
+        import torch  # counting devices does not initialise the GPU
+
+        if 0 < torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)):
+            rccl_leg = {"skipped": "fewer GPUs than ranks on this node: RCCL cannot place two ranks of one communicator on one device"}
+        else:
+            rccl_leg = run_rccl_leg(args)
 
     run = Run(args)
     if run.world != args.gpus and not (run.world == 1 and os.environ.get("GWI_FORCE_SHARDED") == "1"):
