@@ -783,6 +783,18 @@ def rccl_leg_main(argv):
     thetas = [comp.theta(draw_params(comp_name, rng)) for _ in range(64)]
     n = max(200, args.steps)
     blk = np.stack([thetas[i % len(thetas)] for i in range(n)])
+    # before timing: the sharded evaluation (records through the all-gather) against an UNSHARDED engine over the whole
+    # catalog on rank 0's GPU, value and whole gradient (what the shared-memory path reports as sharded_vs_single_gpu)
+    r_sh = eng.evaluate_sharded(thetas[0], total, min_neff_cut=False)
+    sharded_check = None
+    if rank == 0:
+        eng_full = COMPOSITIONS[comp_name](pe, inj).engine(device=local)
+        r_full = eng_full.evaluate(thetas[0], total, min_neff_cut=False)
+        scale = max(1.0, float(np.max(np.abs(r_full.grad))))
+        sharded_check = {"log_likelihood_rel_err": abs(r_sh.log_likelihood - r_full.log_likelihood) / max(1e-300, abs(r_full.log_likelihood)),
+                         "grad_max_err_over_scale": float(np.max(np.abs(r_sh.grad - r_full.grad))) / scale}
+        sharded_check["within_tolerance"] = bool(sharded_check["log_likelihood_rel_err"] <= 1e-9 and sharded_check["grad_max_err_over_scale"] <= 1e-8)
+        eng_full.close()
     eng.evaluate_sequence(blk[:100], total, min_neff_cut=False)
     dist.barrier()
     torch.cuda.synchronize()
@@ -799,7 +811,8 @@ def rccl_leg_main(argv):
     if rank == 0:
         print(json.dumps({"evals_per_s": n / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / n, "steps": n, "rccl_ranks": world, "workload": desc,
                           "exchange": "one ncclAllGather of the ~1 KiB partial records per evaluation, on the engine's own stream (gwi_eval_sharded)",
-                          "last_log_likelihood": float(ll[-1]), "identical_on_all_ranks": bool(same), "two_pass_repeats": eng.two_pass_repeats()}), flush=True)
+                          "last_log_likelihood": float(ll[-1]), "identical_on_all_ranks": bool(same), "sharded_vs_single_gpu": sharded_check,
+                          "two_pass_repeats": eng.two_pass_repeats()}), flush=True)
     eng.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -131,6 +131,8 @@ const Variant kVariants[] = {
     GWI_VARIANT("spline2", K_SP, K_SP),
     // log-normal m1 peak x BSplineRatio (postprocess/calculations.py:94-130)
     GWI_VARIANT("spline+truncnorm", K_SP, K_TN),
+    // merger rate of redshift, (1 + z)^lamb exp(spline(log z)) (postprocess/calculations.py:261-276)
+    GWI_VARIANT("pl+spline", K_PL, K_SP),
     // plpeak_primary_ratio_pdf with the low-mass taper `delta` (parametric.py:39-53) [x PL z]
     GWI_VARIANT("plq+plz+smooth+plpeaksmooth", K_PQ, K_PZ, K_SM, K_PS),
     GWI_VARIANT("plq+smooth+plpeaksmooth", K_PQ, K_SM, K_PS),

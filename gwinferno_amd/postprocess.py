@@ -1,5 +1,5 @@
 """Posterior-predictive density curves on the engine, with the reference's
-function names, arguments, grids and return values (gwinferno/postprocess/calculations.py:20-242).
+function names, arguments, grids and return values (gwinferno/postprocess/calculations.py:20-276: all eight functions).
 
 For every posterior draw the reference evaluates the population density on an 800 x 800 (m1, q) mesh and
 integrates it along each axis with the trapezoid rule (:44-52, :78-84).  That is the likelihood hot path
@@ -11,15 +11,18 @@ prior, and the engine's per-event importance sums ARE the marginals --
 
 so K draws are K hyper-parameter points of ``gwi_eval_batch``: no new kernels, no (N_draws, 800, 800)
 temporaries, and the B-spline models never build their (N_basis, 640 000) design matrices.  The 1-D curves
-(spin magnitudes, tilts) are the engine's per-sample log-weights (``gwi_log_weights``) on an 800-point grid.
+(spin magnitudes, tilts) are the engine's per-sample log-weights (``gwi_log_weights``) on an 800-point grid, and so are
+the merger-rate curves R(z) (:244-276) on the redshift model's own 1000-point grid ``z_model.zs``.
 
 ``rate`` / ``pop_frac`` scale the normalised curves exactly as the reference does (:50-51).
 """
 import numpy as np
 
+from . import _native as N
 from . import models as M
 from .engine import NativePopulationLikelihood
 from .interpolation import LogYBSpline, trapezoid_weights
+from .lazy import Column, Density, Factor, side_of
 
 GRID = 800  # points per axis in every reference PPD function
 
@@ -175,3 +178,43 @@ def calculate_bspline_spin_ppds(a1_cs, tilt1_cs, nspline_dict, a2_cs=None, tilt2
     a2_cs, tilt2_cs = np.atleast_2d(np.asarray(a2_cs, dtype=np.float64)), np.atleast_2d(np.asarray(tilt2_cs, dtype=np.float64))
     return (spin_curves(aa, M.BSplineSpinMagnitude, nspline_dict["a1"], a1_cs), spin_curves(aa, M.BSplineSpinMagnitude, nspline_dict["a2"], a2_cs), aa,
             spin_curves(cc, M.BSplineSpinTilt, nspline_dict["tilt1"], tilt1_cs), spin_curves(cc, M.BSplineSpinTilt, nspline_dict["tilt2"], tilt2_cs), cc)
+
+
+# ---- merger rate as a function of redshift: R(z) = rate * pop_frac * (1 + z)^lamb [* exp(spline(log z))] ----------------
+def _rate_factor(z, lamb):
+    """(1 + z)^lamb, no normaliser and no dVc/dz (calculations.py:253): the bare power law of the engine's term library on
+    the column log(1 + z)."""
+    side = side_of(z)
+    return Factor(N.TERM_POWERLAW, side, [Column("log1p", z)], [lamb], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, tag="rate_of_z")
+
+
+def calculate_powerlaw_rate_of_z_ppds(lamb, rate, z_model, pop_frac=None):
+    """calculations.py:244-258 -> ``(rs, zs)``: ``rs[i] = rate[i] * pop_frac[i] * (1 + zs)^lamb[i]`` on ``z_model.zs``."""
+    lamb = np.atleast_1d(np.asarray(lamb, dtype=np.float64))
+    n = len(lamb)
+    rate, pop_frac = _ones(rate, n), _ones(pop_frac, n)
+    zs = np.asarray(z_model.zs, dtype=np.float64)
+    p = _curves(zs, lambda z, la: Density([_rate_factor(z, la)], side_of(z)), list(lamb), 1.0)
+    return rate[:, None] * pop_frac[:, None] * p, zs
+
+
+def calculate_powerlaw_spline_rate_of_z_ppds(lamb, z_cs, rate, z_model, pop_frac=None):
+    """calculations.py:261-276 -> ``(rs, zs)``: the power law times ``exp(sum_k c_k B_k(log z))`` with the redshift model's
+    un-normalised LogXBSpline (spline_perturbation.py:317) and the first coefficient pinned to 0 (:269)."""
+    lamb = np.atleast_1d(np.asarray(lamb, dtype=np.float64))
+    z_cs = np.atleast_2d(np.asarray(z_cs, dtype=np.float64))
+    n = len(lamb)
+    rate, pop_frac = _ones(rate, n), _ones(pop_frac, n)
+    zs = np.asarray(z_model.zs, dtype=np.float64)
+    it = z_model.interpolator
+    if z_cs.shape[1] != it.N - 1:
+        raise ValueError(f"z_cs must hold {it.N - 1} coefficients per draw (the first of the model's {it.N} is pinned to 0)")
+
+    def dens(z, d):
+        side = side_of(z)
+        sp = Factor(N.TERM_EXP_SPLINE, side, [Column("log", z)], coefs=d[1], consts=(it.lo, it.hi), n_basis=it.N, flags=N.SPLINE_OUTSIDE_ZERO_EXPONENT, tag="rate_of_z_spline")
+        return Density([_rate_factor(z, d[0]), sp], side)
+
+    draws = [(float(lamb[i]), np.concatenate([[0.0], z_cs[i]])) for i in range(n)]
+    p = _curves(zs, dens, draws, (1.0, np.zeros(it.N)))
+    return rate[:, None] * pop_frac[:, None] * p, zs

@@ -882,7 +882,7 @@ def make_catalog_fixture():
 
 
 def make_ppd_fixture():
-    """Posterior-predictive curves (postprocess/calculations.py:20-242) from the unmodified reference for a
+    """Posterior-predictive curves (postprocess/calculations.py:20-242; :244-276 in make_ppd_rz_fixture) from the unmodified reference for a
     few seeded posterior draws; stored with their inputs."""
     from ref_import import load_postprocess
 
@@ -917,6 +917,34 @@ def make_ppd_fixture():
     path = os.path.join(HERE, "ppd.npz")
     np.savez_compressed(path, **out)
     print(f"wrote ppd.npz: {os.path.getsize(path) // 1024} KiB")
+
+
+def make_ppd_rz_fixture():
+    """The two merger-rate-of-redshift curves (postprocess/calculations.py:244-276) from the unmodified reference, on the
+    redshift models the reference builds from a small seeded catalog (parametric.py:112-121, spline_perturbation.py:304-336).
+    A file of its own (ppd_rz.npz) so that ppd.npz keeps its bytes."""
+    from ref_import import load_postprocess
+
+    calc = load_postprocess()
+    rng = np.random.default_rng(BASE_SEED + 33)
+    n, n_z = 4, 7
+    cat = (8, 64, 512, BASE_SEED + 11)
+    pe, inj, _ = make_catalog(*cat)
+    z_pe, z_inj = jnp.asarray(pe["redshift"]), jnp.asarray(inj["redshift"])
+    lamb, rate, frac = rng.normal(2.7, 1.5, n), rng.uniform(10, 40, n), rng.uniform(0.3, 1.0, n)
+    z_cs = rng.normal(size=(n, n_z - 1))  # the first coefficient is pinned to 0 inside the reference function (:269)
+    out = {"catalog": np.asarray(cat, dtype=np.int64), "lamb": lamb, "rate": rate, "pop_frac": frac, "z_cs": z_cs, "n_splines": np.asarray(n_z)}
+    pl_model = ref.parametric.PowerlawRedshiftModel(z_pe, z_inj)
+    rs, zs = calc.calculate_powerlaw_rate_of_z_ppds(lamb, rate, pl_model, pop_frac=frac)
+    out.update({"powerlaw/rs": np.asarray(rs), "powerlaw/zs": np.asarray(zs)})
+    rs, zs = calc.calculate_powerlaw_rate_of_z_ppds(lamb, rate, pl_model)
+    out["powerlaw/rs_default_frac"] = np.asarray(rs)
+    sp_model = ref.spline_perturbation.PowerlawSplineRedshiftModel(n_z, z_pe, z_inj)
+    rs, zs = calc.calculate_powerlaw_spline_rate_of_z_ppds(lamb, z_cs, rate, sp_model, pop_frac=frac)
+    out.update({"spline/rs": np.asarray(rs), "spline/zs": np.asarray(zs)})
+    path = os.path.join(HERE, "ppd_rz.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote ppd_rz.npz: {os.path.getsize(path) // 1024} KiB")
 
 
 def make_pipeline_fixture():
@@ -1050,6 +1078,7 @@ def main(which):
     todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel", "formats"]
     if "ppd" in todo:
         make_ppd_fixture()
+        make_ppd_rz_fixture()
     if "margsel" in todo:
         make_margsel_fixture()
     if "formats" in todo:

@@ -1,6 +1,6 @@
 """CPU, world_size 2, gloo: the N>1 path -- shard bounds, partial-record layout, the single
-all-gather, and the C++ assembly (gwi_combine through a host-only handle) -- against the oracle's
-unsharded evaluation.  The per-rank scan itself (HIP) is replaced by the NumPy BoundModel evaluator;
+all-gather, and the C++ assembly (gwi_combine through a host-only handle) -- against the oracles'
+unsharded evaluation (value: NumPy oracle; gradient: C oracle).  The per-rank scan itself (HIP) is replaced by the NumPy BoundModel evaluator;
 on the GPU box test_gpu_parity.py::test_partial_records_combine_like_single_device covers the
 same path with real device records."""
 import os
@@ -21,8 +21,31 @@ def _free_port():
     return port
 
 
-def _numpy_partial_record(eng, bm, theta):
-    """What gwi_eval_partial would publish for this rank's shard (value part; gradient slots zero)."""
+def _dlogw_dtheta(bm, theta, h=1e-3):
+    """d log w / d theta_p of every sample, [n_theta][...]: fourth-order central differences of the NumPy statement of the
+    bound model (truncation ~ h^4 f^(5) / 30, rounding ~ 1e-16 / h: both far below the 1e-8 the test asks of the assembled
+    gradient).  Excluded samples (log w = -inf) come out as NaN and are given weight 0 by the caller."""
+    from bound_eval import log_weights
+
+    d_pe, d_inj = [], []
+    for p in range(len(theta)):
+        acc_pe = acc_inj = 0.0
+        for k, c in ((-2, 1.0), (-1, -8.0), (1, 8.0), (2, -1.0)):
+            th = np.array(theta, dtype=np.float64)
+            th[p] += k * h
+            with np.errstate(all="ignore"):
+                lpe, linj, _ = log_weights(bm, th, include_consts=False)
+                acc_pe = acc_pe + c * lpe
+                acc_inj = acc_inj + c * linj
+        d_pe.append(acc_pe / (12.0 * h))
+        d_inj.append(acc_inj / (12.0 * h))
+    return np.array(d_pe), np.array(d_inj)
+
+
+def _numpy_partial_record(eng, bm, theta, want_grad=False):
+    """What gwi_eval_partial would publish for this rank's shard: the value part and, with ``want_grad``, the gradient
+    numerators (record layout of gwi_engine.hip: sum_i G_ip / S1_i over the rank's events, then sum_j w_j e^{-M} dl_j over
+    its injections)."""
     from bound_eval import log_weights
     from scipy.special import logsumexp
 
@@ -43,6 +66,16 @@ def _numpy_partial_record(eng, bm, theta):
     rec[4], rec[5], rec[6] = M, w.sum(), (w * w).sum()
     rec[7] = e1 - e0
     rec[8 : 8 + len(norms)] = norms
+    if want_grad:
+        n_theta = len(theta)
+        d_pe, d_inj = _dlogw_dtheta(bm, theta)
+        with np.errstate(all="ignore"):
+            soft = np.exp(lpe - lse[:, None])  # softmax over the samples of an event
+            g_pe = np.array([np.sum(np.where(soft > 0, soft * d_pe[p][e0:e1], 0.0)) for p in range(n_theta)])
+            g_inj = np.array([np.sum(np.where(w > 0, w * d_inj[p][j0:j1], 0.0)) for p in range(n_theta)])
+        off = 8 + len(norms)
+        rec[off : off + n_theta] = g_pe
+        rec[off + n_theta : off + 2 * n_theta] = g_inj
     return rec, lse, log_neff, var
 
 
@@ -70,11 +103,11 @@ def _worker(rank, world, port, comp_name, out_path):
 
         def eval_partial(self, th):
             eng.prepare_combine(th)
-            return _numpy_partial_record(eng, eng.bound, th)
+            return _numpy_partial_record(eng, eng.bound, th, want_grad=True)
 
     sh = ShardedLikelihood(_Eng(), total)
-    res = sh.evaluate(theta, min_neff_cut=False, want_grad=False)
-    np.savez(f"{out_path}.{rank}", log_l=res.log_likelihood, log_bfs=res.log_bfs, ev=np.array(eng.event_range), log_mu=res.summary.log_det_eff,
+    res = sh.evaluate(theta, min_neff_cut=False, want_grad=True)
+    np.savez(f"{out_path}.{rank}", log_l=res.log_likelihood, grad=res.grad, theta=theta, log_bfs=res.log_bfs, ev=np.array(eng.event_range), log_mu=res.summary.log_det_eff,
              neff_inj=res.summary.log_nEff_inj, var=res.summary.variance_log_likelihood, vt=res.summary.surveyed_hypervolume_norm)
     dist.barrier()
     dist.destroy_process_group()
@@ -101,6 +134,18 @@ def test_world2_gloo_matches_oracle(tmp_path, comp_name):
         assert abs(float(r["neff_inj"]) / float(ref["log_nEff_inj"]) - 1) < 1e-9
         assert abs(float(r["var"]) / float(ref["variance_log_likelihood"]) - 1) < 1e-8
     assert float(r0["log_l"]) == float(r1["log_l"])  # bit-identical across ranks
+    # the gradient half of the records crossed the process boundary too: the assembled d log_l / d theta of both ranks
+    # against the C oracle's analytic gradient of the unsharded catalog
+    from gwinferno_amd.compositions import COMPOSITIONS
+    from oracle.c_oracle import COracle
+
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    orc = COracle(comp.engine(device=-2).bound)
+    want = orc.evaluate(r0["theta"], total, min_neff_cut=False)
+    scale = max(1.0, float(np.max(np.abs(want["grad"]))))
+    assert np.any(r0["grad"] != 0.0)
+    assert np.max(np.abs(r0["grad"] - want["grad"])) < 1e-8 * scale
+    assert np.array_equal(r0["grad"], r1["grad"])
     assert list(r0["ev"]) == [0, 4] and list(r1["ev"]) == [4, 7]
     got = np.concatenate([r0["log_bfs"], r1["log_bfs"]])
     assert np.max(np.abs(got - ref["logBFs"])) < 1e-10

@@ -1,6 +1,6 @@
 """GPU (-m gpu): posterior-predictive curves (gwinferno_amd/postprocess.py, computed by the likelihood engine
-on a mesh "catalog") against the unmodified reference functions' outputs (postprocess/calculations.py:20-242)
-stored in tests/golden/ppd.npz."""
+on a mesh "catalog") against the unmodified reference functions' outputs (postprocess/calculations.py:20-276)
+stored in tests/golden/ppd.npz and ppd_rz.npz."""
 import os
 
 import numpy as np
@@ -51,3 +51,21 @@ def test_one_dimensional_spin_curves():
     assert np.array_equal(ct, GOLD["tilt_out/ct"]) and _close(cp, GOLD["tilt_out/ctpdfs"])
     ap, aa, cp, cc = P.calculate_bspline_spin_ppds(GOLD["spin_in/a_cs"], GOLD["spin_in/t_cs"], {"a": 10, "tilt": 9})
     assert _close(ap, GOLD["spin_out/apdfs"]) and _close(cp, GOLD["spin_out/ctpdfs"])
+
+
+def test_rate_of_z_curves():
+    """calculations.py:244-276: R(z) = rate pop_frac (1 + z)^lamb [exp(spline(log z))] on the redshift model's own grid."""
+    from gwinferno_amd import models as M
+    from gwinferno_amd import postprocess as P
+    from gwinferno_amd.synthetic import make_catalog
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppd_rz.npz"))
+    pe, inj, _ = make_catalog(*[int(v) for v in g["catalog"]])
+    zm = M.PowerlawRedshiftModel(pe["redshift"], inj["redshift"])
+    rs, zs = P.calculate_powerlaw_rate_of_z_ppds(g["lamb"], g["rate"], zm, pop_frac=g["pop_frac"])
+    assert np.array_equal(zs, g["powerlaw/zs"]) and _close(rs, g["powerlaw/rs"])
+    rs, _ = P.calculate_powerlaw_rate_of_z_ppds(g["lamb"], g["rate"], zm)
+    assert _close(rs, g["powerlaw/rs_default_frac"])
+    zs_model = M.PowerlawSplineRedshiftModel(int(g["n_splines"]), pe["redshift"], inj["redshift"])
+    rs, zs = P.calculate_powerlaw_spline_rate_of_z_ppds(g["lamb"], g["z_cs"], g["rate"], zs_model, pop_frac=g["pop_frac"])
+    assert np.array_equal(zs, g["spline/zs"]) and _close(rs, g["spline/rs"])
