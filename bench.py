@@ -145,17 +145,22 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
 
     orc = COracle(comp.engine().bound)
     avail = host_cores()
-    # the visible CPU count can exceed what the container may really use: probe a few thread counts and keep the fastest
-    best, cores = None, 1
-    for nt in sorted({1, 2, 4, 8, 16, 32, 64, 128, avail}):
-        if nt > avail:
-            continue
+
+    def rate(nt, repeats=3):
+        """evaluations per second at nt threads: best of `repeats` single evaluations after one untimed"""
         orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
-        t0 = time.perf_counter()
-        orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, nt
+        best = None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return 1.0 / best
+
+    # SURVEY 8d: thread count = the CPUs this process may use (one OpenMP region over (event, sample-block) pairs and injection
+    # blocks keeps them all busy), unless a 3-repeat probe shows that fewer threads are faster; both are reported
+    probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16)})}
+    cores = max(probe, key=probe.get)
     n, t_used = 0, 0.0
     while t_used < budget_s:
         t0 = time.perf_counter()
@@ -171,6 +176,9 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         "cores": cores,
         "kind": "port",
         "sample": f"{n} value+gradient evals of the full catalog by the C/OpenMP oracle on {cores} threads ({t_used:.1f}s)",
+        "threads_probe_evals_per_s": {str(k): v for k, v in probe.items()},
+        "at_all_usable_cpus": {"cores": avail, "evals_per_s": probe[avail]},
+        "parallel_units": "blocks of 512 samples: (event, block) pairs and injection blocks in ONE OpenMP region, merged in block order (oracle/gwpop_oracle.c)",
         "single_thread_evals_per_s": 1.0 / t_single,
         "host": host_description(),
     }
@@ -594,6 +602,28 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
+            # kernel durations of the batched launches (start/stop of each launch, a few timed batches after the loop)
+            eng.set_timing(True)
+            bk = []
+            for _ in range(8):
+                vgb(tb)
+                bk.append(eng.last_kernel_ms())
+            eng.set_timing(False)
+            bk = np.asarray(bk)
+            out["batched"]["avg_kernel_us"] = {"scan": 1e3 * float(np.mean(bk[:, 0])), "combine": 1e3 * float(np.mean(bk[:, 1])), "final": 1e3 * float(np.mean(bk[:, 2]))}
+            if out["batched"]["path"] == "mfma":
+                # matrix-core utilisation of the batched scan (north_star: "MFMA utilisation reported against gfx950 peak"):
+                # v_mfma_f64_16x16x4 instructions per launch from the SQ_INSTS_MFMA counter pass (profiles/<round>/traffic.json,
+                # tools/profile_round.sh; the count is a property of the kernel and the catalog, not of the run) x 2048 flop,
+                # over the LIVE duration of the batched scan launch, against the 78.6 TFLOP/s fp64 matrix peak
+                row = (pmc_table("batched_k16") or {}).get(f"{cfg}_mfma") if K == 16 else None
+                insts = row.get("mfma_instructions_per_launch") if row else None
+                scan_s = 1e-3 * float(np.mean(bk[:, 0]))
+                tfl = (2048.0 * insts / scan_s / 1e12) if (insts and scan_s > 0) else None
+                out["batched"]["mfma"] = {"instruction": "v_mfma_f64_16x16x4_f64", "insts_per_launch": insts, "flop_per_launch": 2048.0 * insts if insts else None, "tflops": tfl,
+                                          "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac_of_78.6": (tfl / FP64_VECTOR_PEAK_TFLOPS) if tfl else None,
+                                          "source": (pmc_table("batched_k16") or {}).get("source"),
+                                          "what": "the design-matrix contraction sum_s w_s B_p(x_s) for 16 hyper-parameter points per wavefront (gwi_mfma.h); A = 16 bases x 4 samples with 4 non-zero taps per column"}
             # the other batched kernels on the same batch, where the model has them (spline models): the 4-tap kernel (one
             # grid row per point, LDS atomics) and the LDS-row variant of the 16-points-per-wavefront kernel
             alts = {}
@@ -628,7 +658,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             # configs 3 / 5: the sampler figure under the reference's priors, on engines of its own
             comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
             engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
-            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas)
+            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 150, "n_samples": 60} if cfg == "c5" else {}))
             for e in engs[1:]:
                 e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
@@ -724,13 +754,16 @@ def reference_priors(comp_name, comp, n_theta):
     return GaussianSmoothingPrior(n_theta).normal(slice(0, n_theta), 10.0), None, "Normal(0, 10) on every parameter"
 
 
-def native_nuts(engines, comp_name, comp, total, thetas):
+def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples=200):
     """The engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain per engine
-    and host thread, under the priors a reference run uses (reference_priors); trees capped at 2^6 leapfrogs so that the
-    line stays within seconds whatever the synthetic posterior looks like.  Likelihood evaluations per second as a sampler
-    sees them, and how many of them the engine had to repeat (gwi_two_pass_repeats: a tile whose weights left the range
-    around the previous evaluation's maximum)."""
-    from gwinferno_amd.sampling import nuts_engine
+    and host thread, under the priors a reference run uses (reference_priors), with the reference's tree depth
+    (numpyro's default max_tree_depth = 10: up to 1023 leapfrogs per iteration) and a warm-up long enough for the step size
+    and the diagonal mass matrix to adapt.  The wall time is bounded through the iteration count (worst case
+    (n_warmup + n_samples) x 1023 evaluations per chain), not through the depth.  Reported: likelihood evaluations per
+    second as a sampler sees them, how many the engine had to repeat (gwi_two_pass_repeats), and the sampler's own
+    diagnostics -- mean tree depth, acceptance rate, adapted step size, divergences after warm-up, and the smallest
+    bulk effective sample size over the free parameters per second of sampling (post-warm-up draws of all chains)."""
+    from gwinferno_amd.sampling import effective_sample_size, nuts_engine
 
     C = len(engines)
     prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
@@ -738,16 +771,29 @@ def native_nuts(engines, comp_name, comp, total, thetas):
     if bij is not None:
         for k in np.flatnonzero(bij.kind == 3):  # pinned entries take their fixed value
             starts[:, k] = bij.lo[k]
-    kw = dict(max_tree_depth=6, seed=1, min_neff_cut=False)
-    nuts_engine(engines, total, prior, bij, starts, n_warmup=5, n_samples=5, **kw)
+    kw = dict(max_tree_depth=10, seed=1, min_neff_cut=False)
+    nuts_engine(engines, total, prior, bij, starts, n_warmup=3, n_samples=3, **dict(kw, max_tree_depth=5))  # threads, buffers, code paths warm
     repeats0 = sum(e.two_pass_repeats() for e in engines)
     t0 = time.perf_counter()
-    res = nuts_engine(engines, total, prior, bij, starts, n_warmup=60, n_samples=60, **kw)
+    res = nuts_engine(engines, total, prior, bij, starts, n_warmup=n_warmup, n_samples=n_samples, **kw)
     dt = time.perf_counter() - t0
     n_lf = sum(r["n_evals"] for r in res)
     reps = sum(e.two_pass_repeats() for e in engines) - repeats0
-    return {"chains": C, "host_threads": C, "iterations_per_chain": 120, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf, "priors": what,
-            "two_pass_repeats": reps, "repeat_fraction": reps / max(n_lf, 1), "mean_tree_depth": float(np.mean([np.mean(r["tree_depth"]) for r in res]))}
+    draws = np.stack([r["samples"] for r in res])
+    ess = effective_sample_size(draws)
+    free = np.isfinite(ess)
+    depth = np.concatenate([r["tree_depth"] for r in res])
+    # share of the wall time spent after warm-up ~ share of the evaluations made there (2^depth - 1 per iteration)
+    n_lf_sampling = float(np.sum(2.0 ** depth - 1.0))
+    t_sampling = dt * min(1.0, n_lf_sampling / max(n_lf, 1))
+    return {"chains": C, "host_threads": C, "warmup_iterations": n_warmup, "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt,
+            "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt, "priors": what, "two_pass_repeats": reps, "repeat_fraction": reps / max(n_lf, 1),
+            "mean_tree_depth": float(np.mean(depth)), "max_tree_depth_reached": int(np.max(depth)), "fraction_at_max_depth": float(np.mean(depth >= 10)),
+            "accept_prob": float(np.mean([r["accept_rate"] for r in res])), "step_size": [float(r["step_size"]) for r in res],
+            "divergences": int(sum(r["n_divergent"] for r in res)),
+            "min_ess": float(np.min(ess[free])) if free.any() else None, "median_ess": float(np.median(ess[free])) if free.any() else None,
+            "min_ess_per_s": float(np.min(ess[free]) / max(t_sampling, 1e-9)) if free.any() else None,
+            "ess_note": "bulk ESS (multi-chain, Geyer) of the post-warm-up draws of all chains; per second of the sampling phase"}
 
 
 RCCL_LEG_FLAG = "--rccl-leg"

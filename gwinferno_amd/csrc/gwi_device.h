@@ -103,8 +103,8 @@ struct KArgs {
   unsigned long long* redo_host;          // pinned host word: a workgroup whose fixed reference exponent turned out too low stores norm_seq here
   unsigned long long* redo_dev;           // ... and here (device word, read by final_kernel: the sharded path's record carries the request to every rank)
   // spline models: the reference exponent (in binades: powers of two) every tile weighs its samples against = the tile's
-  // exact maximum at the PREVIOUS evaluation of this handle, [1 + max_batch][nref_stride] (row 0: single evaluations,
-  // rows 1..K: the points of a batched launch); kNoRef where there is none yet
+  // exact maximum at the PREVIOUS evaluation of this handle, [1 + 2 max_batch][nref_stride] (row 0: single evaluations,
+  // rows 1..: the points of a batched launch, one block of rows per launch geometry); kNoRef where there is none yet
   int* tile_nref;
   int nref_stride;
   int rows_rep;  // scan_rows_kernel (gwi_mfma.h): sample-slot replicas of its gradient rows (4, 2 or 1)

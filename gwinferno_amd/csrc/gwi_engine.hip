@@ -721,7 +721,12 @@ gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_d
 #endif
   const int n_theta = h->spec.n_theta;
   h->kargs.square = square ? 1 : 0;
-  h->kargs.nref_row0 = batch ? 1 : 0;  // tile references: row 0 belongs to single evaluations, rows 1..K to the points of a batch
+  // tile references: row 0 belongs to single evaluations, rows 1..max_batch to the points of a batch on the single
+  // evaluation's tiling, rows 1 + max_batch.. to the points of a batch on the batched launches' own tiling (bgeo: other tile
+  // boundaries, so another tile's maximum).  Row k of a block keeps meaning "point k of the batch": a vectorised caller
+  // should keep chain k in slot k from one call to the next (a reference left by another chain is still only a range
+  // question -- a miss costs one repeat, never a wrong bit).
+  h->kargs.nref_row0 = batch ? ((K >= 4 && h->bgeo.distinct) ? 1 + h->max_batch : 1) : 0;
   // plain evaluations go through the engine's AQL queue; whatever must be ordered with other work on the HIP stream
   // (batched theta uploads, the sharded path's exchange behind record_dev) stays on the stream, and so does everything
   // after gwi_set_timing(h, 2)
@@ -1748,7 +1753,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_fin_dev, h->h_fin, 0));
   std::memset(h->h_fin, 0, sizeof(double) * KB * h->final_groups * record_len(h));
   {  // tile references of spline models (scan_kernel, shared mode): none yet
-    const size_t n = (size_t)(1 + h->max_batch) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1);
+    const size_t n = (size_t)(1 + 2 * h->max_batch) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1);  // rows: see nref_row0
     std::vector<int> none(n, kNoRef);
     GWI_HIP(hipMalloc(&h->d_tile_nref, sizeof(int) * n));
     GWI_HIP(hipMemcpy(h->d_tile_nref, none.data(), sizeof(int) * n, hipMemcpyHostToDevice));

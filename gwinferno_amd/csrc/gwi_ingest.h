@@ -167,7 +167,17 @@ inline gwi_status ingest_check(std::string& err, const gwi_ingest_program* p, in
   for (int t = 0; t < p->n_tables; ++t)
     if (!p->tables[t] || p->table_len[t] < 2 || p->table_len[t] > (1LL << 30)) return bad("an interpolation table needs 2 .. 2^30 entries");
   std::vector<char> stored(n_cols, 0);
+  // a register must have been written by an earlier op of the program before it is read: the kernel's registers carry a
+  // lane's values from one sample of its grid-stride loop to the next, so a program that reads first would see the
+  // previous sample's data, silently
+  std::vector<char> written(GWI_INGEST_MAX_REGS, 0);
+  bool read_unwritten = false;
   auto reg = [&](int v) { return v >= 0 && v < p->n_regs; };
+  auto src = [&](int v) {  // a register operand that is read
+    if (!reg(v)) return false;
+    if (!written[v]) read_unwritten = true;
+    return true;
+  };
   for (int o = 0; o < p->n_ops; ++o) {
     const gwi_ingest_op& op = p->ops[o];
     const std::string at = "op " + std::to_string(o) + ": ";
@@ -179,29 +189,31 @@ inline gwi_status ingest_check(std::string& err, const gwi_ingest_program* p, in
         if (!reg(op.dst)) return bad(at + "register out of range");
         break;
       case GWI_ING_LOG: case GWI_ING_LOG1P: case GWI_ING_NEG: case GWI_ING_ABS: case GWI_ING_NOT: case GWI_ING_SQRT: case GWI_ING_ISFINITE:
-        if (!reg(op.dst) || !reg(op.a)) return bad(at + "register out of range");
+        if (!reg(op.dst) || !src(op.a)) return bad(at + "register out of range");
         break;
       case GWI_ING_ADD: case GWI_ING_SUB: case GWI_ING_MUL: case GWI_ING_DIV: case GWI_ING_LT: case GWI_ING_GT: case GWI_ING_LE: case GWI_ING_GE:
       case GWI_ING_AND: case GWI_ING_OR:
-        if (!reg(op.dst) || !reg(op.a) || !reg(op.b)) return bad(at + "register out of range");
+        if (!reg(op.dst) || !src(op.a) || !src(op.b)) return bad(at + "register out of range");
         break;
       case GWI_ING_WHERE:
-        if (!reg(op.dst) || !reg(op.a) || !reg(op.b) || !reg(op.c)) return bad(at + "register out of range");
+        if (!reg(op.dst) || !src(op.a) || !src(op.b) || !src(op.c)) return bad(at + "register out of range");
         break;
       case GWI_ING_INTERP:
-        if (!reg(op.dst) || !reg(op.a) || op.b < 0 || op.b >= p->n_tables || op.c < 0 || op.c >= p->n_tables || p->table_len[op.b] != p->table_len[op.c])
+        if (!reg(op.dst) || !src(op.a) || op.b < 0 || op.b >= p->n_tables || op.c < 0 || op.c >= p->n_tables || p->table_len[op.b] != p->table_len[op.c])
           return bad(at + "INTERP needs two tables of one length");
         break;
       case GWI_ING_GRIDINDEX:
-        if (!reg(op.dst) || !reg(op.a) || op.b < 0 || op.b >= p->n_tables) return bad(at + "GRIDINDEX table out of range");
+        if (!reg(op.dst) || !src(op.a) || op.b < 0 || op.b >= p->n_tables) return bad(at + "GRIDINDEX table out of range");
         break;
       case GWI_ING_STORE:
-        if (!reg(op.a) || op.dst < 0 || op.dst >= n_cols) return bad(at + "STORE out of range");
+        if (!src(op.a) || op.dst < 0 || op.dst >= n_cols) return bad(at + "STORE out of range");
         stored[op.dst] = 1;
         break;
       default:
         return bad(at + "unknown opcode " + std::to_string(op.op));
     }
+    if (read_unwritten) return bad(at + "reads a register no earlier op has written");
+    if (op.op != GWI_ING_STORE) written[op.dst] = 1;
   }
   for (int c = 0; c < n_cols; ++c)
     if (!stored[c]) return bad("column " + std::to_string(c) + " is never stored");

@@ -376,10 +376,24 @@ class NativePopulationLikelihood:
         j0, j1 = shard_bounds(bm.n_inj, rank, world)
         self.event_range, self.inj_range = (e0, e1), (j0, j1)
         self.n_ev, self.n_pe, self.n_inj = e1 - e0, bm.n_pe, j1 - j0
+        auto_setup = device_setup is None
         if device_setup is None:
             device_setup = device != N.DEVICE_HOST_ONLY and os.environ.get("GWI_HOST_SETUP", "0") in ("", "0")
         if device_setup and device == N.DEVICE_HOST_ONLY:
             raise ValueError("a host-only handle has no device to set the catalog up on")
+        programs = None
+        if device_setup:
+            try:
+                programs = (N.ingest_program(bm.program(PE, events=(e0, e1))), N.ingest_program(bm.program(INJ, samples=(j0, j1))))
+            except ValueError as exc:
+                # a setup program beyond the ingest kernel's limits (64 registers, 32 sources, 16 tables): the host path
+                # computes the same columns with NumPy.  Only an EXPLICIT device_setup=True makes this an error.
+                if not auto_setup:
+                    raise
+                import warnings
+
+                warnings.warn(f"setup program too large for the device ingest kernel ({exc}); computing the catalog columns on the host")
+                device_setup = False
         self.device_setup = bool(device_setup)
         pe_cols = inj_cols = ()
         if not device_setup and device != N.DEVICE_HOST_ONLY:
@@ -423,8 +437,7 @@ class NativePopulationLikelihood:
             nm.us = N.as_dp(g.us)
         handle = C.c_void_p()
         if device_setup:
-            prog_pe, keep_pe = N.ingest_program(bm.program(PE, events=(e0, e1)))
-            prog_inj, keep_inj = N.ingest_program(bm.program(INJ, samples=(j0, j1)))
+            (prog_pe, keep_pe), (prog_inj, keep_inj) = programs
             self._keep.append((keep_pe, keep_inj))
             st = self.lib.gwi_create_ingest(C.byref(spec), C.byref(prog_pe), self.n_ev, self.n_pe, C.byref(prog_inj), self.n_inj, device, C.byref(handle))
         else:

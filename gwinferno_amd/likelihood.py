@@ -147,7 +147,7 @@ def _host_callback(eng, total_inj, Nobs, flags):
             return pack(eng.evaluate(theta, total_inj, want_grad=True, **kw))
         lead = theta.shape[:-1]
         flat = theta.reshape(-1, n_theta)
-        step = max(1, int(os.environ.get("GWI_MAX_BATCH", "16")))
+        step = min(64, max(1, int(os.environ.get("GWI_MAX_BATCH", "16"))))  # the engine clamps max_batch to [1, 64] (gwi_create)
         rows = []
         for i in range(0, flat.shape[0], step):
             rows += [pack(r) for r in eng.evaluate_batch(flat[i : i + step], total_inj, want_grad=True, **kw)]
@@ -171,11 +171,18 @@ def _evaluate_jax(eng, params, total_inj, Nobs, flags):
     )
     host = _host_callback(eng, total_inj, Nobs, flags)
 
+    # batched under vmap (vectorised chains): one call with the batch in front, see _host_callback.  Whether this JAX knows
+    # `vmap_method` is read from the signature once -- a try / except around the call would also swallow unrelated TypeErrors
+    import inspect
+
+    try:
+        has_vmap_method = "vmap_method" in inspect.signature(jax.pure_callback).parameters
+    except (TypeError, ValueError):
+        has_vmap_method = False
+    cb_kw = {"vmap_method": "broadcast_all"} if has_vmap_method else {}
+
     def callback(theta):
-        try:  # batched under vmap (vectorised chains): one call with the batch in front, see _host_callback
-            return jax.pure_callback(host, shapes, theta, vmap_method="broadcast_all")
-        except TypeError:  # a JAX that predates vmap_method
-            return jax.pure_callback(host, shapes, theta)
+        return jax.pure_callback(host, shapes, theta, **cb_kw)
 
     @jax.custom_vjp
     def f(theta):

@@ -418,6 +418,41 @@ def find_map(target, theta0, Niter=100, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
 
 
 # ---- the library's native sampler (include/gwi_sampler.h) ----
+def effective_sample_size(samples):
+    """Bulk effective sample size per parameter of ``samples[chains, draws, dim]``: the multi-chain estimator with Geyer's
+    initial monotone sequence (autocovariances by FFT; what ``arviz.ess`` / ``numpyro.diagnostics.effective_sample_size``
+    compute, which ``mcmc.print_summary()`` shows in the reference's drivers, bin/gwinferno_run_from_config.py:70).  Constant
+    columns (pinned parameters) get NaN."""
+    x = np.asarray(samples, dtype=np.float64)
+    if x.ndim == 2:
+        x = x[None]
+    C, n, dim = x.shape
+    out = np.full(dim, np.nan)
+    if n < 4:
+        return out
+    xc = x - x.mean(axis=1, keepdims=True)
+    m = 1 << int(np.ceil(np.log2(2 * n)))
+    f = np.fft.rfft(xc, n=m, axis=1)
+    acov = np.fft.irfft(f * np.conj(f), n=m, axis=1)[:, :n, :] / n  # biased autocovariance per chain
+    chain_var = acov[:, 0, :] * n / (n - 1.0)
+    W = chain_var.mean(axis=0)
+    B_over_n = x.mean(axis=1).var(axis=0, ddof=1) if C > 1 else 0.0
+    var_plus = W * (n - 1.0) / n + B_over_n
+    for j in range(dim):
+        if not (var_plus[j] > 0.0) or not np.isfinite(var_plus[j]):
+            continue
+        rho = 1.0 - (W[j] - acov[:, :, j].mean(axis=0)) / var_plus[j]
+        # Geyer: sums of adjacent pairs, truncated at the first negative pair, made monotone
+        pairs = rho[: 2 * (n // 2)].reshape(-1, 2).sum(axis=1)
+        neg = np.flatnonzero(pairs < 0.0)
+        k = neg[0] if neg.size else len(pairs)
+        p = np.minimum.accumulate(pairs[:k]) if k > 0 else np.zeros(0)
+        tau = -1.0 + 2.0 * p.sum()
+        tau = max(tau, 1.0 / np.log10(C * n))
+        out[j] = C * n / tau
+    return out
+
+
 def _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed):
     from . import _native as N
 

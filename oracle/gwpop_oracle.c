@@ -11,7 +11,11 @@
  * Only tests/, __graft_entry__ and bench.py's cpu_baseline leg may load it; the product never does.
  *
  * Scalar straight-line code on purpose: one sample at a time, libm transcendentals, a running
- * maximum with rescaling -- no relation to the GPU kernels' organisation.
+ * maximum with rescaling -- no relation to the GPU kernels' organisation.  Parallelism (round 4): ONE OpenMP region over
+ * blocks of GWO_BLOCK consecutive samples -- (event, block) pairs and injection blocks alike, so that a 69-event catalog
+ * keeps 128 host threads busy -- each block reduced on its own and the blocks merged afterwards in block order (the result
+ * does not depend on the thread count).  A sample's d(log w)/d theta is kept as a short list of (index, value) pairs: a
+ * B-spline term touches four coefficients, not all n_theta.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -26,17 +30,34 @@
 
 #define NEG_BIG (-1.7976931348623157e308)
 
+#define GWO_BLOCK 512      /* samples per work unit; fixed, so that the summation order does not depend on the thread count */
+#define GWO_MAX_PAIRS 160  /* (index, value) pairs one sample can produce: 12 terms x (2 grid nodes x 4 taps) at most, + scalars */
+
 typedef struct {
   double m, s1, s2;
-  double g[GWI_MAX_THETA]; /* sum w dl/dtheta, in units of e^m */
-  double h[GWI_MAX_THETA]; /* sum w^2 dl/dtheta, in units of e^2m: the gradient of n_eff needs it (analysis.py:270-271) */
+  double* g; /* [n_theta] sum w dl/dtheta, in units of e^m */
+  double* h; /* [n_theta] sum w^2 dl/dtheta, in units of e^2m (analysis.py:270-271: the gradient of n_eff needs it), or NULL */
 } acc_t;
 
-static void acc_init(acc_t* a) {
+typedef struct {
+  int n;
+  int idx[GWO_MAX_PAIRS];
+  double val[GWO_MAX_PAIRS];
+} pairs_t;
+
+static inline void push(pairs_t* d, int i, double v) {
+  d->idx[d->n] = i;
+  d->val[d->n] = v;
+  d->n++;
+}
+
+static void acc_init(acc_t* a, double* g, double* h, int n_theta) {
   a->m = -INFINITY;
   a->s1 = a->s2 = 0.0;
-  memset(a->g, 0, sizeof(a->g));
-  memset(a->h, 0, sizeof(a->h));
+  a->g = g;
+  a->h = h;
+  memset(g, 0, sizeof(double) * n_theta);
+  if (h) memset(h, 0, sizeof(double) * n_theta);
 }
 
 static void acc_rescale(acc_t* a, double new_m, int n_theta) {
@@ -48,7 +69,8 @@ static void acc_rescale(acc_t* a, double new_m, int n_theta) {
   a->s1 *= sc;
   a->s2 *= sc * sc;
   for (int p = 0; p < n_theta; ++p) a->g[p] *= sc;
-  for (int p = 0; p < n_theta; ++p) a->h[p] *= sc * sc;
+  if (a->h)
+    for (int p = 0; p < n_theta; ++p) a->h[p] *= sc * sc;
   a->m = new_m;
 }
 
@@ -59,7 +81,8 @@ static void acc_merge(acc_t* dst, const acc_t* src, int n_theta) {
   dst->s1 += f * src->s1;
   dst->s2 += f * f * src->s2;
   for (int p = 0; p < n_theta; ++p) dst->g[p] += f * src->g[p];
-  for (int p = 0; p < n_theta; ++p) dst->h[p] += f * f * src->h[p];
+  if (dst->h)
+    for (int p = 0; p < n_theta; ++p) dst->h[p] += f * f * src->h[p];
 }
 
 static void pl_lognorm(double alpha, double lo, double hi, double* la, double* dla) {
@@ -103,7 +126,8 @@ static int locate(double x, double lo, double hi, int n_basis, double* t) {
 }
 
 /* log weight (without sample-independent constants) and d(log weight)/d theta of ONE sample */
-static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t idx, const double* th, const double (*der)[8], double* d) {
+static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t idx, const double* th, const double (*der)[8], pairs_t* d) {
+  d->n = 0;
   double ell = cols[sp->kappa_col][idx];
   for (int t = 0; t < sp->n_terms && ell > -INFINITY; ++t) {
     const gwi_term* tm = &sp->terms[t];
@@ -112,7 +136,7 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
     switch (tm->kind) {
       case GWI_TERM_POWERLAW:
         ell += th[tm->theta[0]] * x0;
-        d[tm->theta[0]] += x0;
+        push(d, tm->theta[0], x0);
         break;
       case GWI_TERM_PLPEAK: { /* one column: log x (include/gwi_engine.h); x0 below is x = exp(log x) */
         const double lx = x0_raw;
@@ -120,17 +144,17 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         const double epl = exp(al * lx + der[t][0]), etn = exp(-0.5 * (x0 - mu) * (x0 - mu) / (sg * sg) + der[t][2]);
         const double P = (1.0 - lam) * epl, T = lam * etn, p = P + T;
         ell += log(p);
-        d[tm->theta[0]] += P * (lx + der[t][1]) / p;
-        d[tm->theta[1]] += T * ((x0 - mu) / (sg * sg) + der[t][3]) / p;
-        d[tm->theta[2]] += T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p;
-        d[tm->theta[3]] += (etn - epl) / p;
+        push(d, tm->theta[0], P * (lx + der[t][1]) / p);
+        push(d, tm->theta[1], T * ((x0 - mu) / (sg * sg) + der[t][3]) / p);
+        push(d, tm->theta[2], T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p);
+        push(d, tm->theta[3], (etn - epl) / p);
         break;
       }
       case GWI_TERM_SMOOTH: { /* distributions.py:16-21: 1/(1+exp(d/y + d/(y-d))) for every y = x - xmin */
         const double dl = th[tm->theta[0]], y = x0;
         const double S = 1.0 / (1.0 + exp(dl / y + dl / (y - dl)));
         ell += log(S);
-        d[tm->theta[0]] += -(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl)));
+        push(d, tm->theta[0], -(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl))));
         break;
       }
       case GWI_TERM_PLPEAK_SMOOTH: { /* parametric.py:49-53 with delta; coef_off = theta index of delta */
@@ -141,30 +165,33 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         const double epl = exp(al * lx + der[t][0]) * S, etn = exp(-0.5 * (x0 - mu) * (x0 - mu) / (sg * sg) + der[t][2]);
         const double P = (1.0 - lam) * epl, T = lam * etn, p = P + T;
         ell += log(p);
-        d[tm->theta[0]] += P * (lx + der[t][1]) / p;
-        d[tm->theta[1]] += T * ((x0 - mu) / (sg * sg) + der[t][3]) / p;
-        d[tm->theta[2]] += T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p;
-        d[tm->theta[3]] += (etn - epl) / p;
-        d[tm->coef_off] += P * (-(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl)))) / p;
+        push(d, tm->theta[0], P * (lx + der[t][1]) / p);
+        push(d, tm->theta[1], T * ((x0 - mu) / (sg * sg) + der[t][3]) / p);
+        push(d, tm->theta[2], T * ((x0 - mu) * (x0 - mu) / (sg * sg * sg) + der[t][4]) / p);
+        push(d, tm->theta[3], (etn - epl) / p);
+        push(d, tm->coef_off, P * (-(1.0 - S) * (1.0 / y + y / ((y - dl) * (y - dl)))) / p);
         break;
       }
       case GWI_TERM_POWERLAW_RATIO: {
+        /* cols[1] = log m1.  Under GWI_RATIO_LOGM_FROM_SPLINE it is the coordinate column of the model's m1 spline, which on
+         * the HOST side -- what this checker is handed -- holds that spline's coordinate x = log m1 itself (only the device
+         * copy is converted to knot coordinates, gwi_engine.hip: spline_knot_kernel): the same read either way. */
         const double lr = tm->p[0] - cols[tm->cols[1]][idx], beta = th[tm->theta[0]], b1 = 1.0 + beta;
         if (b1 == 0.0) {
           ell += -x0 - log(-lr);
-          d[tm->theta[0]] += x0 - 0.5 * lr;
+          push(d, tm->theta[0], x0 - 0.5 * lr);
         } else {
           const double E = exp(b1 * lr);
           ell += beta * x0 + log(b1 / (1.0 - E));
-          d[tm->theta[0]] += x0 + 1.0 / b1 + E * lr / (1.0 - E);
+          push(d, tm->theta[0], x0 + 1.0 / b1 + E * lr / (1.0 - E));
         }
         break;
       }
       case GWI_TERM_BETA: {
         const double l1 = cols[tm->cols[1]][idx];
         ell += (th[tm->theta[0]] - 1.0) * x0 + (th[tm->theta[1]] - 1.0) * l1;
-        d[tm->theta[0]] += x0;
-        d[tm->theta[1]] += l1;
+        push(d, tm->theta[0], x0);
+        push(d, tm->theta[1], l1);
         break;
       }
       case GWI_TERM_TILT_MIXTURE: {
@@ -172,8 +199,8 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         const double e = exp(-0.5 * (x0 - 1.0) * (x0 - 1.0) / (sg * sg) + der[t][0]);
         const double p = 0.5 * (1.0 - xi) + xi * e;
         ell += log(p);
-        d[tm->theta[0]] += (e - 0.5) / p;
-        d[tm->theta[1]] += xi * e * ((x0 - 1.0) * (x0 - 1.0) / (sg * sg * sg) + der[t][1]) / p;
+        push(d, tm->theta[0], (e - 0.5) / p);
+        push(d, tm->theta[1], xi * e * ((x0 - 1.0) * (x0 - 1.0) / (sg * sg * sg) + der[t][1]) / p);
         break;
       }
       case GWI_TERM_TILT_JOINT: {
@@ -182,20 +209,20 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         const double A = exp(-0.5 * r2 / (sg * sg) + 2.0 * der[t][0]);
         const double p = 0.25 * (1.0 - xi) + xi * A;
         ell += log(p);
-        d[tm->theta[0]] += (A - 0.25) / p;
-        d[tm->theta[1]] += xi * A * (r2 / (sg * sg * sg) + 2.0 * der[t][1]) / p;
+        push(d, tm->theta[0], (A - 0.25) / p);
+        push(d, tm->theta[1], xi * A * (r2 / (sg * sg * sg) + 2.0 * der[t][1]) / p);
         break;
       }
       case GWI_TERM_TRUNCNORM: {
         const double mu = th[tm->theta[0]], sg = th[tm->theta[1]];
         ell += -0.5 * (x0 - mu) * (x0 - mu) / (sg * sg);
-        d[tm->theta[0]] += (x0 - mu) / (sg * sg);
-        d[tm->theta[1]] += (x0 - mu) * (x0 - mu) / (sg * sg * sg);
+        push(d, tm->theta[0], (x0 - mu) / (sg * sg));
+        push(d, tm->theta[1], (x0 - mu) * (x0 - mu) / (sg * sg * sg));
         break;
       }
       case GWI_TERM_POWERLAW_REDSHIFT:
         ell += (th[tm->theta[0]] - 1.0) * x0;
-        d[tm->theta[0]] += x0;
+        push(d, tm->theta[0], x0);
         break;
       case GWI_TERM_POWERLAW_BOUNDS: { /* numpyro_distributions.py:127-136: -inf outside [minimum, maximum] (bounds included) */
         const double xv = cols[tm->cols[1]][idx];
@@ -204,7 +231,7 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
           break;
         }
         ell += th[tm->theta[0]] * x0;
-        d[tm->theta[0]] += x0;
+        push(d, tm->theta[0], x0);
         break;
       }
       case GWI_TERM_EXP_SPLINE_LERP: { /* numpyro_distributions.py:273, :296-301: interp(value, grid, cs . grid_dmat) */
@@ -228,7 +255,7 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
           taps(tt, b);
           const double* c = th + tm->coef_off + k;
           val += wts[e] * (c[0] * b[0] + c[1] * b[1] + c[2] * b[2] + c[3] * b[3]);
-          for (int q = 0; q < 4; ++q) d[tm->coef_off + k + q] += wts[e] * b[q];
+          for (int q = 0; q < 4; ++q) push(d, tm->coef_off + k + q, wts[e] * b[q]);
         }
         if (ell > -INFINITY) ell += val;
         break;
@@ -244,14 +271,14 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
         if (tm->kind == GWI_TERM_EXP_SPLINE) {
           if ((tm->flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT) && !inside) break; /* basis 0 outside: factor 1 */
           ell += v;
-          for (int j = 0; j < 4; ++j) d[tm->coef_off + k + j] += b[j];
+          for (int j = 0; j < 4; ++j) push(d, tm->coef_off + k + j, b[j]);
         } else {
           if (!inside || !(v > 0.0)) {
             ell = -INFINITY;
             break;
           }
           ell += log(v);
-          for (int j = 0; j < 4; ++j) d[tm->coef_off + k + j] += b[j] / v;
+          for (int j = 0; j < 4; ++j) push(d, tm->coef_off + k + j, b[j] / v);
         }
         break;
       }
@@ -262,20 +289,20 @@ static double sample_logw(const gwi_spec* sp, const double* const* cols, int64_t
   return ell;
 }
 
+/* one block of consecutive samples reduced on its own (running maximum with rescaling) */
 static void scan_range(const gwi_spec* sp, const double* const* cols, int64_t lo, int64_t hi, const double* th, const double (*der)[8], acc_t* out) {
   const int n_theta = sp->n_theta;
-  acc_init(out);
-  double d[GWI_MAX_THETA];
+  pairs_t d;
   for (int64_t i = lo; i < hi; ++i) {
-    memset(d, 0, sizeof(double) * n_theta);
-    const double ell = sample_logw(sp, cols, i, th, der, d);
+    const double ell = sample_logw(sp, cols, i, th, der, &d);
     if (ell == -INFINITY) continue;
     if (ell > out->m) acc_rescale(out, ell, n_theta);
     const double w = exp(ell - out->m);
     out->s1 += w;
     out->s2 += w * w;
-    for (int p = 0; p < n_theta; ++p) out->g[p] += w * d[p];
-    for (int p = 0; p < n_theta; ++p) out->h[p] += w * w * d[p];
+    for (int k = 0; k < d.n; ++k) out->g[d.idx[k]] += w * d.val[k];
+    if (out->h)
+      for (int k = 0; k < d.n; ++k) out->h[d.idx[k]] += w * w * d.val[k];
   }
 }
 
@@ -351,12 +378,35 @@ int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
-  /* events in parallel; injections in parallel chunks merged in chunk order */
-  double* ev = (double*)malloc(sizeof(double) * (size_t)n_ev * (3 + n_theta));
-#pragma omp parallel for schedule(dynamic, 1)
+  /* ONE parallel region over blocks of GWO_BLOCK samples: blocks [0, n_ev * nb_pe) are (event, block) pairs, the rest injection
+   * blocks; then a fixed-order merge per event (parallel over events) and over the injection blocks (serial: a few hundred
+   * records).  h (sum w^2 dl) only when the marginalised selection term needs it. */
+  const int need_h = opt->marginalize_selection && grad;
+  const int64_t nb_pe = (n_pe + GWO_BLOCK - 1) / GWO_BLOCK, nb_inj = (n_inj + GWO_BLOCK - 1) / GWO_BLOCK;
+  const int64_t n_units = n_ev * nb_pe + nb_inj;
+  const size_t stride = (size_t)n_theta * (need_h ? 2 : 1);
+  acc_t* units = (acc_t*)malloc(sizeof(acc_t) * (size_t)(n_units ? n_units : 1));
+  double* slab = (double*)malloc(sizeof(double) * stride * (size_t)(n_units ? n_units : 1));
+#pragma omp parallel for schedule(dynamic, 2)
+  for (int64_t u = 0; u < n_units; ++u) {
+    double* g = slab + (size_t)u * stride;
+    acc_init(&units[u], g, need_h ? g + n_theta : NULL, n_theta);
+    if (u < n_ev * nb_pe) {
+      const int64_t e = u / nb_pe, b = u - e * nb_pe;
+      const int64_t lo = e * n_pe + b * GWO_BLOCK, hi = e * n_pe + ((b + 1) * GWO_BLOCK < n_pe ? (b + 1) * GWO_BLOCK : n_pe);
+      scan_range(sp, pe_cols, lo, hi, th, der, &units[u]);
+    } else {
+      const int64_t b = u - n_ev * nb_pe;
+      scan_range(sp, inj_cols, b * GWO_BLOCK, (b + 1) * GWO_BLOCK < n_inj ? (b + 1) * GWO_BLOCK : n_inj, th, der, &units[u]);
+    }
+  }
+  double* ev = (double*)malloc(sizeof(double) * (size_t)(n_ev ? n_ev : 1) * (3 + n_theta));
+#pragma omp parallel for schedule(static)
   for (int64_t e = 0; e < n_ev; ++e) {
+    double gbuf[2 * GWI_MAX_THETA];
     acc_t a;
-    scan_range(sp, pe_cols, e * n_pe, (e + 1) * n_pe, th, der, &a);
+    acc_init(&a, gbuf, NULL, n_theta);
+    for (int64_t b = 0; b < nb_pe; ++b) acc_merge(&a, &units[e * nb_pe + b], n_theta); /* block order */
     double* row = ev + e * (3 + n_theta);
     const double log_s1 = log(a.s1);
     row[0] = log_s1 + a.m;                 /* logsumexp */
@@ -364,14 +414,12 @@ int gwo_eval(const gwi_spec* sp, const double* const* pe_cols, int64_t n_ev, int
     row[2] = 1.0 / exp(row[1]) - 1.0 / (double)n_pe;
     for (int p = 0; p < n_theta; ++p) row[3 + p] = a.s1 > 0.0 ? a.g[p] / a.s1 : 0.0;
   }
-  const int n_chunks = 64;
-  acc_t* parts = (acc_t*)malloc(sizeof(acc_t) * n_chunks);
-#pragma omp parallel for schedule(static)
-  for (int c = 0; c < n_chunks; ++c) scan_range(sp, inj_cols, n_inj * c / n_chunks, n_inj * (c + 1) / n_chunks, th, der, &parts[c]);
+  double inj_g[GWI_MAX_THETA], inj_h[GWI_MAX_THETA];
   acc_t inj;
-  acc_init(&inj);
-  for (int c = 0; c < n_chunks; ++c) acc_merge(&inj, &parts[c], n_theta);
-  free(parts);
+  acc_init(&inj, inj_g, need_h ? inj_h : NULL, n_theta);
+  for (int64_t b = 0; b < nb_inj; ++b) acc_merge(&inj, &units[n_ev * nb_pe + b], n_theta);
+  free(units);
+  free(slab);
 
   /* assembly: analysis.py:259-319 */
   const double n_obs = opt->n_obs, n_tot = opt->total_inj;

@@ -78,7 +78,7 @@ def test_invalid_programs_are_rejected_not_run():
     good = E.compile_program([E.log(E.Sym.src(x))])
     st, keep = N.ingest_program(good)
     assert lib.gwi_ingest_columns(C.byref(st), 64, 1, ptrs, -1) == 0 and np.allclose(out[1:], np.log(x[1:]), rtol=1e-15)
-    for breakage in ("reg", "source", "nostore", "opcode"):
+    for breakage in ("reg", "source", "nostore", "opcode", "readfirst"):
         prog = E.compile_program([E.log(E.Sym.src(x))])
         ops = list(prog.ops)
         if breakage == "reg":
@@ -87,6 +87,8 @@ def test_invalid_programs_are_rejected_not_run():
             ops[0] = (E.ING_LOAD, 0, 5, 0, 0, 0.0)                  # source index out of range
         elif breakage == "nostore":
             ops = ops[:-1]                                           # column 0 never stored
+        elif breakage == "readfirst":
+            ops = [ops[1], ops[0]] + ops[2:]                         # the logarithm reads its register before the LOAD has written it
         else:
             ops[1] = (99, ops[1][1], ops[1][2], 0, 0, 0.0)
         prog.ops = ops
@@ -250,3 +252,31 @@ def test_log_m1_from_the_mass_spline_column(monkeypatch):
         assert np.allclose(a.log_bfs, b.log_bfs, rtol=0, atol=1e-11) and np.allclose(a.grad, b.grad, rtol=1e-10, atol=1e-10 * np.max(np.abs(b.grad)))
     folded.close()
     plain.close()
+
+
+def test_oversized_setup_program_falls_back_to_the_host_path(monkeypatch):
+    """A setup program beyond the ingest kernel's register file: the default (auto) setup computes the columns on the host
+    instead, with a warning, and gives the device path's results; an explicit device_setup=True raises."""
+    import warnings
+
+    from gwinferno_amd import expr as E
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(5, 200, 3000, seed=17)
+    ref = COMPOSITIONS["bspline_test"](pe, inj)
+    eng_ref = ref.engine()
+    th = ref.theta(draw_params("bspline_test", np.random.default_rng(2)))
+    want = eng_ref.evaluate(th, total, min_neff_cut=False)
+    assert eng_ref.device_setup
+    monkeypatch.setattr(E, "MAX_REGS", 4)
+    with pytest.raises(ValueError):
+        COMPOSITIONS["bspline_test"](pe, inj).engine(device_setup=True)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        eng = COMPOSITIONS["bspline_test"](pe, inj).engine()
+    assert not eng.device_setup and any("computing the catalog columns on the host" in str(w.message) for w in caught)
+    got = eng.evaluate(th, total, min_neff_cut=False)
+    assert abs(got.log_likelihood - want.log_likelihood) <= 1e-12 * abs(want.log_likelihood)
+    eng.close()
+    eng_ref.close()

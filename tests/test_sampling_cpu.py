@@ -175,3 +175,20 @@ def test_find_map_climbs_to_the_mode_and_backs_off_a_wall():
     assert 0.9 < out["x"][0] <= 1.0 and abs(out["x"][1]) < 0.1 and out["log_prob"] > -0.14  # stops at the wall, short of the (excluded) mode
     with pytest.raises(ValueError):
         find_map(walled, np.array([2.0, 0.0]))
+
+
+def test_effective_sample_size_of_known_processes():
+    """i.i.d. draws: ESS ~ number of draws; AR(1) with coefficient phi: ESS ~ N (1 - phi) / (1 + phi); a pinned column: NaN."""
+    from gwinferno_amd.sampling import effective_sample_size
+
+    rng = np.random.default_rng(0)
+    iid = effective_sample_size(rng.normal(size=(4, 1000, 2)))
+    assert np.all(iid > 2500) and np.all(iid < 5500)
+    phi = 0.9
+    y = np.zeros((4, 4000, 1))
+    e = rng.normal(size=y.shape)
+    for t in range(1, 4000):
+        y[:, t] = phi * y[:, t - 1] + e[:, t]
+    want = 4 * 4000 * (1 - phi) / (1 + phi)
+    assert abs(effective_sample_size(y)[0] / want - 1) < 0.25
+    assert np.isnan(effective_sample_size(np.ones((2, 100, 1)))[0])
