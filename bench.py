@@ -751,6 +751,15 @@ def reference_priors(comp_name, comp, n_theta):
             prior.normal(sl[key], 5.0).smoothing(sl[key], 25.0, 2)
         prior.normal(sl["beta"], 5.0).normal(sl["lamb"], 3.0)
         return prior, bij, "pipeline/utils.py:163-208 (IID spins): N(0,15) m1 tau 1, N(0,5) spins tau 25 degree 2; beta N(0,5), lamb N(0,3)"
+    if comp_name == "plpeak":
+        # examples/simple_powerlaw_peak_example.py:52-56, :77: beta, alpha ~ Normal(0, 5); mu_peak ~ Uniform(mmin, mmax);
+        # sig_peak ~ HalfNormal(10); lambda_m ~ Uniform(0, 1); lamb ~ Normal(0, 5) -- sampled through the bijections numpyro's
+        # biject_to(support) applies to those sites (logistic map onto the interval, exp onto the positive axis)
+        prior, bij = GaussianSmoothingPrior(n_theta), Bijector(n_theta)
+        prior.normal(sl["alpha"], 5.0).normal(sl["beta"], 5.0).normal(sl["sigpp"], 10.0).normal(sl["lamb"], 5.0)
+        bij.interval(sl["mpp"], float(comp.mmin), float(comp.mmax)).positive(sl["sigpp"]).interval(sl["lam"], 0.0, 1.0)
+        return prior, bij, ("examples/simple_powerlaw_peak_example.py:52-56, :77: alpha, beta ~ N(0,5), mu_peak ~ U(mmin, mmax), sig_peak ~ HalfNormal(10), "
+                            "lambda_m ~ U(0,1), lamb ~ N(0,5), through numpyro's support bijections")
     return GaussianSmoothingPrior(n_theta).normal(slice(0, n_theta), 10.0), None, "Normal(0, 10) on every parameter"
 
 
