@@ -22,10 +22,11 @@ constexpr int kBlock = 256;            // 4 wavefronts of 64
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxDerived = 7;          // PLPEAK uses d0..d6; 7 keeps KArgs with 256 hyper-parameters inside 4 KiB
 constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerators in a record
+constexpr int kRegularRepShiftC = 4;   // log2 of the replicas per gradient row in the regular scan kernels (= kRegularRepShift below)
 
 struct TermD {
   int kind, n_basis;
-  int th0, th1, th2, th3;  // EXP_SPLINE: th0 = coef_off
+  int th0, th1, th2, th3;  // EXP_SPLINE / LINEAR_SPLINE: th0 = coef_off, th1 = first gradient row of the term, th2 = log2 of its row groups (spline_scatter)
   int flags, th4;     // th4: fifth hyper-parameter (PLPEAK_SMOOTH: delta)
   double p0, p1, p2;  // spline kinds: lo, hi, 1/dx of the spline coordinate
   double p3;          // spline kinds: number of knot intervals, n_basis - 3 (the closed domain in knot coordinates is [0, p3])
@@ -97,6 +98,7 @@ struct KArgs {
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
   int gacc_rep, gacc_shift;  // spline-gradient LDS rows: replicas per coefficient (power of two <= 64) and log2 of it
+  int n_grad_rows, pad0;     // regular scan kernels: rows of 16 replicas in the workgroup's gradient area: n_theta + the extra rows of terms with row groups (TermD::th2)
   double* norm_out_host;               // pinned host: Z_j of hyper-parameter point k at [k * n_norms + j]
   unsigned long long* norm_stamps_host;  // pinned host: completion stamp per (k, j)
   unsigned long long* seq_dev;            // device word: the scan publishes norm_seq here for the tail launches
@@ -298,6 +300,37 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
   r.b3 = t2 * (t * w6);
   return r;
 }
+// The same with w/6 and 2w/3 handed in -- they are the SAME for every spline term of a sample, but each term's block sits
+// behind its own exec-mask branch, across which the compiler does not share them -- and the inner taps formed from the
+// outer ones, b1 = 2/3 - t^2 + t^3/2 = 2/3 - t^2 + 3 b3:  w b1 = fma(3, w b3, fma(-w, t^2, 2w/3)): 11 vector instructions per
+// term instead of 14 + the w/6 multiply.  (Cancellation is benign: the three addends are O(w), the result >= w/6.)
+struct Weight {
+  double w, w6, w23;
+};
+__device__ __forceinline__ Weight make_weight(double w) {
+  Weight r;
+  r.w = w;
+  r.w6 = w * (1.0 / 6.0);
+  r.w23 = w * (2.0 / 3.0);
+  return r;
+}
+__device__ __forceinline__ Taps cubic_taps_weighted(double t, const Weight& ww) {
+#ifdef GWI_AB_OLD_TAPS
+  return cubic_taps_weighted(t, ww.w);
+#else
+#ifndef GWI_KEEP_TAPS
+  asm("" : "+v"(t));
+#endif
+  const double v = 1.0 - t;
+  const double t2 = t * t, v2 = v * v;
+  Taps r;
+  r.b3 = (ww.w6 * t) * t2;
+  r.b0 = (ww.w6 * v) * v2;
+  r.b1 = fma(3.0, r.b3, fma(-ww.w, t2, ww.w23));
+  r.b2 = fma(3.0, r.b0, fma(-ww.w, v2, ww.w23));
+  return r;
+#endif
+}
 // The spline VALUE in the local power basis: on knot interval k the uniform cubic B-spline sum is one cubic in t,
 //   sum_i c_{k+i} b_i(t) = A + B t + C t^2 + D t^3,   A = (c0 + 4 c1 + c2)/6, B = (c2 - c0)/2, C = (c0 - 2 c1 + c2)/2, D = (c3 - c0)/6 + (c1 - c2)/2,
 // tabulated per workgroup when theta is staged: four arrays A[], B[], C[], D[] indexed like the coefficients (position
@@ -306,7 +339,16 @@ __device__ __forceinline__ Taps cubic_taps_weighted(double t, double w) {
 // than the taps, profiles/round3/EXPERIMENTS.md section 8), and the constant stride lets one ds_read2st64_b64 fetch two of them.
 // A sample's value is then 3 FMAs instead of the four taps + dot product (15 vector instructions); the taps are only formed
 // once per sample, weighted, for the gradient rows.
+// The stride is deliberately NOT a multiple of 64 doubles: with 256 the compiler fuses the four reads of a sample into two
+// ds_read2st64_b64, which the LDS serves as two 4 x 16-lane accesses each (8 LDS cycles per instruction, 16 per term);
+// 257 keeps them four ds_read_b64 at immediate offsets (2 x 32 lanes, ~2.3 cycles each: 9 per term, conflict-free for any
+// mix of knot intervals -- neighbouring intervals are neighbouring 8-byte words).  The LDS pipe is what config 5 waits for
+// (SQ_WAIT_INST_LDS 24 % of its wave cycles in round 3): profiles/round4/EXPERIMENTS.md section 2.
+#ifdef GWI_AB_POLY_STRIDE_256
 constexpr int kPolyStride = GWI_MAX_THETA;
+#else
+constexpr int kPolyStride = GWI_MAX_THETA + 1;
+#endif
 __device__ __forceinline__ void spline_poly(double c0, double c1, double c2, double c3, double* out) {
   out[0] = (c0 + 4.0 * c1 + c2) * (1.0 / 6.0);
   out[kPolyStride] = (c2 - c0) * 0.5;
@@ -369,6 +411,9 @@ struct Ctx {
   double* gacc;                 // LDS gradient numerators [n_theta][rep] + this lane's replica: coefficient p lives at gacc[p << rep_shift]
   int rep_shift;
   const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
+  int lane_group;               // lane >> 4: which of the four 16-lane rows of the wavefront this lane sits in
+  bool row_groups;              // regular scan kernels: honour the terms' row groups (the SAFE instantiation keeps one row per coefficient)
+  mutable Weight wt;                // the weight of the sample being accumulated with w/6 and 2w/3 (set by the scan loop: shared by its spline terms)
 #ifdef GWI_ABL_SCATTER_TO_REG
   mutable double sink = 0.0;  // timing-only ablation: the weighted taps end up here instead of in the LDS rows
 #endif
@@ -402,8 +447,49 @@ __device__ __forceinline__ void spline_scatter(const Ctx& c, int first, const Ta
   c.sink += (b.b0 + b.b1) + (b.b2 + b.b3) + (double)first;
   return;
 #endif
+#ifdef GWI_ABL_ALL_REP64  // timing-only: every lane an address of its own (64 "replicas" that overlap the neighbouring rows): no two lanes of a wave instruction ever meet
+  double* g = c.gacc - (__lane_id() & 15) + __lane_id() + (first << c.rep_shift);
+#else
   double* g = c.gacc + (first << c.rep_shift);
+#endif
   const int step = 1 << c.rep_shift;
+  unsafeAtomicAdd(g, b.b0);
+  unsafeAtomicAdd(g + step, b.b1);
+  unsafeAtomicAdd(g + 2 * step, b.b2);
+  unsafeAtomicAdd(g + 3 * step, b.b3);
+}
+#ifdef GWI_ABL_Z_REP64  // timing-only: the same for zero-outside terms alone (the redshift spline of configs 5 / bspline_test)
+__device__ __forceinline__ void spline_scatter_rep64(const Ctx& c, int first, const Taps& b) {
+  double* g = c.gacc - (__lane_id() & 15) + __lane_id() + (first << c.rep_shift);
+  const int step = 1 << c.rep_shift;
+  unsafeAtomicAdd(g, b.b0);
+  unsafeAtomicAdd(g + step, b.b1);
+  unsafeAtomicAdd(g + 2 * step, b.b2);
+  unsafeAtomicAdd(g + 3 * step, b.b3);
+}
+#endif
+// ROW GROUPS (round 4).  The 16 replicas of a row are shared by the lanes l, l + 16, l + 32, l + 48 of a wavefront -- the
+// four 16-lane rows the LDS serves a ds_add_f64 in.  When those four samples fall into the SAME knot interval they meet
+// on one address, and the atomic pipe serialises them (measured: 8 LDS cycles per conflict-free wave instruction, 20 /
+// 44 with 2 / 4 lanes per address).  That is the rule, not the exception, for a quantity an event's posterior pins down to
+// one or two knot intervals (redshift; primary mass): config 5 spent 18 % of its LDS cycles in address conflicts.
+// A term with 2^gs row groups keeps 2^gs rows per coefficient -- row = base + (k << gs) + (lane_group & (2^gs - 1)) -- so
+// with gs = 2 every lane of a wave instruction has an address of its own whatever the data look like (16 replicas x 4
+// groups = 64 lanes).  gwi_create gives the groups to the terms whose samples collide most, as far as the LDS of the
+// resident workgroups allows (gwi_engine.hip: assign_row_groups); the rows are folded back per coefficient at the end.
+__device__ __forceinline__ void spline_scatter_grouped(const Ctx& c, int row_base, int gs, int k, const Taps& b) {
+#if defined(GWI_ABL_NO_SCATTER) || defined(GWI_ABL_SCATTER_TO_REG)
+  spline_scatter(c, row_base + k, b);
+  return;
+#endif
+  if (gs == 0) {  // wave-uniform: a scalar branch; one row per coefficient, the four taps at immediate offsets
+    asm volatile("");
+    spline_scatter(c, row_base + k, b);
+    return;
+  }
+  const int row = row_base + (k << gs) + (c.lane_group & ((1 << gs) - 1));
+  double* g = c.gacc + (row << kRegularRepShiftC);
+  const int step = (1 << kRegularRepShiftC) << gs;
   unsafeAtomicAdd(g, b.b0);
   unsafeAtomicAdd(g + step, b.b1);
   unsafeAtomicAdd(g + 2 * step, b.b2);
@@ -763,7 +849,17 @@ struct Term<GWI_TERM_EXP_SPLINE> {
     return v;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-    if (s.k >= 0 && w != 0.0) spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, w));
+    if (s.k >= 0 && w != 0.0) {  // c.wt.w == w
+      if (c.row_groups)
+        spline_scatter_grouped(c, t.th1, t.th2, s.k, cubic_taps_weighted(s.t, c.wt));
+      else
+#ifdef GWI_ABL_Z_REP64
+      if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT)
+        spline_scatter_rep64(c, t.th0 + s.k, cubic_taps_weighted(s.t, c.wt));
+      else
+#endif
+        spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, c.wt));
+    }
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
@@ -799,7 +895,12 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
     return 0.0;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-    if (w != 0.0) spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, w * s.inv_f));
+    if (w != 0.0) {
+      if (c.row_groups)
+        spline_scatter_grouped(c, t.th1, t.th2, s.k, cubic_taps_weighted(s.t, make_weight(w * s.inv_f)));
+      else
+        spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, make_weight(w * s.inv_f)));
+    }
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
@@ -1055,8 +1156,8 @@ struct Term<GWI_TERM_EXP_SPLINE_LERP> {
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
     if (w != 0.0) {
-      if (s.k0 >= 0) spline_scatter(c, t.th0 + s.k0, cubic_taps_weighted(s.t0, w * (1.0 - s.f)));
-      if (s.k1 >= 0) spline_scatter(c, t.th0 + s.k1, cubic_taps_weighted(s.t1, w * s.f));
+      if (s.k0 >= 0) spline_scatter(c, t.th0 + s.k0, cubic_taps_weighted(s.t0, make_weight(w * (1.0 - s.f))));
+      if (s.k1 >= 0) spline_scatter(c, t.th0 + s.k1, cubic_taps_weighted(s.t1, make_weight(w * s.f)));
     }
   }
   __device__ static void init(Acc&) {}
@@ -1208,6 +1309,7 @@ struct ChainImpl<U, false, kGenericChain> {
   __device__ void finish(int, int, const Ctx&, double&, double, int) {}
   __device__ void accumulate(int u, int, const Ctx& c, double w) {
     if (w == 0.0) return;
+    c.wt = make_weight(w);
     for (int t = 0; t < c.a->n_terms; ++t) {
       const TermD& td = c.a->terms[t];
       switch (td.kind) {
@@ -1566,7 +1668,8 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
 // carries kU samples (256 apart) per trip so polynomial constants, the wave maximum and the loop
 // overhead are shared between them.
 constexpr int kRedChunk = 8;
-constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular (non-SAFE) scan kernels  // values per pass of the block-level transposed reduction (16 KiB LDS)
+constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular (non-SAFE) scan kernels
+static_assert(kRegularRepShift == kRegularRepShiftC, "one constant, declared twice for the order of definitions");
 
 #ifndef GWI_SCAN_WAVES_PER_EU
 #define GWI_SCAN_WAVES_PER_EU 1
@@ -1648,7 +1751,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
   const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
   const int rep = 1 << rep_shift;
-  const int n_rows = a.n_theta << rep_shift;  // doubles in the shared rows
+  const int n_rows = SAFE ? (a.n_theta << rep_shift) : (a.n_grad_rows << kRegularRepShift);  // doubles in the shared rows
   if (kShared)
     for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
@@ -1663,6 +1766,12 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   ctx.poly = s_poly;
   ctx.gacc = s_gacc + (lane & (rep - 1));
   ctx.rep_shift = rep_shift;
+  ctx.lane_group = lane >> 4;
+#ifdef GWI_ROW_GROUPS
+  ctx.row_groups = !SAFE;
+#else
+  ctx.row_groups = false;  // compile-time: the grouped path and its per-term scalars (TermD::th1, th2) drop out of the kernel
+#endif
   double* logw;
   if (b < n_pe_blocks) {
     const int e = b / a.tiles_per_event;
@@ -1800,6 +1909,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
                 if (a.square) w *= w;
                 s1 += w;
                 s2 += w * w;
+                if (ChainT::kSpline) ctx.wt = make_weight(w);
                 chain.accumulate(u, 0, ctx, w);
               }
             }
@@ -1841,6 +1951,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
           if (a.square) w *= w;
           s1 += w;
           s2 += w * w;
+          if (ChainT::kSpline) ctx.wt = make_weight(w);
           chain.accumulate(u, 0, ctx, w);
         }
       }
@@ -1939,6 +2050,21 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       out[1] = has_sum ? ldexp(S1, -e_norm) : 0.0;
       out[2] = has_sum ? ldexp(S2, -2 * e_norm) : 0.0;
     }
+  }
+  // terms with row groups: their rows (2^gs per coefficient, behind the n_theta plain rows) are folded into s_out first
+  if (kShared && !SAFE && ctx.row_groups && a.n_grad_rows > a.n_theta) {  // workgroup-uniform
+    for (int t = 0; t < a.n_terms; ++t) {
+      const TermD& td = a.terms[t];
+      if ((td.kind != GWI_TERM_EXP_SPLINE && td.kind != GWI_TERM_LINEAR_SPLINE) || td.th2 == 0) continue;
+      const int per = (1 << td.th2) << kRegularRepShift;  // doubles per coefficient
+      for (int j = tid; j < td.n_basis; j += kBlock) {
+        const double* rows = s_gacc + ((long)(td.th1 + (j << td.th2)) << kRegularRepShift);
+        double gw = 0.0;
+        for (int r = 0; r < per; ++r) gw += rows[(r + j) & (per - 1)];  // rotated start: the threads of a wave read different banks
+        unsafeAtomicAdd(&s_out[td.th0 + j], gw);  // two terms may share their coefficients (IID spins)
+      }
+    }
+    __syncthreads();
   }
   // gradient numerators: scalar sums from s_out, spline-coefficient sums from the shared rows (replicas in fixed order)
   for (int p = tid; p < a.n_theta; p += kBlock) {

@@ -230,3 +230,21 @@ def test_host_callback_takes_batches_of_points():
     summ2, per_event2, grad2 = host(thetas.reshape(2, 3, -1))  # nested vmaps: two
     assert summ2.shape == (2, 3, len(L._SUMMARY_FIELDS)) and np.array_equal(summ2.reshape(6, -1), summ) and np.array_equal(grad2.reshape(6, -1), grad)
     assert per_event2.shape == (2, 3, 3, 6)
+
+
+def test_jax_check_command_reports_a_missing_jax(capsys):
+    """``python -m gwinferno_amd.jax_check`` on a box without JAX (this image): a JSON report that says so, exit status 2."""
+    import json
+
+    pytest.importorskip("numpy")
+    try:
+        import jax  # noqa: F401
+    except ImportError:
+        pass
+    else:
+        pytest.skip("a real JAX is importable here")
+    from gwinferno_amd import jax_check
+
+    assert jax_check.main([]) == 2
+    report = json.loads(capsys.readouterr().out)
+    assert "jax / numpyro not importable" in report["error"] and "python" in report
