@@ -22,11 +22,10 @@ constexpr int kBlock = 256;            // 4 wavefronts of 64
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxDerived = 7;          // PLPEAK uses d0..d6; 7 keeps KArgs with 256 hyper-parameters inside 4 KiB
 constexpr int kRecHeader = 3;          // m, S1, S2 precede the gradient numerators in a record
-constexpr int kRegularRepShiftC = 4;   // log2 of the replicas per gradient row in the regular scan kernels (= kRegularRepShift below)
 
 struct TermD {
   int kind, n_basis;
-  int th0, th1, th2, th3;  // EXP_SPLINE / LINEAR_SPLINE: th0 = coef_off, th1 = first gradient row of the term, th2 = log2 of its row groups (spline_scatter)
+  int th0, th1, th2, th3;  // EXP_SPLINE: th0 = coef_off
   int flags, th4;     // th4: fifth hyper-parameter (PLPEAK_SMOOTH: delta)
   double p0, p1, p2;  // spline kinds: lo, hi, 1/dx of the spline coordinate
   double p3;          // spline kinds: number of knot intervals, n_basis - 3 (the closed domain in knot coordinates is [0, p3])
@@ -98,7 +97,6 @@ struct KArgs {
   int n_ev, tiles_per_event, chunk_pe, n_inj_tiles, chunk_inj, n_norms;
   int n_terms, n_theta, kappa_col, rec_stride;
   int gacc_rep, gacc_shift;  // spline-gradient LDS rows: replicas per coefficient (power of two <= 64) and log2 of it
-  int n_grad_rows, pad0;     // regular scan kernels: rows of 16 replicas in the workgroup's gradient area: n_theta + the extra rows of terms with row groups (TermD::th2)
   double* norm_out_host;               // pinned host: Z_j of hyper-parameter point k at [k * n_norms + j]
   unsigned long long* norm_stamps_host;  // pinned host: completion stamp per (k, j)
   unsigned long long* seq_dev;            // device word: the scan publishes norm_seq here for the tail launches
@@ -411,8 +409,6 @@ struct Ctx {
   double* gacc;                 // LDS gradient numerators [n_theta][rep] + this lane's replica: coefficient p lives at gacc[p << rep_shift]
   int rep_shift;
   const double* const (*tcols)[2];  // per-term column pointers of the sample set this workgroup scans
-  int lane_group;               // lane >> 4: which of the four 16-lane rows of the wavefront this lane sits in
-  bool row_groups;              // regular scan kernels: honour the terms' row groups (the SAFE instantiation keeps one row per coefficient)
   mutable Weight wt;                // the weight of the sample being accumulated with w/6 and 2w/3 (set by the scan loop: shared by its spline terms)
 #ifdef GWI_ABL_SCATTER_TO_REG
   mutable double sink = 0.0;  // timing-only ablation: the weighted taps end up here instead of in the LDS rows
@@ -468,34 +464,6 @@ __device__ __forceinline__ void spline_scatter_rep64(const Ctx& c, int first, co
   unsafeAtomicAdd(g + 3 * step, b.b3);
 }
 #endif
-// ROW GROUPS (round 4).  The 16 replicas of a row are shared by the lanes l, l + 16, l + 32, l + 48 of a wavefront -- the
-// four 16-lane rows the LDS serves a ds_add_f64 in.  When those four samples fall into the SAME knot interval they meet
-// on one address, and the atomic pipe serialises them (measured: 8 LDS cycles per conflict-free wave instruction, 20 /
-// 44 with 2 / 4 lanes per address).  That is the rule, not the exception, for a quantity an event's posterior pins down to
-// one or two knot intervals (redshift; primary mass): config 5 spent 18 % of its LDS cycles in address conflicts.
-// A term with 2^gs row groups keeps 2^gs rows per coefficient -- row = base + (k << gs) + (lane_group & (2^gs - 1)) -- so
-// with gs = 2 every lane of a wave instruction has an address of its own whatever the data look like (16 replicas x 4
-// groups = 64 lanes).  gwi_create gives the groups to the terms whose samples collide most, as far as the LDS of the
-// resident workgroups allows (gwi_engine.hip: assign_row_groups); the rows are folded back per coefficient at the end.
-__device__ __forceinline__ void spline_scatter_grouped(const Ctx& c, int row_base, int gs, int k, const Taps& b) {
-#if defined(GWI_ABL_NO_SCATTER) || defined(GWI_ABL_SCATTER_TO_REG)
-  spline_scatter(c, row_base + k, b);
-  return;
-#endif
-  if (gs == 0) {  // wave-uniform: a scalar branch; one row per coefficient, the four taps at immediate offsets
-    asm volatile("");
-    spline_scatter(c, row_base + k, b);
-    return;
-  }
-  const int row = row_base + (k << gs) + (c.lane_group & ((1 << gs) - 1));
-  double* g = c.gacc + (row << kRegularRepShiftC);
-  const int step = (1 << kRegularRepShiftC) << gs;
-  unsafeAtomicAdd(g, b.b0);
-  unsafeAtomicAdd(g + step, b.b1);
-  unsafeAtomicAdd(g + 2 * step, b.b2);
-  unsafeAtomicAdd(g + 3 * step, b.b3);
-}
-
 // ---- term library --------------------------------------------------------------------------
 // A sample's weight is  w = L * exp(l - m):  each term either adds to the log part l (power laws,
 // splines: already exponents) or multiplies the linear part L (mixtures, the ratio normaliser:
@@ -850,9 +818,6 @@ struct Term<GWI_TERM_EXP_SPLINE> {
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
     if (s.k >= 0 && w != 0.0) {  // c.wt.w == w
-      if (c.row_groups)
-        spline_scatter_grouped(c, t.th1, t.th2, s.k, cubic_taps_weighted(s.t, c.wt));
-      else
 #ifdef GWI_ABL_Z_REP64
       if (t.flags & GWI_SPLINE_OUTSIDE_ZERO_EXPONENT)
         spline_scatter_rep64(c, t.th0 + s.k, cubic_taps_weighted(s.t, c.wt));
@@ -895,12 +860,7 @@ struct Term<GWI_TERM_LINEAR_SPLINE> {
     return 0.0;
   }
   __device__ static void accumulate(const TermD& t, const Ctx& c, double w, const State& s, Acc&) {
-    if (w != 0.0) {
-      if (c.row_groups)
-        spline_scatter_grouped(c, t.th1, t.th2, s.k, cubic_taps_weighted(s.t, make_weight(w * s.inv_f)));
-      else
-        spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, make_weight(w * s.inv_f)));
-    }
+    if (w != 0.0) spline_scatter(c, t.th0 + s.k, cubic_taps_weighted(s.t, make_weight(w * s.inv_f)));
   }
   __device__ static void init(Acc&) {}
   __device__ static void rescale(Acc&, double) {}
@@ -1669,7 +1629,6 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
 // overhead are shared between them.
 constexpr int kRedChunk = 8;
 constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular (non-SAFE) scan kernels
-static_assert(kRegularRepShift == kRegularRepShiftC, "one constant, declared twice for the order of definitions");
 
 #ifndef GWI_SCAN_WAVES_PER_EU
 #define GWI_SCAN_WAVES_PER_EU 1
@@ -1751,7 +1710,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
   const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
   const int rep = 1 << rep_shift;
-  const int n_rows = SAFE ? (a.n_theta << rep_shift) : (a.n_grad_rows << kRegularRepShift);  // doubles in the shared rows
+  const int n_rows = a.n_theta << rep_shift;  // doubles in the shared rows
   if (kShared)
     for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
   for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
@@ -1766,12 +1725,6 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   ctx.poly = s_poly;
   ctx.gacc = s_gacc + (lane & (rep - 1));
   ctx.rep_shift = rep_shift;
-  ctx.lane_group = lane >> 4;
-#ifdef GWI_ROW_GROUPS
-  ctx.row_groups = !SAFE;
-#else
-  ctx.row_groups = false;  // compile-time: the grouped path and its per-term scalars (TermD::th1, th2) drop out of the kernel
-#endif
   double* logw;
   if (b < n_pe_blocks) {
     const int e = b / a.tiles_per_event;
@@ -2050,21 +2003,6 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
       out[1] = has_sum ? ldexp(S1, -e_norm) : 0.0;
       out[2] = has_sum ? ldexp(S2, -2 * e_norm) : 0.0;
     }
-  }
-  // terms with row groups: their rows (2^gs per coefficient, behind the n_theta plain rows) are folded into s_out first
-  if (kShared && !SAFE && ctx.row_groups && a.n_grad_rows > a.n_theta) {  // workgroup-uniform
-    for (int t = 0; t < a.n_terms; ++t) {
-      const TermD& td = a.terms[t];
-      if ((td.kind != GWI_TERM_EXP_SPLINE && td.kind != GWI_TERM_LINEAR_SPLINE) || td.th2 == 0) continue;
-      const int per = (1 << td.th2) << kRegularRepShift;  // doubles per coefficient
-      for (int j = tid; j < td.n_basis; j += kBlock) {
-        const double* rows = s_gacc + ((long)(td.th1 + (j << td.th2)) << kRegularRepShift);
-        double gw = 0.0;
-        for (int r = 0; r < per; ++r) gw += rows[(r + j) & (per - 1)];  // rotated start: the threads of a wave read different banks
-        unsafeAtomicAdd(&s_out[td.th0 + j], gw);  // two terms may share their coefficients (IID spins)
-      }
-    }
-    __syncthreads();
   }
   // gradient numerators: scalar sums from s_out, spline-coefficient sums from the shared rows (replicas in fixed order)
   for (int p = tid; p < a.n_theta; p += kBlock) {

@@ -369,9 +369,6 @@ struct gwi_engine {
 
   size_t scan_lds_bytes = 0;
   int gacc_rep = 1;
-  int n_grad_rows = 0;                 // rows of 16 replicas in the regular scan kernels' gradient area (KArgs::n_grad_rows)
-  int row_group_shift[GWI_MAX_TERMS] = {0};  // log2 of the row groups of each term (spline terms; gwi_device.h: spline_scatter_grouped)
-  int row_base[GWI_MAX_TERMS] = {0};
   bool deterministic = false;   // GWI_DETERMINISTIC=1: replay mode of the shared gradient rows (scan_kernel)
   unsigned long long* d_seq = nullptr;                              // device words: [0] sequence number of the evaluation in flight, [1] redo request
   int* d_tile_nref = nullptr;   // spline models: every tile's reference exponent = its exact maximum at the previous evaluation (KArgs::tile_nref)
@@ -1318,97 +1315,6 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
   h->aql_note = "active";
 }
 
-// Row groups of the spline terms (gwi_device.h: spline_scatter_grouped): which terms get 2 or 4 rows per coefficient, within
-// the LDS that `wgs` resident workgroups per CU leave.  The need is measured on the catalog (collision_kernel: how many of
-// the four lanes that share a replica hold samples of one knot interval); the upgrades 1 -> 2 -> 4 groups are handed out
-// greedily by collisions removed per row spent.  GWI_ROW_GROUPS=0 switches the feature off, GWI_ROW_GROUP_WGS sets `wgs`
-// (default: what the registers allow, but not more than 4 -- the fifth resident workgroup measured nothing),
-// GWI_TERM_ROWGROUPS="0,0,2,..." (log2 per term, in the engine's term order) dictates the result.
-static void assign_row_groups(gwi_engine* h, const gwi_spec* spec, const std::vector<const double*>& u_pe, const std::vector<const double*>& u_inj, long long n_ev, long long n_pe,
-                              long long n_inj, size_t base_lds_without_rows, size_t lds_per_cu, int occ_regs) {
-  if (const char* env = std::getenv("GWI_ROW_GROUPS"))
-    if (std::atoi(env) == 0) return;
-  auto is_knot_term = [](const gwi_term& tm) { return tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE; };
-  const int n_terms = spec->n_terms;
-  int shift[GWI_MAX_TERMS] = {0};
-  bool dictated = false;
-  if (const char* env = std::getenv("GWI_TERM_ROWGROUPS")) {
-    dictated = true;
-    int t = 0;
-    for (const char* p = env; *p && t < n_terms; ++t) {
-      shift[t] = std::max(0, std::min(2, std::atoi(p)));
-      while (*p && *p != ',') ++p;
-      if (*p == ',') ++p;
-    }
-    for (int t2 = 0; t2 < n_terms; ++t2)
-      if (!is_knot_term(spec->terms[t2])) shift[t2] = 0;
-  } else {
-    int wgs = std::min(occ_regs, 4);
-    if (const char* env = std::getenv("GWI_ROW_GROUP_WGS")) wgs = std::max(1, std::atoi(env));
-    const size_t row_bytes = sizeof(double) << kRegularRepShift;
-    const size_t base = base_lds_without_rows + row_bytes * (size_t)spec->n_theta;
-    // never fewer resident workgroups than the plain layout reaches at this target
-    const size_t per_wg = lds_per_cu / (size_t)wgs;
-    if (per_wg <= base) return;
-    long budget = (long)((per_wg - base) / row_bytes);
-    unsigned long long* d_cnt = nullptr;
-    if (hipMalloc(&d_cnt, sizeof(unsigned long long) * 2 * GWI_MAX_TERMS) != hipSuccess) return;
-    (void)hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * 2 * GWI_MAX_TERMS, h->stream);
-    for (int t = 0; t < n_terms; ++t) {
-      if (!is_knot_term(spec->terms[t]) || !u_pe[t] || !u_inj[t]) continue;
-      const int n_int = spec->terms[t].n_basis - 3;
-      (void)collision_run(u_pe[t], n_pe, n_ev, n_int, d_cnt + 2 * t, h->stream);
-      (void)collision_run(u_inj[t], n_inj, 1, n_int, d_cnt + 2 * t, h->stream);
-    }
-    unsigned long long cnt[2 * GWI_MAX_TERMS] = {0};
-    const bool ok = hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
-    (void)hipFree(d_cnt);
-    if (!ok) return;
-    // a term is worth rows only if a noticeable share of its atomics collide: below ~0.3 colliding lanes per group of four
-    // (of at most 3) the conflict-free rate is what the instruction costs anyway
-    const double quads = (double)((n_pe / 64) * 16 * n_ev + (n_inj / 64) * 16);
-    if (std::getenv("GWI_ROW_GROUP_REPORT") && quads > 0) {
-      std::fprintf(stderr, "gwi: lanes meeting another on an address per group of four (1 row group / 2 row groups), budget %ld rows at %d workgroups per CU:", budget, wgs);
-      for (int t = 0; t < n_terms; ++t)
-        if (is_knot_term(spec->terms[t])) std::fprintf(stderr, " term %d: %.2f / %.2f", t, (double)cnt[2 * t] / quads, (double)cnt[2 * t + 1] / quads);
-      std::fprintf(stderr, "\n");
-    }
-    for (;;) {
-      int best = -1;
-      double best_ratio = 0.0;
-      for (int t = 0; t < n_terms; ++t) {
-        if (!is_knot_term(spec->terms[t]) || shift[t] >= 2) continue;
-        const double gain = shift[t] == 0 ? (double)cnt[2 * t] - (double)cnt[2 * t + 1] : (double)cnt[2 * t + 1];
-        const long cost = (long)spec->terms[t].n_basis * ((2 << shift[t]) - (1 << shift[t]));
-        if (cost > budget || quads <= 0 || gain / quads < 0.15) continue;
-        const double ratio = gain / (double)cost;
-        if (ratio > best_ratio) {
-          best_ratio = ratio;
-          best = t;
-        }
-      }
-      if (best < 0) break;
-      budget -= (long)spec->terms[best].n_basis * ((2 << shift[best]) - (1 << shift[best]));
-      ++shift[best];
-    }
-  }
-  int next = spec->n_theta;
-  for (int t = 0; t < n_terms; ++t) {
-    h->row_group_shift[t] = shift[t];
-    if (shift[t] > 0) {
-      h->row_base[t] = next;
-      next += spec->terms[t].n_basis << shift[t];
-    }
-  }
-  h->n_grad_rows = next;
-  if (std::getenv("GWI_ROW_GROUP_REPORT")) {
-    std::fprintf(stderr, "gwi: row groups%s:", dictated ? " (dictated)" : "");
-    for (int t = 0; t < n_terms; ++t)
-      if (is_knot_term(spec->terms[t])) std::fprintf(stderr, " term %d (n_basis %d): %d", t, spec->terms[t].n_basis, 1 << shift[t]);
-    std::fprintf(stderr, "; gradient rows %d (n_theta %d)\n", next, spec->n_theta);
-  }
-}
-
 // gwi_create / gwi_create_ingest: the columns either come from the host ready-made (pe_cols / inj_cols) or are computed
 // on the device from raw sources by the two setup programs (gwi_ingest.h)
 static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols, int64_t n_ev, int64_t n_pe, const double* const* inj_cols, int64_t n_inj,
@@ -1666,21 +1572,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + static_lds > lds_per_cu) rep >>= 1;
     const size_t poly_lds = 4 * sizeof(double) * (size_t)kPolyStride;  // the power-basis table of the spline values (gwi_device.h: spline_poly), behind the rows
     while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + poly_lds + static_lds > lds_per_cu) rep >>= 1;
-    // row groups of the regular kernels (16 replicas): see assign_row_groups below; the SAFE instantiation ignores them
-    h->n_grad_rows = spec->n_theta;
-    for (int t = 0; t < spec->n_terms; ++t) {
-      h->row_group_shift[t] = 0;
-      h->row_base[t] = spec->terms[t].coef_off;
-    }
-#ifdef GWI_ROW_GROUPS
-    if (rep == (1 << kRegularRepShift) && !h->generic) {
-      int occ_regs = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_regs, h->variant->scan, kBlock, 0) != hipSuccess || occ_regs < 1) occ_regs = 4;
-      assign_row_groups(h, spec, over_pe, over_inj, n_ev, n_pe, n_inj, static_lds + poly_lds, lds_per_cu, occ_regs);
-    }
-#endif
-    const size_t rows_regular = sizeof(double) * (size_t)h->n_grad_rows << kRegularRepShift, rows_safe = sizeof(double) * (size_t)spec->n_theta * rep;
-    scan_lds = (rows_regular > rows_safe ? rows_regular : rows_safe) + poly_lds;
+    scan_lds = sizeof(double) * (size_t)spec->n_theta * rep + poly_lds;
     if (scan_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a HIP launch (the AQL packets carry any size)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
@@ -1924,7 +1816,6 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
 #endif
   k.gacc_rep = rep;
   k.gacc_shift = __builtin_ctz((unsigned)rep);
-  k.n_grad_rows = h->n_grad_rows;
   k.seq_dev = h->d_seq;
   k.tile_nref = h->d_tile_nref;
   k.nref_stride = h->n_scan_blocks ? h->n_scan_blocks : 1;
@@ -1949,10 +1840,6 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     d.p3 = tm.p[3];
     d.th4 = tm.kind == GWI_TERM_PLPEAK_SMOOTH ? tm.coef_off : 0;
     if (tm.kind == GWI_TERM_EXP_SPLINE_LERP) d.th1 = tm.norm;  // the grid's spline coordinates live in that normaliser's `us`
-    if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE) {
-      d.th1 = h->row_base[t];          // first gradient row of the term (its coefficients' own rows, or extra rows behind them)
-      d.th2 = h->row_group_shift[t];   // log2 of its row groups
-    }
     if (tm.kind == GWI_TERM_EXP_SPLINE || tm.kind == GWI_TERM_LINEAR_SPLINE || tm.kind == GWI_TERM_EXP_SPLINE_LERP) {
       d.th0 = tm.coef_off;
       d.p2 = (double)(tm.n_basis - 3) / (tm.p[1] - tm.p[0]);  // 1/dx of the uniform knots (interpolation.py:100-101)

@@ -148,56 +148,6 @@ inline hipError_t spline_knot_run(const double* x, double* u, long long n, doubl
   return hipGetLastError();
 }
 
-// How often do the lanes l, l + 16, l + 32, l + 48 of a wavefront -- the four lanes that share a replica of a gradient row
-// (gwi_device.h: spline_scatter_grouped) -- hold samples of the SAME knot interval?  Counted once per catalog and spline term
-// over aligned blocks of 64 consecutive samples of every segment (an event's samples / the injections): out[0] += the lanes
-// that meet another one on an address with one row per coefficient (4 - distinct intervals among the four), out[1] += the
-// same with two row groups (lanes l, l + 32 and l + 16, l + 48 still share).  gwi_create hands the row groups to the terms
-// where this is largest.
-struct CollideArgs {
-  const double* u;  // knot coordinates of the term's column
-  long long seg_len, n_segs, blocks_per_seg, stride;
-  int n_int;
-  unsigned long long* out;  // [2]
-};
-__global__ __launch_bounds__(256) void collision_kernel(const CollideArgs a) {
-  unsigned c1 = 0, c2 = 0;
-  const long long total = a.n_segs * a.blocks_per_seg * 16;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += a.stride) {
-    const long long blk = idx >> 4, seg = blk / a.blocks_per_seg, b = blk - seg * a.blocks_per_seg;
-    const double* p = a.u + seg * a.seg_len + b * 64 + (idx & 15);
-    int k[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const double u = p[16 * g];
-      int kk = (u == u) ? (int)fmin(fmax(u, 0.0), (double)(a.n_int - 1)) : 0;
-      k[g] = kk;
-    }
-    const int same01 = k[0] == k[1], same02 = k[0] == k[2], same03 = k[0] == k[3], same12 = k[1] == k[2], same13 = k[1] == k[3], same23 = k[2] == k[3];
-    // distinct values among four: 4 - (lanes that repeat an earlier one)
-    const int rep1 = same01, rep2 = same02 | same12, rep3 = same03 | same13 | same23;
-    c1 += (unsigned)(rep1 + rep2 + rep3);
-    c2 += (unsigned)(same02 + same13);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    c1 += __shfl_xor(c1, o);
-    c2 += __shfl_xor(c2, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(a.out, (unsigned long long)c1);
-    atomicAdd(a.out + 1, (unsigned long long)c2);
-  }
-}
-inline hipError_t collision_run(const double* u, long long seg_len, long long n_segs, int n_int, unsigned long long* d_out, hipStream_t stream) {
-  const long long bps = seg_len / 64;
-  if (bps <= 0 || n_segs <= 0) return hipSuccess;
-  long long blocks = (n_segs * bps * 16 + 255) / 256;
-  if (blocks > 256LL * 16) blocks = 256LL * 16;
-  const CollideArgs a{u, seg_len, n_segs, bps, blocks * 256, n_int, d_out};
-  hipLaunchKernelGGL(collision_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  return hipGetLastError();
-}
-
 // Host side: validate, upload sources / tables / ops, run, release.  `d_out[c]` are device arrays of n doubles the
 // caller owns.  Returns GWI_OK or a status with `err` filled in.
 inline gwi_status ingest_check(std::string& err, const gwi_ingest_program* p, int n_cols) {
