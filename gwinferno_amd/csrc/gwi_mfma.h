@@ -39,6 +39,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kPts = 16;      // hyper-parameter points per wavefront (the N of the MFMA tile)
 
+// LDS reads of phase B go through a volatile pointer: left alone, the compiler pairs neighbouring 8-byte reads into
+// ds_read2_b64, which the LDS serves as two 4 x 16-lane accesses (8 cycles per instruction = half the rate of two ds_read_b64
+// at 2.3 each; MI355X_MICROARCH.md, LDS table), and this kernel's round is bound by the LDS pipe and the issue port in turn
+// (profiles/round3/EXPERIMENTS.md section 6): 29 ds_read2_b64 + 9 ds_read_b64 per round of config 5 -> 67 ds_read_b64.
+typedef const volatile double __attribute__((address_space(3))) * lds_ro;  // LDS address space spelled out: a volatile generic pointer would be read with flat loads
+
 // the tap of basis function `first + d` for a sample whose non-zero bases start at `first`: b_d for d in 0..3, else 0
 __device__ __forceinline__ double tap_select(const Taps& b, int d) {
   double v = 0.0;
@@ -70,8 +76,13 @@ struct Stage {  // every kind without spline coefficients: the term's column val
 #pragma unroll
     for (int i = 0; i < kDoubles; ++i) row[i] = src[i];
   }
-  __device__ static void b_rows(const double* row, Keep& kp) {
+  __device__ static void b_rows(const double* row_, Keep& kp) {
     double* dst = reinterpret_cast<double*>(&kp.in);
+#ifdef GWI_AB_MFMA_READ2
+    const double* row = row_;
+#else
+    lds_ro row = (lds_ro)row_;
+#endif
 #pragma unroll
     for (int i = 0; i < kDoubles; ++i) dst[i] = row[i];
   }
@@ -110,7 +121,12 @@ __device__ __forceinline__ void stage_spline(const TermD& t, double x, bool zero
   row[5] = b.b3;
   row[6] = 0.0;
 }
-__device__ __forceinline__ void spline_rows(const double* row, SplineKeep& kp) {
+__device__ __forceinline__ void spline_rows(const double* row_, SplineKeep& kp) {
+#ifdef GWI_AB_MFMA_READ2
+  const double* row = row_;
+#else
+  lds_ro row = (lds_ro)row_;
+#endif
   kp.k = __double2loint(row[0]);
 #ifdef GWI_ABL_NO_TAPREAD  // timing-only ablation: the taps not read from the staging row
   kp.b.b0 = kp.b.b1 = kp.b.b2 = kp.b.b3 = 0.25;
@@ -127,7 +143,11 @@ __device__ __forceinline__ void spline_coefs(const TermD& t, const Ctx& c, Splin
 #pragma unroll
   for (int i = 0; i < 4; ++i) kp.cf[i] = 1.0 + kp.k;
 #else
+#ifdef GWI_AB_MFMA_READ2
   const double* cf = c.coefs + t.th0 + kp.k;
+#else
+  lds_ro cf = (lds_ro)(c.coefs + t.th0 + kp.k);
+#endif
 #pragma unroll
   for (int i = 0; i < 4; ++i) kp.cf[i] = cf[i];
 #endif
