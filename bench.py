@@ -159,7 +159,13 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
 
     # thread count = the CPUs this process may use (one OpenMP region over (event, sample-block) pairs and injection
     # blocks keeps them all busy), unless a 3-repeat probe shows that fewer threads are faster; both are reported
-    probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16)})}
+    # (`avail` honours the container's CPU quota; the thread count the scheduler affinity alone would allow is probed too, so
+    # that the line shows what asking for every visible CPU gives on a box whose quota is smaller)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = avail
+    probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16), min(affinity, 256)})}
     cores = max(probe, key=probe.get)
     n, t_used = 0, 0.0
     while t_used < budget_s:
@@ -177,7 +183,8 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         "kind": "port",
         "sample": f"{n} value+gradient evals of the full catalog by the C/OpenMP oracle on {cores} threads ({t_used:.1f}s)",
         "threads_probe_evals_per_s": {str(k): v for k, v in probe.items()},
-        "at_all_usable_cpus": {"cores": avail, "evals_per_s": probe[avail]},
+        "at_all_usable_cpus": {"cores": avail, "evals_per_s": probe[avail], "what": "CPUs this process may use: scheduler affinity capped by the cgroup CPU quota"},
+        "at_affinity_count": {"cores": min(affinity, 256), "evals_per_s": probe[min(affinity, 256)]},
         "parallel_units": "blocks of 512 samples: (event, block) pairs and injection blocks in ONE OpenMP region, merged in block order (oracle/gwpop_oracle.c)",
         "single_thread_evals_per_s": 1.0 / t_single,
         "host": host_description(),
@@ -219,7 +226,13 @@ def host_description():
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = None
-    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable}
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "cgroup_cpu_quota": quota}
 
 
 _MEASURED_PEAK = {}

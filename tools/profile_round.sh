@@ -35,7 +35,7 @@ done
 cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_form.json 2> /dev/null
 # summarise on the box (the raw traces exceed what gpurun carries back) and keep only the summary
 unset GWI_BATCH_MFMA
-python3 tools/summarize_profiles.py ${ROUND:-round3} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
+python3 tools/summarize_profiles.py ${ROUND:-round4} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
 cp gpurun_out/prof/bench_driver_form.json gpurun_out/profile_summary/ 2>/dev/null
 rm -rf $R/gpurun_out/prof
 ls -la $R/gpurun_out/profile_summary
