@@ -38,6 +38,16 @@ namespace gwi {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kPts = 16;      // hyper-parameter points per wavefront (the N of the MFMA tile)
+// build knobs of the matrix-core kernel (A/B: profiles/round4/EXPERIMENTS.md section 7)
+#ifndef GWI_MFMA_STAGE
+#define GWI_MFMA_STAGE 32     // samples per wavefront and trip in the staging rows
+#endif
+#ifndef GWI_MFMA_FWD_GROUP
+#define GWI_MFMA_FWD_GROUP 4  // spline terms whose staged words and coefficients are in flight together in the forward half
+#endif
+#ifndef GWI_MFMA_WAVES
+#define GWI_MFMA_WAVES 2      // resident waves per SIMD the register allocation aims at
+#endif
 
 // LDS reads of phase B go through a volatile pointer: left alone, the compiler pairs neighbouring 8-byte reads into
 // ds_read2_b64, which the LDS serves as two 4 x 16-lane accesses (8 cycles per instruction = half the rate of two ds_read_b64
@@ -248,7 +258,7 @@ struct MChain<ROWS, KT, Rest...> {
   // spline term of the group its four coefficients (which needs k), then the arithmetic -- the LDS round trips of a group
   // overlap, and only one group's operands (16 registers per spline term) are live at a time (all seven terms of config 5 at
   // once: 256 registers and spills)
-  static constexpr int kFwdGroup = 4;
+  static constexpr int kFwdGroup = GWI_MFMA_FWD_GROUP;
   template <int N>
   __device__ void g_rows(const double* row) {
     if constexpr (N > 0) {
@@ -342,7 +352,7 @@ struct MChain<ROWS, KT, Rest...> {
 // sample-slot replicas (4, 2 or 1) of scan_rows_kernel's gradient rows
 __host__ __device__ inline size_t mfma_lds_doubles(int n_theta, int n_terms, int row_doubles, int rows_rep) {
   const size_t th_pad = (size_t)n_theta | 1, der_pad = (size_t)(n_terms * kMaxDerived) | 1;
-  const size_t S = rows_rep ? 16 : 32;
+  const size_t S = rows_rep ? 16 : GWI_MFMA_STAGE;
   size_t stage = (size_t)kWaves * S * (size_t)((row_doubles + 1) | 1);  // + kappa; odd stride
   if (rows_rep) {
     if (stage < 256) stage = 256;  // the scalar-sum staging of the epilogue aliases the rows
@@ -357,7 +367,7 @@ template <bool ROWS, int... KTs>
 __device__ __forceinline__ void scan_points_body(const KArgs& a) {
   using ChainT = MChain<ROWS, KTs...>;
   constexpr int kRow = ((ChainT::kRowDoubles + 1) | 1);  // doubles per staged sample (kappa first), odd
-  constexpr int kStageS = ROWS ? 16 : 32;                // samples per wavefront and trip (phase A lanes)
+  constexpr int kStageS = ROWS ? 16 : GWI_MFMA_STAGE;    // samples per wavefront and trip (phase A lanes)
   extern __shared__ double s_dyn[];
   __shared__ double s_mx[kWaves][64];
   __shared__ int s_enorm[kPts];
@@ -591,7 +601,7 @@ __device__ __forceinline__ void scan_points_body(const KArgs& a) {
 
 // the two instantiations of the body: gradient tiles on the matrix cores / gradient rows in LDS
 template <int U_UNUSED, int... KTs>
-__global__ __launch_bounds__(kBlock, 2) void scan_mfma_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, GWI_MFMA_WAVES) void scan_mfma_kernel(const KArgs a) {
   scan_points_body<false, KTs...>(a);
 }
 template <int U_UNUSED, int... KTs>

@@ -4,7 +4,9 @@
 // around one value_and_grad per leapfrog step.  This is the native counterpart for environments without
 // JAX/NumPyro, so that sampling runs at the engine's evaluation rate instead of a Python interpreter's:
 // multinomial NUTS with the generalised U-turn criterion (Betancourt 2017; the scheme of Stan / NumPyro),
-// dual-averaging step size (Hoffman & Gelman 2014, alg. 5) and one diagonal mass-matrix update in warm-up.
+// dual-averaging step size (Hoffman & Gelman 2014, alg. 5) and the windowed warm-up of Stan / NumPyro for the diagonal mass
+// matrix (an initial fast buffer, slow windows of doubling length each ending in a regularised variance estimate, a re-found
+// step size and a restarted dual averaging, a final fast buffer: warmup_schedule below).
 // gwinferno_amd/sampling.py holds the same algorithm in NumPy (the two are tested against the same targets).
 //
 //   gwi_nuts_run      any target given as a C callback (log-probability and gradient)
@@ -163,6 +165,39 @@ struct Sampler {
   }
 };
 
+// End indices (exclusive, in warm-up iterations) of the slow adaptation windows, and the first iteration of the slow phase:
+// Stan's schedule as NumPyro builds it (numpyro.infer.hmc_util.build_adaptation_schedule): 75 fast iterations, windows of
+// 25, 50, 100, ... (the last one stretched to the end of the slow phase), 50 fast iterations; shrunk to 15 % / 75 % / 10 % when
+// the warm-up is shorter than 150 iterations; no mass-matrix adaptation below 20.
+struct WarmupSchedule {
+  int slow_start = 0;
+  std::vector<int> window_end;
+};
+WarmupSchedule warmup_schedule(int n) {
+  WarmupSchedule w;
+  if (n < 20) {
+    w.slow_start = n;
+    return w;
+  }
+  int init = 75, term = 50, base = 25;
+  if (init + base + term > n) {
+    init = (int)(0.15 * n);
+    term = (int)(0.1 * n);
+    base = n - init - term;
+  }
+  w.slow_start = init;
+  const int slow_end = n - term;
+  int start = init, size = base;
+  while (start < slow_end) {
+    int end = start + size;
+    if (end + 2 * size > slow_end) end = slow_end;  // the next window would not fit: this one takes the rest
+    w.window_end.push_back(end);
+    start = end;
+    size *= 2;
+  }
+  return w;
+}
+
 int run_nuts(Target& t, const double* x0, const gwi_nuts_options& o, double* samples, double* logp, int32_t* tree_depth, gwi_nuts_result* res) {
   const int d = t.dim;
   Sampler s(t, o.seed);
@@ -177,7 +212,10 @@ int run_nuts(Target& t, const double* x0, const gwi_nuts_options& o, double* sam
   double mu = std::log(10 * eps), log_eps_bar = 0.0, h_bar = 0.0;
   const double gamma = 0.05, t0 = 10.0, kappa = 0.75;
   int da_count = 0;
-  std::vector<Vec> warm;
+  const WarmupSchedule sched = warmup_schedule(o.n_warmup);
+  size_t next_window = 0;
+  Vec w_mean(d, 0.0), w_m2(d, 0.0);  // Welford accumulators of the current slow window
+  int w_count = 0;
   double acc_sum = 0.0;
   int n_div = 0;
   const int max_depth = o.max_tree_depth > 0 ? o.max_tree_depth : 10;
@@ -230,22 +268,31 @@ int run_nuts(Target& t, const double* x0, const gwi_nuts_options& o, double* sam
       const double w = std::pow((double)da_count, -kappa);
       log_eps_bar = w * log_eps + (1 - w) * log_eps_bar;
       eps = std::exp(log_eps);
-      warm.push_back(cur.th);
-      if (m == (2 * o.n_warmup) / 3 && warm.size() > 20) {  // one diagonal mass-matrix update, then re-tune the step
-        const size_t first = warm.size() / 3, cnt = warm.size() - first;
+      if (it >= sched.slow_start && next_window < sched.window_end.size()) {  // slow phase: this draw feeds the window's variance
+        ++w_count;
         for (int i = 0; i < d; ++i) {
-          double mean = 0.0, var = 0.0;
-          for (size_t k = first; k < warm.size(); ++k) mean += warm[k][i];
-          mean /= cnt;
-          for (size_t k = first; k < warm.size(); ++k) var += (warm[k][i] - mean) * (warm[k][i] - mean);
-          var /= cnt;
-          s.inv_mass[i] = var > 1e-12 ? var : 1.0;
+          const double delta = cur.th[i] - w_mean[i];
+          w_mean[i] += delta / w_count;
+          w_m2[i] += delta * (cur.th[i] - w_mean[i]);
         }
-        eps = s.find_step_size(cur, std::exp(log_eps_bar));
-        mu = std::log(10 * eps);
-        log_eps_bar = 0.0;
-        h_bar = 0.0;
-        da_count = 0;
+        if (m == sched.window_end[next_window]) {  // end of a window: new metric, re-found step size, dual averaging restarted
+          if (w_count > 1)
+            for (int i = 0; i < d; ++i) {
+              const double var = w_m2[i] / (w_count - 1);
+              // Stan's shrinkage towards the unit metric: (n / (n + 5)) var + 1e-3 (5 / (n + 5))
+              const double reg = (w_count / (w_count + 5.0)) * var + 1e-3 * (5.0 / (w_count + 5.0));
+              s.inv_mass[i] = (std::isfinite(reg) && reg > 0.0) ? reg : 1.0;
+            }
+          std::fill(w_mean.begin(), w_mean.end(), 0.0);
+          std::fill(w_m2.begin(), w_m2.end(), 0.0);
+          w_count = 0;
+          ++next_window;
+          eps = s.find_step_size(cur, std::exp(log_eps_bar));
+          mu = std::log(10 * eps);
+          log_eps_bar = 0.0;
+          h_bar = 0.0;
+          da_count = 0;
+        }
       }
       if (m == o.n_warmup && da_count > 0) eps = std::exp(log_eps_bar);
     } else {

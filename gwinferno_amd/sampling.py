@@ -202,6 +202,28 @@ def _find_step_size(th, lp, g, inv_mass, rng, eps=0.1):
     return eps
 
 
+def warmup_schedule(n_warmup):
+    """``(slow_start, window_ends)`` of the warm-up: Stan's schedule as NumPyro builds it
+    (``numpyro.infer.hmc_util.build_adaptation_schedule``) -- 75 fast iterations (step size only), slow windows of 25, 50, 100, ...
+    iterations (the last stretched to the end of the slow phase) each ending in a new diagonal metric, 50 fast iterations; shrunk to
+    15 % / 75 % / 10 % below 150 warm-up iterations, no metric adaptation below 20.  ``gwi_sampler.cpp`` holds the same function."""
+    n = int(n_warmup)
+    if n < 20:
+        return n, []
+    init, term, base = 75, 50, 25
+    if init + base + term > n:
+        init, term = int(0.15 * n), int(0.1 * n)
+        base = n - init - term
+    slow_end, start, size, ends = n - term, init, base, []
+    while start < slow_end:
+        end = start + size
+        if end + 2 * size > slow_end:
+            end = slow_end
+        ends.append(end)
+        start, size = end, 2 * size
+    return init, ends
+
+
 def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, progress, tag=""):
     """Generator: yields points to evaluate, receives (log_prob, grad); returns the result dict."""
     rng = np.random.default_rng(seed)
@@ -261,7 +283,8 @@ def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, 
 
     samples, lps, accepts, depths = [], [], [], []
     n_div = 0
-    warm = []
+    slow_start, window_ends = warmup_schedule(n_warmup)
+    next_window, w_count, w_mean, w_m2 = 0, 0, np.zeros(dim), np.zeros(dim)  # Welford accumulators of the current slow window
     for it in range(n_warmup + n_samples):
         p0 = rng.normal(size=dim) / np.sqrt(inv_mass)
         h0 = -lp + 0.5 * np.sum(inv_mass * p0**2)
@@ -292,7 +315,7 @@ def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, 
                 break
         theta, lp, grad = prop
         acc = sum_alpha / max(n_alpha, 1)
-        n_div += int(diverged)
+        n_div += int(diverged and it >= n_warmup)  # post-warm-up transitions only, as numpyro reports them (and gwi_sampler.cpp counts them)
         if it < n_warmup:
             m = it + 1
             da_count += 1
@@ -300,12 +323,20 @@ def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, 
             log_eps = mu - np.sqrt(da_count) / gamma * h_bar
             log_eps_bar = da_count**-kappa * log_eps + (1 - da_count**-kappa) * log_eps_bar
             eps = float(np.exp(log_eps))
-            warm.append(theta.copy())
-            if m == (2 * n_warmup) // 3 and len(warm) > 20:  # one diagonal mass-matrix update, then re-tune the step
-                var = np.var(np.array(warm[len(warm) // 3 :]), axis=0)
-                inv_mass = np.where(var > 1e-12, var, 1.0)
-                eps = yield from step_size(theta, lp, grad, float(np.exp(log_eps_bar)))
-                mu, log_eps_bar, h_bar, da_count = np.log(10 * eps), 0.0, 0.0, 0
+            if it >= slow_start and next_window < len(window_ends):  # slow phase: this draw feeds the window's variance
+                w_count += 1
+                delta = theta - w_mean
+                w_mean = w_mean + delta / w_count
+                w_m2 = w_m2 + delta * (theta - w_mean)
+                if m == window_ends[next_window]:  # end of a window: new metric, re-found step size, dual averaging restarted
+                    if w_count > 1:
+                        var = w_m2 / (w_count - 1)
+                        reg = (w_count / (w_count + 5.0)) * var + 1e-3 * (5.0 / (w_count + 5.0))  # Stan's shrinkage towards the unit metric
+                        inv_mass = np.where(np.isfinite(reg) & (reg > 0), reg, 1.0)
+                    w_count, w_mean, w_m2 = 0, np.zeros(dim), np.zeros(dim)
+                    next_window += 1
+                    eps = yield from step_size(theta, lp, grad, float(np.exp(log_eps_bar)))
+                    mu, log_eps_bar, h_bar, da_count = np.log(10 * eps), 0.0, 0.0, 0
             if m == n_warmup:
                 eps = float(np.exp(log_eps_bar)) if da_count > 0 else eps
         else:
@@ -321,7 +352,7 @@ def _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, 
 
 def nuts(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, progress=None):
     """Multinomial NUTS with the generalised U-turn criterion (Betancourt 2017, as in Stan / NumPyro), dual-
-    averaging step size and one diagonal mass-matrix update during warm-up.  Every leapfrog step is one
+    averaging step size and the windowed diagonal-metric warm-up of Stan / NumPyro (:func:`warmup_schedule`).  Every leapfrog step is one
     engine evaluation (value + gradient).  Returns dict(samples, log_prob, accept_rate, step_size,
     n_evals, tree_depth, n_divergent)."""
     gen = _nuts_gen(theta0, n_warmup, n_samples, max_tree_depth, target_accept, seed, progress)
