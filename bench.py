@@ -671,7 +671,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             # configs 3 / 5: the sampler figure under the reference's priors, on engines of its own
             comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
             engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
-            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 150, "n_samples": 60} if cfg == "c5" else {}))
+            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 300, "n_samples": 100} if cfg == "c5" else {}))
             for e in engs[1:]:
                 e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
@@ -785,7 +785,7 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
     second as a sampler sees them, how many the engine had to repeat (gwi_two_pass_repeats), and the sampler's own
     diagnostics -- mean tree depth, acceptance rate, adapted step size, divergences after warm-up, and the smallest
     bulk effective sample size over the free parameters per second of sampling (post-warm-up draws of all chains)."""
-    from gwinferno_amd.sampling import effective_sample_size, nuts_engine
+    from gwinferno_amd.sampling import effective_sample_size, nuts_engine, split_rhat
 
     C = len(engines)
     prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
@@ -804,6 +804,9 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
     draws = np.stack([r["samples"] for r in res])
     ess = effective_sample_size(draws)
     free = np.isfinite(ess)
+    within = np.stack([effective_sample_size(draws[c]) for c in range(C)])  # each chain by itself
+    rhat = split_rhat(draws)
+    logp_chain = [float(np.mean(r["log_prob"])) for r in res]
     depth = np.concatenate([r["tree_depth"] for r in res])
     # share of the wall time spent after warm-up ~ share of the evaluations made there (2^depth - 1 per iteration)
     n_lf_sampling = float(np.sum(2.0 ** depth - 1.0))
@@ -815,7 +818,12 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
             "divergences": int(sum(r["n_divergent"] for r in res)),
             "min_ess": float(np.min(ess[free])) if free.any() else None, "median_ess": float(np.median(ess[free])) if free.any() else None,
             "min_ess_per_s": float(np.min(ess[free]) / max(t_sampling, 1e-9)) if free.any() else None,
-            "ess_note": "bulk ESS (multi-chain, Geyer) of the post-warm-up draws of all chains; per second of the sampling phase"}
+            "within_chain_min_ess": [float(np.min(w[free])) for w in within] if free.any() else None,
+            "within_chain_median_ess": [float(np.median(w[free])) for w in within] if free.any() else None,
+            "max_split_rhat": float(np.nanmax(rhat[free])) if free.any() else None, "mean_log_prob_per_chain": logp_chain,
+            "ess_note": ("bulk ESS (multi-chain, Geyer) of the post-warm-up draws of all chains, per second of the sampling phase; within_chain_*: the same "
+                         "estimator on each chain alone.  A multi-chain ESS near the chain count with healthy within-chain ESS and a large split R-hat means the "
+                         "chains sit in different modes of this synthetic catalog's posterior (compare mean_log_prob_per_chain), not that they mix slowly")}
 
 
 RCCL_LEG_FLAG = "--rccl-leg"

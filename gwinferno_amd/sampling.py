@@ -484,6 +484,24 @@ def effective_sample_size(samples):
     return out
 
 
+def split_rhat(samples):
+    """Split R-hat per parameter of ``samples[chains, draws, dim]`` (each chain halved; Gelman et al. 2013, the ``r_hat``
+    column of ``mcmc.print_summary()``).  Values far above 1 with healthy within-chain ESS mean the chains sit in different
+    modes, not that they mix slowly.  Constant columns get NaN."""
+    x = np.asarray(samples, dtype=np.float64)
+    if x.ndim == 2:
+        x = x[None]
+    h = x.shape[1] // 2
+    if h < 2:
+        return np.full(x.shape[2], np.nan)
+    y = np.concatenate([x[:, :h], x[:, h:2 * h]], axis=0)
+    W = y.var(axis=1, ddof=1).mean(axis=0)
+    B = h * y.mean(axis=1).var(axis=0, ddof=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = np.sqrt(((h - 1.0) / h * W + B / h) / W)
+    return np.where(W > 0.0, r, np.nan)
+
+
 def _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed):
     from . import _native as N
 

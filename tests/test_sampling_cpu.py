@@ -224,3 +224,22 @@ def test_windowed_adaptation_learns_an_anisotropic_metric(native):
     assert np.mean(r["tree_depth"]) < 4.5, np.mean(r["tree_depth"])
     got = np.std(r["samples"], axis=0)
     assert np.all(np.abs(got / sig - 1.0) < 0.25), got / sig
+
+
+def test_split_rhat_tells_separated_chains_from_mixed_ones():
+    """split_rhat ~ 1 for chains drawing from one distribution, >> 1 for chains in different places whose own ESS is fine
+    (the multi-chain ESS then collapses to about the chain count: what bench.py's native_nuts reports for such a run)."""
+    from gwinferno_amd.sampling import effective_sample_size, split_rhat
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, 400, 3))
+    x[:, :, 2] = 1.5  # a pinned column
+    r = split_rhat(x)
+    assert np.all(np.abs(r[:2] - 1.0) < 0.05) and np.isnan(r[2])
+    y = x.copy()
+    y[1::2, :, 0] += 30.0  # two of the four chains elsewhere in coordinate 0
+    r = split_rhat(y)
+    assert r[0] > 10.0 and abs(r[1] - 1.0) < 0.05
+    ess = effective_sample_size(y)
+    assert ess[0] < 10.0 and ess[1] > 800.0
+    assert all(effective_sample_size(y[c])[0] > 200.0 for c in range(4))
