@@ -169,6 +169,48 @@ __device__ __forceinline__ double wave_max(double v) {
   return lane63(v);
 }
 
+// Eight sums over the wavefront at once: a halving butterfly.  v_permlane32_swap / v_permlane16_swap (gfx950) exchange the
+// halves / the odd and even rows of TWO registers in one instruction, so a step that adds lanes l and l + 32 (l and l + 16)
+// of eight (four) values leaves four (two) values per lane and needs no select; one step on lane bit 3 (row_ror:8 + select)
+// leaves one, and three DPP steps finish inside the groups of eight lanes.  Every lane of the group 8k .. 8k + 7 returns
+// the total of v[k]: 54 vector instructions and six dependent steps for eight values, where eight row-shift reductions
+// (wave_sum) are 160 and measured three times as long (tools/microbench/wave_sum8.hip: 544 against 1 620 cycles).  The
+// order of the additions is fixed: results are bit-reproducible.
+__device__ __forceinline__ void swap_halves(double& a, double& b) {  // a <- [a.lanes 0-31 | b.lanes 0-31], b <- [a.lanes 32-63 | b.lanes 32-63]
+  auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]);
+  b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap_rows(double& a, double& b) {  // the same for rows of 16 lanes inside each half
+  auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]);
+  b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ double wave_sum8(const double* v) {
+  double x[4], y[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double p = v[j], q = v[j + 4];
+    swap_halves(p, q);
+    x[j] = p + q;  // lanes 0-31: v[j] over lanes l, l + 32; lanes 32-63: v[j + 4]
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    double p = x[j], q = x[j + 2];
+    swap_rows(p, q);
+    y[j] = p + q;  // rows 0 / 1 / 2 / 3: v[j], v[j + 2], v[j + 4], v[j + 6] over four lanes each
+  }
+  const bool up = (__lane_id() & 8) != 0;  // lanes with bit 3 clear keep y[0] and take y[0] of lane ^ 8; the others y[1]
+  const double keep = up ? y[1] : y[0], send = up ? y[0] : y[1];
+  double z = keep + dpp_take<0x128, 0xf>(send);  // row_ror:8
+  z += dpp_take<0x141, 0xf>(z);                  // row_half_mirror: lane i <-> 7 - i of its group of eight
+  z += dpp_take<0xB1, 0xf>(z);                   // quad_perm [1,0,3,2]
+  z += dpp_take<0x4E, 0xf>(z);                   // quad_perm [2,3,0,1]
+  return z;
+}
+
 // Below this a mixture density counts as zero for its gradient states: fast_rcp returns NaN for subnormal arguments
 // (seed = inf, Newton step inf - inf), and a mixture term that has absorbed the closing exponential (Absorbs<K>) sees
 // densities times e^{l - m}, i.e. down to the bottom of the range for samples ~700 e-folds under the tile's best one
@@ -1654,8 +1696,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // spline models carry few scalar sums (their gradient lives in the s_gacc rows): a narrower staging
   // area leaves the LDS to those rows
   constexpr int kNVals = 2 + ChainT::kNumAcc;
+#ifdef GWI_AB_OLD_RECORD  // A/B: the scalar sums of a workgroup through a transposed LDS staging area and one row-shift reduction per value
   constexpr int kChunk = ChainT::kSpline ? (kNVals < 4 ? kNVals : 4) : kRedChunk;
   __shared__ double s_red[kChunk][kBlock];
+#else
+  // the scalar sums of the four waves, eight per butterfly (wave_sum8): [wave][value]
+  constexpr int kSumGroups = (kNVals + 7) / 8;
+  __shared__ double s_part[kWaves][kSumGroups * 8];
+#endif
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef GWI_STAMPS
@@ -1926,6 +1974,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   if (WRITE_LOGW) return;
   GWI_STAMP(3);
 
+#ifdef GWI_AB_OLD_RECORD
   // ---- workgroup record: common exponent M, then a transposed LDS reduction of every scalar sum
   double M = GWI_NEG_INF, f = 1.0;
   if (kShared) {
@@ -1942,6 +1991,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     if (a.square) f *= f;
   }
 
+  GWI_STAMP(6);  // diagnostic build: the waves' references exchanged
   constexpr int kNV = 2 + ChainT::kNumAcc;
   double vals[kNV];
   int th[kNV];
@@ -1981,6 +2031,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   }
   if (!kShared && tid == 0) out[0] = a.square ? 2.0 * M : M;
   __syncthreads();
+  GWI_STAMP(7);  // diagnostic build: scalar sums reduced
   // Shared mode: the record is normalised to the tile's own S1 -- S1 in [1, 2), everything else scaled by the same exact
   // power of two, the exponent M a whole number of binades -- so that it is, to the bit, the record any other reference
   // n_ref would have produced (see n_ref above).
@@ -2015,6 +2066,107 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     }
     out[kRecHeader + p] = g;
   }
+#else
+  // ---- workgroup record.  Every wave sums its lanes' scalar sums eight at a time (wave_sum8: no LDS, no barrier) and
+  // leaves them in s_part[wave][.]; ONE barrier later they are added across the waves in wave order.  (Before: a transposed
+  // LDS staging area, three barriers and one row-shift reduction per value -- 1.2 us of config 2's 4.8 us wave lifetime.)
+  constexpr int kNV = kNVals;
+  double vals[kSumGroups * 8];
+  int th[kNV];
+#ifdef GWI_ABL_SCATTER_TO_REG
+  s1 += 1e-300 * ctx.sink;
+#endif
+  vals[0] = s1;
+  vals[1] = s2;
+  th[0] = th[1] = -1;
+  chain.collect(0, ctx, vals + 2, th + 2);
+#pragma unroll
+  for (int v = kNV; v < kSumGroups * 8; ++v) vals[v] = 0.0;
+#pragma unroll
+  for (int g = 0; g < kSumGroups; ++g) {
+    const double z = wave_sum8(vals + 8 * g);
+    if ((lane & 7) == 0) s_part[wave][8 * g + (lane >> 3)] = z;
+  }
+  if (kShared) {
+    // every wave used the tile's reference n_ref; the tile's true maximum decides below whether that was good enough
+    const double mx = wave_max(lane_max);
+    if (lane == 0) s_wrec[wave][2] = mx;
+  } else {
+    if (lane == 0) s_wrec[wave][0] = m;  // the wave's own reference exponent: its sums are relative to it
+  }
+  double* out = a.partials + ((long long)kb * (n_pe_blocks + a.n_inj_tiles) + b) * a.rec_stride;
+  __syncthreads();  // shared mode: also every wave's additions to the gradient rows
+  GWI_STAMP(6);     // diagnostic build: the waves' sums are in place
+  if (!kShared) {
+    // Parametric models: wave 0 finishes alone -- lane v (< kNV) moves value v of the four waves to the common exponent
+    // M = max of their references and adds them in wave order; the other waves are done.
+    if (wave != 0) {
+      GWI_STAMP(4);
+      return;
+    }
+    // lane l holds the reference of wave l & 3: ONE exponential gives the four rescale factors (a quad holds all of them),
+    // quad broadcasts hand every lane all four -- one dependent chain where a loop over the waves would run four
+    static_assert(kWaves == 4, "the quad broadcasts below assume four waves");
+    const double my_m = s_wrec[lane & 3][0];
+    const int vi = lane < kSumGroups * 8 ? lane : 0;
+    double part[kWaves];
+#pragma unroll
+    for (int w_ = 0; w_ < kWaves; ++w_) part[w_] = s_part[w_][vi];
+    double M = fmax(my_m, dpp_take<0xB1, 0xf>(my_m));  // quad_perm [1,0,3,2]
+    M = fmax(M, dpp_take<0x4E, 0xf>(M));               // quad_perm [2,3,0,1]: the maximum of the four references, in every lane
+    double f_mine = (my_m == GWI_NEG_INF) ? 0.0 : fast_exp(my_m - M);  // wave (l & 3)'s rescale factor
+    if (a.square) f_mine *= f_mine;
+    const double f0 = dpp_take<0x00, 0xf>(f_mine), f1 = dpp_take<0x55, 0xf>(f_mine), f2 = dpp_take<0xAA, 0xf>(f_mine), f3 = dpp_take<0xFF, 0xf>(f_mine);
+    const double t1 = fma(part[3], f3, fma(part[2], f2, fma(part[1], f1, part[0] * f0)));                      // sums of w: in wave order
+    const double t2 = fma(part[3], f3 * f3, fma(part[2], f2 * f2, fma(part[1], f1 * f1, part[0] * (f0 * f0))));  // S2 holds w^2
+    const double tot = lane == 1 ? t2 : t1;
+    if (lane == 0) out[0] = a.square ? 2.0 * M : M;
+    if (lane < 2) out[1 + lane] = tot;
+    // gradient numerators: lane v adds its total to the theta slot of accumulator v (several accumulators may feed one slot),
+    // then the slots are read out -- LDS operations of ONE wave, executed in program order
+    int slot = 0;
+#pragma unroll
+    for (int v = 2; v < kNV; ++v) slot = (lane == v) ? th[v] : slot;
+    if (lane >= 2 && lane < kNV) unsafeAtomicAdd(&s_out[slot], tot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int p = lane; p < a.n_theta; p += 64) out[kRecHeader + p] = s_out[p];
+    GWI_STAMP(4);
+    return;
+  }
+  // Shared mode: the record is normalised to the tile's own S1 -- S1 in [1, 2), everything else scaled by the same exact
+  // power of two, the exponent M a whole number of binades -- so that it is, to the bit, the record any other reference
+  // n_ref would have produced (see n_ref above).
+  auto total = [&](int v) { return (s_part[0][v] + s_part[1][v]) + (s_part[2][v] + s_part[3][v]); };
+  const double S1 = total(0), S2 = total(1);
+  const bool has_sum = S1 > 0.0 && S1 < GWI_POS_INF;
+  const int e_norm = has_sum ? ilogb(S1) : 0;
+  if (tid == 0) {
+    const double mm = fmax(fmax(s_wrec[0][2], s_wrec[1][2]), fmax(s_wrec[2][2], s_wrec[3][2]));
+    const int n_max = (mm == GWI_NEG_INF) ? kNoRef : (int)__builtin_rint(fmin(fmax(mm, -7.0e5), 7.0e5) * kLog2e);
+    *nref_slot = n_max;  // the next evaluation's reference (and, if this one has to be repeated, the repeat's: exact)
+    const int dist = n_max - n_ref;
+    if (n_max != kNoRef && (dist > ref_slack || dist < -ref_slack)) {
+      __hip_atomic_store(a.redo_host, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.redo_dev, a.norm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int n_tot = (a.square ? 2 * n_ref : n_ref) + e_norm;
+    out[0] = has_sum ? (double)n_tot * kLn2 : GWI_NEG_INF;
+    out[1] = has_sum ? ldexp(S1, -e_norm) : 0.0;
+    out[2] = has_sum ? ldexp(S2, -2 * e_norm) : 0.0;
+  }
+  // gradient numerators: spline coefficients from the shared rows (replicas in fixed order), scalar parameters from the
+  // waves' sums of the accumulators that feed them (few in a spline model: a compare per accumulator)
+  for (int p = tid; p < a.n_theta; p += kBlock) {
+    double g = 0.0;
+#pragma unroll
+    for (int v = 2; v < kNV; ++v)
+      if (th[v] == p) g += total(v);
+    const double* rows = s_gacc + ((long)p << rep_shift);
+    double gw = 0.0;
+    for (int r = 0; r < rep; ++r) gw += rows[(r + p) & (rep - 1)];  // rotated start: the threads of a wave read different banks
+    out[kRecHeader + p] = ldexp(g + gw, -e_norm);
+  }
+#endif
   GWI_STAMP(4);
 }
 

@@ -1554,7 +1554,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   size_t scan_lds = 0;
   int rep = 1;
   if (has_spline) {
-    size_t lds_per_cu = 160 * 1024, static_lds = 14 * 1024;  // gfx950: 160 KiB per CU; static: s_theta + s_out + s_red + s_wrec
+    size_t lds_per_cu = 160 * 1024, static_lds = 14 * 1024;  // gfx950: 160 KiB per CU; static: s_theta + s_out + s_part + s_wrec (what the kernel reports replaces this guess)
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(h->variant->scan)) == hipSuccess && fa.sharedSizeBytes > 0) static_lds = fa.sharedSizeBytes;
     int occ0 = 0;

@@ -1,0 +1,41 @@
+// Device side of l2_resident.cpp: the scan's access pattern (struct-of-array fp64 columns, contiguous tiles, 256 lanes, one-trip-ahead
+// register prefetch) with W stand-in FMAs per sample; no gridDim / blockDim use, so the kernel takes no implicit arguments.
+//   hipcc --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 l2_resident_kernel.hip -o l2_resident_kernel.hsaco
+#include <hip/hip_runtime.h>
+
+constexpr int kMaxCols = 9;
+struct Args {
+  const double* col[kMaxCols];
+  double* out;
+  long long n;
+  int n_cols, tile, work, pad;
+};
+
+extern "C" __global__ __launch_bounds__(256) void stream_kernel(const Args a) {
+  const long long t0 = (long long)blockIdx.x * a.tile;
+  const long long t1 = t0 + a.tile < a.n ? t0 + a.tile : a.n;
+  double acc = 0.0;
+  double cur[kMaxCols], nxt[kMaxCols];
+  auto load = [&](double* dst, long long i) {
+#pragma unroll
+    for (int c = 0; c < kMaxCols; ++c) {
+      if (c >= a.n_cols) break;
+      dst[c] = a.col[c][i];
+    }
+  };
+  long long i = t0 + threadIdx.x;
+  if (i < t1) load(cur, i);
+  for (; i < t1; i += 256) {
+    if (i + 256 < t1) load(nxt, i + 256);
+    double x = 0.0;
+#pragma unroll
+    for (int c = 0; c < kMaxCols; ++c)
+      if (c < a.n_cols) x += cur[c];
+    double y = x;
+    for (int w = 0; w < a.work; ++w) y = fma(y, 0.999999, x);
+    acc += y;
+#pragma unroll
+    for (int c = 0; c < kMaxCols; ++c) cur[c] = nxt[c];
+  }
+  if (acc == 12345.678) a.out[0] = acc;
+}

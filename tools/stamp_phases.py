@@ -49,6 +49,22 @@ prev = np.zeros(len(us))
 for k in range(5):
     d = us[:, k] - (us[:, k - 1] if k else 0.0)
     print(f"  {names[k]:26s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us   (absolute median end {np.median(us[:, k]):6.2f})")
+# inside the record phase: stamp 6 = the waves' sums in place (after the workgroup barrier); a -DGWI_AB_OLD_RECORD build also
+# has 7 = scalar sums reduced (there 6 = the waves' references exchanged)
+ext = raw[:, 6:8].astype(np.int64)[ok]
+if (ext[:, 0] > 0).all():
+    e6 = (ext[:, 0] - st[:, 3]) / 100.0
+    if (ext[:, 1] > 0).all():
+        e7 = (ext[:, 1] - ext[:, 0]) / 100.0
+        e8 = (st[:, 4] - ext[:, 1]) / 100.0
+        print(f"  record phase split (old record): reference exchange {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}), sums through LDS {np.median(e7):.2f} (p90 {np.percentile(e7, 90):.2f}), "
+              f"row readout + record stores {np.median(e8):.2f} (p90 {np.percentile(e8, 90):.2f}) us")
+    else:
+        e8 = (st[:, 4] - ext[:, 0]) / 100.0
+        print(f"  record phase split: own sums + wait for the workgroup {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}, min {e6.min():.2f}), cross-wave sum + readout + stores {np.median(e8):.2f} "
+              f"(p90 {np.percentile(e8, 90):.2f}) us")
+# how long after the last wave's record does the kernel end?  (the dispatch's own end stamp is not visible here; the span is)
+print(f"  last wave entry at {us[:, 0].max():.2f} us; last 'loop done' at {us[:, 3].max():.2f}; per-wave lifetime median {np.median(us[:, 4] - us[:, 0]):.2f} us")
 
 # ---- placement: which SIMD of which CU every wave ran on (HW_ID: SIMD_ID bits 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13; XCC_ID low bits)
 simd = (hw >> np.uint64(4)) & np.uint64(3)
