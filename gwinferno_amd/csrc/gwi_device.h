@@ -1663,6 +1663,36 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
   if (tid == 0) __hip_atomic_store(stamp_slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- kernel-argument warm-up ---------------------------------------------------------------------
+// The caches are invalidated when a launch starts, so a wave's first scalar load of every 64-byte line of the argument block
+// goes to memory, and the compiler places those loads where their values are first used: behind branches, one dependent round
+// trip after the other (header -> sizes -> PE-or-injection choice -> column pointers: 1.0 us from wave entry to the first
+// column load at config 2, 1.8 at config 3 by the phase stamps).  One dword of every line the start-up and the first trip
+// will read, loaded in ONE clause at wave entry, turns all but the first of those round trips into scalar-cache hits.
+template <int N_TERMS, bool BATCH_THETA>
+__device__ __forceinline__ void kernarg_warm(const KArgs& a) {
+#ifndef GWI_AB_NO_KERNARG_WARM
+  const int* w = reinterpret_cast<const int*>(&a);
+  // byte ranges -> one dword per 64-byte line: the column pointers of both sample sets; pointers, sizes and the terms'
+  // descriptors; the per-evaluation tail up to the last term's derived scalars
+  constexpr size_t kLo[4] = {offsetof(KArgs, pe_tcols), offsetof(KArgs, inj_tcols), offsetof(KArgs, kappa_pe), offsetof(KArgs, norm_seq)};
+  constexpr size_t kHi[4] = {offsetof(KArgs, pe_tcols) + 16 * N_TERMS, offsetof(KArgs, inj_tcols) + 16 * N_TERMS, offsetof(KArgs, terms) + sizeof(TermD) * N_TERMS,
+                             BATCH_THETA ? offsetof(KArgs, derived) : offsetof(KArgs, derived) + sizeof(double) * kMaxDerived * N_TERMS};
+  constexpr int kMaxLines = 32;
+  int t[kMaxLines];
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (size_t o = kLo[r] & ~(size_t)63; o < kHi[r]; o += 64)
+      if (n < kMaxLines) t[n++] = w[o / 4];
+  // every value stays live until all of them have arrived: the loads form one clause (no destination register is reused in between)
+#pragma unroll
+  for (int k = 0; k < kMaxLines; ++k)
+    if (k < n) asm volatile("" ::"s"(t[k]));
+#endif
+}
+
 // ---- the scan kernel -----------------------------------------------------------------------------
 // grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
 // belongs to that event's logsumexp; an injection workgroup owns `chunk_inj` consecutive
@@ -1727,19 +1757,25 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     if (lane == 0) stamp_row[5] = ((unsigned long long)xcc_id << 32) | hw_id;
   }
 #endif
+  kernarg_warm<(int)sizeof...(Ks), BATCH>(a);
+  // the sizes the start-up branches on, loaded in the same clause and pinned: the compiler would otherwise fetch each one
+  // where it is first used, a scalar round trip per dependent branch
+  int h_n_norms = a.n_norms, h_n_ev = a.n_ev, h_tiles = a.tiles_per_event, h_chunk_pe = a.chunk_pe, h_chunk_inj = a.chunk_inj, h_n_theta = a.n_theta;
+  long long h_n_pe = a.n_pe, h_n_inj = a.n_inj;
+  asm volatile("" : "+s"(h_n_norms), "+s"(h_n_ev), "+s"(h_tiles), "+s"(h_chunk_pe), "+s"(h_chunk_inj), "+s"(h_n_theta), "+s"(h_n_pe), "+s"(h_n_inj));
   // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
   const bool batch = BATCH || (SAFE && a.tblocks != nullptr);
   const int kb = batch ? (int)blockIdx.y : 0;
   const double* theta_src = batch ? a.tblocks[kb].theta : a.theta;
-  const int n_norm_blocks = WRITE_LOGW ? 0 : a.n_norms;
+  const int n_norm_blocks = WRITE_LOGW ? 0 : h_n_norms;
   if (!WRITE_LOGW && blockIdx.x == 0 && kb == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // the tail launches stamp their results with it
   if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
     const int j = blockIdx.x;
-    norm_block(a.norms, theta_src, a.n_theta, j, a.norm_out_host + kb * a.n_norms + j, a.norm_stamps_host + kb * a.n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
+    norm_block(a.norms, theta_src, h_n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
     return;
   }
   const int b = (int)blockIdx.x - n_norm_blocks;
-  const int n_pe_blocks = a.n_ev * a.tiles_per_event;
+  const int n_pe_blocks = h_n_ev * h_tiles;
 
   // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids).  The loads go out HERE
   // (one value per thread: n_theta <= kBlock), the LDS writes follow the first trip's column loads further down: the two
@@ -1748,7 +1784,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   static_assert(GWI_MAX_THETA <= kBlock, "one hyper-parameter per thread in the theta staging");
   double theta_mine = 0.0, theta_next[3] = {0.0, 0.0, 0.0};  // theta[tid .. tid + 3]: this thread's entries of the power-basis table (spline_poly)
   if (ChainT::kSpline) {
-    const int last = a.n_theta - 1;
+    const int last = h_n_theta - 1;
     theta_mine = theta_src[tid < last ? tid : last];  // unconditional (clamped index): no control flow between these loads and the columns', so the wait below can count
 #pragma unroll
     for (int j = 0; j < 3; ++j) theta_next[j] = theta_src[tid + 1 + j < last ? tid + 1 + j : last];
@@ -1758,10 +1794,10 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
   const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
   const int rep = 1 << rep_shift;
-  const int n_rows = a.n_theta << rep_shift;  // doubles in the shared rows
+  const int n_rows = h_n_theta << rep_shift;  // doubles in the shared rows
   if (kShared)
     for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
-  for (int p = tid; p < a.n_theta; p += kBlock) s_out[p] = 0.0;
+  for (int p = tid; p < h_n_theta; p += kBlock) s_out[p] = 0.0;
 
   long long start, end, base;
   Ctx ctx;
@@ -1775,17 +1811,17 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   ctx.rep_shift = rep_shift;
   double* logw;
   if (b < n_pe_blocks) {
-    const int e = b / a.tiles_per_event;
-    const int t = b - e * a.tiles_per_event;
-    start = (long long)t * a.chunk_pe;
-    end = start + a.chunk_pe < a.n_pe ? start + a.chunk_pe : a.n_pe;
-    base = (long long)e * a.n_pe;
+    const int e = b / h_tiles;
+    const int t = b - e * h_tiles;
+    start = (long long)t * h_chunk_pe;
+    end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
+    base = (long long)e * h_n_pe;
     ctx.tcols = a.pe_tcols;
     logw = a.logw_pe;
   } else {
     const int t = b - n_pe_blocks;
-    start = (long long)t * a.chunk_inj;
-    end = start + a.chunk_inj < a.n_inj ? start + a.chunk_inj : a.n_inj;
+    start = (long long)t * h_chunk_inj;
+    end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
     base = 0;
     ctx.tcols = a.inj_tcols;
     logw = a.logw_inj;
@@ -1825,19 +1861,20 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   // which finds the exact maximum of THIS evaluation in tile_nref already: the repeat cannot miss.
   int n_ref = 0;
   int* nref_slot = nullptr;
-  if (kShared) {
-    nref_slot = a.tile_nref + ((long long)(a.nref_row0 + kb) * a.nref_stride + b);
-    const int prev = *nref_slot;
-    n_ref = __builtin_amdgcn_readfirstlane(prev == kNoRef ? 0 : prev);
-  }
   double lane_max = GWI_NEG_INF;   // shared mode: this lane's largest live exponent
   // S2 holds w^2 (w^4 in a squared pass): 2 x 430 (4 x 215) binades stay inside fp64's +-1022 with room for the sum
   const int ref_slack = a.square ? 215 : 430;
   // two-pass mode (SAFE, shared only; the last resort): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
   const int first_pass = (SAFE && kShared && a.two_pass) ? 0 : 1;
   if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns, in flight before theta is waited for
+  GWI_STAMP(7);  // diagnostic build: the first trip's loads are issued
+  if (kShared) {  // behind the column loads: the v_readfirstlane waits for this load, and the columns must not wait with it
+    nref_slot = a.tile_nref + ((long long)(a.nref_row0 + kb) * a.nref_stride + b);
+    const int prev = *nref_slot;
+    n_ref = __builtin_amdgcn_readfirstlane(prev == kNoRef ? 0 : prev);
+  }
   if (ChainT::kSpline) {
-    if (tid < a.n_theta) {
+    if (tid < h_n_theta) {
       s_theta[tid] = theta_mine;
       spline_poly(theta_mine, theta_next[0], theta_next[1], theta_next[2], s_poly + tid);
     }

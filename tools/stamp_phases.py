@@ -54,12 +54,16 @@ for k in range(5):
 ext = raw[:, 6:8].astype(np.int64)[ok]
 if (ext[:, 0] > 0).all():
     e6 = (ext[:, 0] - st[:, 3]) / 100.0
-    if (ext[:, 1] > 0).all():
+    if (ext[:, 1] > 0).all() and os.environ.get('GWI_OLD_RECORD_STAMPS'):
         e7 = (ext[:, 1] - ext[:, 0]) / 100.0
         e8 = (st[:, 4] - ext[:, 1]) / 100.0
         print(f"  record phase split (old record): reference exchange {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}), sums through LDS {np.median(e7):.2f} (p90 {np.percentile(e7, 90):.2f}), "
               f"row readout + record stores {np.median(e8):.2f} (p90 {np.percentile(e8, 90):.2f}) us")
     else:
+        if (ext[:, 1] > 0).all():  # 7 = the first trip's loads issued (inside "first loads land")
+            i7 = (ext[:, 1] - st[:, 1]) / 100.0
+            l7 = (st[:, 2] - ext[:, 1]) / 100.0
+            print(f"  start-up split: stamp 1 -> first loads issued {np.median(i7):.2f} (p90 {np.percentile(i7, 90):.2f}), issued -> landed (+ theta staging and barrier) {np.median(l7):.2f} (p90 {np.percentile(l7, 90):.2f}) us")
         e8 = (st[:, 4] - ext[:, 0]) / 100.0
         print(f"  record phase split: own sums + wait for the workgroup {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}, min {e6.min():.2f}), cross-wave sum + readout + stores {np.median(e8):.2f} "
               f"(p90 {np.percentile(e8, 90):.2f}) us")
