@@ -118,7 +118,7 @@ struct Queue {
   bool failed() const { return sq && sq->failed; }
   const std::string& why() const { return sq->why; }
 };
-constexpr unsigned kSlots = 16, kSlotBytes = 4096;
+constexpr unsigned kSlots = 16, kSlotBytes = 4352;  // the scan's segment: 56 bytes of preloaded scalars + the 4 KiB argument block (a multiple of 256)
 constexpr size_t kExtraBytes = 256 * 1024;
 inline char* extra_area(const Queue& q) { return q.kernarg ? q.kernarg + (size_t)kSlots * kSlotBytes : nullptr; }
 

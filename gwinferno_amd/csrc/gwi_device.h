@@ -1177,6 +1177,7 @@ template <int U, bool TAKEN, int... Ks>
 struct ChainImpl;
 template <int U, bool TAKEN>
 struct ChainImpl<U, TAKEN> {
+  static constexpr bool kGeneric = false;
   static constexpr bool kSpline = false;
   static constexpr bool kAbsorb = false;
   static constexpr int kNumAcc = 0;
@@ -1193,6 +1194,7 @@ template <int U, bool TAKEN, int K, int... Rest>
 struct ChainImpl<U, TAKEN, K, Rest...> {
   static constexpr bool kDefer = !TAKEN && Absorbs<K>::value;
   using RestT = ChainImpl<U, TAKEN || kDefer, Rest...>;
+  static constexpr bool kGeneric = false;
   static constexpr bool kSpline = Term<K>::kSpline || RestT::kSpline;
   static constexpr bool kAbsorb = kDefer || RestT::kAbsorb;
   static constexpr int kNumAcc = Term<K>::kNumAcc + RestT::kNumAcc;
@@ -1284,6 +1286,7 @@ __device__ __forceinline__ void generic_gradient(const TermD& t, const double* d
 }
 template <int U>
 struct ChainImpl<U, false, kGenericChain> {
+  static constexpr bool kGeneric = true;
   static constexpr bool kSpline = true;
   static constexpr bool kAbsorb = false;
   static constexpr int kNumAcc = 0;
@@ -1663,6 +1666,49 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
   if (tid == 0) __hip_atomic_store(stamp_slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the scan's preloaded arguments ----------------------------------------------------------------
+// The first 16 dwords of a kernel's SCALAR arguments can be placed in scalar registers by the command processor before a wave
+// starts (kernel-argument preload; -mllvm -amdgpu-kernarg-preload-count=16; by-value structs are not covered).  The scan
+// takes there exactly what its first column loads depend on -- the tile geometry and the first five column pointers -- so
+// that those loads leave at wave entry instead of after a scalar round trip to the argument block in memory (0.7 us: a
+// launch starts with invalidated caches), and the argument block's own first trip runs beside them instead of before them
+// (tools/microbench/l2_resident.cpp: a streaming stand-in with 48 FMAs per sample 5.5 -> 4.7 us at config 2's size).
+// One pointer serves both sample sets: every column is ONE allocation, posterior samples first, the injections
+// `inj_off` elements behind (gwi_engine.hip: alloc_pair), so a workgroup's choice between the sets is an offset, not a load.
+// Slot 0 is kappa; the terms' columns follow in term order (Term<K>::In holds one double per column); columns beyond the
+// fifth slot are read from KArgs::pe_tcols as before.
+constexpr int kHeadCols = 5;
+struct ScanHead {  // 14 dwords: the kernel-argument pointer takes two of the sixteen user registers
+  const double* col[kHeadCols];
+  unsigned geom;    // n_ev (bits 0-19) | tiles_per_event (20-26) | n_norms (27-31)
+  unsigned chunks;  // tile sizes of the two sample sets, 16 bits each (pack_chunk)
+  unsigned n_pe, n_inj;
+};
+static_assert(sizeof(ScanHead) == 56, "fourteen dwords: what the command processor preloads next to the kernel-argument pointer");
+constexpr unsigned kGeomEventBits = 20, kGeomTilesBits = 7;
+// a tile size in 16 bits: exact below 32 768, in units of 256 samples above (tiles that large are whole trips: multiples of 256)
+__host__ __device__ inline bool chunk_packs(long long c) { return c > 0 && (c < 32768 || (c % 256 == 0 && c / 256 < 32768)); }
+__host__ __device__ inline unsigned pack_chunk(long long c) { return c < 32768 ? (unsigned)c : (0x8000u | (unsigned)(c / 256)); }
+__host__ __device__ inline int unpack_chunk(unsigned v) { return (v & 0x8000u) ? (int)((v & 0x7fffu) * 256u) : (int)v; }
+// where the injections start inside every column (elements): behind the posterior samples, on a 256-byte boundary
+__host__ __device__ inline long long inj_offset(long long n_ev, long long n_pe) { return (n_ev * n_pe + 31) / 32 * 32; }
+
+template <int SLOT, int T, int... Ks>
+struct ColFill;
+template <int SLOT, int T>
+struct ColFill<SLOT, T> {
+  __device__ static void run(const double* (*)[2], const double* const*, const KArgs&) {}
+};
+template <int SLOT, int T, int K, int... Rest>
+struct ColFill<SLOT, T, K, Rest...> {
+  static constexpr int kCols = (int)(sizeof(typename Term<K>::In) / sizeof(double));
+  __device__ __forceinline__ static void run(const double* (*lc)[2], const double* const* head, const KArgs& a) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) lc[T][k] = k < kCols ? (SLOT + k < kHeadCols ? head[SLOT + k < kHeadCols ? SLOT + k : 0] : a.pe_tcols[T][k]) : nullptr;
+    ColFill<SLOT + kCols, T + 1, Rest...>::run(lc, head, a);
+  }
+};
+
 // ---- kernel-argument warm-up ---------------------------------------------------------------------
 // The caches are invalidated when a launch starts, so a wave's first scalar load of every 64-byte line of the argument block
 // goes to memory, and the compiler places those loads where their values are first used: behind branches, one dependent round
@@ -1670,28 +1716,58 @@ __device__ __forceinline__ void norm_block(const NormD* norms, const double* the
 // column load at config 2, 1.8 at config 3 by the phase stamps).  One dword of every line the start-up and the first trip
 // will read, loaded in ONE clause at wave entry, turns all but the first of those round trips into scalar-cache hits.
 template <int N_TERMS, bool BATCH_THETA>
-__device__ __forceinline__ void kernarg_warm(const KArgs& a) {
+struct KernargWarm {
+  // byte ranges of the argument block -> one dword per 64-byte line: the column pointers (those beyond the preloaded ones come
+  // from here); pointers, sizes and the terms' descriptors; the per-evaluation tail up to the last term's derived scalars; the
+  // first sixteen hyper-parameters (a parametric model reads its scalars from there with scalar loads whose addresses come out
+  // of the term descriptors: a second full round trip behind the first otherwise)
+  static constexpr int kRanges = 4;
+  static constexpr size_t lo(int r) {
+    return r == 0 ? offsetof(KArgs, pe_tcols) : r == 1 ? offsetof(KArgs, kappa_pe) : r == 2 ? offsetof(KArgs, norm_seq) : offsetof(KArgs, theta);
+  }
+  static constexpr size_t hi(int r) {
+    return r == 0   ? offsetof(KArgs, pe_tcols) + 16 * N_TERMS
+           : r == 1 ? offsetof(KArgs, terms) + sizeof(TermD) * N_TERMS
+           : r == 2 ? (BATCH_THETA ? offsetof(KArgs, derived) : offsetof(KArgs, derived) + sizeof(double) * kMaxDerived * N_TERMS)
+                    : (BATCH_THETA ? offsetof(KArgs, theta) : offsetof(KArgs, theta) + 128);
+  }
+  static constexpr int count() {
+    int n = 0;
+    for (int r = 0; r < kRanges; ++r)
+      for (size_t o = lo(r) & ~(size_t)63; o < hi(r); o += 64) ++n;
+    return n;
+  }
+  static constexpr size_t offset(int k) {
+    int n = 0;
+    for (int r = 0; r < kRanges; ++r)
+      for (size_t o = lo(r) & ~(size_t)63; o < hi(r); o += 64) {
+        if (n == k) return o;
+        ++n;
+      }
+    return 0;
+  }
 #ifndef GWI_AB_NO_KERNARG_WARM
-  const int* w = reinterpret_cast<const int*>(&a);
-  // byte ranges -> one dword per 64-byte line: the column pointers of both sample sets; pointers, sizes and the terms'
-  // descriptors; the per-evaluation tail up to the last term's derived scalars
-  constexpr size_t kLo[4] = {offsetof(KArgs, pe_tcols), offsetof(KArgs, inj_tcols), offsetof(KArgs, kappa_pe), offsetof(KArgs, norm_seq)};
-  constexpr size_t kHi[4] = {offsetof(KArgs, pe_tcols) + 16 * N_TERMS, offsetof(KArgs, inj_tcols) + 16 * N_TERMS, offsetof(KArgs, terms) + sizeof(TermD) * N_TERMS,
-                             BATCH_THETA ? offsetof(KArgs, derived) : offsetof(KArgs, derived) + sizeof(double) * kMaxDerived * N_TERMS};
-  constexpr int kMaxLines = 32;
-  int t[kMaxLines];
-  int n = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (size_t o = kLo[r] & ~(size_t)63; o < kHi[r]; o += 64)
-      if (n < kMaxLines) t[n++] = w[o / 4];
-  // every value stays live until all of them have arrived: the loads form one clause (no destination register is reused in between)
-#pragma unroll
-  for (int k = 0; k < kMaxLines; ++k)
-    if (k < n) asm volatile("" ::"s"(t[k]));
+  static constexpr int kN = count();
+#else
+  static constexpr int kN = 0;
 #endif
-}
+  int t[kN > 0 ? kN : 1];
+  __device__ __forceinline__ void issue() {
+    // the argument block inside the kernel-argument segment (behind the preloaded scalars); not &a: taking the address of the
+    // by-value struct for an asm operand makes the compiler copy all of it to scratch.  Written out as asm: left to itself the
+    // compiler widens, merges and serialises such loads (a wait between every two)
+    const char __attribute__((address_space(4)))* w = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ScanHead);
+#pragma unroll
+    for (int k = 0; k < kN; ++k) asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(t[k]) : "s"(w + offset(k)));
+  }
+  // every destination stays allocated until here (nothing else can land in it while its load is in flight); the wait comes
+  // after whatever the caller put in between (the first trip's column loads).  The compiler does not count these loads.
+  __device__ __forceinline__ void settle() {
+    if (kN > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < kN; ++k) asm volatile("" ::"s"(t[k]));
+  }
+};
 
 // ---- the scan kernel -----------------------------------------------------------------------------
 // grid = n_ev*tiles_per_event PE workgroups + n_inj_tiles injection workgroups.  A PE workgroup owns `chunk_pe` consecutive samples of ONE event, so its record
@@ -1709,7 +1785,8 @@ constexpr int kRegularRepShift = 4;  // 16 gradient-row replicas in the regular 
 // and the replay (deterministic) mode as run-time options -- and the batch index as one too, so that there is ONE such kernel per term sequence.  Carrying these
 // options in the regular kernel cost it 50-90 VGPRs (config 5: 125 -> 213), i.e. one or two resident waves per SIMD.
 template <bool WRITE_LOGW, bool BATCH, bool SAFE, int U, int... Ks>
-__global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(const double* hc0, const double* hc1, const double* hc2, const double* hc3, const double* hc4, const unsigned h_geom,
+                                                                             const unsigned h_chunks, const unsigned hu_n_pe, const unsigned hu_n_inj, const KArgs a) {
   using ChainT = Chain<U, Ks...>;
   constexpr int kU = U;
   // Models with spline terms ("shared" mode): the workgroup keeps ONE set of gradient rows in LDS ([coefficient][replica],
@@ -1737,11 +1814,16 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   __shared__ double s_wrec[kWaves][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef GWI_STAMPS
-  unsigned long long* stamp_row = a.stamps + ((long long)blockIdx.x * kWaves + wave) * 8;
-#define GWI_STAMP(k)                                                        \
-  do {                                                                      \
-    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();         \
-    if (lane == 0) stamp_row[k] = t_;                                       \
+  // diagnostic build: the stamps stay in registers and are written when the wave ends (stamp 4) -- reading the row pointer
+  // out of the argument block at wave entry would put a memory round trip in front of everything the stamps are there to time
+  unsigned long long stamp_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GWI_STAMP(k)                                                                                   \
+  do {                                                                                                 \
+    stamp_v[k] = __builtin_amdgcn_s_memrealtime();                                                     \
+    if ((k) == 4 && lane == 0) {                                                                       \
+      unsigned long long* stamp_row_ = a.stamps + ((long long)blockIdx.x * kWaves + wave) * 8;         \
+      for (int q_ = 0; q_ < 8; ++q_) stamp_row_[q_] = stamp_v[q_];                                     \
+    }                                                                                                  \
   } while (0)
 #else
 #define GWI_STAMP(k) \
@@ -1754,79 +1836,59 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     unsigned hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-    if (lane == 0) stamp_row[5] = ((unsigned long long)xcc_id << 32) | hw_id;
+    stamp_v[5] = ((unsigned long long)xcc_id << 32) | hw_id;
   }
 #endif
-  kernarg_warm<(int)sizeof...(Ks), BATCH>(a);
-  // the sizes the start-up branches on, loaded in the same clause and pinned: the compiler would otherwise fetch each one
-  // where it is first used, a scalar round trip per dependent branch
-  int h_n_norms = a.n_norms, h_n_ev = a.n_ev, h_tiles = a.tiles_per_event, h_chunk_pe = a.chunk_pe, h_chunk_inj = a.chunk_inj, h_n_theta = a.n_theta;
-  long long h_n_pe = a.n_pe, h_n_inj = a.n_inj;
-  asm volatile("" : "+s"(h_n_norms), "+s"(h_n_ev), "+s"(h_tiles), "+s"(h_chunk_pe), "+s"(h_chunk_inj), "+s"(h_n_theta), "+s"(h_n_pe), "+s"(h_n_inj));
-  // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1
-  const bool batch = BATCH || (SAFE && a.tblocks != nullptr);
-  const int kb = batch ? (int)blockIdx.y : 0;
-  const double* theta_src = batch ? a.tblocks[kb].theta : a.theta;
+  // geometry and the first column pointers arrive in scalar registers (ScanHead); everything else comes from the argument block,
+  // whose lines are requested now and waited for only after the first trip's column loads have left
+  const int h_n_norms = (int)(h_geom >> (kGeomEventBits + kGeomTilesBits)), h_tiles = (int)((h_geom >> kGeomEventBits) & ((1u << kGeomTilesBits) - 1u));
+  const int h_n_ev = (int)(h_geom & ((1u << kGeomEventBits) - 1u));
+  const int h_chunk_pe = unpack_chunk(h_chunks & 0xffffu), h_chunk_inj = unpack_chunk(h_chunks >> 16);
+  const long long h_n_pe = hu_n_pe, h_n_inj = hu_n_inj;
+  KernargWarm<(int)sizeof...(Ks), BATCH> warm;
+  warm.issue();
+  // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1 (a single launch of the SAFE
+  // instantiation has one grid row)
+  const int kb = (BATCH || SAFE) ? (int)blockIdx.y : 0;
   const int n_norm_blocks = WRITE_LOGW ? 0 : h_n_norms;
-  if (!WRITE_LOGW && blockIdx.x == 0 && kb == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // the tail launches stamp their results with it
   if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
+    const bool batch_n = BATCH || (SAFE && a.tblocks != nullptr);
     const int j = blockIdx.x;
-    norm_block(a.norms, theta_src, h_n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
+    if (blockIdx.x == 0 && kb == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // the tail launches stamp their results with it
+    norm_block(a.norms, batch_n ? a.tblocks[kb].theta : a.theta, a.n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
     return;
   }
   const int b = (int)blockIdx.x - n_norm_blocks;
   const int n_pe_blocks = h_n_ev * h_tiles;
 
-  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids).  The loads go out HERE
-  // (one value per thread: n_theta <= kBlock), the LDS writes follow the first trip's column loads further down: the two
-  // memory round trips of a workgroup's start -- theta out of the argument block, then the columns -- overlap instead of
-  // queueing at the barrier (the caches were invalidated when the launch started: both come from memory)
-  static_assert(GWI_MAX_THETA <= kBlock, "one hyper-parameter per thread in the theta staging");
-  double theta_mine = 0.0, theta_next[3] = {0.0, 0.0, 0.0};  // theta[tid .. tid + 3]: this thread's entries of the power-basis table (spline_poly)
-  if (ChainT::kSpline) {
-    const int last = h_n_theta - 1;
-    theta_mine = theta_src[tid < last ? tid : last];  // unconditional (clamped index): no control flow between these loads and the columns', so the wait below can count
-#pragma unroll
-    for (int j = 0; j < 3; ++j) theta_next[j] = theta_src[tid + 1 + j < last ? tid + 1 + j : last];
-  }
-  // Replicas per coefficient: the regular kernels are built for 16 (the four rows of a sample then sit at immediate
-  // offsets of one LDS address: three address adds per spline term and sample less); the SAFE instantiation takes the
-  // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
-  const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
-  const int rep = 1 << rep_shift;
-  const int n_rows = h_n_theta << rep_shift;  // doubles in the shared rows
-  if (kShared)
-    for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
-  for (int p = tid; p < h_n_theta; p += kBlock) s_out[p] = 0.0;
-
+  // ---- this workgroup's tile and its first trip's column loads
   long long start, end, base;
-  Ctx ctx;
-  ctx.a = &a;
-  ctx.theta = theta_src;
-  ctx.derived = batch ? a.tblocks[kb].derived : a.derived;
-  ctx.coefs = s_theta;
-  double* const s_poly = s_gacc + (kShared ? n_rows : 0);  // behind the gradient rows in the dynamic LDS (log-weight launches keep no rows)
-  ctx.poly = s_poly;
-  ctx.gacc = s_gacc + (lane & (rep - 1));
-  ctx.rep_shift = rep_shift;
-  double* logw;
   if (b < n_pe_blocks) {
     const int e = b / h_tiles;
     const int t = b - e * h_tiles;
     start = (long long)t * h_chunk_pe;
     end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
     base = (long long)e * h_n_pe;
-    ctx.tcols = a.pe_tcols;
-    logw = a.logw_pe;
   } else {
     const int t = b - n_pe_blocks;
     start = (long long)t * h_chunk_inj;
     end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
     base = 0;
-    ctx.tcols = a.inj_tcols;
-    logw = a.logw_inj;
   }
-  const double* kappa_col = b < n_pe_blocks ? a.kappa_pe : a.kappa_inj;
+  const long long col_base = b < n_pe_blocks ? base : inj_offset(h_n_ev, h_n_pe);  // where this workgroup's sample set starts inside every column
+  // column pointers: the first kHeadCols slots from the preloaded arguments, the rest from the argument block (the generic
+  // chain indexes the block's table at run time); one pointer serves both sample sets
+  const double* const head_cols[kHeadCols] = {hc0, hc1, hc2, hc3, hc4};
+  const double* lcols[sizeof...(Ks)][2];
+  constexpr bool kGenericCols = ChainT::kGeneric;
+  if constexpr (!kGenericCols) ColFill<1, 0, Ks...>::run(lcols, head_cols, a);
+  Ctx ctx;
+  ctx.a = &a;
+  if constexpr (kGenericCols)
+    ctx.tcols = a.pe_tcols;
+  else
+    ctx.tcols = (const double* const (*)[2])lcols;
+  const double* kappa_col = hc0;
 
   double m = GWI_NEG_INF, s1 = 0.0, s2 = 0.0;
   ChainT chain;
@@ -1843,13 +1905,50 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     for (int u = 0; u < kU; ++u) {
       const int iu = i + u * kBlock;
       if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
-      const SIdx idx{base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
+      const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
       kap[buf][u] = gload(kappa_col, idx);
       chain.load(buf, u, 0, ctx, idx);
     }
   };
   const int i0 = tid;
-  GWI_STAMP(1);
+  if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns: nothing before them has waited for memory
+  GWI_STAMP(7);  // diagnostic build: the first trip's loads are issued
+
+  // ---- now the argument block
+  warm.settle();
+  GWI_STAMP(1);  // diagnostic build: the argument block's lines have arrived
+  const int h_n_theta = a.n_theta;
+  const bool batch = BATCH || (SAFE && a.tblocks != nullptr);
+  const double* theta_src = batch ? a.tblocks[kb].theta : a.theta;
+  if (!WRITE_LOGW && n_norm_blocks == 0 && blockIdx.x == 0 && kb == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // (with normaliser workgroups, the first of them does it)
+  double* const logw = b < n_pe_blocks ? a.logw_pe : a.logw_inj;
+
+  // theta -> LDS only where lane-varying indices need it (spline coefficients, normaliser grids): one value per thread
+  // (n_theta <= kBlock), in flight beside the columns; the LDS writes follow further down
+  static_assert(GWI_MAX_THETA <= kBlock, "one hyper-parameter per thread in the theta staging");
+  double theta_mine = 0.0, theta_next[3] = {0.0, 0.0, 0.0};  // theta[tid .. tid + 3]: this thread's entries of the power-basis table (spline_poly)
+  if (ChainT::kSpline) {
+    const int last = h_n_theta - 1;
+    theta_mine = theta_src[tid < last ? tid : last];  // unconditional (clamped index)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) theta_next[j] = theta_src[tid + 1 + j < last ? tid + 1 + j : last];
+  }
+  // Replicas per coefficient: the regular kernels are built for 16 (the four rows of a sample then sit at immediate
+  // offsets of one LDS address: three address adds per spline term and sample less); the SAFE instantiation takes the
+  // count at run time (64 in replay mode, whatever GWI_GACC_REP asks for)
+  const int rep_shift = SAFE ? a.gacc_shift : kRegularRepShift;
+  const int rep = 1 << rep_shift;
+  const int n_rows = h_n_theta << rep_shift;  // doubles in the shared rows
+  if (kShared)
+    for (int p = tid; p < n_rows; p += kBlock) s_gacc[p] = 0.0;
+  for (int p = tid; p < h_n_theta; p += kBlock) s_out[p] = 0.0;
+  ctx.theta = theta_src;
+  ctx.derived = batch ? a.tblocks[kb].derived : a.derived;
+  ctx.coefs = s_theta;
+  double* const s_poly = s_gacc + (kShared ? n_rows : 0);  // behind the gradient rows in the dynamic LDS (log-weight launches keep no rows)
+  ctx.poly = s_poly;
+  ctx.gacc = s_gacc + (lane & (rep - 1));
+  ctx.rep_shift = rep_shift;
 
   // shared mode: the reference exponent of this tile, in binades, workgroup-uniform and in a SCALAR register: the tile's
   // exact maximum at the previous evaluation of this (handle, point) -- a sampler moves theta by a leapfrog step between
@@ -1866,8 +1965,6 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   const int ref_slack = a.square ? 215 : 430;
   // two-pass mode (SAFE, shared only; the last resort): pass 0 sweeps the tile for its exact maximum, pass 1 is the regular loop
   const int first_pass = (SAFE && kShared && a.two_pass) ? 0 : 1;
-  if (i0 - lane < n_tile) issue_loads(0, i0);  // the first trip's columns, in flight before theta is waited for
-  GWI_STAMP(7);  // diagnostic build: the first trip's loads are issued
   if (kShared) {  // behind the column loads: the v_readfirstlane waits for this load, and the columns must not wait with it
     nref_slot = a.tile_nref + ((long long)(a.nref_row0 + kb) * a.nref_stride + b);
     const int prev = *nref_slot;

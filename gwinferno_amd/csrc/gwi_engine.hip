@@ -34,7 +34,16 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // compiled term sequences: each entry below is one explicit instantiation of scan_kernel.
 // ------------------------------------------------------------------------------------------------
-using ScanFn = void (*)(const KArgs);
+// the scan takes its tile geometry and first column pointers as fourteen scalar dwords ahead of the argument block (ScanHead,
+// gwi_device.h): the command processor preloads those into scalar registers
+using ScanFn = void (*)(const double*, const double*, const double*, const double*, const double*, unsigned, unsigned, unsigned, unsigned, const KArgs);
+using MfmaFn = void (*)(const KArgs);
+// the scan's kernel-argument segment as the host stages it
+struct ScanBlock {
+  ScanHead head;
+  KArgs k;
+};
+static_assert(offsetof(ScanBlock, k) == sizeof(ScanHead) && sizeof(ScanHead) % alignof(KArgs) == 0, "the struct follows the scalars without padding, as in the kernel's argument list");
 
 struct Variant {
   const char* name;
@@ -177,8 +186,8 @@ struct MfmaVariant {
   int n;
   int kinds[GWI_MAX_TERMS];
   int tiles[GWI_MAX_TERMS];
-  ScanFn fn;        // gradient tiles on the matrix cores (scan_mfma_kernel)
-  ScanFn rows_fn;   // gradient rows in LDS (scan_rows_kernel)
+  MfmaFn fn;        // gradient tiles on the matrix cores (scan_mfma_kernel)
+  MfmaFn rows_fn;   // gradient rows in LDS (scan_rows_kernel)
   int row_doubles;  // doubles a staged sample occupies (gwi_mfma.h: MChain::kRowDoubles)
 };
 #define T1(K) (100 + (K))
@@ -423,7 +432,9 @@ struct gwi_engine {
   int shm_rank = 0, shm_world = 0;
   unsigned long long shm_seq = 0;
   std::vector<double> shm_gather;
-  KArgs kargs;
+  ScanBlock sblock;          // what a scan launch takes: preloaded head + argument block
+  KArgs& kargs = sblock.k;
+  long long inj_off = 0;     // element offset of the injections inside every column allocation (inj_offset)
 };
 
 namespace {
@@ -596,17 +607,18 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
       (void)aql::dispatch_staged(h->aq, k, staged, grid.x, grid.y, block.x, (uint32_t)lds, done, /*acquire=*/slot != 1 || h->combine_acquire);
       return;
     }
-    if constexpr (std::is_same<A, KArgs>::value) if (!h->aql_tail_only) {  // GWI_AQL_TAIL=0: the whole block into a ring slot per launch (A/B only)
-      (void)aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done);
-      return;
-    }
-    if constexpr (std::is_same<A, KArgs>::value) {
+    if constexpr (std::is_same<A, ScanBlock>::value) {
+      constexpr size_t kOff = offsetof(ScanBlock, k);  // the argument block sits behind the preloaded scalars
+      if (!h->aql_tail_only) {  // GWI_AQL_TAIL=0: the whole block into a ring slot per launch (A/B only)
+        (void)aql::dispatch(h->aq, k, &args, kOff + used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done);
+        return;
+      }
       // the scan's block: fixed head in place, only the per-evaluation tail through the BAR (aql::dispatch_tail)
-      const size_t off_theta = offsetof(KArgs, theta);
-      const size_t ranges[3][2] = {{offsetof(KArgs, norm_seq), offsetof(KArgs, derived) - offsetof(KArgs, norm_seq)},
-                                   {offsetof(KArgs, derived), sizeof(double) * kMaxDerived * (size_t)h->spec.n_terms},
-                                   {off_theta, used_bytes > off_theta ? used_bytes - off_theta : 0}};
-      (void)aql::dispatch_tail(h->aq, k, h->tail_parity++, &args, offsetof(KArgs, norm_seq), used_bytes, ranges, 3, grid.x, grid.y, block.x, (uint32_t)lds, done);
+      const size_t off_theta = kOff + offsetof(KArgs, theta);
+      const size_t ranges[3][2] = {{kOff + offsetof(KArgs, norm_seq), offsetof(KArgs, derived) - offsetof(KArgs, norm_seq)},
+                                   {kOff + offsetof(KArgs, derived), sizeof(double) * kMaxDerived * (size_t)h->spec.n_terms},
+                                   {off_theta, kOff + used_bytes > off_theta ? kOff + used_bytes - off_theta : 0}};
+      (void)aql::dispatch_tail(h->aq, k, h->tail_parity++, &args, kOff + offsetof(KArgs, norm_seq), kOff + used_bytes, ranges, 3, grid.x, grid.y, block.x, (uint32_t)lds, done);
       return;  // on a queue error nothing was submitted; the waiters surface it
     } else {
       if (aql::dispatch(h->aq, k, &args, used_bytes, grid.x, grid.y, block.x, (uint32_t)lds, done)) return;
@@ -614,10 +626,18 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
       return;
     }
   }
-  if (h->timing)
-    hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, args);
-  else
-    hipLaunchKernelGGL(fn, grid, block, lds, h->stream, args);
+  if constexpr (std::is_same<A, ScanBlock>::value) {
+    const ScanHead& hd = args.head;
+    if (h->timing)
+      hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, hd.col[0], hd.col[1], hd.col[2], hd.col[3], hd.col[4], hd.geom, hd.chunks, hd.n_pe, hd.n_inj, args.k);
+    else
+      hipLaunchKernelGGL(fn, grid, block, lds, h->stream, hd.col[0], hd.col[1], hd.col[2], hd.col[3], hd.col[4], hd.geom, hd.chunks, hd.n_pe, hd.n_inj, args.k);
+  } else {
+    if (h->timing)
+      hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, args);
+    else
+      hipLaunchKernelGGL(fn, grid, block, lds, h->stream, args);
+  }
 }
 
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
@@ -639,7 +659,7 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   }
   // theta is the LAST member of the argument block: only the hyper-parameters in use travel through the BAR
   const size_t used = offsetof(KArgs, theta) + sizeof(double) * (size_t)h->spec.n_theta;
-  launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->kargs, used);
+  launch_timed(h, 0, fn, dim3(grid, batch ? K : 1), dim3(kBlock), h->scan_lds_bytes, h->sblock, used);
   GWI_HIP(hipGetLastError());
   return GWI_OK;
 }
@@ -712,6 +732,20 @@ void set_geometry(gwi_engine* h, bool batched) {
   h->kargs.chunk_pe = batched ? h->bgeo.chunk_pe : h->chunk_pe;
   h->kargs.n_inj_tiles = batched ? h->bgeo.n_inj_tiles : h->n_inj_tiles;
   h->kargs.chunk_inj = batched ? h->bgeo.chunk_inj : h->chunk_inj;
+  ScanHead& hd = h->sblock.head;
+  hd.geom = (unsigned)h->kargs.n_ev | ((unsigned)h->kargs.tiles_per_event << kGeomEventBits) | ((unsigned)h->kargs.n_norms << (kGeomEventBits + kGeomTilesBits));
+  hd.chunks = pack_chunk(h->kargs.chunk_pe) | (pack_chunk(h->kargs.chunk_inj) << 16);
+}
+
+// columns a term kind reads (= the doubles of its Term<K>::In): the order of the scan's preloaded column slots
+int term_cols(int kind) {
+  switch (kind) {
+#define GWI_X(K) \
+  case K: return (int)(sizeof(typename Term<K>::In) / sizeof(double));
+    GWI_FOR_EACH_KIND(GWI_X)
+#undef GWI_X
+    default: return 0;
+  }
 }
 
 gwi_status run_pipeline_once(gwi_handle h, const double* theta, double* record_dev, bool wait, int K, bool batch, bool square) {
@@ -1186,8 +1220,7 @@ void destroy_impl(gwi_engine* h) {
   }
   if (h->poisoned) (void)hipDeviceSynchronize();
   aql::close_queue(h->aq);
-  for (double* p : h->d_cols_pe) (void)hipFree(p);
-  for (double* p : h->d_cols_inj) (void)hipFree(p);
+  for (double* p : h->d_cols_pe) (void)hipFree(p);  // each holds both sample sets (alloc_pair); d_cols_inj are interior pointers
   for (double* p : h->d_norm_arrays) (void)hipFree(p);
   (void)hipFree(h->d_norms);
   (void)hipFree(h->d_partials);
@@ -1224,6 +1257,20 @@ gwi_status upload(gwi_handle h, const double* src, size_t n, double** dst, std::
   keep->push_back(d);
   if (n) GWI_HIP(hipMemcpy(d, src, sizeof(double) * n, hipMemcpyHostToDevice));
   *dst = d;
+  return GWI_OK;
+}
+
+// One allocation per column for BOTH sample sets: the posterior samples first, the injections inj_offset() elements behind
+// (a 256-byte boundary).  The scan addresses either set through the same pointer (ScanHead, gwi_device.h).  d_cols_pe owns
+// the allocations; d_cols_inj holds the interior pointers.
+gwi_status alloc_pair(gwi_handle h, double** dpe, double** dinj) {
+  double* d = nullptr;
+  const size_t n = (size_t)h->inj_off + (size_t)(h->n_inj ? h->n_inj : 1);
+  GWI_HIP(hipMalloc(&d, sizeof(double) * n));
+  h->d_cols_pe.push_back(d);
+  h->d_cols_inj.push_back(d + h->inj_off);
+  *dpe = d;
+  *dinj = d + h->inj_off;
   return GWI_OK;
 }
 
@@ -1285,7 +1332,7 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
   for (int i = 0; i < 3; ++i)
     if (!aql::find_kernel(dev, hipKernelNameRefByPtr(fns[i], h->stream), *out[i], h->aql_note)) return;
   if (h->variant->scan_safe && !aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->scan_safe), h->stream), h->aq_scan_safe, h->aql_note)) return;
-  if (h->aq_scan.kernarg_bytes != sizeof(KArgs) || h->aq_combine.kernarg_bytes != sizeof(TailArgs) || h->aq_final.kernarg_bytes != sizeof(TailArgs)) {
+  if (h->aq_scan.kernarg_bytes != sizeof(ScanBlock) || h->aq_combine.kernarg_bytes != sizeof(TailArgs) || h->aq_final.kernarg_bytes != sizeof(TailArgs)) {
     h->aql_note = "kernel argument sizes of the code object differ from this build (stale gwi_kernels.hsaco?)";
     return;
   }
@@ -1399,29 +1446,28 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   h->n_ev = n_ev;
   h->n_pe = n_pe;
   h->n_inj = n_inj;
+  h->inj_off = inj_offset(n_ev, n_pe);
 
   // ---- columns -> HBM (struct-of-arrays: one contiguous fp64 array per column and sample set)
   std::vector<const double*> tab_pe(spec->n_cols), tab_inj(spec->n_cols);
   if (ingest) {
     // setup on the device: raw catalog columns up, one kernel per sample set writes the engine's columns (gwi_ingest.h)
     for (int c = 0; c < spec->n_cols; ++c) {
-      double* d = nullptr;
-      GWI_HIP(hipMalloc(&d, sizeof(double) * (size_t)(n_ev * n_pe ? n_ev * n_pe : 1)));
-      h->d_cols_pe.push_back(d);
-      tab_pe[c] = d;
-      GWI_HIP(hipMalloc(&d, sizeof(double) * (size_t)(n_inj ? n_inj : 1)));
-      h->d_cols_inj.push_back(d);
-      tab_inj[c] = d;
+      double *dpe = nullptr, *dinj = nullptr;
+      if ((st = alloc_pair(h, &dpe, &dinj)) != GWI_OK) return st;
+      tab_pe[c] = dpe;
+      tab_inj[c] = dinj;
     }
     if ((st = ingest_run(h->err, ing_pe, n_ev * n_pe, spec->n_cols, h->d_cols_pe.data(), h->stream)) != GWI_OK) return st;
     if ((st = ingest_run(h->err, ing_inj, n_inj, spec->n_cols, h->d_cols_inj.data(), h->stream)) != GWI_OK) return st;
   } else {
     for (int c = 0; c < spec->n_cols; ++c) {
-      double* d;
-      if ((st = upload(h, pe_cols[c], (size_t)(n_ev * n_pe), &d, &h->d_cols_pe)) != GWI_OK) return st;
-      tab_pe[c] = d;
-      if ((st = upload(h, inj_cols[c], (size_t)n_inj, &d, &h->d_cols_inj)) != GWI_OK) return st;
-      tab_inj[c] = d;
+      double *dpe = nullptr, *dinj = nullptr;
+      if ((st = alloc_pair(h, &dpe, &dinj)) != GWI_OK) return st;
+      if (n_ev * n_pe) GWI_HIP(hipMemcpy(dpe, pe_cols[c], sizeof(double) * (size_t)(n_ev * n_pe), hipMemcpyHostToDevice));
+      if (n_inj) GWI_HIP(hipMemcpy(dinj, inj_cols[c], sizeof(double) * (size_t)n_inj, hipMemcpyHostToDevice));
+      tab_pe[c] = dpe;
+      tab_inj[c] = dinj;
     }
   }
 
@@ -1474,10 +1520,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
         }
         double *dpe = h->d_cols_pe[c], *dinj = h->d_cols_inj[c];
         if (!all_agree) {  // a private copy for this use
-          GWI_HIP(hipMalloc(&dpe, sizeof(double) * (size_t)(n_ev * n_pe ? n_ev * n_pe : 1)));
-          h->d_cols_pe.push_back(dpe);
-          GWI_HIP(hipMalloc(&dinj, sizeof(double) * (size_t)(n_inj ? n_inj : 1)));
-          h->d_cols_inj.push_back(dinj);
+          if ((st = alloc_pair(h, &dpe, &dinj)) != GWI_OK) return st;
         }
         GWI_HIP(spline_knot_run(tab_pe[c], dpe, n_ev * n_pe, u.lo, u.inv_dx, u.top, h->stream));
         GWI_HIP(spline_knot_run(tab_inj[c], dinj, n_inj, u.lo, u.inv_dx, u.top, h->stream));
@@ -1696,6 +1739,10 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     if (h->chunk_pe < min_pe) h->chunk_pe = (int)min_pe;
     if (h->chunk_inj < min_inj) h->chunk_inj = (int)min_inj;
   }
+  // the scan receives its tile sizes in 16 bits each (ScanHead::chunks): exact below 32 768 samples, multiples of 256 above
+  auto packable = [](int c) { return c >= 32768 && c % 256 ? (c / 256 + 1) * 256 : c; };
+  h->chunk_pe = packable(h->chunk_pe);
+  h->chunk_inj = packable(h->chunk_inj);
   h->tiles_per_event = (int)((n_pe + h->chunk_pe - 1) / h->chunk_pe);
   h->n_inj_tiles = (int)((n_inj + h->chunk_inj - 1) / h->chunk_inj);
   h->n_scan_blocks = (int)(n_ev * h->tiles_per_event + h->n_inj_tiles);
@@ -1718,8 +1765,8 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   }
   if (spb_batch > 0 && !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK")) {
     auto& b = h->bgeo;
-    b.chunk_pe = (int)(spb_batch < n_pe_pad ? spb_batch : n_pe_pad);
-    b.chunk_inj = (int)spb_batch;
+    b.chunk_pe = packable((int)(spb_batch < n_pe_pad ? spb_batch : n_pe_pad));
+    b.chunk_inj = packable((int)spb_batch);
     b.tiles_per_event = (int)((n_pe + b.chunk_pe - 1) / b.chunk_pe);
     b.n_inj_tiles = (int)((n_inj + b.chunk_inj - 1) / b.chunk_inj);
     b.n_scan_blocks = (int)(n_ev * b.tiles_per_event + b.n_inj_tiles);
@@ -1824,6 +1871,27 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   k.redo_dev = h->d_seq + 1;
   k.two_pass = 0;
   k.deterministic = h->deterministic ? 1 : 0;
+  {  // the scan's preloaded arguments (ScanHead): kappa, then the terms' columns in term order; geometry by set_geometry
+    ScanHead& hd = h->sblock.head;
+    std::memset(&hd, 0, sizeof(hd));
+    int slot = 0;
+    bool joint = true;
+    auto put = [&](const double* pe, const double* inj) {
+      joint = joint && inj == pe + h->inj_off;
+      if (slot < kHeadCols) hd.col[slot] = pe;
+      ++slot;
+    };
+    put(k.kappa_pe, k.kappa_inj);
+    for (int t = 0; t < spec->n_terms; ++t)
+      for (int j = 0; j < term_cols(spec->terms[t].kind) && j < 2; ++j) put(k.pe_tcols[t][j], k.inj_tcols[t][j]);
+    for (; slot < kHeadCols; ++slot) hd.col[slot] = k.kappa_pe;  // unused slots: any valid address
+    if (!joint) return fail(h, GWI_ERR_INVALID, "internal error: a column's injection part does not sit inj_offset() behind its posterior-sample part");
+    if (n_ev >= (1LL << kGeomEventBits) || n_pe >= (1LL << 32) || n_inj >= (1LL << 32) || spec->n_norms >= 16 || h->tiles_per_event >= (1 << kGeomTilesBits) ||
+        !chunk_packs(h->chunk_pe) || !chunk_packs(h->chunk_inj) || (h->bgeo.distinct && (!chunk_packs(h->bgeo.chunk_pe) || !chunk_packs(h->bgeo.chunk_inj))))
+      return fail(h, GWI_ERR_INVALID, "catalog shape outside the scan's packed geometry (events < 2^20, samples per event and injections < 2^32, tiles < 8.4 M samples)");
+    hd.n_pe = (unsigned)n_pe;
+    hd.n_inj = (unsigned)n_inj;
+  }
   for (int t = 0; t < spec->n_terms; ++t) {
     const gwi_term& tm = spec->terms[t];
     TermD& d = k.terms[t];

@@ -105,7 +105,7 @@ def test_raw_code_object_for_the_aql_path(lib):
     safe = [n for n in scans if "scan_kernelILb0ELb0ELb1E" in n]  # the two-pass / replay instantiation of the spline term sequences
     # value / log-weight / batched instantiation per compiled term sequence, + the SAFE instantiation of the spline sequences,
     # + the generic (run-time term loop) chain: one SAFE instantiation for every role and its log-weight variant
-    generic = [n for n in scans if n.endswith("JLi0EEEEvNS_5KArgsE")]
+    generic = [n for n in scans if re.search(r"JLi0EEEEv.*NS_5KArgsE$", n)]  # (scalar head arguments, then the argument block)
     assert len(generic) == 2 and sum(n in safe for n in generic) == 1
     assert len(scans) == 3 * n_variants + (len(safe) - 1) + 2
     assert 0 < len(safe) - 1 < n_variants

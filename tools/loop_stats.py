@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction mix of the largest loop of a kernel in a `hipcc -S` listing (VALU / SALU / LDS / s_waitcnt counts):
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude -Igwinferno_amd/csrc --cuda-device-only -S -o one.s one.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-kernarg-preload-count=16 -Iinclude -Igwinferno_amd/csrc --cuda-device-only -S -o one.s one.hip
     python tools/loop_stats.py one.s
 where one.hip instantiates ONE kernel (template __global__ void gwi::scan_kernel<...>(const KArgs);)."""
 import re,sys

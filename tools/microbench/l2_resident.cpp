@@ -103,7 +103,21 @@ int main(int argc, char** argv) {
   CK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group));
   CK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
   std::printf("kernarg %u B (explicit %zu), LDS %u B, scratch %u B\n", karg_size, sizeof(Args), group, priv);
-  if (karg_size > 1024) return std::printf("unexpected kernarg size\n"), 1;
+  hsa_executable_symbol_t sym_p;
+  CK(hsa_executable_get_symbol_by_name(exe, "stream_kernel_preload.kd", &g_gpu, &sym_p));
+  uint64_t kobj_p = 0;
+  uint32_t karg_size_p = 0;
+  CK(hsa_executable_symbol_get_info(sym_p, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj_p));
+  CK(hsa_executable_symbol_get_info(sym_p, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &karg_size_p));
+  struct ArgsP {
+    const double* c[4];
+    int tile, n_cols;
+    long long n;
+    int work, pad;
+    Args a;
+  };
+  std::printf("preload variant: kernarg %u B (explicit %zu)\n", karg_size_p, sizeof(ArgsP));
+  if (karg_size > 1024 || karg_size_p > 1024) return std::printf("unexpected kernarg size\n"), 1;
   CK(hsa_amd_agent_iterate_memory_pools(g_gpu, pick_pool, nullptr));
   if (!g_have_pool) return std::printf("no device pool\n"), 1;
   char* karg = nullptr;
@@ -145,7 +159,16 @@ int main(int argc, char** argv) {
       __sync_synchronize();
       volatile char sink = karg[sizeof(a) - 1];  // read back through the BAR: the posted writes have landed
       (void)sink;
-      for (int scope : {HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE}) {
+      ArgsP ap;
+      std::memset(&ap, 0, sizeof(ap));
+      for (int c = 0; c < 4; ++c) ap.c[c] = a.col[c];
+      ap.tile = a.tile, ap.n_cols = a.n_cols, ap.n = a.n, ap.work = a.work, ap.a = a;
+      std::memcpy(karg + 2048, &ap, sizeof(ap));
+      __sync_synchronize();
+      sink = karg[2048 + sizeof(ap) - 1];
+      for (int scope : {(int)HSA_FENCE_SCOPE_AGENT, (int)HSA_FENCE_SCOPE_NONE, (int)HSA_FENCE_SCOPE_SYSTEM, (int)HSA_FENCE_SCOPE_NONE, -1, (int)HSA_FENCE_SCOPE_AGENT, -1}) {
+        const bool preload = scope < 0;
+        if (preload) scope = HSA_FENCE_SCOPE_AGENT;
         const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                 (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
         std::vector<double> kern, host;
@@ -158,8 +181,8 @@ int main(int argc, char** argv) {
           p->workgroup_size_x = 256, p->workgroup_size_y = 1, p->workgroup_size_z = 1;
           p->grid_size_x = (uint32_t)grid * 256, p->grid_size_y = 1, p->grid_size_z = 1;
           p->private_segment_size = priv, p->group_segment_size = group;
-          p->kernel_object = kobj;
-          p->kernarg_address = karg;
+          p->kernel_object = preload ? kobj_p : kobj;
+          p->kernarg_address = preload ? karg + 2048 : karg;
           p->completion_signal = done;
           __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)p->setup << 16), __ATOMIC_RELEASE);
           hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
@@ -174,7 +197,7 @@ int main(int argc, char** argv) {
         }
         std::sort(kern.begin(), kern.end());
         std::sort(host.begin(), host.end());
-        const char* sname = scope == HSA_FENCE_SCOPE_NONE ? "none  " : (scope == HSA_FENCE_SCOPE_AGENT ? "agent " : "system");
+        const char* sname = preload ? "agent, scalar arguments preloaded" : (scope == HSA_FENCE_SCOPE_NONE ? "none  " : (scope == HSA_FENCE_SCOPE_AGENT ? "agent " : "system"));
         std::printf("%-40s W = %2d  acquire %s: kernel median %7.2f us (min %7.2f)   doorbell -> signal median %7.2f us\n", cs.name, work, sname, kern[kern.size() / 2], kern[0],
                     host[host.size() / 2]);
       }

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): per-wave phase timeline of the scan kernel from s_memrealtime stamps.
 Build the stamped library first:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DGWI_STAMPS -Iinclude \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -mllvm -amdgpu-kernarg-preload-count=16 -DGWI_STAMPS -Iinclude \
         gwinferno_amd/csrc/gwi_engine.hip -o gwinferno_amd/_lib/libgwi_engine_stamps.so -ldl
   GWI_ENGINE_LIB=gwinferno_amd/_lib/libgwi_engine_stamps.so python tools/stamp_phases.py c2
-Stamps: 0 wave entry, 1 prologue done, 2 first trip's loads landed, 3 loop done, 4 record written."""
+Stamps: 0 wave entry, 7 first trip's column loads issued, 1 the argument block's lines arrived, 2 first trip's loads landed,
+3 loop done, 6 the waves' sums in place, 4 record written (the stamps stay in registers until then)."""
 import ctypes as C
 import os
 import sys
@@ -44,11 +45,17 @@ for x in range(8):
         print(f"  xcd-group {x}: first entry tick offset vs global min {(st[sel, 0].min() - st[:, 0].min()) / 100.0:7.2f} us, waves {sel.sum()}")
         us[sel] = (st[sel] - st[sel, 0].min()) / 100.0
 print(f"{cfg}: {len(st)} waves; kernel span (first entry -> last record) {us[:, 4].max():.2f} us")
-names = ["entry (dispatch skew)", "prologue", "first loads land", "evaluate + accumulate", "epilogue (record)"]
-prev = np.zeros(len(us))
-for k in range(5):
-    d = us[:, k] - (us[:, k - 1] if k else 0.0)
-    print(f"  {names[k]:26s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us   (absolute median end {np.median(us[:, k]):6.2f})")
+names = ["entry (dispatch skew)", "column loads issued", "argument block arrived", "first loads land (+ theta staging)", "evaluate + accumulate", "record"]
+order = [0, 7, 1, 2, 3, 4]
+raw_ok = raw[ok].astype(np.int64)
+tt = np.zeros((len(st), 6))
+for x in range(8):
+    sel = xcd == x
+    if sel.any():
+        tt[sel] = (raw_ok[sel][:, order] - st[sel, 0].min()) / 100.0
+for k in range(6):
+    d = tt[:, k] - (tt[:, k - 1] if k else 0.0)
+    print(f"  {names[k]:36s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us   (absolute median end {np.median(tt[:, k]):6.2f})")
 # inside the record phase: stamp 6 = the waves' sums in place (after the workgroup barrier); a -DGWI_AB_OLD_RECORD build also
 # has 7 = scalar sums reduced (there 6 = the waves' references exchanged)
 ext = raw[:, 6:8].astype(np.int64)[ok]
@@ -60,10 +67,6 @@ if (ext[:, 0] > 0).all():
         print(f"  record phase split (old record): reference exchange {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}), sums through LDS {np.median(e7):.2f} (p90 {np.percentile(e7, 90):.2f}), "
               f"row readout + record stores {np.median(e8):.2f} (p90 {np.percentile(e8, 90):.2f}) us")
     else:
-        if (ext[:, 1] > 0).all():  # 7 = the first trip's loads issued (inside "first loads land")
-            i7 = (ext[:, 1] - st[:, 1]) / 100.0
-            l7 = (st[:, 2] - ext[:, 1]) / 100.0
-            print(f"  start-up split: stamp 1 -> first loads issued {np.median(i7):.2f} (p90 {np.percentile(i7, 90):.2f}), issued -> landed (+ theta staging and barrier) {np.median(l7):.2f} (p90 {np.percentile(l7, 90):.2f}) us")
         e8 = (st[:, 4] - ext[:, 0]) / 100.0
         print(f"  record phase split: own sums + wait for the workgroup {np.median(e6):.2f} (p90 {np.percentile(e6, 90):.2f}, min {e6.min():.2f}), cross-wave sum + readout + stores {np.median(e8):.2f} "
               f"(p90 {np.percentile(e8, 90):.2f}) us")
