@@ -166,13 +166,20 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
     except (AttributeError, OSError):
         affinity = avail
     probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16), min(affinity, 256)})}
-    cores = max(probe, key=probe.get)
-    n, t_used = 0, 0.0
-    while t_used < budget_s:
-        t0 = time.perf_counter()
-        orc.evaluate(thetas[n % len(thetas)], total, min_neff_cut=False, n_threads=cores)
-        t_used += time.perf_counter() - t0
-        n += 1
+    # ... and the probe's two best counts are then run SUSTAINED (half the budget each, the smaller count first): a burst of a few
+    # evaluations on every visible CPU can beat the cgroup's CPU quota that a run of seconds is throttled to (a 16-CPU quota
+    # on a 128-CPU box: 356 evals/s in the probe, 8 sustained)
+    sustained = {}
+    for nt in sorted(sorted(probe, key=probe.get, reverse=True)[:2]):
+        k, t_nt = 0, 0.0
+        while t_nt < budget_s / 2.0:
+            t0 = time.perf_counter()
+            orc.evaluate(thetas[k % len(thetas)], total, min_neff_cut=False, n_threads=nt)
+            t_nt += time.perf_counter() - t0
+            k += 1
+        sustained[nt] = (k, t_nt)
+    cores = max(sustained, key=lambda nt: sustained[nt][0] / sustained[nt][1])
+    n, t_used = sustained[cores]
     t0 = time.perf_counter()
     orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=1)
     t_single = time.perf_counter() - t0
@@ -183,6 +190,7 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         "kind": "port",
         "sample": f"{n} value+gradient evals of the full catalog by the C/OpenMP oracle on {cores} threads ({t_used:.1f}s)",
         "threads_probe_evals_per_s": {str(k): v for k, v in probe.items()},
+        "sustained_evals_per_s": {str(nt): k / t for nt, (k, t) in sustained.items()},
         "at_all_usable_cpus": {"cores": avail, "evals_per_s": probe[avail], "what": "CPUs this process may use: scheduler affinity capped by the cgroup CPU quota"},
         "at_affinity_count": {"cores": min(affinity, 256), "evals_per_s": probe[min(affinity, 256)]},
         "parallel_units": "blocks of 512 samples: (event, block) pairs and injection blocks in ONE OpenMP region, merged in block order (oracle/gwpop_oracle.c)",

@@ -1746,8 +1746,11 @@ struct KernargWarm {
       }
     return 0;
   }
+  // single evaluations only: a batched launch runs many workgroups per CU one after the other, whose argument lines are in the
+  // scalar cache after the first -- there the fourteen extra loads per wave cost the config-2 batch 11 % (4.65 -> 5.2 us per
+  // evaluation at K = 16) for nothing
 #ifndef GWI_AB_NO_KERNARG_WARM
-  static constexpr int kN = count();
+  static constexpr int kN = BATCH_THETA ? 0 : count();
 #else
   static constexpr int kN = 0;
 #endif

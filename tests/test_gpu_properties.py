@@ -269,3 +269,30 @@ def test_few_events_with_many_samples_get_at_most_16_tiles_per_event(monkeypatch
         assert np.allclose(a.log_bfs, b.log_bfs, rtol=0, atol=1e-11) and np.allclose(a.grad, b.grad, rtol=1e-10, atol=1e-10 * np.max(np.abs(b.grad)))
     eng.close()
     ref.close()
+
+
+def test_tiles_beyond_32768_samples_against_the_c_oracle():
+    """Two events of 2.3 M posterior samples each: 64 tiles per event need tiles of >= 35 938 samples, which the scan's preloaded
+    geometry carries in units of 256 (ScanHead::chunks, gwi_device.h) -- the launch geometry rounds them to whole multiples, and
+    the likelihood, the per-event sites and the gradient still match the C oracle.  (Also: injections that start on an odd
+    offset inside the columns' joint allocations -- 2 x 2 300 001 samples -- i.e. the padding of inj_offset().)"""
+    from golden_util import rel_err
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    pe, inj, total = make_catalog(2, 2_300_001, 30_000, seed=41)
+    comp = COMPOSITIONS["pl_test"](pe, inj)
+    eng = comp.engine()
+    geo = eng.launch_geometry()
+    assert geo["chunk_pe"] >= 32768 and geo["chunk_pe"] % 256 == 0 and geo["tiles_per_event"] <= 64, geo
+    orc = COracle(eng.bound)
+    th = comp.theta(draw_params("pl_test", np.random.default_rng(4)))
+    got = eng.evaluate(th, total, min_neff_cut=False)
+    ref = orc.evaluate(th, total, min_neff_cut=False)
+    assert rel_err(got.log_likelihood, ref["log_likelihood"]) < 1e-9
+    assert rel_err(got.log_bfs, ref["logBFs"]) < 1e-9
+    scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+    assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    eng.close()

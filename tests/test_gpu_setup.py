@@ -263,6 +263,7 @@ def test_oversized_setup_program_falls_back_to_the_host_path(monkeypatch):
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
 
+    monkeypatch.delenv("GWI_HOST_SETUP", raising=False)  # (the suite is also run with the host path forced: this test is about the default)
     pe, inj, total = make_catalog(5, 200, 3000, seed=17)
     ref = COMPOSITIONS["bspline_test"](pe, inj)
     eng_ref = ref.engine()
