@@ -166,11 +166,12 @@ int main(int argc, char** argv) {
       std::memcpy(karg + 2048, &ap, sizeof(ap));
       __sync_synchronize();
       sink = karg[2048 + sizeof(ap) - 1];
-      for (int scope : {(int)HSA_FENCE_SCOPE_AGENT, (int)HSA_FENCE_SCOPE_NONE, (int)HSA_FENCE_SCOPE_SYSTEM, (int)HSA_FENCE_SCOPE_NONE, -1, (int)HSA_FENCE_SCOPE_AGENT, -1}) {
-        const bool preload = scope < 0;
-        if (preload) scope = HSA_FENCE_SCOPE_AGENT;
+      for (int scope : {(int)HSA_FENCE_SCOPE_AGENT, (int)HSA_FENCE_SCOPE_NONE, (int)HSA_FENCE_SCOPE_SYSTEM, (int)HSA_FENCE_SCOPE_NONE, -1, (int)HSA_FENCE_SCOPE_AGENT, -1, -2, (int)HSA_FENCE_SCOPE_AGENT, -2}) {
+        const bool preload = scope == -1;
+        const bool no_release = scope == -2;  // agent-scope acquire, NO release fence at the end of the kernel
+        if (scope < 0) scope = HSA_FENCE_SCOPE_AGENT;
         const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                                (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | ((no_release ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
         std::vector<double> kern, host;
         for (int it = 0; it < 60; ++it) {
           hsa_signal_store_relaxed(done, 1);
@@ -197,7 +198,7 @@ int main(int argc, char** argv) {
         }
         std::sort(kern.begin(), kern.end());
         std::sort(host.begin(), host.end());
-        const char* sname = preload ? "agent, scalar arguments preloaded" : (scope == HSA_FENCE_SCOPE_NONE ? "none  " : (scope == HSA_FENCE_SCOPE_AGENT ? "agent " : "system"));
+        const char* sname = no_release ? "agent, no release fence" : preload ? "agent, scalar arguments preloaded" : (scope == HSA_FENCE_SCOPE_NONE ? "none  " : (scope == HSA_FENCE_SCOPE_AGENT ? "agent " : "system"));
         std::printf("%-40s W = %2d  acquire %s: kernel median %7.2f us (min %7.2f)   doorbell -> signal median %7.2f us\n", cs.name, work, sname, kern[kern.size() / 2], kern[0],
                     host[host.size() / 2]);
       }
