@@ -515,13 +515,9 @@ inline bool dispatch_staged(Queue& q, const Kernel& k, char* ka, uint32_t grid_x
   p->kernarg_address = ka;
   p->reserved2 = 0;
   p->completion_signal = completion;
-  static const int release_scope = [] {  // GWI_AQL_RELEASE=0: no release fence (timing probe only: results may be stale)
-    const char* env = std::getenv("GWI_AQL_RELEASE");
-    return (env && std::atoi(env) == 0) ? (int)HSA_FENCE_SCOPE_NONE : (int)HSA_FENCE_SCOPE_AGENT;
-  }();
   const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                           ((acquire ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-                          (release_scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                          (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
   __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
   a.signal_store(hq->doorbell_signal, (hsa_signal_value_t)idx);
   return true;
