@@ -52,10 +52,12 @@ __global__ __launch_bounds__(64) void combine_kernel(const Args a) {  // one wav
   const double m = has ? __hip_atomic_load(r + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : -1e300;
   double mx = m;
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  double mts[kPerGroup];  // every lane takes part in the shuffles: lane 9 holds a tile's exponent too (inside the branch below it is inactive)
+  for (int t = 0; t < kPerGroup; ++t) mts[t] = __shfl(m, t);
   if (lane < kVals) {
     double s = 0.0;
     for (int t = 0; t < kPerGroup; ++t) {
-      const double mt = __shfl(m, t);
+      const double mt = mts[t];
       const double v = __hip_atomic_load(r + t * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       s += lane == 0 ? 0.0 : ldexp(v, (int)(mt - mx) * (lane == 2 ? 2 : 1));
     }
