@@ -735,6 +735,30 @@ def multi_chain(eng, eng_comp, comp_name, pe, inj, total, thetas, C, steps, dev)
     for w in workers:
         w.join()
     out["threaded_chains"] = {"chains": C, "host_threads": C, "evals_per_s": C * n_c / dt, "us_per_eval": 1e6 * dt / (C * n_c)}
+    # ... and with twice as many chains: how much of the GPU one chain's kernels leave idle (a single scan keeps three waves per
+    # SIMD busy; the kernels of other chains fill the gaps until vector issue saturates)
+    more = [COMPOSITIONS[comp_name](pe, inj) for _ in range(C)]
+    engines2 = all_engines + [c.engine() for c in more]
+    gate2 = threading.Barrier(2 * C + 1)
+
+    def chain2(e, th):
+        e.selftime(th, total, n_iter=50, min_neff_cut=False)
+        gate2.wait()
+        e.selftime(th, total, n_iter=n_c, min_neff_cut=False)
+        gate2.wait()
+
+    workers = [threading.Thread(target=chain2, args=(e, thetas[i])) for i, e in enumerate(engines2)]
+    for w in workers:
+        w.start()
+    gate2.wait()
+    t0 = time.perf_counter()
+    gate2.wait()
+    dt2 = time.perf_counter() - t0
+    for w in workers:
+        w.join()
+    out["threaded_chains"]["with_twice_the_chains"] = {"chains": 2 * C, "host_threads": 2 * C, "evals_per_s": 2 * C * n_c / dt2, "us_per_eval": 1e6 * dt2 / (2 * C * n_c)}
+    for c in more:
+        c.engine().close()
     out["native_nuts"] = native_nuts(all_engines, comp_name, eng_comp, total, thetas)
     for c in extra:
         c.engine().close()
