@@ -1715,7 +1715,7 @@ struct ColFill<SLOT, T, K, Rest...> {
 // trip after the other (header -> sizes -> PE-or-injection choice -> column pointers: 1.0 us from wave entry to the first
 // column load at config 2, 1.8 at config 3 by the phase stamps).  One dword of every line the start-up and the first trip
 // will read, loaded in ONE clause at wave entry, turns all but the first of those round trips into scalar-cache hits.
-template <int N_TERMS, bool BATCH_THETA>
+template <int N_TERMS, bool BATCHED>
 struct KernargWarm {
   // byte ranges of the argument block -> one dword per 64-byte line: the column pointers (those beyond the preloaded ones come
   // from here); pointers, sizes and the terms' descriptors; the per-evaluation tail up to the last term's derived scalars; the
@@ -1728,8 +1728,8 @@ struct KernargWarm {
   static constexpr size_t hi(int r) {
     return r == 0   ? offsetof(KArgs, pe_tcols) + 16 * N_TERMS
            : r == 1 ? offsetof(KArgs, terms) + sizeof(TermD) * N_TERMS
-           : r == 2 ? (BATCH_THETA ? offsetof(KArgs, derived) : offsetof(KArgs, derived) + sizeof(double) * kMaxDerived * N_TERMS)
-                    : (BATCH_THETA ? offsetof(KArgs, theta) : offsetof(KArgs, theta) + 128);
+           : r == 2 ? offsetof(KArgs, derived) + sizeof(double) * kMaxDerived * N_TERMS
+                    : offsetof(KArgs, theta) + 128;
   }
   static constexpr int count() {
     int n = 0;
@@ -1750,7 +1750,7 @@ struct KernargWarm {
   // scalar cache after the first -- there the fourteen extra loads per wave cost the config-2 batch 11 % (4.65 -> 5.2 us per
   // evaluation at K = 16) for nothing
 #ifndef GWI_AB_NO_KERNARG_WARM
-  static constexpr int kN = BATCH_THETA ? 0 : count();
+  static constexpr int kN = BATCHED ? 0 : count();
 #else
   static constexpr int kN = 0;
 #endif
