@@ -296,3 +296,27 @@ def test_tiles_beyond_32768_samples_against_the_c_oracle():
     scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
     assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
     eng.close()
+
+
+def test_geometry_flips_between_single_and_batched_launches_many_times():
+    """The scan's tile geometry travels as PRELOADED kernel arguments (ScanHead: the command processor reads them out of the
+    argument block before the wave starts), and a batched launch (K >= 4) of config 2 runs on another geometry than a single
+    evaluation, in the same persistent argument slots: 600 alternations single / batched / single must each reproduce the
+    first results to the bit -- a stale head (the other launch's tile size or event count) would show as a different sum."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_config_catalog
+
+    pe, inj, total = make_config_catalog("c2")
+    comp = COMPOSITIONS["plpeak"](pe, inj)
+    eng = comp.engine()
+    rng = np.random.default_rng(11)
+    thetas = np.stack([comp.theta(draw_params("plpeak", rng)) for _ in range(4)])
+    single0 = [eng.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    batch0 = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+    for it in range(600):
+        k = it & 3
+        s = eng.evaluate(thetas[k], total, min_neff_cut=False)
+        assert s.log_likelihood == single0[k].log_likelihood and np.array_equal(s.grad, single0[k].grad), it
+        b = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+        assert all(b[j].log_likelihood == batch0[j].log_likelihood and np.array_equal(b[j].grad, batch0[j].grad) for j in range(4)), it
+    eng.close()
