@@ -34,3 +34,26 @@ def test_measured_hbm_bandwidth_is_plausible():
     assert 2000.0 < read < 9000.0 and 2000.0 < triad < 9000.0
     with pytest.raises(N.NativeEngineError):
         hbm_bandwidth(0, n_doubles=8)
+
+
+def test_creating_and_destroying_engines_leaves_device_memory_where_it_was():
+    """gwi_create / gwi_destroy in a loop (host-setup and device-setup paths, a spline model with private knot-coordinate
+    copies): the device's free memory after 40 engines is what it was after the first -- every column is ONE allocation
+    holding both sample sets, freed once."""
+    import numpy as np
+    import torch
+
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(12, 2000, 20000, seed=9)
+    free = []
+    for it in range(41):
+        comp = COMPOSITIONS["bspline_iid" if it % 2 else "plpeak"](pe, inj)
+        eng = comp.engine(device_setup=bool(it & 2))
+        th = comp.theta(draw_params("bspline_iid" if it % 2 else "plpeak", np.random.default_rng(it)))
+        assert np.isfinite(eng.evaluate(th, total, min_neff_cut=False).log_likelihood)
+        eng.close()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert abs(free[-1] - free[4]) <= 8 << 20, (free[4], free[-1])  # (the runtime's own pools settle in the first few)
