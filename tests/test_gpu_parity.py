@@ -808,7 +808,7 @@ def test_aql_dispatch_path_equals_the_hip_stream_path(replay, monkeypatch):
     comps = [COMPOSITIONS["bspline_test"](pe, inj) for _ in range(6)]
     engs = [c.engine() for c in comps]
     eng = engs[0]
-    if "not found" in eng.dispatch_info():  # the raw code object did not travel with the library: the HIP stream serves everything
+    if "not found" in eng.dispatch_info() or "disabled by GWI_AQL=0" in eng.dispatch_info():  # no raw code object next to the library, or the suite is being run on the HIP stream on purpose
         pytest.skip(eng.dispatch_info())
     assert eng.dispatch_info() == "aql: active", eng.dispatch_info()
     rng = np.random.default_rng(8)
