@@ -77,3 +77,19 @@ extern "C" __global__ __launch_bounds__(256) void stream_kernel_preload(const do
   }
   if (acc == 12345.678) a.out[0] = acc;
 }
+
+// The same stand-in with workgroups of 1 024 lanes (16 waves: four per SIMD of one CU) -- the shape a single-launch config 2
+// would need (EXPERIMENTS section 15: ~250 fat workgroups instead of 788) -- to see what the kernel side of that design costs.
+extern "C" __global__ __launch_bounds__(1024) void stream_kernel_fat(const double* c0, const double* c1, const double* c2, const double* c3, int tile, int n_cols, long long n, int work, int pad,
+                                                                     const Args a) {
+  const long long t0 = (long long)blockIdx.x * tile;
+  const long long t1 = t0 + tile < n ? t0 + tile : n;
+  double acc = 0.0;
+  for (long long i = t0 + threadIdx.x; i < t1; i += 1024) {
+    const double x = c0[i] + c1[i] + c2[i] + c3[i];
+    double y = x;
+    for (int w = 0; w < work; ++w) y = fma(y, 0.999999, x);
+    acc += y;
+  }
+  if (acc == 12345.678) a.out[0] = acc;
+}
