@@ -248,6 +248,8 @@ EXPORTED_SYMBOLS = [
     "gwi_kernel_variants",
     "gwi_kernel_variant_name",
     "gwi_scan_kernel_name",
+    "gwi_jit_compile",
+    "gwi_jit_info",
 ]
 # ... and include/gwi_sampler.h
 EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine"]
@@ -358,6 +360,11 @@ def load_library():
         lib.gwi_scan_kernel_name.restype = C.c_char_p
         lib.gwi_scan_kernel_name.argtypes = [vp]
     _IP = C.POINTER(C.c_int32)
+    if hasattr(lib, "gwi_jit_compile"):  # absent from older builds loaded through GWI_ENGINE_LIB for A/B timing
+        lib.gwi_jit_compile.restype = C.c_int32
+        lib.gwi_jit_compile.argtypes = [_IP, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, _DP, _IP]
+        lib.gwi_jit_info.restype = C.c_int32
+        lib.gwi_jit_info.argtypes = [vp, _IP, _DP, _IP, C.POINTER(C.c_char_p)]
     lib.gwi_nuts_run.restype = C.c_int32
     lib.gwi_nuts_run.argtypes = [GWI_TARGET_FN, vp, C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
     lib.gwi_nuts_engine.restype = C.c_int32
@@ -375,3 +382,17 @@ def as_dp(arr):
 
 def f64(x):
     return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def jit_compile(kinds, samples_per_lane=2):
+    """Compile (or find in the disk cache) the scan chain of a term-kind sequence with hipRTC -- no GPU needed
+    (include/gwi_engine.h: gwi_jit_compile).  Returns ``{"path", "compile_seconds", "from_cache"}``; raises
+    ``NativeEngineError`` with hipRTC's reason when the chain cannot be built."""
+    lib = load_library()
+    arr = (C.c_int32 * len(kinds))(*[int(k) for k in kinds])
+    buf = C.create_string_buffer(4096)
+    sec, hit = C.c_double(0.0), C.c_int32(0)
+    st = lib.gwi_jit_compile(arr, len(kinds), int(samples_per_lane), buf, len(buf), C.byref(sec), C.byref(hit))
+    if st != 0:
+        raise NativeEngineError(f"gwi_jit_compile({list(kinds)}): {STATUS_NAMES.get(st, st)}: {buf.value.decode(errors='replace')}")
+    return {"path": buf.value.decode(), "compile_seconds": sec.value, "from_cache": bool(hit.value)}

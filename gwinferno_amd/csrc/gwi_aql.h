@@ -290,7 +290,23 @@ inline Device* open_device(uint32_t domain, uint32_t bus, uint32_t device, uint3
   return d;
 }
 
-inline bool find_kernel(Device* d, const char* mangled_name, Kernel& out, std::string& why) {
+// A second code object on the same device: a scan chain compiled at gwi_create (gwi_jit.h).  The blob must outlive the
+// executable (the caller keeps it: jit::Chain::code); executables live as long as the process.
+inline bool load_code(Device* d, const void* blob, size_t bytes, hsa_executable_t& exe, std::string& why) {
+  Api& a = api();
+  hsa_code_object_reader_t reader;
+  hsa_status_t st = a.reader_create(blob, bytes, &reader);
+  if (st == HSA_STATUS_SUCCESS) st = a.executable_create(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe);
+  if (st == HSA_STATUS_SUCCESS) st = a.load_code_object(exe, d->gpu, reader, nullptr, nullptr);
+  if (st == HSA_STATUS_SUCCESS) st = a.freeze(exe, nullptr);
+  if (st != HSA_STATUS_SUCCESS) {
+    why = "loading a run-time compiled chain into the HSA executable: " + status_text(st);
+    return false;
+  }
+  return true;
+}
+
+inline bool find_kernel(Device* d, const char* mangled_name, Kernel& out, std::string& why, const hsa_executable_t* in_exe = nullptr) {
   if (!mangled_name) {
     why = "HIP did not report a kernel name";
     return false;
@@ -298,7 +314,7 @@ inline bool find_kernel(Device* d, const char* mangled_name, Kernel& out, std::s
   Api& a = api();
   const std::string sym_name = std::string(mangled_name) + ".kd";
   hsa_executable_symbol_t sym;
-  hsa_status_t st = a.get_symbol(d->exe, sym_name.c_str(), &d->gpu, &sym);
+  hsa_status_t st = a.get_symbol(in_exe ? *in_exe : d->exe, sym_name.c_str(), &d->gpu, &sym);
   if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &out.object);
   if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &out.kernarg_bytes);
   if (st == HSA_STATUS_SUCCESS) st = a.symbol_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &out.group_bytes);

@@ -12,7 +12,9 @@
 //   masked scatter            models/bsplines/single.py:77-109 (here: kappa = -inf)
 //   reductions                pipeline/analysis.py:50-136
 #pragma once
+#ifndef __HIPCC_RTC__  // hipRTC (gwi_jit.h: chains compiled at gwi_create) brings the device runtime with it and has no system headers
 #include <hip/hip_runtime.h>
+#endif
 
 #include "gwi_engine.h"
 
@@ -116,7 +118,8 @@ struct KArgs {
   int two_pass, deterministic;            // two_pass: find each tile's exact maximum first; deterministic: waves take turns at the shared rows
   int square, k_batch;     // k_batch: hyper-parameter points of a batched launch (scan_mfma_kernel: 16 per grid row); square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
-  int nref_row0, pad1;     // first row of tile_nref this launch reads and writes (0: single evaluation, 1: batched launch)
+  int nref_row0;           // first row of tile_nref this launch reads and writes (0: single evaluation, 1: batched launch)
+  int pbatch_pts;          // scan_pbatch_kernel: hyper-parameter points per grid row (<= kPbatchMaxPts)
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
@@ -2305,6 +2308,191 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   }
 #endif
   GWI_STAMP(4);
+}
+
+// ---- batched launches of PARAMETRIC chains: every sample is loaded once for all the points of the batch ---------------
+// scan_kernel<.., BATCH = true, ..> runs one grid row per hyper-parameter point: K points stream the catalog K times
+// (through L2 / the Infinity Cache) and redo K times whatever a sample needs that does not depend on theta (PL+Peak:
+// m1 = exp(log m1), a quarter of its exponentials; log(mmin / m1); the address arithmetic, the prologue, the argument
+// block).  Here a workgroup owns ONE single-trip tile (<= U x 256 samples): its lanes load their samples' columns once,
+// keep them in registers and loop over the `pbatch_pts` points of their grid row (blockIdx.y; KArgs::pbatch_pts of the
+// k_batch points -- the host splits a batch over rows only as far as load balance needs: a tile x 16 points is a long
+// workgroup, and 788 of them on 256 CUs leave a quarter of the chip idle at the end).  The loop over the points is a real
+// loop, so the compiler hoists the theta-independent arithmetic out of it (checked in the disassembly:
+// tests/test_library_abi.py counts the exponentials inside the loop).  Per point a wave evaluates its samples against its
+// own exact maximum (single trip: no running reference, no rescaling), sums eight values per butterfly (wave_sum8) and
+// parks them in LDS; after ONE barrier wave w completes the records of points w, w + 4, ... exactly as scan_kernel's wave 0
+// does for one.  Records, combine and final launches are those of the batched scan (same layout, same bits per point up to
+// the order in which the four waves' sums are added, which is the same too).
+// Hyper-parameters come through scalar loads from the point's ThetaBlock in device memory (wave-uniform addresses).
+constexpr int kPbatchMaxPts = 16;  // points per workgroup (rows of the LDS staging area)
+template <int U, int... Ks>
+__global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_kernel(const double* hc0, const double* hc1, const double* hc2, const double* hc3, const double* hc4, const unsigned h_geom,
+                                                                                    const unsigned h_chunks, const unsigned hu_n_pe, const unsigned hu_n_inj, const KArgs a) {
+  using ChainT = Chain<U, Ks...>;
+  static_assert(!ChainT::kSpline && !ChainT::kGeneric, "parametric chains only: spline models batch on gwi_mfma.h / the 4-tap kernel");
+  constexpr int kU = U;
+  constexpr int kNV = 2 + ChainT::kNumAcc;
+  constexpr int kSumGroups = (kNV + 7) / 8;
+  __shared__ double s_part[kWaves][kPbatchMaxPts][kSumGroups * 8];
+  __shared__ double s_m[kWaves][kPbatchMaxPts];
+  __shared__ double s_out[kWaves][GWI_MAX_THETA];  // per wave: theta slots of the record being completed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h_n_norms = (int)(h_geom >> (kGeomEventBits + kGeomTilesBits)), h_tiles = (int)((h_geom >> kGeomEventBits) & ((1u << kGeomTilesBits) - 1u));
+  const int h_n_ev = (int)(h_geom & ((1u << kGeomEventBits) - 1u));
+  const int h_chunk_pe = unpack_chunk(h_chunks & 0xffffu), h_chunk_inj = unpack_chunk(h_chunks >> 16);
+  const long long h_n_pe = hu_n_pe, h_n_inj = hu_n_inj;
+  const int K = a.k_batch;
+  // the first n_norms x K workgroups of grid row 0 integrate the normaliser grids, one (normaliser, point) each
+  const int n_norm_blocks = h_n_norms * K;
+  if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
+    if (blockIdx.y != 0) return;
+    const int kb = (int)blockIdx.x / h_n_norms, j = (int)blockIdx.x - kb * h_n_norms;
+    if (blockIdx.x == 0 && tid == 0) *a.seq_dev = a.norm_seq;  // the tail launches stamp their results with it
+    norm_block(a.norms, a.tblocks[kb].theta, a.n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, &s_out[0][0], &s_m[0][0]);
+    return;
+  }
+  const int b = (int)blockIdx.x - n_norm_blocks;
+  const int n_pe_blocks = h_n_ev * h_tiles;
+  long long start, end, base;
+  if (b < n_pe_blocks) {
+    const int e = b / h_tiles;
+    const int t = b - e * h_tiles;
+    start = (long long)t * h_chunk_pe;
+    end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
+    base = (long long)e * h_n_pe;
+  } else {
+    const int t = b - n_pe_blocks;
+    start = (long long)t * h_chunk_inj;
+    end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
+    base = 0;
+  }
+  const long long col_base = b < n_pe_blocks ? base : inj_offset(h_n_ev, h_n_pe);
+  const double* const head_cols[kHeadCols] = {hc0, hc1, hc2, hc3, hc4};
+  const double* lcols[sizeof...(Ks)][2];
+  ColFill<1, 0, Ks...>::run(lcols, head_cols, a);
+  Ctx ctx;
+  ctx.a = &a;
+  ctx.tcols = (const double* const (*)[2])lcols;
+  ctx.coefs = nullptr;
+  ctx.poly = nullptr;
+  ctx.gacc = nullptr;
+  ctx.rep_shift = 0;
+  const double* kappa_col = hc0;
+
+  // ---- the tile's samples: ONE trip (the host sizes the tiles of this launch to <= kU x 256 samples), resident in registers
+  ChainT chain;
+  double kap[kU];
+  const int n_tile = (int)(end - start);
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int iu = tid + u * kBlock;
+    if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
+    const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
+    kap[u] = gload(kappa_col, idx);
+    chain.load(0, u, 0, ctx, idx);
+  }
+  if (n_norm_blocks == 0 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.seq_dev = a.norm_seq;
+  for (int p = lane; p < a.n_theta; p += 64) s_out[wave][p] = 0.0;  // wave-private: no barrier needed before its own use
+  // theta slot of every scalar sum (the same for every point)
+  int th[kNV];
+  {
+    double unused[kSumGroups * 8];
+    th[0] = th[1] = -1;
+    chain.init();
+    chain.collect(0, ctx, unused + 2, th + 2);
+  }
+  const int pts = a.pbatch_pts < kPbatchMaxPts ? a.pbatch_pts : kPbatchMaxPts;
+  const int k0 = (int)blockIdx.y * pts;
+  const int n_k = K - k0 < pts ? K - k0 : pts;  // points of this grid row (wave-uniform)
+  for (int kk = 0; kk < n_k; ++kk) {
+    const ThetaBlock* tb = a.tblocks + (k0 + kk);
+    ctx.theta = tb->theta;
+    ctx.derived = tb->derived;
+    chain.init();
+    double ell[kU], lin[kU];
+    bool live[kU];
+    double mx_lane = GWI_NEG_INF;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int iu = tid + u * kBlock;
+      if (iu - lane >= n_tile) {  // wave-uniform: this wave has no u-th sample
+        live[u] = false;
+        ell[u] = GWI_NEG_INF;
+        lin[u] = 0.0;
+        continue;
+      }
+      lin[u] = 1.0;
+      ell[u] = kap[u] + chain.eval(u, 0, ctx, lin[u]);
+      // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
+      live[u] = (iu < n_tile) && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
+      if (!live[u]) ell[u] = GWI_NEG_INF;
+      mx_lane = fmax(mx_lane, ell[u]);
+    }
+    const double m = wave_max(mx_lane);  // the wave's exact maximum for this point: every weight is <= 1 x its linear part
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (tid + u * kBlock - lane >= n_tile) continue;
+      double w;
+      if constexpr (ChainT::kAbsorb) {
+        double f = lin[u];
+        chain.finish(u, 0, ctx, f, ell[u] - m, 0);
+        w = (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+      } else {
+        w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+      }
+      if (a.square) w *= w;
+      s1 += w;
+      s2 += w * w;
+      chain.accumulate(u, 0, ctx, w);
+    }
+    double vals[kSumGroups * 8];
+    int th_unused[kNV];
+    vals[0] = s1;
+    vals[1] = s2;
+    chain.collect(0, ctx, vals + 2, th_unused + 2);
+#pragma unroll
+    for (int v = kNV; v < kSumGroups * 8; ++v) vals[v] = 0.0;
+#pragma unroll
+    for (int g = 0; g < kSumGroups; ++g) {
+      const double z = wave_sum8(vals + 8 * g);
+      if ((lane & 7) == 0) s_part[wave][kk][8 * g + (lane >> 3)] = z;
+    }
+    if (lane == 0) s_m[wave][kk] = m;
+  }
+  __syncthreads();
+  // ---- records: wave w completes points w, w + 4, ... of this row (scan_kernel's parametric epilogue, per point)
+  static_assert(kWaves == 4, "the quad broadcasts below assume four waves");
+  const long long n_blocks_total = (long long)n_pe_blocks + a.n_inj_tiles;
+  int slot = 0;
+#pragma unroll
+  for (int v = 2; v < kNV; ++v) slot = (lane == v) ? th[v] : slot;
+  const int vi = lane < kSumGroups * 8 ? lane : 0;
+  for (int kk = wave; kk < n_k; kk += kWaves) {
+    const double my_m = s_m[lane & 3][kk];
+    double part[kWaves];
+#pragma unroll
+    for (int w_ = 0; w_ < kWaves; ++w_) part[w_] = s_part[w_][kk][vi];
+    double M = fmax(my_m, dpp_take<0xB1, 0xf>(my_m));  // quad_perm [1,0,3,2]
+    M = fmax(M, dpp_take<0x4E, 0xf>(M));               // quad_perm [2,3,0,1]: the maximum of the four references, in every lane
+    double f_mine = (my_m == GWI_NEG_INF) ? 0.0 : fast_exp(my_m - M);
+    if (a.square) f_mine *= f_mine;
+    const double f0 = dpp_take<0x00, 0xf>(f_mine), f1 = dpp_take<0x55, 0xf>(f_mine), f2 = dpp_take<0xAA, 0xf>(f_mine), f3 = dpp_take<0xFF, 0xf>(f_mine);
+    const double t1 = fma(part[3], f3, fma(part[2], f2, fma(part[1], f1, part[0] * f0)));                      // sums of w: in wave order
+    const double t2 = fma(part[3], f3 * f3, fma(part[2], f2 * f2, fma(part[1], f1 * f1, part[0] * (f0 * f0))));  // S2 holds w^2
+    const double tot = lane == 1 ? t2 : t1;
+    double* out = a.partials + ((long long)(k0 + kk) * n_blocks_total + b) * a.rec_stride;
+    if (lane == 0) out[0] = a.square ? 2.0 * M : M;
+    if (lane < 2) out[1 + lane] = tot;
+    if (lane >= 2 && lane < kNV) unsafeAtomicAdd(&s_out[wave][slot], tot);  // several accumulators may feed one theta slot
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int p = lane; p < a.n_theta; p += 64) {
+      out[kRecHeader + p] = s_out[wave][p];
+      s_out[wave][p] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
 }
 
 // ---- the tail as separate launches (GWI_FUSED_TAIL=0, and the reference point for A/B timing) -------

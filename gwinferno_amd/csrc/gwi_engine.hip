@@ -4,6 +4,7 @@
 #include "gwi_mfma.h"
 #include "gwi_aql.h"
 #include "gwi_ingest.h"
+#include "gwi_jit.h"
 
 #include <hip/hip_ext.h>
 
@@ -29,6 +30,24 @@
 
 using namespace gwi;
 
+// The two headers a scan chain is compiled from, embedded as text: what hipRTC gets when a model's term sequence has no
+// ahead-of-time instantiation (gwi_jit.h).  (.incbin searches the -I directories of the build; host pass only.)
+#ifndef __HIP_DEVICE_COMPILE__
+__asm__(
+    ".pushsection .rodata\n"
+    ".global gwi_embedded_device_h\n"
+    "gwi_embedded_device_h:\n"
+    ".incbin \"gwi_device.h\"\n"
+    ".byte 0\n"
+    ".global gwi_embedded_engine_h\n"
+    "gwi_embedded_engine_h:\n"
+    ".incbin \"gwi_engine.h\"\n"
+    ".byte 0\n"
+    ".popsection\n");
+#endif
+extern "C" const char gwi_embedded_device_h[];
+extern "C" const char gwi_embedded_engine_h[];
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -45,24 +64,33 @@ struct ScanBlock {
 };
 static_assert(offsetof(ScanBlock, k) == sizeof(ScanHead) && sizeof(ScanHead) % alignof(KArgs) == 0, "the struct follows the scalars without padding, as in the kernel's argument list");
 
+// Kernel roles of a term sequence (jit::Role): scan (single evaluation), logw (per-sample log-weights), batch (one grid row
+// per point), safe (spline models: two-pass / replay instantiation, single and batched launches), pbatch (parametric models:
+// batched launches that load every sample once, scan_pbatch_kernel).
 struct Variant {
   const char* name;
   int n;
   int kinds[GWI_MAX_TERMS];
   int samples_per_lane;
-  ScanFn scan;
-  ScanFn logw;
-  ScanFn scan_batch;
-  ScanFn scan_safe;  // spline models: two-pass / replay instantiation (single and batched launches), nullptr otherwise
+  ScanFn fn[jit::kRoles];  // nullptr where the role has no instantiation -- and for every role of a chain compiled at run time:
+  jit::Chain* jit;         // ... whose kernels come out of this chain's code object (gwi_jit.h)
+  bool has(int role) const { return jit ? !jit->lowered[role].empty() : fn[role] != nullptr; }
 };
 
-// the SAFE instantiation exists for spline term sequences only
+// the SAFE instantiation exists for spline term sequences only, the pbatch one for the others
 template <int U, int... Ks>
 constexpr ScanFn safe_scan() {
   if constexpr (Chain<U, Ks...>::kSpline)
     return &scan_kernel<false, false, true, U, Ks...>;
   else
     return nullptr;
+}
+template <int U, int... Ks>
+constexpr ScanFn pbatch_scan() {
+  if constexpr (Chain<U, Ks...>::kSpline)
+    return nullptr;
+  else
+    return &scan_pbatch_kernel<U, Ks...>;
 }
 
 #define K_PL GWI_TERM_POWERLAW
@@ -82,9 +110,9 @@ constexpr ScanFn safe_scan() {
 
 // U = samples per lane per trip (2 for the register-light parametric models, 1 or 2 for spline models)
 #define GWI_VARIANT_U(NAME, U, ...) \
-  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, &scan_kernel<false, false, false, U, __VA_ARGS__>, \
-    &scan_kernel<true, false, false, U, __VA_ARGS__>, &scan_kernel<false, true, false, U, __VA_ARGS__>,                          \
-    safe_scan<U, __VA_ARGS__>() }
+  { NAME, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}, U, {&scan_kernel<false, false, false, U, __VA_ARGS__>, \
+    &scan_kernel<true, false, false, U, __VA_ARGS__>, &scan_kernel<false, true, false, U, __VA_ARGS__>,                           \
+    safe_scan<U, __VA_ARGS__>(), pbatch_scan<U, __VA_ARGS__>()}, nullptr }
 #define GWI_VARIANT(NAME, ...) GWI_VARIANT_U(NAME, 2, __VA_ARGS__)
 
 // Term sequences are canonical: the host sorts a model's terms by kind id (stable).
@@ -175,8 +203,8 @@ constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 // The fallback for every other product of terms: the generic chain (gwi_device.h, kGenericChain), whose term kinds are read
 // from the argument block at run time.  One kernel plays every role (single / batched / two-pass / replay: the SAFE
 // instantiation takes those as run-time options) plus the log-weight variant.
-const Variant kGenericVariant = {"generic (run-time term loop)", 0, {0}, 1, &scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<true, false, false, 1, kGenericChain>,
-                                 &scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<false, false, true, 1, kGenericChain>};
+const Variant kGenericVariant = {"generic (run-time term loop)", 0, {0}, 1, {&scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<true, false, false, 1, kGenericChain>,
+                                 &scan_kernel<false, false, true, 1, kGenericChain>, &scan_kernel<false, false, true, 1, kGenericChain>, nullptr}, nullptr};
 
 // ---- batched launches of spline models on the matrix cores (gwi_mfma.h): term sequences with the number of 16-basis
 // gradient tiles of every spline term fixed at compile time.  A model qualifies when its kinds match and every spline
@@ -336,6 +364,12 @@ bool load_nccl(const char* path, std::string* err) {
 struct gwi_engine {
   gwi_spec spec;
   const Variant* variant = nullptr;
+  Variant* jit_variant = nullptr;     // owned: the variant record of a chain compiled at gwi_create (variant points at it)
+  hipFunction_t jit_fn[jit::kRoles] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // ... its kernels in the chain's module on this device
+  std::string jit_note;               // why the generic kernel runs although a chain could have been compiled (gwi_jit_info)
+  bool pbatch = false;                // parametric model: batched launches load every sample once (scan_pbatch_kernel)
+  int pbatch_pts = 0;                 // ... points per grid row (0: chosen per launch from the batch size and the grid)
+  int scan_role = jit::kScan;         // role of the scan launch being issued
   const MfmaVariant* mfma = nullptr;  // batched launches with 16 points per wavefront (gwi_mfma.h), when the model qualifies
   bool batch_rows = false;            // ... with the gradient in LDS rows (scan_rows_kernel) instead of MFMA tiles
   int rows_rep = 4;
@@ -345,6 +379,7 @@ struct gwi_engine {
   bool batch_events = true;           // gwi_eval_batch: the caller wants the per-event sites
   int combine_threads = kBlock;       // workgroup size of the combine launch
   int device = 0;
+  int n_cus = 256;
   hipStream_t stream = nullptr;
   long long n_ev = 0, n_pe = 0, n_inj = 0;
   // device memory
@@ -409,7 +444,8 @@ struct gwi_engine {
   std::string err;
   // the engine's own AQL queue (gwi_aql.h): plain single-point evaluations are dispatched through it
   aql::Queue aq;
-  aql::Kernel aq_scan, aq_scan_safe, aq_scan_batch, aq_combine, aq_final;
+  aql::Kernel aq_scan, aq_scan_safe, aq_scan_batch, aq_scan_pbatch, aq_combine, aq_final;
+  bool aq_have_pbatch = false;
   bool aql_batch = false;          // batched launches (4-tap kernel) can go through the AQL queue too
   char* aq_tail_batch[2] = {nullptr, nullptr};  // persistent TailArgs of batched launches: [publish_events]
   bool scan_is_batch = false;
@@ -599,7 +635,8 @@ void prelude(gwi_engine* h, const double* theta, double* theta_out, double (*der
 template <typename F, typename A>
 void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t lds, const A& args, size_t used_bytes = sizeof(A)) {
   if (h->aql_now) {  // slot 0 / 1 / 2 = scan / combine / final of the plain evaluation path
-    const aql::Kernel& k = slot == 0 ? (h->scan_is_safe ? h->aq_scan_safe : (h->scan_is_batch ? h->aq_scan_batch : h->aq_scan)) : (slot == 1 ? h->aq_combine : h->aq_final);
+    const aql::Kernel& k = slot == 0 ? (h->scan_role == jit::kSafe ? h->aq_scan_safe : (h->scan_role == jit::kPbatch ? h->aq_scan_pbatch : (h->scan_role == jit::kBatch ? h->aq_scan_batch : h->aq_scan)))
+                                     : (slot == 1 ? h->aq_combine : h->aq_final);
     const hsa_signal_t done = h->timing ? h->aq.done[slot] : hsa_signal_t{0};
     if (slot > 0 && h->aq_tail_args) {  // constant arguments, staged once at gwi_create
       char* staged = h->aql_tail_variant == 0 ? h->aq_tail_args : h->aq_tail_batch[h->aql_tail_variant - 1];
@@ -628,6 +665,18 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
   }
   if constexpr (std::is_same<A, ScanBlock>::value) {
     const ScanHead& hd = args.head;
+    if (h->variant->jit) {
+      // a chain compiled at gwi_create: its kernel lives in a module, and the staged block IS the kernel-argument segment
+      // (preloaded scalars + argument block: static_assert on ScanBlock above)
+      size_t bytes = sizeof(ScanBlock);
+      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<ScanBlock*>(&args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+      hipFunction_t f = h->jit_fn[h->scan_role];
+      if (h->timing)
+        (void)hipExtModuleLaunchKernel(f, grid.x * block.x, grid.y, 1, block.x, 1, 1, lds, h->stream, nullptr, extra, h->ev[2 * slot], h->ev[2 * slot + 1], 0);
+      else
+        (void)hipModuleLaunchKernel(f, grid.x, grid.y, 1, block.x, 1, 1, (unsigned)lds, h->stream, nullptr, extra);
+      return;
+    }
     if (h->timing)
       hipExtLaunchKernelGGL(fn, grid, block, (unsigned)lds, h->stream, h->ev[2 * slot], h->ev[2 * slot + 1], 0, hd.col[0], hd.col[1], hd.col[2], hd.col[3], hd.col[4], hd.geom, hd.chunks, hd.n_pe, hd.n_inj, args.k);
     else
@@ -640,15 +689,46 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
   }
 }
 
+// scan_pbatch_kernel takes single-trip tiles: it applies when the geometry of the launch being issued has them
+bool pbatch_applies(const gwi_engine* h) {
+  if (!h->pbatch) return false;
+  const long long gran = (long long)h->variant->samples_per_lane * kBlock;
+  return h->kargs.chunk_pe <= gran && h->kargs.chunk_inj <= gran;
+}
+// Points per grid row of a pbatch launch of K points.  One row (every sample loaded once for all K points) is the least work,
+// but a tile x K points is a long workgroup: the rows are split until the launch has about eight workgroups per CU to balance
+// (config 2, K = 16: 788 tiles on 256 CUs -- one row leaves a quarter of the chip idle behind the CUs that drew four tiles).
+int pbatch_points(const gwi_engine* h, int K) {
+  int pts = h->pbatch_pts;
+  if (pts <= 0) {
+    const long long blocks = h->use_bgeo ? h->bgeo.n_scan_blocks : h->n_scan_blocks;
+    int rows = 1;
+    while (rows < K && blocks * rows < 8LL * h->n_cus) rows *= 2;
+    pts = (K + rows - 1) / rows;
+  }
+  return std::max(1, std::min(pts, kPbatchMaxPts));
+}
+
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = (h->use_bgeo && !logw ? h->bgeo.n_scan_blocks : h->n_scan_blocks) + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
   // two-pass repeats and the replay mode run the SAFE instantiation (spline models; it takes single and batched launches)
   // ... and so does any replica count other than the 16 the regular kernels are built for (GWI_GACC_REP)
-  const bool safe = !logw && h->variant->scan_safe && (h->generic || h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
-  ScanFn fn = logw ? h->variant->logw : (safe ? h->variant->scan_safe : (batch ? h->variant->scan_batch : h->variant->scan));
+  const bool safe = !logw && h->variant->has(jit::kSafe) && (h->generic || h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
+  // parametric models: a batched launch on single-trip tiles loads every sample once for all its points (scan_pbatch_kernel)
+  const bool pb = batch && !safe && !logw && pbatch_applies(h);
+  h->scan_role = logw ? jit::kLogw : (safe ? jit::kSafe : (pb ? jit::kPbatch : (batch ? jit::kBatch : jit::kScan)));
+  ScanFn fn = h->variant->fn[h->scan_role];
   h->scan_is_safe = safe;
   h->kargs.k_batch = batch ? K : 1;
+  if (pb) {
+    const int pts = pbatch_points(h, K);
+    h->kargs.pbatch_pts = pts;
+    const size_t used = offsetof(KArgs, theta);  // the points' hyper-parameters travel in their ThetaBlocks
+    launch_timed(h, 0, fn, dim3(grid - h->spec.n_norms + h->spec.n_norms * K, (K + pts - 1) / pts), dim3(kBlock), 0, h->sblock, used);
+    GWI_HIP(hipGetLastError());
+    return GWI_OK;
+  }
   if (batch && !safe && !logw) {
     h->batch_used_mfma = h->mfma && K >= h->mfma_min_batch;
     if (h->batch_used_mfma) {  // 16 points per wavefront: the grid's second dimension counts groups of 16
@@ -848,7 +928,7 @@ bool redo_requested(const gwi_engine* h) { return *reinterpret_cast<volatile uns
 gwi_status repeat_after_redo(gwi_handle h, const double* theta, double* record_dev, int K, bool batch, bool square) {
   ++h->redo_count;
   gwi_status st = run_pipeline_once(h, theta, record_dev, true, K, batch, square);
-  if (st == GWI_OK && redo_requested(h) && h->variant->scan_safe) {
+  if (st == GWI_OK && redo_requested(h) && h->variant->has(jit::kSafe)) {
     h->kargs.two_pass = 1;
     st = run_pipeline_once(h, theta, record_dev, true, K, batch, square);
     h->kargs.two_pass = 0;
@@ -1204,6 +1284,11 @@ gwi_status wait_for_rows(gwi_handle h, int K) {
 
 void destroy_impl(gwi_engine* h) {
   if (!h) return;
+  struct VariantGuard {  // the variant record of a run-time compiled chain goes with the handle (the chain itself is process-wide)
+    Variant* v;
+    ~VariantGuard() { delete v; }
+  } guard{h->jit_variant};
+  h->jit_variant = nullptr;
   if (h->host_only) {
     if (h->shm_base) munmap(h->shm_base, h->shm_bytes);
     delete h;
@@ -1327,16 +1412,36 @@ static void setup_aql(gwi_engine* h, const hipDeviceProp_t& prop) {
     h->aql_note = dev->why;
     return;
   }
-  const void* fns[3] = {reinterpret_cast<const void*>(h->variant->scan), reinterpret_cast<const void*>(&combine_kernel), reinterpret_cast<const void*>(&final_kernel)};
-  aql::Kernel* out[3] = {&h->aq_scan, &h->aq_combine, &h->aq_final};
-  for (int i = 0; i < 3; ++i)
-    if (!aql::find_kernel(dev, hipKernelNameRefByPtr(fns[i], h->stream), *out[i], h->aql_note)) return;
-  if (h->variant->scan_safe && !aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->scan_safe), h->stream), h->aq_scan_safe, h->aql_note)) return;
+  // the scan kernels of a chain compiled at gwi_create come out of its own code object, loaded into a second executable
+  hsa_executable_t jit_exe{};
+  jit::Chain* jc = h->variant->jit;
+  if (jc) {
+    std::lock_guard<std::mutex> lock(jc->mu);
+    bool have = false;
+    for (auto& kv : jc->hsa_executables)
+      if (kv.first == dev) jit_exe.handle = kv.second, have = true;
+    if (!have) {
+      if (!aql::load_code(dev, jc->code.data(), jc->code.size(), jit_exe, h->aql_note)) return;
+      jc->hsa_executables.emplace_back(dev, jit_exe.handle);
+    }
+  }
+  auto find_scan = [&](int role, aql::Kernel& out) {
+    if (!h->variant->has(role)) return false;
+    if (jc) return aql::find_kernel(dev, jc->lowered[role].c_str(), out, h->aql_note, &jit_exe);
+    return aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->fn[role]), h->stream), out, h->aql_note);
+  };
+  if (!find_scan(jit::kScan, h->aq_scan)) return;
+  if (!aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(&combine_kernel), h->stream), h->aq_combine, h->aql_note)) return;
+  if (!aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(&final_kernel), h->stream), h->aq_final, h->aql_note)) return;
+  if (h->variant->has(jit::kSafe) && !find_scan(jit::kSafe, h->aq_scan_safe)) return;
   if (h->aq_scan.kernarg_bytes != sizeof(ScanBlock) || h->aq_combine.kernarg_bytes != sizeof(TailArgs) || h->aq_final.kernarg_bytes != sizeof(TailArgs)) {
     h->aql_note = "kernel argument sizes of the code object differ from this build (stale gwi_kernels.hsaco?)";
     return;
   }
-  const bool have_batch_kernel = aql::find_kernel(dev, hipKernelNameRefByPtr(reinterpret_cast<const void*>(h->variant->scan_batch), h->stream), h->aq_scan_batch, h->aql_note);
+  bool have_batch_kernel = find_scan(jit::kBatch, h->aq_scan_batch);
+  // the batched launches of a parametric model are pbatch launches wherever their tiles are single trips: both kernels or neither
+  h->aq_have_pbatch = h->variant->has(jit::kPbatch) && find_scan(jit::kPbatch, h->aq_scan_pbatch);
+  if (h->pbatch && !h->aq_have_pbatch) have_batch_kernel = false;
   if (!aql::open_queue(dev, h->aq, h->aql_note)) return;
   if (have_batch_kernel && sizeof(ThetaBlock) * (size_t)h->max_batch <= aql::kExtraBytes) {
     for (int ev = 0; ev < 2; ++ev) {
@@ -1388,23 +1493,6 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     std::memset(&h->kargs, 0, sizeof(h->kargs));
     return GWI_OK;
   }
-  h->variant = find_variant(*spec);
-  if (const char* env = std::getenv("GWI_FORCE_GENERIC"))  // tests: run models that do have a compiled chain through the generic kernel
-    if (std::atoi(env) != 0) h->variant = nullptr;
-  if (!h->variant) {
-    // no compiled chain for this product of terms: the generic scan kernel evaluates it (term kinds read at run time)
-    h->variant = &kGenericVariant;
-    h->generic = true;
-    static std::atomic<bool> warned{false};
-    if (!warned.exchange(true) && !std::getenv("GWI_QUIET")) {
-      std::string cmd;
-      for (int t = 0; t < spec->n_terms; ++t) cmd += (t ? " " : "") + std::to_string(spec->terms[t].kind);
-      std::fprintf(stderr,
-                   "gwi: term-kind sequence [%s] has no compiled scan kernel: using the generic one (run-time term loop, several times slower).  "
-                   "`python -m gwinferno_amd.add_variant %s` builds a compiled chain for it (~1 min, then restart the process).\n",
-                   cmd.c_str(), cmd.c_str());
-    }
-  }
   if (device < 0) {
     GWI_HIP(hipGetDevice(&h->device));
   } else {
@@ -1416,12 +1504,82 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   GWI_HIP(hipGetDeviceProperties(&prop, h->device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(h, GWI_ERR_NO_DEVICE, std::string("engine is built for gfx950 only; device reports ") + prop.gcnArchName);
+  h->n_cus = prop.multiProcessorCount;
+  // ---- the scan kernel of this product of terms: an ahead-of-time chain (kVariants), else a chain compiled now for exactly
+  // this sequence (gwi_jit.h: hipRTC, cached on disk), else -- hipRTC missing, GWI_JIT=0 -- the generic kernel
+  auto env_on = [](const char* name) {
+    const char* e = std::getenv(name);
+    return e && std::atoi(e) != 0;
+  };
+  const bool force_generic = env_on("GWI_FORCE_GENERIC");  // tests / measurements: the generic kernel for a model that has a compiled chain
+  const bool force_jit = env_on("GWI_FORCE_JIT");          // ... a run-time compiled chain for a model that has an ahead-of-time one
+  h->variant = (force_generic || force_jit) ? nullptr : find_variant(*spec);
+  bool jit_allowed = !force_generic;
+  if (const char* env = std::getenv("GWI_JIT")) jit_allowed = jit_allowed && std::atoi(env) != 0;
+  if (!h->variant && jit_allowed) {
+    int kinds[GWI_MAX_TERMS], n_spline = 0;
+    for (int t = 0; t < spec->n_terms; ++t) {
+      kinds[t] = spec->terms[t].kind;
+      n_spline += jit::is_spline_kind(kinds[t]) ? 1 : 0;
+    }
+    // samples per lane: 2, or 1 from six spline terms on (the register budget of the config-5 chain) and for small catalogs
+    // of spline models (the rule below: one round of small workgroups)
+    int U = n_spline >= 6 ? 1 : 2;
+    const long long total = n_ev * n_pe + n_inj;
+    const bool geometry_knobs = std::getenv("GWI_SAMPLES_PER_BLOCK") || std::getenv("GWI_PE_CHUNK") || std::getenv("GWI_INJ_CHUNK") ||
+                                (std::getenv("GWI_SMALL_GEOMETRY") && std::atoi(std::getenv("GWI_SMALL_GEOMETRY")) == 0);
+    bool small = false;
+    if (U == 2 && n_spline > 0 && !geometry_knobs && total < 2816LL * prop.multiProcessorCount && total >= 64LL * prop.multiProcessorCount) U = 1, small = true;
+    if (const char* env = std::getenv("GWI_SAMPLES_PER_LANE"))
+      if (std::atoi(env) == 1 || std::atoi(env) == 2) U = std::atoi(env), small = false;
+    std::string why;
+    jit::Chain* jc = jit::get_chain(kinds, spec->n_terms, U, gwi_embedded_device_h, gwi_embedded_engine_h, why);
+    hipModule_t mod = jc ? jit::module_on(jc, h->device, why) : nullptr;
+    bool ok = mod != nullptr;
+    for (int role = 0; role < jit::kRoles && ok; ++role) {
+      if (jc->lowered[role].empty()) continue;
+      const hipError_t e = hipModuleGetFunction(&h->jit_fn[role], mod, jc->lowered[role].c_str());
+      if (e != hipSuccess) {
+        why = "jit: hipModuleGetFunction(" + jc->lowered[role] + "): " + hipGetErrorString(e);
+        ok = false;
+      }
+    }
+    if (ok) {
+      Variant* v = new Variant();
+      std::memset(v, 0, sizeof(*v));
+      v->name = jc->name.c_str();
+      v->n = jc->n;
+      for (int t = 0; t < jc->n; ++t) v->kinds[t] = jc->kinds[t];
+      v->samples_per_lane = jc->samples_per_lane;
+      v->jit = jc;
+      h->jit_variant = v;
+      h->variant = v;
+      h->small_geometry = small;
+    } else {
+      h->jit_note = why;
+    }
+  } else if (!h->variant) {
+    h->jit_note = force_generic ? "GWI_FORCE_GENERIC" : "switched off (GWI_JIT=0)";
+  }
+  if (!h->variant) {
+    // no compiled chain for this product of terms: the generic scan kernel evaluates it (term kinds read at run time)
+    h->variant = &kGenericVariant;
+    h->generic = true;
+    static std::atomic<bool> warned{false};
+    if (!force_generic && !warned.exchange(true) && !std::getenv("GWI_QUIET")) {
+      std::string cmd;
+      for (int t = 0; t < spec->n_terms; ++t) cmd += (t ? " " : "") + std::to_string(spec->terms[t].kind);
+      std::fprintf(stderr,
+                   "gwi: term-kind sequence [%s] has no ahead-of-time scan kernel and none could be compiled now (%s): using the generic one (run-time term loop, "
+                   "several times slower).  `python -m gwinferno_amd.add_variant %s` adds an ahead-of-time chain (~1 min, then restart the process).\n",
+                   cmd.c_str(), h->jit_note.c_str(), cmd.c_str());
+    }
+  }
   // Small catalogs of spline models (fewer than ~11 trips of 256 samples per CU: BASELINE config 3) are a chain of latencies, not
   // a throughput problem: more and smaller workgroups of the one-sample-per-lane sibling -- four per CU, equal tiles inside an
   // event -- measured 12.5-12.9 us for the config-3 scan against 13.4-14.3 for 443 workgroups of two samples per lane and two trips
   // (tools/geometry_sweep.py; profiles/round3/EXPERIMENTS.md).  Explicit geometry knobs switch the rule off.
-  h->small_geometry = false;
-  if (h->variant->samples_per_lane == 2 && h->variant->scan_safe && !h->generic && !std::getenv("GWI_SAMPLES_PER_LANE") && !std::getenv("GWI_SAMPLES_PER_BLOCK") &&
+  if (!h->variant->jit && h->variant->samples_per_lane == 2 && h->variant->has(jit::kSafe) && !h->generic && !std::getenv("GWI_SAMPLES_PER_LANE") && !std::getenv("GWI_SAMPLES_PER_BLOCK") &&
       !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK") && !(std::getenv("GWI_SMALL_GEOMETRY") && std::atoi(std::getenv("GWI_SMALL_GEOMETRY")) == 0)) {
     const Variant* sib = nullptr;
     for (int v = 0; v < kNumVariants; ++v) {
@@ -1598,15 +1756,17 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   int rep = 1;
   if (has_spline) {
     size_t lds_per_cu = 160 * 1024, static_lds = 14 * 1024;  // gfx950: 160 KiB per CU; static: s_theta + s_out + s_part + s_wrec (what the kernel reports replaces this guess)
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(h->variant->scan)) == hipSuccess && fa.sharedSizeBytes > 0) static_lds = fa.sharedSizeBytes;
-    int occ0 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, h->variant->scan, kBlock, 0) != hipSuccess || occ0 < 1) occ0 = 2;
+    if (h->variant->jit) {
+      int v = 0;
+      if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, h->jit_fn[jit::kScan]) == hipSuccess && v > 0) static_lds = (size_t)v;
+    } else {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(h->variant->fn[jit::kScan])) == hipSuccess && fa.sharedSizeBytes > 0) static_lds = fa.sharedSizeBytes;
+    }
     // 16 replicas: what the regular scan kernels are compiled for (immediate row offsets).  Where rows that wide cost a
     // resident workgroup (n_theta beyond ~100), that is the cheaper loss: 8 replicas measured 20 % slower at config 5.
     // Any other count (GWI_GACC_REP, the replay mode's 64) runs the SAFE instantiation, which takes it at run time.
     rep = 1 << kRegularRepShift;
-    (void)occ0;
     if (const char* env = std::getenv("GWI_GACC_REP")) rep = std::atoi(env);
     if (h->deterministic) rep = 64;  // one replica per lane: a wave instruction never meets itself on an address
     if (rep < 1) rep = 1;
@@ -1616,11 +1776,9 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     const size_t poly_lds = 4 * sizeof(double) * (size_t)kPolyStride;  // the power-basis table of the spline values (gwi_device.h: spline_poly), behind the rows
     while (rep > 1 && sizeof(double) * (size_t)spec->n_theta * rep + poly_lds + static_lds > lds_per_cu) rep >>= 1;
     scan_lds = sizeof(double) * (size_t)spec->n_theta * rep + poly_lds;
-    if (scan_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a HIP launch (the AQL packets carry any size)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->logw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
-      if (h->variant->scan_safe) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->scan_safe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+    if (scan_lds > 48 * 1024 && !h->variant->jit) {  // beyond the default dynamic-LDS limit of a HIP launch (the AQL packets carry any size; so do module launches)
+      for (int role = 0; role < jit::kRoles; ++role)
+        if (h->variant->fn[role]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h->variant->fn[role]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
     }
   }
   h->gacc_rep = rep;
@@ -1673,7 +1831,9 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     int occ = 0;
     bool single_round = true;
     if (const char* env = std::getenv("GWI_SINGLE_ROUND")) single_round = std::atoi(env) != 0;
-    if (single_round && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->variant->scan, kBlock, scan_lds) == hipSuccess && occ > 0) {
+    const hipError_t occ_rc = h->variant->jit ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->jit_fn[jit::kScan], kBlock, scan_lds)
+                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->variant->fn[jit::kScan], kBlock, scan_lds);
+    if (single_round && occ_rc == hipSuccess && occ > 0) {
       const long long capacity = (long long)prop.multiProcessorCount * occ;
       for (long long cand = gran; cand <= 4 * gran; cand += gran) {
         const long long pad = ((n_pe + gran - 1) / gran) * gran;
@@ -1763,6 +1923,13 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   if (const char* env = std::getenv("GWI_BATCH_GEOMETRY")) {  // 0: batched launches on the single evaluation's geometry
     if (std::atoi(env) == 0) spb_batch = 0;
   }
+  // Parametric models batch on scan_pbatch_kernel (every sample loaded once for all the points of a launch), which takes
+  // single-trip tiles: the single evaluation's where those are single trips already (the BASELINE catalogs), else a batch
+  // geometry of one trip per workgroup.  GWI_PBATCH=0 keeps the one-grid-row-per-point kernel (A/B).
+  h->pbatch = h->variant->has(jit::kPbatch) && !h->generic;
+  if (const char* env = std::getenv("GWI_PBATCH")) h->pbatch = h->pbatch && std::atoi(env) != 0;
+  if (const char* env = std::getenv("GWI_PBATCH_PTS")) h->pbatch_pts = std::max(0, std::atoi(env));
+  if (h->pbatch && !std::getenv("GWI_BATCH_GEOMETRY")) spb_batch = (h->chunk_pe <= gran && h->chunk_inj <= gran) ? 0 : gran;
   if (spb_batch > 0 && !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK")) {
     auto& b = h->bgeo;
     b.chunk_pe = packable((int)(spb_batch < n_pe_pad ? spb_batch : n_pe_pad));
@@ -1772,17 +1939,23 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     b.n_scan_blocks = (int)(n_ev * b.tiles_per_event + b.n_inj_tiles);
     b.tiles_per_inj_group = 16;
     b.n_inj_groups = std::max(1, (b.n_inj_tiles + b.tiles_per_inj_group - 1) / b.tiles_per_inj_group);
-    // larger tiles than the single geometry's: fewer records and groups than the buffers (sized for that one) hold
-    b.distinct = b.tiles_per_event <= h->tiles_per_event && b.n_scan_blocks <= h->n_scan_blocks && b.n_inj_groups <= h->n_inj_groups &&
+    if (b.n_inj_groups > 64) {  // final_kernel maps groups to the lanes of one wave
+      b.tiles_per_inj_group = (b.n_inj_tiles + 63) / 64;
+      b.n_inj_groups = (b.n_inj_tiles + b.tiles_per_inj_group - 1) / b.tiles_per_inj_group;
+    }
+    // within what the tail kernels take (64 tile records per group, 64 groups); the buffers below hold either geometry
+    b.distinct = b.tiles_per_event <= 64 && b.tiles_per_event < (1 << kGeomTilesBits) && b.tiles_per_inj_group <= 64 && b.n_inj_groups <= 64 &&
                  (b.chunk_pe != h->chunk_pe || b.chunk_inj != h->chunk_inj);
   }
+  const int max_scan_blocks = std::max(h->n_scan_blocks, h->bgeo.distinct ? h->bgeo.n_scan_blocks : 0);
+  const int max_inj_groups = std::max(h->n_inj_groups, h->bgeo.distinct ? h->bgeo.n_inj_groups : 0);
 
   const size_t KB = (size_t)h->max_batch;  // every per-evaluation buffer holds max_batch hyper-parameter points
-  GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * KB * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1) * h->rec_stride));
+  GWI_HIP(hipMalloc(&h->d_partials, sizeof(double) * KB * (size_t)(max_scan_blocks ? max_scan_blocks : 1) * h->rec_stride));
   GWI_HIP(hipMalloc(&h->d_ev_out, sizeof(double) * KB * 4 * (size_t)(n_ev ? n_ev : 1)));
   GWI_HIP(hipMalloc(&h->d_ev_grad, sizeof(double) * KB * (size_t)(n_ev ? n_ev : 1) * spec->n_theta));
-  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * KB * 4 * (size_t)h->n_inj_groups));
-  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * KB * (size_t)h->n_inj_groups * spec->n_theta));
+  GWI_HIP(hipMalloc(&h->d_inj_out, sizeof(double) * KB * 4 * (size_t)max_inj_groups));
+  GWI_HIP(hipMalloc(&h->d_inj_grad, sizeof(double) * KB * (size_t)max_inj_groups * spec->n_theta));
   GWI_HIP(hipMalloc(&h->d_tblocks, sizeof(ThetaBlock) * KB));
   GWI_HIP(hipHostMalloc((void**)&h->h_tblocks, sizeof(ThetaBlock) * KB, hipHostMallocMapped));
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_tblocks_dev, h->h_tblocks, 0));
@@ -1800,7 +1973,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   GWI_HIP(hipHostGetDevicePointer((void**)&h->h_fin_dev, h->h_fin, 0));
   std::memset(h->h_fin, 0, sizeof(double) * KB * h->final_groups * record_len(h));
   {  // tile references of spline models (scan_kernel, shared mode): none yet
-    const size_t n = (size_t)(1 + 2 * h->max_batch) * (size_t)(h->n_scan_blocks ? h->n_scan_blocks : 1);  // rows: see nref_row0
+    const size_t n = (size_t)(1 + 2 * h->max_batch) * (size_t)(max_scan_blocks ? max_scan_blocks : 1);  // rows: see nref_row0
     std::vector<int> none(n, kNoRef);
     GWI_HIP(hipMalloc(&h->d_tile_nref, sizeof(int) * n));
     GWI_HIP(hipMemcpy(h->d_tile_nref, none.data(), sizeof(int) * n, hipMemcpyHostToDevice));
@@ -1865,7 +2038,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   k.gacc_shift = __builtin_ctz((unsigned)rep);
   k.seq_dev = h->d_seq;
   k.tile_nref = h->d_tile_nref;
-  k.nref_stride = h->n_scan_blocks ? h->n_scan_blocks : 1;
+  k.nref_stride = max_scan_blocks ? max_scan_blocks : 1;
   k.rows_rep = h->rows_rep;
   k.redo_host = h->h_redo_dev;
   k.redo_dev = h->d_seq + 1;
@@ -2105,8 +2278,41 @@ int64_t gwi_partial_len(gwi_handle h) { return h ? record_len(h) : 0; }
 int64_t gwi_two_pass_repeats(gwi_handle h) { return h ? h->redo_count : 0; }
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   if (!h || h->host_only) return "none";
-  const bool safe = h->variant && h->variant->scan_safe && h->kargs.deterministic;
+  const bool safe = h->variant && h->variant->has(jit::kSafe) && h->kargs.deterministic;
+  if (h->pbatch) {  // parametric model: one load per sample where the tiles of a launch of k_batch points are single trips
+    const long long gran = (long long)h->variant->samples_per_lane * kBlock;
+    const bool bg = k_batch >= 4 && h->bgeo.distinct;
+    if ((bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran) return "pbatch";
+    return "rows-per-point";
+  }
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";
+}
+
+gwi_status gwi_jit_compile(const int32_t* kinds, int32_t n_kinds, int32_t samples_per_lane, char* path_out, int64_t path_cap, double* compile_seconds, int32_t* from_cache) {
+  if (!kinds || n_kinds < 1 || n_kinds > GWI_MAX_TERMS) return GWI_ERR_INVALID;
+  int ks[GWI_MAX_TERMS];
+  for (int t = 0; t < n_kinds; ++t) ks[t] = kinds[t];
+  std::string why;
+  jit::Chain* c = jit::get_chain(ks, n_kinds, samples_per_lane, gwi_embedded_device_h, gwi_embedded_engine_h, why);
+  if (!c) {
+    std::fprintf(stderr, "gwi_jit_compile: %s\n", why.c_str());
+    if (path_out && path_cap > 0) std::snprintf(path_out, (size_t)path_cap, "%s", why.c_str());
+    return why.find("kinds") != std::string::npos ? GWI_ERR_INVALID : GWI_ERR_UNSUPPORTED;
+  }
+  if (path_out && path_cap > 0) std::snprintf(path_out, (size_t)path_cap, "%s", c->path.c_str());
+  if (compile_seconds) *compile_seconds = c->compile_seconds;
+  if (from_cache) *from_cache = c->from_cache ? 1 : 0;
+  return GWI_OK;
+}
+
+gwi_status gwi_jit_info(gwi_handle h, int32_t* compiled_at_run_time, double* compile_seconds, int32_t* from_cache, const char** note) {
+  if (!h) return GWI_ERR_INVALID;
+  const jit::Chain* c = h->variant ? h->variant->jit : nullptr;
+  if (compiled_at_run_time) *compiled_at_run_time = c ? 1 : 0;
+  if (compile_seconds) *compile_seconds = c ? c->compile_seconds : 0.0;
+  if (from_cache) *from_cache = (c && c->from_cache) ? 1 : 0;
+  if (note) *note = h->jit_note.c_str();
+  return GWI_OK;
 }
 
 gwi_status gwi_prepare_combine(gwi_handle h, const double* theta) {
@@ -2376,7 +2582,7 @@ gwi_status gwi_eval_sharded(gwi_handle h, const double* theta, const gwi_options
     if (st_ != GWI_OK) return st_;
     redo = false;
     for (int r = 0; r < h->comm_world; ++r) redo = redo || h->h_gather[(size_t)r * len + 7] < 0.0;
-    if (!redo || !h->variant->scan_safe) return GWI_OK;
+    if (!redo || !h->variant->has(jit::kSafe)) return GWI_OK;
     h->kargs.two_pass = 1;
     st_ = run(square);
     h->kargs.two_pass = 0;

@@ -758,12 +758,21 @@ class NativePopulationLikelihood:
         return float(out[0])
 
     def batch_path(self, k_batch=16):
-        """"mfma" or "taps": the kernel a batched launch of ``k_batch`` points uses (``gwi_batch_path``)."""
+        """"mfma" / "taps" (spline models) or "pbatch" / "rows-per-point" (parametric models): the kernel a batched launch of
+        ``k_batch`` points uses (``gwi_batch_path``)."""
         return self.lib.gwi_batch_path(self.handle, int(k_batch)).decode()
 
     def scan_kernel_name(self):
         """The compiled term chain this engine's scan runs, or "generic (run-time term loop)" (``gwi_scan_kernel_name``)."""
         return self.lib.gwi_scan_kernel_name(self.handle).decode()
+
+    def jit_info(self):
+        """Whether this engine's scan chain was compiled at ``gwi_create`` (hipRTC, ``gwinferno_amd/csrc/gwi_jit.h``), what that cost
+        this process and whether the disk cache supplied the code object; ``note`` says why the generic kernel runs where it
+        does (``gwi_jit_info``)."""
+        on, sec, hit, note = C.c_int32(0), C.c_double(0.0), C.c_int32(0), C.c_char_p()
+        self._check(self.lib.gwi_jit_info(self.handle, C.byref(on), C.byref(sec), C.byref(hit), C.byref(note)))
+        return {"compiled_at_run_time": bool(on.value), "compile_seconds": sec.value, "from_cache": bool(hit.value), "note": (note.value or b"").decode()}
 
     def two_pass_repeats(self):
         """Evaluations this engine had to repeat because a tile's weights lay outside the safe range around its reference

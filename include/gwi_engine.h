@@ -30,7 +30,9 @@
 #ifndef GWI_ENGINE_H
 #define GWI_ENGINE_H
 
+#ifndef __HIPCC_RTC__ /* hipRTC defines the fixed-width integer types itself and has no system headers */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -308,7 +310,9 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
 /* Which kernel a batched launch of k_batch points would use: "taps" (one grid row per point, 4-tap gradient into LDS rows;
  * the default) or "mfma" (GWI_BATCH_MFMA=1 at gwi_create, models with spline terms whose term sequence and basis counts
  * have a matrix-core instantiation, k_batch >= 9: the spline-coefficient gradient as a v_mfma_f64_16x16x4 GEMM over 16
- * points per wavefront, gwinferno_amd/csrc/gwi_mfma.h).  Both are kept because both are measured: see DESIGN.md. */
+ * points per wavefront, gwinferno_amd/csrc/gwi_mfma.h).  Both are kept because both are measured: see DESIGN.md.
+ * Models without spline terms: "pbatch" (every sample loaded once for all the points of a grid row, scan_pbatch_kernel;
+ * GWI_PBATCH=0 or tiles of more than one trip: "rows-per-point", one grid row per point). */
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
 
 /* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the
@@ -416,6 +420,23 @@ const char* gwi_dispatch_info(gwi_handle h);
  * products outside the compiled set run the generic kernel, several times slower, and `python -m gwinferno_amd.add_variant`
  * adds a compiled chain where that matters. */
 const char* gwi_scan_kernel_name(gwi_handle h);
+
+/* ---- scan chains compiled at run time (gwinferno_amd/csrc/gwi_jit.h) ---------------------------------------------------
+ * The reference's user model multiplies whatever densities the user picks (tests/inference_test.py:256-260,
+ * models/bsplines/separable.py:295-778).  A product of terms whose kind sequence has no ahead-of-time scan kernel gets one
+ * at gwi_create: the scan template instantiated for exactly that sequence by hipRTC (gfx950, the flags of the library's
+ * own build, from the headers embedded in the library), kept as a code object under $GWI_JIT_CACHE (default
+ * ~/.cache/gwinferno_amd).  Without hipRTC (or with GWI_JIT=0) such models run the generic kernel.
+ *
+ * gwi_jit_compile(): compile (or find in the cache) the chain of `kinds` (GWI_TERM_* numbers, ascending) with
+ * `samples_per_lane` (1 | 2) samples per lane -- needs no GPU.  path_out (nullable, path_cap bytes) receives the cache file
+ * ("" when no cache directory is writable), or the reason on failure; compile_seconds = hipRTC time spent by THIS call chain
+ * (0 when the code object came from the cache), from_cache = 1 then.  GWI_ERR_UNSUPPORTED: hipRTC missing / compilation failed.
+ * gwi_jit_info(): whether this engine's scan kernel was compiled at run time, what that cost this process and whether the
+ * disk cache supplied it; note = why the generic kernel runs where it does ("" otherwise).  All outputs nullable. */
+gwi_status gwi_jit_compile(const int32_t* kinds, int32_t n_kinds, int32_t samples_per_lane, char* path_out, int64_t path_cap, double* compile_seconds,
+                           int32_t* from_cache);
+gwi_status gwi_jit_info(gwi_handle h, int32_t* compiled_at_run_time, double* compile_seconds, int32_t* from_cache, const char** note);
 
 const char* gwi_last_error(gwi_handle h);
 void gwi_destroy(gwi_handle h);

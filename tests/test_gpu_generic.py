@@ -1,11 +1,15 @@
-"""GPU: the generic scan kernel (run-time term loop) behind the same C ABI.
+"""GPU: products of densities that have no ahead-of-time scan kernel, behind the same C ABI.
 
 The reference's user model multiplies whatever densities the user picks (tests/inference_test.py:256-260,
-examples/simple_bspline_example.py:58-71).  Products whose sorted term-kind sequence has a compiled chain run that chain;
-every other product of <= GWI_MAX_TERMS terms runs the generic kernel -- `gwi_create` never refuses a model for lack of a
-kernel.  Held against the C oracle (values 1e-9, analytic gradients 1e-8) on three products written with
-the drop-in model API that have no compiled chain, and against the compiled chains on models that do (GWI_FORCE_GENERIC=1).
+examples/simple_bspline_example.py:58-71).  Products whose sorted term-kind sequence has an ahead-of-time chain run that chain;
+every other product of <= GWI_MAX_TERMS terms gets a chain compiled for it at gwi_create (hipRTC: gwinferno_amd/csrc/gwi_jit.h)
+and, where hipRTC is missing or switched off (GWI_JIT=0), runs the generic kernel (run-time term loop) -- `gwi_create` never
+refuses a model for lack of a kernel.  Both are held against the C oracle (values 1e-9, analytic gradients 1e-8) on three
+products written with the drop-in model API that have no ahead-of-time chain; the generic kernel (GWI_FORCE_GENERIC=1) and a
+run-time compiled chain (GWI_FORCE_JIT=1) against the ahead-of-time chains on models that do have one.
 """
+import os
+
 import numpy as np
 import pytest
 from golden_util import rel_err
@@ -121,16 +125,29 @@ def _compositions():
     return [PLPeakBetaMagSplineTilt, SplineMassMixtureTilt, PowerlawJointTiltSplineSpinsSplineZ]
 
 
+@pytest.mark.parametrize("mode", ["jit", "generic"])
 @pytest.mark.parametrize("which", [0, 1, 2])
-def test_products_without_a_compiled_chain_match_the_c_oracle(which):
+def test_products_without_a_compiled_chain_match_the_c_oracle(which, mode, monkeypatch, tmp_path):
     from gwinferno_amd.synthetic import make_catalog
     from oracle.c_oracle import COracle
 
+    if mode == "generic":
+        monkeypatch.setenv("GWI_JIT", "0")
+    else:
+        monkeypatch.setenv("GWI_JIT_CACHE", str(tmp_path))
     pe, inj, total = make_catalog(11, 1300, 9000, seed=31 + which)
     cls = _compositions()[which]
     comp = cls(pe, inj)
     eng = comp.engine()
-    assert eng.scan_kernel_name().startswith("generic"), eng.scan_kernel_name()
+    info = eng.jit_info()
+    if mode == "generic":
+        assert eng.scan_kernel_name().startswith("generic"), eng.scan_kernel_name()
+        assert not info["compiled_at_run_time"] and "GWI_JIT=0" in info["note"]
+    else:
+        # a chain of its own, compiled for exactly this kind sequence; dispatched through the AQL queue like an ahead-of-time one
+        assert eng.scan_kernel_name().startswith("jit:"), (eng.scan_kernel_name(), info)
+        assert info["compiled_at_run_time"] and info["note"] == ""
+        assert eng.dispatch_info() == "aql: active", eng.dispatch_info()
     orc = COracle(eng.bound)
     rng = np.random.default_rng(5 + which)
     thetas = np.stack([comp.theta(cls.draw(rng)) for _ in range(4)])
@@ -198,3 +215,50 @@ def test_generic_kernel_equals_the_compiled_chain(comp_name, monkeypatch):
             assert np.max(np.abs(x[ok] - y[ok])) < 1e-11
     ef.close()
     es.close()
+
+
+@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_iid", "plpeak_full", "bspline_chieff", "chm_bspline"])
+def test_run_time_compiled_chain_is_the_ahead_of_time_chain(comp_name, monkeypatch, tmp_path):
+    """GWI_FORCE_JIT=1 compiles the chain of a model that has an ahead-of-time one with hipRTC: same template, same flags, same
+    headers -- the results agree bit for bit (single evaluations through the AQL queue and the HIP stream, batches, log-weights)
+    and a second engine finds the code object in the process-wide cache."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    pe, inj, total = make_catalog(9, 1100, 7000, seed=23)
+    rng = np.random.default_rng(11)
+    aot = COMPOSITIONS[comp_name](pe, inj).engine()
+    assert not aot.scan_kernel_name().startswith(("jit:", "generic"))
+    monkeypatch.setenv("GWI_FORCE_JIT", "1")
+    monkeypatch.setenv("GWI_JIT_CACHE", str(tmp_path))
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    jit = comp.engine()
+    info = jit.jit_info()
+    assert jit.scan_kernel_name().startswith("jit:") and info["compiled_at_run_time"], (jit.scan_kernel_name(), info)
+    assert jit.dispatch_info() == "aql: active"
+    assert any(f.endswith(".gwijit") for f in os.listdir(tmp_path)), os.listdir(tmp_path)
+    spline = "bspline" in comp_name
+    thetas = np.stack([comp.theta(draw_params(comp_name, rng)) for _ in range(5)])
+    for th in thetas:
+        a, b = aot.evaluate(th, total, min_neff_cut=False), jit.evaluate(th, total, min_neff_cut=False)
+        assert a.log_likelihood == b.log_likelihood
+        assert np.array_equal(a.log_bfs, b.log_bfs) and np.array_equal(a.log_neffs, b.log_neffs)
+        if spline:  # spline-coefficient numerators are LDS atomics from four waves: the last bit varies from launch to launch
+            assert np.allclose(a.grad, b.grad, rtol=1e-12, atol=1e-12)
+        else:
+            assert np.array_equal(a.grad, b.grad)
+        jit.set_timing(2)  # the same through the HIP stream (hipModuleLaunchKernel)
+        c = jit.evaluate(th, total, min_neff_cut=False)
+        jit.set_timing(0)
+        assert c.log_likelihood == b.log_likelihood
+        for x, y in zip(aot.log_weights(th), jit.log_weights(th)):
+            assert np.array_equal(x, y, equal_nan=True)
+    ba, bj = aot.evaluate_batch(thetas, total, min_neff_cut=False), jit.evaluate_batch(thetas, total, min_neff_cut=False)
+    for x, y in zip(ba, bj):
+        assert x.log_likelihood == y.log_likelihood
+        assert np.allclose(x.grad, y.grad, rtol=1e-12, atol=1e-12)
+    again = COMPOSITIONS[comp_name](pe, inj).engine()
+    assert again.scan_kernel_name() == jit.scan_kernel_name()
+    assert again.evaluate(thetas[0], total, min_neff_cut=False).log_likelihood == ba[0].log_likelihood
+    for e in (aot, jit, again):
+        e.close()

@@ -957,3 +957,66 @@ def test_device_gradient_against_finite_differences_of_the_device_value(comp_nam
         fd = (vals[0] - 8.0 * vals[1] + 8.0 * vals[2] - vals[3]) / (12.0 * h)
         assert abs(fd - base.grad[p]) < 2e-6 * scale, (comp_name, int(p), fd, float(base.grad[p]))
     eng.close()
+
+
+@pytest.mark.parametrize("comp_name,n_ev,n_pe,n_inj,env", [
+    ("plpeak", 11, 700, 5003, {}),                                   # ragged tiles; the BASELINE config-2 chain
+    ("plpeak_full", 7, 1000, 4000, {}),                              # config 1: 16 scalar sums per sample -> two butterflies per point
+    ("plpeak", 5, 300, 70, {"GWI_PBATCH_PTS": "3"}),                 # rows of 3, 3, ... points: a last row with fewer; waves without samples
+    ("plpeak_smooth", 9, 512, 2048, {"GWI_PBATCH_PTS": "16"}),       # exactly one full trip per tile; one grid row for the whole batch
+    ("chm_powerlaw", 6, 900, 3000, {}),                              # theta-dependent truncation (POWERLAW_BOUNDS)
+    ("plpeak", 20, 30000, 300000, {}),                               # tiles of several trips for single evaluations: batches on single-trip tiles of their own
+])
+def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe, n_inj, env, monkeypatch):
+    """scan_pbatch_kernel (batched launches of models without spline terms: every sample loaded once for all the points of a
+    grid row) against the C oracle, against single evaluations and against the one-grid-row-per-point kernel (GWI_PBATCH=0),
+    for batch sizes on both sides of the host-final / device-final switch, with and without the squared-weight pass."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pe, inj, total = make_catalog(n_ev, n_pe, n_inj, seed=77)
+    comp = COMPOSITIONS[comp_name](pe, inj)
+    eng = comp.engine()
+    assert eng.batch_path(16) == "pbatch", eng.batch_path(16)
+    monkeypatch.setenv("GWI_PBATCH", "0")
+    old = COMPOSITIONS[comp_name](pe, inj).engine()
+    monkeypatch.delenv("GWI_PBATCH")
+    assert old.batch_path(16) == "rows-per-point"
+    orc = COracle(eng.bound)
+    rng = np.random.default_rng(15)
+
+    def draw():
+        p = draw_params(comp_name, rng)
+        if comp_name == "chm_powerlaw":
+            p["mmin"], p["mmax"] = rng.uniform(3.0, 8.0), rng.uniform(70.0, 120.0)
+        return comp.theta(p)
+
+    for K in (1, 2, 5, 16):
+        thetas = np.stack([draw() for _ in range(K)])
+        for flags in (dict(min_neff_cut=False), dict(min_neff_cut=False, marginalize_selection=True)):
+            if flags.get("marginalize_selection") and K not in (2, 16):
+                continue
+            new_b, old_b = eng.evaluate_batch(thetas, total, **flags), old.evaluate_batch(thetas, total, **flags)
+            for k in range(K):
+                one = eng.evaluate(thetas[k], total, **flags)
+                b = new_b[k]
+                assert rel_err(b.log_likelihood, one.log_likelihood) < 1e-12
+                assert np.allclose(b.log_bfs, one.log_bfs, rtol=1e-12, atol=1e-12) and np.allclose(b.log_neffs, one.log_neffs, rtol=1e-10, atol=1e-12)
+                assert np.allclose(b.grad, one.grad, rtol=1e-10, atol=1e-11)
+                assert np.allclose(b.norms, one.norms, rtol=1e-13)
+                assert rel_err(b.log_likelihood, old_b[k].log_likelihood) < 1e-12 and np.allclose(b.grad, old_b[k].grad, rtol=1e-10, atol=1e-11)
+                if k in (0, K - 1):
+                    ref = orc.evaluate(thetas[k], total, **flags)
+                    assert rel_err(b.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+                    scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+                    assert float(np.max(np.abs(b.grad - ref["grad"]))) / scale < 1e-8
+    # a batch repeats bit for bit (fixed summation order everywhere)
+    thetas = np.stack([draw() for _ in range(16)])
+    a, b = eng.evaluate_batch(thetas, total, min_neff_cut=False), eng.evaluate_batch(thetas, total, min_neff_cut=False)
+    for x, y in zip(a, b):
+        assert x.log_likelihood == y.log_likelihood and np.array_equal(x.grad, y.grad)
+    eng.close()
+    old.close()

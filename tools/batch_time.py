@@ -43,4 +43,11 @@ for K in [int(k) for k in os.environ.get("BT_KS", "1,4,16").split(",")]:
             for _ in range(n):
                 eng.lib.gwi_eval_batch(*args)
             dt = time.perf_counter() - t0
-            print(f"{cfg} K={K:2d} {env}: {1e6 * dt / n:7.1f} us/batch  {1e6 * dt / n / K:6.2f} us/eval", flush=True)
+            eng.set_timing(1)
+            ks = []
+            for _ in range(40):
+                eng.lib.gwi_eval_batch(*args)
+                ks.append(eng.last_kernel_ms())
+            eng.set_timing(0)
+            ks = 1e3 * np.median(np.array(ks), axis=0)
+            print(f"{cfg} K={K:2d} {env} [{eng.batch_path(K)}]: {1e6 * dt / n:7.1f} us/batch  {1e6 * dt / n / K:6.2f} us/eval   scan/combine/final us {np.round(ks, 1)}", flush=True)
