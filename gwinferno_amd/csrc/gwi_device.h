@@ -606,6 +606,35 @@ struct Term<GWI_TERM_PLPEAK> {
     a.g[2] += w * s.dsg;
     a.g[3] += w * s.dlam;
   }
+  // The chain's absorbing term, evaluated last (Chain::finish): L = the product of the sample's other linear factors (0 for a
+  // dead sample), E = its closing exponent l - m.  Returns the sample's WEIGHT w = L p e^E 2^-nshift and leaves the states
+  // as w dl/dtheta already: w (P/p)(...) = (L P)(...) -- the division by the mixture density p cancels against the weight, so
+  // this form needs no reciprocal at all (the ratio form above: v_rcp_f64 + two Newton steps + the guard against p = 0, and a
+  // multiplication by 1/p per state; 13 of config 2's ~170 vector instructions per sample).  Dead samples arrive with L = 0
+  // and E = -inf: both exponentials are 0, every state an exact 0 (columns are finite for every sample: the binder parks a
+  // finite value where the data are not, engine.py bind()).
+  __device__ static double finish(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double L, double E, int nshift) {
+    const double lx = in.x1;
+    const double x = fast_exp(lx);
+    const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
+    const double dx = x - mu;
+    const double dx2 = dx * dx;
+    const double e_pl = fast_exp_shift(fma(alpha, lx, d[0] + E), nshift);
+    const double e_tn = fast_exp_shift(fma(-0.5 * dx2, d[5], d[2] + E), nshift);
+    const double LP = (L * (1.0 - lam)) * e_pl, LT = (L * lam) * e_tn;
+    s.da = LP * (lx + d[1]);
+    s.dmu = LT * fma(dx, d[5], d[3]);
+    s.dsg = LT * fma(dx2, d[6], d[4]);
+    s.dlam = L * (e_tn - e_pl);
+    return LP + LT;
+  }
+  // ... and their accumulation: wfac = 1, or the weight itself in a squared-weight pass (w^2 dl = w x (w dl))
+  __device__ static void accumulate_weighted(double wfac, const State& s, Acc& a) {
+    a.g[0] = fma(wfac, s.da, a.g[0]);
+    a.g[1] = fma(wfac, s.dmu, a.g[1]);
+    a.g[2] = fma(wfac, s.dsg, a.g[2]);
+    a.g[3] = fma(wfac, s.dlam, a.g[3]);
+  }
   __device__ static void init(Acc& a) { a.g[0] = a.g[1] = a.g[2] = a.g[3] = 0; }
   __device__ static void rescale(Acc& a, double sc) {
 #pragma unroll
@@ -1051,6 +1080,32 @@ struct Term<GWI_TERM_PLPEAK_SMOOTH> {
     a.g[3] += w * s.dlam;
     a.g[4] += w * s.ddel;
   }
+  // the absorbing form (see Term<GWI_TERM_PLPEAK>::finish): returns the weight, states are w dl/dtheta
+  __device__ static double finish(const TermD& t, const double* d, const Ctx& c, const In& in, State& s, double L, double E, int nshift) {
+    const double x = in.x0;
+    const double lx = in.x1;
+    const double alpha = c.theta[t.th0], mu = c.theta[t.th1], lam = c.theta[t.th3];
+    const double dx = x - mu;
+    const double dx2 = dx * dx;
+    double dlogS;
+    const double S = taper(x - t.p0, c.theta[t.th4], dlogS);
+    const double e_pl = fast_exp_shift(fma(alpha, lx, d[0] + E), nshift) * S;
+    const double e_tn = fast_exp_shift(fma(-0.5 * dx2, d[5], d[2] + E), nshift);
+    const double LP = (L * (1.0 - lam)) * e_pl, LT = (L * lam) * e_tn;
+    s.da = LP * (lx + d[1]);
+    s.dmu = LT * fma(dx, d[5], d[3]);
+    s.dsg = LT * fma(dx2, d[6], d[4]);
+    s.dlam = L * (e_tn - e_pl);
+    s.ddel = (LP > 0.0) ? LP * dlogS : 0.0;  // S = 0: the power-law part and its delta-derivative vanish
+    return LP + LT;
+  }
+  __device__ static void accumulate_weighted(double wfac, const State& s, Acc& a) {
+    a.g[0] = fma(wfac, s.da, a.g[0]);
+    a.g[1] = fma(wfac, s.dmu, a.g[1]);
+    a.g[2] = fma(wfac, s.dsg, a.g[2]);
+    a.g[3] = fma(wfac, s.dlam, a.g[3]);
+    a.g[4] = fma(wfac, s.ddel, a.g[4]);
+  }
   __device__ static void init(Acc& a) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) a.g[j] = 0;
@@ -1188,8 +1243,8 @@ struct ChainImpl<U, TAKEN> {
   __device__ void load(int, int, int, const Ctx&, SIdx) {}
   __device__ void advance() {}
   __device__ double eval(int, int, const Ctx&, double&) { return 0.0; }
-  __device__ void finish(int, int, const Ctx&, double&, double, int) {}
-  __device__ void accumulate(int, int, const Ctx&, double) {}
+  __device__ double finish(int, int, const Ctx&, double, double, int) { return 0.0; }
+  __device__ void accumulate(int, int, const Ctx&, double, double) {}
   __device__ void rescale(double) {}
   __device__ void collect(int, const Ctx&, double*, int*) {}
 };
@@ -1226,16 +1281,21 @@ struct ChainImpl<U, TAKEN, K, Rest...> {
       return l + rest.eval(u, ti + 1, c, lin);
     }
   }
-  // the deferred term: lin *= its density times exp(E) 2^-nshift
-  __device__ void finish(int u, int ti, const Ctx& c, double& lin, double E, int nshift) {
+  // the deferred term: returns the sample's weight L x (its density) x exp(E) 2^-nshift, its states pre-weighted (Term<K>::finish)
+  __device__ double finish(int u, int ti, const Ctx& c, double L, double E, int nshift) {
     if constexpr (kDefer)
-      Term<K>::template eval_shifted<true>(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], lin, E, nshift);
+      return Term<K>::finish(c.a->terms[ti], c.derived[ti], c, in[0][u], st[u], L, E, nshift);
     else
-      rest.finish(u, ti + 1, c, lin, E, nshift);
+      return rest.finish(u, ti + 1, c, L, E, nshift);
   }
-  __device__ void accumulate(int u, int ti, const Ctx& c, double w) {
-    Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
-    rest.accumulate(u, ti + 1, c, w);
+  // w: the sample's weight (squared in a squared-weight pass); wfac: what the deferred term's pre-weighted states take (1, or
+  // the unsquared weight in a squared-weight pass)
+  __device__ void accumulate(int u, int ti, const Ctx& c, double w, double wfac) {
+    if constexpr (kDefer)
+      Term<K>::accumulate_weighted(wfac, st[u], acc);
+    else
+      Term<K>::accumulate(c.a->terms[ti], c, w, st[u], acc);
+    rest.accumulate(u, ti + 1, c, w, wfac);
   }
   __device__ void rescale(double sc) {
     Term<K>::rescale(acc, sc);
@@ -1314,8 +1374,8 @@ struct ChainImpl<U, false, kGenericChain> {
     }
     return l;
   }
-  __device__ void finish(int, int, const Ctx&, double&, double, int) {}
-  __device__ void accumulate(int u, int, const Ctx& c, double w) {
+  __device__ double finish(int, int, const Ctx&, double, double, int) { return 0.0; }
+  __device__ void accumulate(int u, int, const Ctx& c, double w, double) {
     if (w == 0.0) return;
     c.wt = make_weight(w);
     for (int t = 0; t < c.a->n_terms; ++t) {
@@ -2015,7 +2075,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         const bool valid = iu < n_tile;
         lin[u] = 1.0;
         ell[u] = kap[0][u] + chain.eval(u, 0, ctx, lin[u]);
-        if constexpr (WRITE_LOGW && ChainT::kAbsorb) chain.finish(u, 0, ctx, lin[u], 0.0, 0);  // the log-weight wants the plain density
+        if constexpr (WRITE_LOGW && ChainT::kAbsorb) lin[u] = chain.finish(u, 0, ctx, lin[u], 0.0, 0);  // the log-weight wants the plain density
         // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
         live[u] = valid && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
         if (!live[u]) ell[u] = GWI_NEG_INF;
@@ -2031,9 +2091,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
           // one (which is evaluated here, last); a zero, overflowing or NaN density counts as 0
           auto weight = [&](int u) -> double {
             if constexpr (ChainT::kAbsorb) {
-              double f = lin[u];
-              chain.finish(u, 0, ctx, f, ell[u], n_ref);
-              return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+              const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u], n_ref);
+              return (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
             } else {
               return live[u] ? lin[u] * fast_exp_shift(ell[u], n_ref) : 0.0;
             }
@@ -2046,12 +2105,15 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 #pragma unroll
               for (int u = 0; u < kU; ++u) {
                 if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
-                double w = weight(u);
-                if (a.square) w *= w;
+                double w = weight(u), wfac = 1.0;
+                if (a.square) {
+                  wfac = w;
+                  w *= w;
+                }
                 s1 += w;
                 s2 += w * w;
                 if (ChainT::kSpline) ctx.wt = make_weight(w);
-                chain.accumulate(u, 0, ctx, w);
+                chain.accumulate(u, 0, ctx, w, wfac);
               }
             }
             if (SAFE && det) __syncthreads();
@@ -2061,9 +2123,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         // the weight of sample u against the wave's reference exponent: L exp(l - ref)
         auto weight = [&](int u, double ref) -> double {
           if constexpr (ChainT::kAbsorb) {
-            double f = lin[u];
-            chain.finish(u, 0, ctx, f, ell[u] - ref, 0);
-            return (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+            const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u] - ref, 0);
+            return (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
           } else {
             return live[u] ? lin[u] * fast_exp(ell[u] - ref) : 0.0;
           }
@@ -2088,12 +2149,15 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
-          double w = weight(u, m);
-          if (a.square) w *= w;
+          double w = weight(u, m), wfac = 1.0;
+          if (a.square) {
+            wfac = w;
+            w *= w;
+          }
           s1 += w;
           s2 += w * w;
           if (ChainT::kSpline) ctx.wt = make_weight(w);
-          chain.accumulate(u, 0, ctx, w);
+          chain.accumulate(u, 0, ctx, w, wfac);
         }
       }
       if (has_next) {
@@ -2326,6 +2390,11 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 // the order in which the four waves' sums are added, which is the same too).
 // Hyper-parameters come through scalar loads from the point's ThetaBlock in device memory (wave-uniform addresses).
 constexpr int kPbatchMaxPts = 16;  // points per workgroup (rows of the LDS staging area)
+// samples per lane of the pbatch kernel that goes with a chain of U samples per lane
+#ifndef GWI_PBATCH_U
+#define GWI_PBATCH_U 0
+#endif
+constexpr int pbatch_u(int chain_u) { return GWI_PBATCH_U ? GWI_PBATCH_U : chain_u; }
 template <int U, int... Ks>
 __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_kernel(const double* hc0, const double* hc1, const double* hc2, const double* hc3, const double* hc4, const unsigned h_geom,
                                                                                     const unsigned h_chunks, const unsigned hu_n_pe, const unsigned hu_n_inj, const KArgs a) {
@@ -2405,6 +2474,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
   const int pts = a.pbatch_pts < kPbatchMaxPts ? a.pbatch_pts : kPbatchMaxPts;
   const int k0 = (int)blockIdx.y * pts;
   const int n_k = K - k0 < pts ? K - k0 : pts;  // points of this grid row (wave-uniform)
+#ifdef GWI_PBATCH_CHEAP_REF
+  double m_prev = GWI_NEG_INF;
+#endif
   for (int kk = 0; kk < n_k; ++kk) {
     const ThetaBlock* tb = a.tblocks + (k0 + kk);
     ctx.theta = tb->theta;
@@ -2429,23 +2501,32 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
       if (!live[u]) ell[u] = GWI_NEG_INF;
       mx_lane = fmax(mx_lane, ell[u]);
     }
+#ifdef GWI_PBATCH_CHEAP_REF
+    // the reference only has to lie within ~150 e-folds of the wave's maximum (fp64 range; any such reference is exact to
+    // rounding): try the previous point's (two compares + ballots) before paying the 20-instruction DPP maximum
+    if (kk == 0 || __builtin_amdgcn_ballot_w64(mx_lane > m_prev + 150.0) != 0 || __builtin_amdgcn_ballot_w64(mx_lane > m_prev - 150.0) == 0) m_prev = wave_max(mx_lane);
+    const double m = m_prev;
+#else
     const double m = wave_max(mx_lane);  // the wave's exact maximum for this point: every weight is <= 1 x its linear part
+#endif
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       if (tid + u * kBlock - lane >= n_tile) continue;
-      double w;
+      double w, wfac = 1.0;
       if constexpr (ChainT::kAbsorb) {
-        double f = lin[u];
-        chain.finish(u, 0, ctx, f, ell[u] - m, 0);
-        w = (live[u] && f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+        const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u] - m, 0);
+        w = (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
       } else {
         w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
       }
-      if (a.square) w *= w;
+      if (a.square) {
+        wfac = w;
+        w *= w;
+      }
       s1 += w;
       s2 += w * w;
-      chain.accumulate(u, 0, ctx, w);
+      chain.accumulate(u, 0, ctx, w, wfac);
     }
     double vals[kSumGroups * 8];
     int th_unused[kNV];

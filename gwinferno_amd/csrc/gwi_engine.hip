@@ -90,7 +90,7 @@ constexpr ScanFn pbatch_scan() {
   if constexpr (Chain<U, Ks...>::kSpline)
     return nullptr;
   else
-    return &scan_pbatch_kernel<U, Ks...>;
+    return &scan_pbatch_kernel<pbatch_u(U), Ks...>;
 }
 
 #define K_PL GWI_TERM_POWERLAW
@@ -117,6 +117,13 @@ constexpr ScanFn pbatch_scan() {
 
 // Term sequences are canonical: the host sorts a model's terms by kind id (stable).
 const Variant kVariants[] = {
+#ifdef GWI_AB_FEW_VARIANTS  // quick experiment builds (tools/build_ablations.sh): the chains of the BASELINE configurations only
+    GWI_VARIANT("plpeak+plq+plz", K_PP, K_PQ, K_PZ),
+    GWI_VARIANT("plpeak+plq+beta2+tilt2+plz", K_PP, K_PQ, K_BE, K_BE, K_TI, K_TI, K_PZ),
+    GWI_VARIANT("plq+plz+spline5", K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plq+plz+spline5/u1", 1, K_PQ, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP),
+    GWI_VARIANT_U("plz+spline7", 1, K_PZ, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP, K_SP),
+#else
     // tests/inference_test.py:162-197 -- powerlaw_primary_ratio_pdf x PowerlawRedshiftModel
     GWI_VARIANT("pl+plq+plz", K_PL, K_PQ, K_PZ),
     // BASELINE config 2 -- PL+Peak m1 x PL q [x PL z]
@@ -196,6 +203,7 @@ const Variant kVariants[] = {
     GWI_VARIANT("truncnorm", K_TN),
     GWI_VARIANT("smooth", K_SM),
     GWI_VARIANT("plpeaksmooth", K_PS),
+#endif
 #include "gwi_user_variants.inc"
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -692,7 +700,7 @@ void launch_timed(gwi_handle h, int slot, F fn, dim3 grid, dim3 block, size_t ld
 // scan_pbatch_kernel takes single-trip tiles: it applies when the geometry of the launch being issued has them
 bool pbatch_applies(const gwi_engine* h) {
   if (!h->pbatch) return false;
-  const long long gran = (long long)h->variant->samples_per_lane * kBlock;
+  const long long gran = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;
   return h->kargs.chunk_pe <= gran && h->kargs.chunk_inj <= gran;
 }
 // Points per grid row of a pbatch launch of K points.  One row (every sample loaded once for all K points) is the least work,
@@ -1929,7 +1937,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   h->pbatch = h->variant->has(jit::kPbatch) && !h->generic;
   if (const char* env = std::getenv("GWI_PBATCH")) h->pbatch = h->pbatch && std::atoi(env) != 0;
   if (const char* env = std::getenv("GWI_PBATCH_PTS")) h->pbatch_pts = std::max(0, std::atoi(env));
-  if (h->pbatch && !std::getenv("GWI_BATCH_GEOMETRY")) spb_batch = (h->chunk_pe <= gran && h->chunk_inj <= gran) ? 0 : gran;
+  if (h->pbatch && !std::getenv("GWI_BATCH_GEOMETRY")) spb_batch = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;  // (not distinct below where that is the single geometry)
   if (spb_batch > 0 && !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK")) {
     auto& b = h->bgeo;
     b.chunk_pe = packable((int)(spb_batch < n_pe_pad ? spb_batch : n_pe_pad));
@@ -2279,10 +2287,10 @@ int64_t gwi_two_pass_repeats(gwi_handle h) { return h ? h->redo_count : 0; }
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   if (!h || h->host_only) return "none";
   const bool safe = h->variant && h->variant->has(jit::kSafe) && h->kargs.deterministic;
-  if (h->pbatch) {  // parametric model: one load per sample where the tiles of a launch of k_batch points are single trips
-    const long long gran = (long long)h->variant->samples_per_lane * kBlock;
+  if (h->variant && h->variant->has(jit::kPbatch) && !h->generic) {  // parametric model: one load per sample where the tiles of a launch of k_batch points are single trips
+    const long long gran = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;
     const bool bg = k_batch >= 4 && h->bgeo.distinct;
-    if ((bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran) return "pbatch";
+    if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran) return "pbatch";
     return "rows-per-point";
   }
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";

@@ -40,6 +40,7 @@
 #include "gwi_engine.h"
 
 namespace gwi {
+constexpr int pbatch_u(int chain_u);  // gwi_device.h
 namespace jit {
 
 // kernel roles of one term sequence (the template arguments <WRITE_LOGW, BATCH, SAFE> of scan_kernel, and scan_pbatch_kernel)
@@ -119,7 +120,10 @@ inline bool is_spline_kind(int k) { return k == GWI_TERM_EXP_SPLINE || k == GWI_
 
 // The flags of the ahead-of-time build (__graft_entry__.build): a chain compiled here is the chain hipcc would have built.
 inline const std::vector<const char*>& flags() {
-  static const std::vector<const char*> f = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-kernarg-preload-count=16"};
+  // (the two inliner switches are what the hipcc driver's device pipeline does by default and hipRTC's does not: with them the
+  // instruction streams agree; without, config 2's chain came out 2 % longer and measured 8 % slower)
+  static const std::vector<const char*> f = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                                             "-mllvm", "-amdgpu-early-inline-all=true", "-mllvm", "-amdgpu-function-calls=false"};
   return f;
 }
 
@@ -207,7 +211,7 @@ inline std::string name_expression(const Chain& c, int role) {
     case kLogw: return "&gwi::scan_kernel<true, false, false, " + u + ks + ">";
     case kBatch: return "&gwi::scan_kernel<false, true, false, " + u + ks + ">";
     case kSafe: return c.spline ? "&gwi::scan_kernel<false, false, true, " + u + ks + ">" : "";
-    case kPbatch: return c.spline ? "" : "&gwi::scan_pbatch_kernel<" + u + ks + ">";
+    case kPbatch: return c.spline ? "" : "&gwi::scan_pbatch_kernel<" + std::to_string(pbatch_u(c.samples_per_lane)) + ks + ">";
     default: return "";
   }
 }

@@ -485,7 +485,7 @@ def test_jax_host_callback_routes_batches_through_the_batched_kernels():
     thetas = np.stack([eng.bound.theta_of(comp.weights(draw_params("bspline_iid", rng), True)) for _ in range(20)])
     summ, per_event, grad = host(thetas)
     assert summ.shape == (20, len(L._SUMMARY_FIELDS)) and per_event.shape == (20, 3, 12) and grad.shape == (20, eng.n_theta)
-    assert eng.lib.gwi_batch_path(eng.handle, 16).decode() in ("mfma", "taps", "rows")
+    assert eng.lib.gwi_batch_path(eng.handle, 16).decode() in ("mfma", "taps", "rows", "pbatch", "rows-per-point")
     for k in (0, 7, 19):
         s1, p1, g1 = host(thetas[k])
         assert abs(s1[0] - summ[k, 0]) <= 1e-11 * abs(s1[0]) and np.allclose(p1, per_event[k], rtol=1e-10, atol=1e-10)
