@@ -2474,9 +2474,6 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
   const int pts = a.pbatch_pts < kPbatchMaxPts ? a.pbatch_pts : kPbatchMaxPts;
   const int k0 = (int)blockIdx.y * pts;
   const int n_k = K - k0 < pts ? K - k0 : pts;  // points of this grid row (wave-uniform)
-#ifdef GWI_PBATCH_CHEAP_REF
-  double m_prev = GWI_NEG_INF;
-#endif
   for (int kk = 0; kk < n_k; ++kk) {
     const ThetaBlock* tb = a.tblocks + (k0 + kk);
     ctx.theta = tb->theta;
@@ -2501,14 +2498,9 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
       if (!live[u]) ell[u] = GWI_NEG_INF;
       mx_lane = fmax(mx_lane, ell[u]);
     }
-#ifdef GWI_PBATCH_CHEAP_REF
-    // the reference only has to lie within ~150 e-folds of the wave's maximum (fp64 range; any such reference is exact to
-    // rounding): try the previous point's (two compares + ballots) before paying the 20-instruction DPP maximum
-    if (kk == 0 || __builtin_amdgcn_ballot_w64(mx_lane > m_prev + 150.0) != 0 || __builtin_amdgcn_ballot_w64(mx_lane > m_prev - 150.0) == 0) m_prev = wave_max(mx_lane);
-    const double m = m_prev;
-#else
-    const double m = wave_max(mx_lane);  // the wave's exact maximum for this point: every weight is <= 1 x its linear part
-#endif
+    // the wave's exact maximum for this point: every weight is <= 1 x its linear part.  (Reusing the previous point's reference
+    // where it lies within 150 e-folds -- two compares and ballots instead of the DPP maximum -- measured nothing: EXPERIMENTS.md)
+    const double m = wave_max(mx_lane);
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {

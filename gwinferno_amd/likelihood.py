@@ -157,6 +157,32 @@ def _host_callback(eng, total_inj, Nobs, flags):
     return host
 
 
+_WARNED_F32 = []
+
+
+def _jax_dtypes(jax):
+    """``(float dtype, int dtype)`` that cross the JAX seam: float64 / int64 where ``jax_enable_x64`` is on, else JAX's
+    defaults float32 / int32.  The reference runs in whatever precision JAX is configured for -- fp32 unless the user exports
+    ``JAX_ENABLE_X64=1`` -- so the seam follows the configuration instead of insisting on fp64: with x64
+    off, hyper-parameters arrive as fp32, the engine evaluates them in fp64 as always, and value, sites and gradient go back
+    as fp32 (declaring float64 results to ``pure_callback`` under x64-off JAX is a dtype error inside the callback, not a
+    message).  Says so once."""
+    try:
+        f = np.dtype(jax.dtypes.canonicalize_dtype(np.float64))
+        i = np.dtype(jax.dtypes.canonicalize_dtype(np.int64))
+    except Exception:  # a JAX without jax.dtypes.canonicalize_dtype: read the switch
+        on = bool(getattr(jax.config, "jax_enable_x64", False))
+        f, i = (np.dtype(np.float64), np.dtype(np.int64)) if on else (np.dtype(np.float32), np.dtype(np.int32))
+    if f != np.float64 and not _WARNED_F32:
+        import warnings
+
+        _WARNED_F32.append(True)
+        warnings.warn("gwinferno_amd: JAX runs without jax_enable_x64, so hyper-parameters, sites and gradients cross the NumPyro seam in float32 "
+                      "(the engine itself computes in float64).  Export JAX_ENABLE_X64=1 (or jax.config.update('jax_enable_x64', True)) for the "
+                      "fp64 behaviour the <= 1e-9 parity figures refer to.", RuntimeWarning, stacklevel=3)
+    return f, i
+
+
 def _evaluate_jax(eng, params, total_inj, Nobs, flags):
     """``jax.custom_vjp`` over ``jax.pure_callback``: value and every site from one engine call, the
     gradient handed to JAX's reverse mode.  (Exercised only where jax is installed.)"""
@@ -164,12 +190,27 @@ def _evaluate_jax(eng, params, total_inj, Nobs, flags):
     import jax.numpy as jnp
 
     n_ev, n_theta, n_sum = eng.n_ev, eng.n_theta, len(_SUMMARY_FIELDS)
+    fdt, _ = _jax_dtypes(jax)
     shapes = (
-        jax.ShapeDtypeStruct((n_sum,), jnp.float64),
-        jax.ShapeDtypeStruct((3, n_ev), jnp.float64),
-        jax.ShapeDtypeStruct((n_theta,), jnp.float64),
+        jax.ShapeDtypeStruct((n_sum,), fdt),
+        jax.ShapeDtypeStruct((3, n_ev), fdt),
+        jax.ShapeDtypeStruct((n_theta,), fdt),
     )
-    host = _host_callback(eng, total_inj, Nobs, flags)
+    host64 = _host_callback(eng, total_inj, Nobs, flags)
+    if fdt == np.float64:
+        host = host64
+    else:  # x64 off: the engine's float64 results leave in the dtype JAX was told to expect (nan_to_num(-inf) becomes float32's)
+
+        def narrow(o):
+            o = np.asarray(o, dtype=np.float64)
+            with np.errstate(over="ignore"):
+                out = o.astype(fdt)
+            big = np.isfinite(o) & ~np.isfinite(out)  # finite in float64 (the cuts' nan_to_num(-inf)), beyond float32: its extreme value, as jnp.nan_to_num gives there
+            out[big] = np.sign(o[big]) * np.finfo(fdt).max
+            return out
+
+        def host(theta):
+            return tuple(narrow(o) for o in host64(theta))
 
     # batched under vmap (vectorised chains): one call with the batch in front, see _host_callback.  Whether this JAX knows
     # `vmap_method` is read from the signature once -- a try / except around the call would also swallow unrelated TypeErrors
@@ -199,7 +240,7 @@ def _evaluate_jax(eng, params, total_inj, Nobs, flags):
         return (ct_summ[0] * grad,)
 
     f.defvjp(f_fwd, f_bwd)
-    theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=jnp.float64)) for p in params])
+    theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=fdt)) for p in params])
     summ, per_event = f(theta)
     summary = {k: summ[i] for i, k in enumerate(_SUMMARY_FIELDS)}
     return {"summary": summary, "log_bfs": per_event[0], "log_neffs": per_event[1], "variances": per_event[2], "grad": None}
@@ -233,9 +274,10 @@ def _posterior_predictive_sites(eng, params, n_obs, param_names, pedata, injdata
         import jax
         import jax.numpy as jnp
 
-        theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=jnp.float64)) for p in params])
-        idx = jax.pure_callback(lambda th: _ppc_indices(eng, np.asarray(th, dtype=np.float64), pedata, injdata, n_obs, m1min, m2min, mmax),
-                                jax.ShapeDtypeStruct((2, n_obs), jnp.int64), theta)
+        fdt, idt = _jax_dtypes(jax)
+        theta = jnp.concatenate([jnp.ravel(jnp.asarray(p, dtype=fdt)) for p in params])
+        idx = jax.pure_callback(lambda th: _ppc_indices(eng, np.asarray(th, dtype=np.float64), pedata, injdata, n_obs, m1min, m2min, mmax).astype(idt),
+                                jax.ShapeDtypeStruct((2, n_obs), idt), theta)
         take_pe = lambda p, ev: jnp.asarray(pedata[p])[ev, idx[0, ev]]  # noqa: E731
         take_inj = lambda p, ev: jnp.asarray(injdata[p])[idx[1, ev]]  # noqa: E731
     else:
@@ -290,9 +332,23 @@ def hierarchical_likelihood(
         raise NotImplementedError("categorical sub-population assignment (analysis.py:246-254) is outside the accelerated path")
     if marginal_qs:
         raise NotImplementedError("marginal_qs belongs to the categorical branch (analysis.py:246-254, :347-349), outside the accelerated path")
+    # Plain arrays of weights, as the reference takes them (analysis.py:139-163: `pe_weights` (N_ev, N_pe), `inj_weights`
+    # (N_inj,); log-weights with log=True): the same engine on a unit factor (see _array_density).  They carry no
+    # hyper-parameters, so there is nothing to differentiate and `surveyed_hypervolume` is the caller's number.
+    hypervolume_value = None
+    arrays = not isinstance(pe_weights, Density) and not isinstance(inj_weights, Density)
+    if arrays:
+        if _is_traced([pe_weights, inj_weights]):
+            raise TypeError("array-valued pe_weights / inj_weights must be concrete (NumPy) arrays: inside a traced model function build them from "
+                            "gwinferno_amd.models, whose lazy products the engine differentiates")
+        pe_weights, inj_weights = _array_density(np.asarray(pe_weights), log), _array_density(np.asarray(inj_weights), log)
+        if reconstruct_rate:
+            if surveyed_hypervolume is None or isinstance(surveyed_hypervolume, LazyNorm):
+                raise TypeError("with array-valued weights surveyed_hypervolume must be a number (z_model.normalization evaluated by the caller) when reconstruct_rate=True")
+            hypervolume_value, surveyed_hypervolume = float(surveyed_hypervolume), None
     if not isinstance(pe_weights, Density) or not isinstance(inj_weights, Density):
-        raise TypeError("pe_weights / inj_weights must be lazy densities from gwinferno_amd.models")
-    if reconstruct_rate and not isinstance(surveyed_hypervolume, LazyNorm):
+        raise TypeError("pe_weights / inj_weights must both be lazy densities from gwinferno_amd.models, or both arrays of weights")
+    if reconstruct_rate and not arrays and not isinstance(surveyed_hypervolume, LazyNorm):
         raise TypeError("surveyed_hypervolume must be z_model.normalization(...) when reconstruct_rate=True")
 
     flags = dict(marginalize_selection=bool(marginalize_selection), min_neff_cut=bool(min_neff_cut), max_variance_cut=bool(max_variance_cut), reconstruct_rate=bool(reconstruct_rate))
@@ -317,6 +373,8 @@ def hierarchical_likelihood(
         theta = np.concatenate([np.ravel(np.asarray(p, dtype=np.float64)) for p in params])
         res, xp = _evaluate_numpy(eng, theta, float(total_inj), float(Nobs), flags), np
 
+    if hypervolume_value is not None:
+        res["summary"]["surveyed_hypervolume_norm"] = hypervolume_value
     sites = _sites_from_result(res, Nobs, Tobs, unscaled_rate, flags, xp=xp)
     log_l = res["summary"]["log_likelihood"]
     if posterior_predictive_check and param_names is not None and injdata is not None and pedata is not None:  # analysis.py:320-355
@@ -441,9 +499,30 @@ def _mirror(density, side):
     return Density(factors, other, [(sgn, LogValues(expr=cut(static_log_expr(a)))) for sgn, a in density.log_static], density.log_const)
 
 
-def _one_sided(weights):
-    if not isinstance(weights, Density) or not weights.factors:
-        raise TypeError("weights must be a lazy density from gwinferno_amd.models")
+def _array_density(weights, log):
+    """A plain array of importance weights (what the reference's two functions take, analysis.py:50-136) as a lazy density:
+    ``exp(kappa)`` with ``kappa = log(weights)`` (``weights`` itself when ``log``) times a unit factor -- a bare power law
+    ``x^0`` on a column of zeros (the engine's one-term chain "pl"), so that the same scan, the same online-maximum
+    reductions and the same record assembly serve arrays as serve models.  Zero weights (``log``: ``-inf``) are excluded
+    samples, as they contribute nothing to the reference's sums; NaN / negative weights count as zero like every NaN weight
+    on this path (tests/inference_test.py:172)."""
+    from . import _native as N
+
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    side = side_of(w)
+    zeros = np.zeros(w.shape)
+    unit = Factor(N.TERM_POWERLAW, side, [Column("id", zeros)], [0.0], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, tag="array-weights")
+    return Density([unit], side, [(1.0, LogValues(values=w) if log else w)], 0.0)
+
+
+def _one_sided(weights, log=False):
+    if not isinstance(weights, Density):
+        if isinstance(weights, (np.ndarray, list, tuple)) or (hasattr(weights, "__array__") and np.ndim(weights) > 0):
+            weights = _array_density(np.asarray(weights), log)
+        else:
+            raise TypeError("weights must be a lazy density from gwinferno_amd.models or an array of importance weights")
+    if not weights.factors:
+        raise TypeError("weights must be a lazy density from gwinferno_amd.models or an array of importance weights")
     side = weights.side if weights.side is not None else side_of(weights.factors[0].columns[0].expr())
     key = (side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in weights.factors), tuple((sgn, static_key(a)) for sgn, a in weights.log_static))
     hit = _ONE_SIDED.get(key)
@@ -459,12 +538,12 @@ def _one_sided(weights):
 
 
 def per_event_log_bayes_factors(weights, log=False):
-    """analysis.py:50-88 for a lazy PE product ``(N_ev, N_pe)``: returns ``(logBFs, logn_effs,
-    variances)``, each ``(N_ev,)``.  ``log`` is accepted for signature compatibility (the engine works
-    in the log domain with an online maximum, where the reference's two branches coincide).  Inside a
-    likelihood prefer :func:`hierarchical_likelihood`, which produces the same arrays as sites from
-    the one fused scan."""
-    side, eng, theta = _one_sided(weights)
+    """analysis.py:50-88 for a lazy PE product ``(N_ev, N_pe)`` -- or, as in the reference, a plain ``(N_ev, N_pe)`` array of
+    weights (``log=True``: of log-weights): returns ``(logBFs, logn_effs, variances)``, each ``(N_ev,)``.  For a lazy product
+    ``log`` only matters for the signature (the engine works in the log domain with an online maximum, where the reference's two
+    branches coincide).  Inside a likelihood prefer :func:`hierarchical_likelihood`, which produces the same arrays as sites
+    from the one fused scan."""
+    side, eng, theta = _one_sided(weights, log)
     if side != PE:
         raise ValueError("per_event_log_bayes_factors expects the (N_events, N_samples) PE product")
     r = eng.evaluate(theta, float(eng.n_inj), min_neff_cut=False, want_grad=False)
@@ -472,9 +551,9 @@ def per_event_log_bayes_factors(weights, log=False):
 
 
 def detection_efficiency(weights, Ninj, log=False):
-    """analysis.py:91-136 for a lazy injection product ``(N_found,)``: returns ``(logmu, logn_eff,
-    variance)``."""
-    side, eng, theta = _one_sided(weights)
+    """analysis.py:91-136 for a lazy injection product ``(N_found,)`` or a plain array of weights (``log=True``: log-weights):
+    returns ``(logmu, logn_eff, variance)``."""
+    side, eng, theta = _one_sided(weights, log)
     if side != INJ:
         raise ValueError("detection_efficiency expects the (N_found_injections,) injection product")
     r = eng.evaluate(theta, float(Ninj), min_neff_cut=False, want_grad=False)

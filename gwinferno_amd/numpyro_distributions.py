@@ -4,7 +4,8 @@
 (examples/config_files/model.py:17-22).  ``log_prob(value)`` returns a lazy :class:`~gwinferno_amd.lazy.LogDensity`
 for ``value``'s sample set: ``+`` between them and ``- log(prior)`` compose exactly as the reference's array code
 does (``*`` and ``/ prior`` of the linear-space models work on them too).  Sampling / cdf / icdf are not on the
-log-prob path and are not provided.
+log-prob path and are not provided.  :class:`PSplineCoeficientPrior` (numpyro_distributions.py:302-325) acts on
+hyper-parameters only and is mirrored whole.
 
 A distribution object is rebuilt on every model call (analysis.py:381-399).  Whatever identifies the kernel and
 the device-resident data -- grids, design-matrix descriptors -- is therefore keyed on the identity of the arrays
@@ -136,3 +137,78 @@ class BSplineDistribution:
     def log_prob(self, value):
         f, side = self._factor(value)
         return LogDensity([f], side)
+
+
+class PSplineCoeficientPrior:
+    """numpyro_distributions.py:302-325: the P-spline smoothing prior as a distribution over a coefficient vector of
+    length ``N``: ``log_prob(value) = apply_difference_prior(value, inv_var, diff_order)`` (models/bsplines/smoothing.py:8-28).
+    It touches hyper-parameters only -- never sample data -- so it stays host / JAX arithmetic: ``value`` may be a NumPy
+    array or a JAX tracer.  Where NumPyro is installed the object is a ``numpyro.distributions.Distribution`` (same
+    ``arg_constraints``, real-vector support, event shape ``(N,)``), so ``numpyro.sample(name, PSplineCoeficientPrior(N, tau))``
+    works as it does with the reference's class; without NumPyro it is a plain object with the same ``log_prob`` / ``sample``.
+    ``sample`` returns ones of shape ``sample_shape + batch_shape`` exactly as the reference's does (:316-318: a placeholder,
+    the prior is improper)."""
+
+    def __new__(cls, N, inv_var, diff_order=2, validate_args=None):
+        impl = _pspline_numpyro_class()
+        if impl is not None and cls is PSplineCoeficientPrior:
+            return impl(N, inv_var, diff_order=diff_order, validate_args=validate_args)
+        return object.__new__(cls)
+
+    def __init__(self, N, inv_var, diff_order=2, validate_args=None):
+        self.N, self.inv_var, self.diff_order = int(N), inv_var, int(diff_order)
+        self.batch_shape, self.event_shape = tuple(np.shape(inv_var)), (self.N,)
+
+    def sample(self, key=None, sample_shape=()):
+        return np.ones(tuple(sample_shape) + self.batch_shape)
+
+    def log_prob(self, value):
+        from .smoothing import apply_difference_prior
+
+        assert tuple(np.shape(value)) == (self.N,)
+        return apply_difference_prior(value, self.inv_var, self.diff_order)
+
+
+_PSPLINE_IMPL = []
+
+
+def _pspline_numpyro_class():
+    """The NumPyro-backed class, built once where numpyro imports (None elsewhere)."""
+    if _PSPLINE_IMPL:
+        return _PSPLINE_IMPL[0]
+    try:
+        import jax.numpy as jnp
+        from jax import lax
+        from numpyro.distributions import Distribution, constraints
+        from numpyro.distributions.util import is_prng_key, promote_shapes, validate_sample
+    except Exception:
+        _PSPLINE_IMPL.append(None)
+        return None
+    from .smoothing import apply_difference_prior
+
+    class _NumpyroPSplineCoeficientPrior(Distribution):
+        arg_constraints = {"inv_var": constraints.positive}
+        reparametrized_params = ["inv_var"]
+
+        def __init__(self, N, inv_var, diff_order=2, validate_args=None):
+            (self.inv_var,) = promote_shapes(inv_var)
+            self._support = constraints.real_vector
+            super().__init__(batch_shape=lax.broadcast_shapes(jnp.shape(inv_var)), validate_args=validate_args, event_shape=(N,))
+            self.diff_order, self.N = diff_order, N
+
+        @constraints.dependent_property(is_discrete=False, event_dim=0)
+        def support(self):
+            return self._support
+
+        def sample(self, key, sample_shape=()):
+            assert is_prng_key(key)
+            return jnp.ones(shape=sample_shape + self.batch_shape)
+
+        @validate_sample
+        def log_prob(self, value):
+            assert value.shape == (self.N,)
+            return apply_difference_prior(value, self.inv_var, self.diff_order)
+
+    _NumpyroPSplineCoeficientPrior.__name__ = _NumpyroPSplineCoeficientPrior.__qualname__ = "PSplineCoeficientPrior"
+    _PSPLINE_IMPL.append(_NumpyroPSplineCoeficientPrior)
+    return _NumpyroPSplineCoeficientPrior

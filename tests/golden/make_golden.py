@@ -1017,6 +1017,45 @@ def make_margsel_fixture():
     print("wrote margsel_grad.npz", sorted(k for k in out if k.endswith("log_likelihood")))
 
 
+def make_array_weights_fixture():
+    """The reference's reductions on PLAIN ARRAYS of weights (analysis.py:50-136: per_event_log_bayes_factors,
+    detection_efficiency; :139-319: hierarchical_likelihood), linear and log, on seeded weights that span 40 e-folds and
+    include exact zeros (log: -inf) -- what the drop-ins of gwinferno_amd.likelihood must return when handed arrays instead
+    of lazy products, and the PSplineCoeficientPrior log-probabilities (numpyro_distributions.py:302-325 = smoothing.py:8-28)."""
+    rng = np.random.default_rng(BASE_SEED + 77)
+    n_ev, n_pe, n_inj, total = 7, 300, 2500, 40000.0
+    lw_pe = rng.normal(-3.0, 6.0, size=(n_ev, n_pe))
+    lw_inj = rng.normal(-9.0, 5.0, size=n_inj)
+    lw_pe[rng.random(lw_pe.shape) < 0.05] = -np.inf  # zero weights
+    lw_inj[rng.random(n_inj) < 0.05] = -np.inf
+    lw_pe[3, :17] = -np.inf
+    out = {"lw_pe": lw_pe, "lw_inj": lw_inj, "total_inj": np.asarray(total), "hypervolume": np.asarray(3.7e11)}
+    with np.errstate(all="ignore"):
+        for log in (False, True):
+            tag = "log" if log else "lin"
+            a, b = (jnp.asarray(lw_pe), jnp.asarray(lw_inj)) if log else (jnp.exp(jnp.asarray(lw_pe)), jnp.exp(jnp.asarray(lw_inj)))
+            for name, v in zip(("logBFs", "log_nEffs", "variances"), ref.analysis.per_event_log_bayes_factors(a, log=log)):
+                out[f"{tag}/pe/{name}"] = np.asarray(v, dtype=np.float64)
+            for name, v in zip(("logmu", "log_nEff", "variance"), ref.analysis.detection_efficiency(b, total, log=log)):
+                out[f"{tag}/inj/{name}"] = np.asarray(v, dtype=np.float64)
+            for fname, flags in (("cut", dict(min_neff_cut=True)), ("nocut", dict(min_neff_cut=False)), ("marg", dict(min_neff_cut=False, marginalize_selection=True))):
+                numpyro.reset()
+                rate = ref.analysis.hierarchical_likelihood(a, b, total_inj=total, Nobs=n_ev, Tobs=TOBS, surveyed_hypervolume=3.7e11, log=log, **flags)
+                for k, v in numpyro.SITES.items():
+                    out[f"{tag}/hl_{fname}/{k}"] = np.asarray(v, dtype=np.float64)
+                out[f"{tag}/hl_{fname}/rate_return"] = np.asarray(rate, dtype=np.float64)
+    # PSplineCoeficientPrior.log_prob through the reference's own class (under the numpyro stand-in), cross-checked against
+    # the unmodified smoothing module it wraps
+    for i, (n, tau, order) in enumerate(((20, 1.0, 2), (12, 3.5, 1), (30, 0.25, 3))):
+        cs = rng.normal(size=n)
+        out[f"pspline/{i}/coefs"], out[f"pspline/{i}/args"] = cs, np.asarray([n, tau, order], dtype=np.float64)
+        lp = ref.numpyro_distributions.PSplineCoeficientPrior(n, tau, diff_order=order).log_prob(jnp.asarray(cs))
+        assert float(lp) == float(ref.smoothing.apply_difference_prior(jnp.asarray(cs), tau, order))
+        out[f"pspline/{i}/log_prob"] = np.asarray(lp, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "array_weights.npz"), **out)
+    print("wrote array_weights.npz", len(out), "arrays")
+
+
 def make_formats_fixture():
     """f4 on the GPU: what the reference computes from the two catalog FILES the product readers
     load.  (a) tests/golden/idata_small.h5 (InferenceData layout; its arrays are in idata_small.npz, written together by
@@ -1075,7 +1114,7 @@ def load_gwtc3(n_samples=64):
 
 
 def main(which):
-    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel", "formats"]
+    todo = which or ["terms", "bases", "cases", "cases2", "cases3", "cases4", "cases5", "cases6", "cases7", "gwtc3", "catalog", "ppd", "pipeline", "margsel", "formats", "arrays"]
     if "ppd" in todo:
         make_ppd_fixture()
         make_ppd_rz_fixture()
@@ -1083,6 +1122,8 @@ def main(which):
         make_margsel_fixture()
     if "formats" in todo:
         make_formats_fixture()
+    if "arrays" in todo:
+        make_array_weights_fixture()
     if "pipeline" in todo:
         make_pipeline_fixture()
     if "catalog" in todo:

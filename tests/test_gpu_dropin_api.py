@@ -491,3 +491,38 @@ def test_jax_host_callback_routes_batches_through_the_batched_kernels():
         assert abs(s1[0] - summ[k, 0]) <= 1e-11 * abs(s1[0]) and np.allclose(p1, per_event[k], rtol=1e-10, atol=1e-10)
         assert np.allclose(g1, grad[k], rtol=1e-9, atol=1e-9 * np.max(np.abs(g1)))
     eng.close()
+
+
+@pytest.mark.parametrize("log", [False, True])
+def test_array_valued_weights_through_the_engine(log):
+    """The reference's reductions take plain arrays of weights (analysis.py:50-163).  The drop-ins accept them too: the same
+    scan kernel on exp(kappa) x a unit factor.  Golden: the unmodified reference functions on seeded arrays spanning 40
+    e-folds with exact zeros (tests/golden/make_golden.py arrays), linear and log."""
+    import os
+
+    from gwinferno_amd import likelihood as L
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "array_weights.npz"))
+    with np.errstate(all="ignore"):
+        a, b = (g["lw_pe"], g["lw_inj"]) if log else (np.exp(g["lw_pe"]), np.exp(g["lw_inj"]))
+    tag = "log" if log else "lin"
+    total = float(g["total_inj"])
+    lbf, lne, var = L.per_event_log_bayes_factors(a, log=log)
+    assert rel_err(lbf, g[f"{tag}/pe/logBFs"]) < 1e-9 and rel_err(lne, g[f"{tag}/pe/log_nEffs"]) < 1e-9 and rel_err(var, g[f"{tag}/pe/variances"]) < 1e-8
+    lmu, lneff, v = L.detection_efficiency(b, total, log=log)
+    assert rel_err(lmu, g[f"{tag}/inj/logmu"]) < 1e-9 and rel_err(lneff, g[f"{tag}/inj/log_nEff"]) < 1e-9 and rel_err(v, g[f"{tag}/inj/variance"]) < 1e-8
+    with pytest.raises(ValueError):
+        L.detection_efficiency(a, total, log=log)  # a (N_ev, N_pe) array is not an injection set
+    L.SAMPLE_VALUES["unscaled_rate"] = 30.0
+    for fname, flags in (("cut", dict(min_neff_cut=True)), ("nocut", dict(min_neff_cut=False)), ("marg", dict(min_neff_cut=False, marginalize_selection=True))):
+        rate = L.hierarchical_likelihood(a, b, total_inj=total, Nobs=a.shape[0], Tobs=1.0, surveyed_hypervolume=float(g["hypervolume"]), log=log, **flags)
+        sites = L.last_sites()
+        for k in ("log_likelihood", "log_l", "logBFs", "log_nEffs", "log_nEff_inj", "detection_efficiency", "selection_factor", "sum_logBFs", "variance_log_BFs",
+                  "variance_log_detection_efficiency", "variance_log_likelihood", "surveyed_hypervolume", "rate"):
+            want = g[f"{tag}/hl_{fname}/{k}"]
+            assert np.array_equal(np.isfinite(sites[k]), np.isfinite(want)), (fname, k)
+            assert rel_err(sites[k], want) < (1e-8 if "variance" in k else 1e-9), (fname, k)
+        assert rel_err(rate, g[f"{tag}/hl_{fname}/rate_return"]) < 1e-9
+    with pytest.raises(TypeError):  # arrays carry no normaliser: the hypervolume is the caller's number
+        L.hierarchical_likelihood(a, b, total_inj=total, Nobs=a.shape[0], Tobs=1.0, log=log)
+    L.clear_engine_cache()

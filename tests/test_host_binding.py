@@ -192,3 +192,52 @@ def test_ratio_term_takes_log_m1_from_the_mass_spline(monkeypatch):
     assert len(bm0.pe_cols) == 9 and not any(t["flags"] & N.RATIO_LOGM_FROM_SPLINE for t in bm0.terms if t["kind"] == N.TERM_POWERLAW_RATIO)
     lpe0, linj0, _ = log_weights(bm0, theta)
     assert np.array_equal(lpe, lpe0) and np.array_equal(linj, linj0)
+
+
+def _array_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "array_weights.npz"))
+
+
+@pytest.mark.parametrize("log", [False, True])
+def test_array_valued_weights_bind_to_a_unit_factor(log):
+    """per_event_log_bayes_factors / detection_efficiency / hierarchical_likelihood take plain arrays in the reference
+    (analysis.py:50-163).  The drop-ins wrap an array as exp(kappa) x a unit factor (likelihood._array_density): the bound
+    model's per-sample log-weights are the array's logarithms, zeros (log: -inf) excluded, and the oracle's reductions on
+    them give the reference's numbers for the same arrays (golden from the unmodified reference functions)."""
+    from gwinferno_amd.likelihood import _array_density
+
+    g = _array_golden()
+    with np.errstate(all="ignore"):
+        a, b = (g["lw_pe"], g["lw_inj"]) if log else (np.exp(g["lw_pe"]), np.exp(g["lw_inj"]))
+    pw, iw = _array_density(a, log), _array_density(b, log)
+    assert pw.side == "pe" and iw.side == "inj"
+    bm = bind(pw, iw, None)
+    assert [t["kind"] for t in bm.terms] == [N.TERM_POWERLAW] and bm.n_theta == 1
+    theta = bm.theta_of(pw)
+    assert np.array_equal(theta, [0.0])
+    lpe, linj, _ = log_weights(bm, theta)
+    assert np.array_equal(np.isneginf(lpe), np.isneginf(g["lw_pe"])) and np.array_equal(np.isneginf(linj), np.isneginf(g["lw_inj"]))
+    ok = np.isfinite(g["lw_pe"])
+    assert np.max(np.abs(lpe[ok] - g["lw_pe"][ok])) < 1e-13
+    tag = "log" if log else "lin"
+    got = O.hierarchical_likelihood(lpe, linj, float(g["total_inj"]), lpe.shape[0], 1.0, float(g["hypervolume"]) , log=True, min_neff_cut=False)
+    for site in ("log_likelihood", "logBFs", "log_nEffs", "log_nEff_inj", "detection_efficiency"):
+        assert rel_err(got[site], g[f"{tag}/hl_nocut/{site}"]) < 1e-10, site
+    assert rel_err(got["logBFs"], g[f"{tag}/pe/logBFs"]) < 1e-10
+    assert rel_err(np.log(got["detection_efficiency"]), g[f"{tag}/inj/logmu"]) < 1e-10
+
+
+def test_pspline_coefficient_prior_mirror():
+    """numpyro_distributions.py:302-325: log_prob = apply_difference_prior(value, inv_var, diff_order); golden from the
+    reference's own class.  (Where numpyro is installed the mirror IS a numpyro Distribution; here it is the plain object.)"""
+    from gwinferno_amd.numpyro_distributions import PSplineCoeficientPrior
+
+    g = _array_golden()
+    for i in range(3):
+        n, tau, order = g[f"pspline/{i}/args"]
+        d = PSplineCoeficientPrior(int(n), float(tau), diff_order=int(order))
+        assert abs(float(d.log_prob(g[f"pspline/{i}/coefs"])) - float(g[f"pspline/{i}/log_prob"])) < 1e-13 * max(1.0, abs(float(g[f"pspline/{i}/log_prob"])))
+        assert d.event_shape == (int(n),) and np.array_equal(d.sample(None, sample_shape=(2,)), np.ones(2))
+        with pytest.raises(AssertionError):
+            d.log_prob(np.zeros(int(n) + 1))
+    assert PSplineCoeficientPrior(20, 1.0).diff_order == 2  # the reference's default

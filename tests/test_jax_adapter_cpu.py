@@ -248,3 +248,124 @@ def test_jax_check_command_reports_a_missing_jax(capsys):
     assert jax_check.main([]) == 2
     report = json.loads(capsys.readouterr().out)
     assert "jax / numpyro not importable" in report["error"] and "python" in report
+
+
+def _spline_model(L, pe, inj, total, comp, nobs, **flags):
+    """A model function with VECTOR-valued sites (the B-spline coefficient vectors of tests/inference_test.py:244-285) written
+    with the drop-in names; returns the potential NUTS differentiates, U = -(log_likelihood factor + log priors), with unit
+    normal priors on every coefficient (:228-229) -- built from the traced `log_likelihood` site."""
+    import jax.numpy as jnp
+
+    def potential(params):
+        L.hierarchical_likelihood(comp.weights(params, True), comp.weights(params, False), total_inj=total, Nobs=nobs, Tobs=1.0,
+                                  surveyed_hypervolume=comp.hypervolume(params), **flags)
+        ll = L.last_sites()["log_likelihood"]
+        prior = 0.0
+        for name, shape in comp.PARAMS.items():
+            if shape:
+                prior = prior + (-0.5) * jnp.sum(params[name] * params[name])
+        return -(ll + prior)
+
+    return potential
+
+
+def _spline_setup(monkeypatch):
+    from gwinferno_amd import _native as N
+    from gwinferno_amd import likelihood as L
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.engine import NativePopulationLikelihood
+
+    pe, inj, total = _model_pieces()
+    comp = COMPOSITIONS["bspline_test"](pe, inj)
+    made = {}
+
+    def fake_engine_for(pe_w, inj_w, hv=None, device=-1):
+        if "eng" not in made:
+            made["eng"] = _OracleEngine(NativePopulationLikelihood(pe_w, inj_w, hv, device=N.DEVICE_HOST_ONLY))
+        return made["eng"]
+
+    monkeypatch.setattr(L, "engine_for", fake_engine_for)
+    monkeypatch.setattr(L, "_NUMPYRO", [None])
+    monkeypatch.setattr(L, "_WARNED_F32", [])
+    L.SAMPLE_VALUES["unscaled_rate"] = 6.0
+    rng = np.random.default_rng(21)
+    points = [draw_params("bspline_test", rng) for _ in range(5)]
+    return L, comp, pe, inj, total, made, points
+
+
+def _expected(L, comp, potential, p, made):
+    """value and gradient of the potential from the NumPy branch (concrete numbers): the yardstick for the traced calls"""
+    pn = {k: np.asarray(v, dtype=np.float64) for k, v in p.items()}
+    # the NumPy branch wants plain numbers; the prior part is evaluated by hand
+    L.hierarchical_likelihood(comp.weights(pn, True), comp.weights(pn, False), total_inj=potential.total, Nobs=potential.nobs, Tobs=1.0,
+                              surveyed_hypervolume=comp.hypervolume(pn), **potential.flags)
+    s = L.last_sites()
+    theta = made["eng"].bound.theta_of(comp.weights(pn, True))
+    value = -(s["log_likelihood"] + sum(-0.5 * float(np.sum(pn[k] ** 2)) for k, shp in comp.PARAMS.items() if shp))
+    grads = {}
+    for k, shp in comp.PARAMS.items():
+        v = np.ravel(pn[k])
+        off = next(o for o in range(len(theta) - v.size + 1) if np.array_equal(theta[o : o + v.size], v))
+        g = -np.asarray(s["grad_log_likelihood"][off : off + v.size])
+        grads[k] = (g + v).reshape(shp) if shp else g.reshape(())
+    return value, grads
+
+
+@pytest.mark.parametrize("x64", [True, False])
+def test_value_and_grad_of_a_potential_with_vector_sites(shim, monkeypatch, x64):
+    """jit(value_and_grad(potential)) -- what NUTS runs (tests/inference_test.py:320-326) -- over a dict of parameters that holds
+    coefficient VECTORS, under the shim's reverse sweep: the custom_vjp's backward rule delivers d log_l / d theta, split back
+    onto the sites in layout order, next to the prior terms JAX differentiates itself.  With jax_enable_x64 OFF (JAX's default,
+    what a reference user has unless they export JAX_ENABLE_X64) everything crosses the seam as float32 and says so once."""
+    jax = shim
+    L, comp, pe, inj, total, made, points = _spline_setup(monkeypatch)
+    jax.config.update("jax_enable_x64", x64)
+    try:
+        flags = dict(min_neff_cut=False)
+        potential = _spline_model(L, pe, inj, total, comp, 6, **flags)
+        potential.total, potential.nobs, potential.flags = total, 6, flags
+        want_v, want_g = _expected(L, comp, potential, points[0], made)
+        import warnings
+
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            value, grads = jax.jit(jax.value_and_grad(potential))(points[0])
+            jax.jit(jax.value_and_grad(potential))(points[0])
+        said = [w for w in caught if "jax_enable_x64" in str(w.message)]
+        assert len(said) == (0 if x64 else 1)  # once, naming the switch
+        dt = np.float64 if x64 else np.float32
+        tol = 1e-12 if x64 else 2e-5
+        assert value.dtype == dt and abs(float(value) - want_v) <= tol * abs(want_v)
+        for k, shp in comp.PARAMS.items():
+            assert grads[k].dtype == dt and grads[k].shape == shp, k
+            assert np.allclose(grads[k], want_g[k], rtol=tol, atol=tol * max(1.0, float(np.max(np.abs(want_g[k]))))), k
+        # a cut replaces log_l by nan_to_num(-inf): finite in either precision (analysis.py:280-303), with a zero gradient
+        cut = _spline_model(L, pe, inj, total, comp, 5000, min_neff_cut=True)  # 4 N_obs far above any n_eff of 600 injections
+        v, g = jax.value_and_grad(cut)(points[0])
+        assert np.isfinite(v) and float(v) >= 0.99 * float(np.finfo(dt).max)
+        assert all(np.allclose(g[k], np.asarray(points[0][k], dtype=np.float64), rtol=1e-6) for k, shp in comp.PARAMS.items() if shp)  # only the prior part is left
+    finally:
+        jax.config.update("jax_enable_x64", True)
+
+
+def test_vmap_over_chains_makes_one_batched_callback(shim, monkeypatch):
+    """NumPyro's vectorised chains: vmap(value_and_grad(potential)) over K parameter sets.  The callback is declared with
+    vmap_method="broadcast_all", so the K points reach the host in ONE call (gwi_eval_batch behind it) and every chain gets
+    what a call of its own gives."""
+    jax = shim
+    L, comp, pe, inj, total, made, points = _spline_setup(monkeypatch)
+    flags = dict(min_neff_cut=False)
+    potential = _spline_model(L, pe, inj, total, comp, 6, **flags)
+    potential.total, potential.nobs, potential.flags = total, 6, flags
+    singles = [jax.value_and_grad(potential)(p) for p in points]
+    batched = {k: np.stack([np.asarray(p[k], dtype=np.float64) for p in points]) for k in comp.PARAMS}
+    n_before, calls_before = len(jax.CALLBACK_CALLS), made["eng"].calls
+    values, grads = jax.vmap(jax.value_and_grad(potential))(batched)
+    assert len(jax.CALLBACK_CALLS) == n_before + 2  # primal + forward rule: one batched call each, not one per chain
+    assert made["eng"].calls == calls_before + 2 * len(points)
+    assert values.shape == (len(points),)
+    for i, (v, g) in enumerate(singles):
+        assert np.allclose(values[i], v, rtol=1e-13)
+        for k, shp in comp.PARAMS.items():
+            assert grads[k].shape == (len(points),) + shp
+            assert np.allclose(grads[k][i], g[k], rtol=1e-12, atol=1e-12), (i, k)
