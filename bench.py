@@ -8,8 +8,9 @@ results, with the catalog already resident in HBM -- what one NUTS leapfrog cost
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5]
 
 N = 1: a single engine.  N > 1: one rank per GPU (events and injections sharded across ranks, each rank scans
-its shard, ONE exchange of the ~1 KiB partial records, every rank assembles the same result; "strong" scaling:
-the BASELINE catalog size is fixed).  Launched plainly (`python bench.py --gpus N`) the script starts its own
+its shard, ONE exchange of the ~1 KiB partial records -- an ncclAllGather (RCCL over xGMI) inside the engine, with the
+shared-memory exchange as the secondary figure and the fallback -- every rank assembles the same result; "strong"
+scaling: the BASELINE catalog size is fixed).  Launched plainly (`python bench.py --gpus N`) the script starts its own
 ranks -- a fresh `python -m torch.distributed.run` child, before this process has touched a GPU -- and relays
 the child's JSON line; under torch.distributed.run it is a rank.  Prints ONE JSON line on rank 0.
 
@@ -344,7 +345,7 @@ class Run:
         return box
 
 
-def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4, nuts_chains=0):
+def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4, nuts_chains=0, prefer_rccl=False):
     """One configuration: W warm-up + exactly K timed steps (barrier + synchronise on both sides, max over ranks), then
     the latency distribution of >= 1000 further evaluations, kernel durations of >= 20 timed launches, and the secondary
     throughput figures.  Returns the dict that goes into the JSON line (rank 0) or None."""
@@ -378,24 +379,16 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
 
     exchange, sharded = None, None
     if dist is not None:
-        # hot loop inside the engine (no Python/torch in the data path).  Preferred exchange: the node's shared memory
-        # (publish + poll of the ~1 KiB records between host cores, no collective launch); GWI_BENCH_EXCHANGE=rccl selects
-        # the in-engine ncclAllGather over xGMI, =torch the torch.distributed all_gather_into_tensor variant
+        # hot loop inside the engine (no Python/torch in the data path).  The headline exchange is the one BASELINE.json's
+        # north_star names -- ONE ncclAllGather (RCCL over xGMI) of the ~1 KiB partial records on the engine's own stream --
+        # whenever the probe of exactly that exchange (a child process per rank with a time limit, run before this process
+        # touched a GPU: run_rccl_leg) came back clean on every rank; otherwise, and as the secondary figure next to it, the
+        # node's shared memory (publish + poll between host cores, no collective launch).  GWI_BENCH_EXCHANGE=shm|rccl|torch
+        # overrides the choice.
         from gwinferno_amd.distributed import ShardedLikelihood, init_engine_communicator, init_shared_memory_exchange
 
-        want = os.environ.get("GWI_BENCH_EXCHANGE", "shm")
-        if want == "shm":
-            try:
-                init_shared_memory_exchange(eng)
-                ok = True
-            except Exception as exc:
-                print(f"[rank {rank}] shared-memory exchange unavailable ({exc})", file=sys.stderr)
-                ok = False
-            if run.all_agree(ok):
-                exchange = "host shared-memory segment: every rank publishes its record and polls the others' stamps (no collective launch)"
-            else:
-                want = "rccl"
-        if exchange is None and want == "rccl" and run.backend == "nccl":
+        want = os.environ.get("GWI_BENCH_EXCHANGE", "rccl" if (prefer_rccl and run.backend == "nccl") else "shm")
+        if want == "rccl" and run.backend == "nccl":
             try:
                 init_engine_communicator(eng)
                 ok = True
@@ -404,6 +397,17 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 ok = False
             if run.all_agree(ok):
                 exchange = "ncclAllGather (RCCL over xGMI) on the engine's own stream"
+            else:
+                want = "shm"
+        if exchange is None and want == "shm":
+            try:
+                init_shared_memory_exchange(eng)
+                ok = True
+            except Exception as exc:
+                print(f"[rank {rank}] shared-memory exchange unavailable ({exc})", file=sys.stderr)
+                ok = False
+            if run.all_agree(ok):
+                exchange = "host shared-memory segment: every rank publishes its record and polls the others' stamps (no collective launch)"
         if exchange is None:
             exchange = "torch.distributed all_gather_into_tensor"
             sharded = ShardedLikelihood(eng, total, device=torch.device("cuda", dev) if run.backend == "nccl" else None)
@@ -529,6 +533,33 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
     # ---- N > 1, secondary figures: (a) one independent chain per GPU over the WHOLE catalog (numpyro
     # chain_method="parallel"): no exchange, per-GPU work fixed (weak scaling); (b) the same sharded evaluation with the
     # in-engine ncclAllGather instead of the shared-memory exchange
+    shm_side = None
+    if dist is not None and exchange.startswith("ncclAllGather") and headline:
+        # the same sharded evaluation with the records exchanged through the node's shared memory instead: same procedure
+        # (warm-up, K steps between barriers, max over ranks) on an engine of its own
+        try:
+            comp_shm = COMPOSITIONS[comp_name](pe, inj)
+            eng_shm = comp_shm.engine(device=dev, rank=rank, world=world)
+            init_shared_memory_exchange(eng_shm)
+            ok = True
+        except Exception as exc:
+            print(f"[rank {rank}] shared-memory exchange unavailable ({exc})", file=sys.stderr)
+            ok = False
+        if run.all_agree(ok):
+            n_shm = max(200, min(steps, 2000))
+            blk = np.stack([thetas[i % len(thetas)] for i in range(n_shm)])
+            eng_shm.evaluate_sequence(blk[:100], total, min_neff_cut=False)
+            timed_shm = eng_shm.configure_sequence(blk, total, min_neff_cut=False)
+            run.fence()
+            t0s = time.perf_counter()
+            ll_shm, _ = timed_shm()
+            run.fence()
+            ts = run.max_over_ranks(time.perf_counter() - t0s)
+            shm_side = {"evals_per_s": n_shm / ts, "ms_per_step": 1e3 * ts / n_shm, "steps": n_shm, "last_log_likelihood": float(ll_shm[-1]),
+                        "exchange": "host shared-memory segment: every rank publishes its record and polls the others' stamps (no collective launch)"}
+        if ok:
+            eng_shm.close()
+
     replicas = None
     if dist is not None:
         rep = COMPOSITIONS[comp_name](pe, inj)
@@ -607,6 +638,8 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             out["multi_gpu"] = {"ranks": world, "rccl_ranks": rccl_ranks, "headline_exchange_key": key, "rendezvous_backend": run.backend, "exchange": exchange,
                                 "devices_shared_between_ranks": run.shared_devices, "per_rank": per_rank, "sharded_vs_single_gpu": sharded_check,
                                 "independent_chains": replicas}
+            if shm_side is not None:
+                out["multi_gpu"]["shm_side"] = shm_side
         else:
             out["c_loop_us_per_eval"] = 1e6 * eng.selftime(thetas[0], total, n_iter=min(max(steps, 200), 2000), min_neff_cut=False)
         if dist is None and k_batch > 1:
@@ -623,6 +656,13 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 vgb(tb)
             dt = time.perf_counter() - t0
             out["batched"] = {"k_batch": K, "evals_per_s": n_b * K / dt, "us_per_eval": 1e6 * dt / (n_b * K), "launch_sets": n_b, "path": eng.batch_path(K)}
+            cal = eng.batch_calibration()
+            if cal["measured"]:  # spline models: the engine timed both of its batched kernels on its first batched launch and kept the faster
+                out["batched"]["path_choice"] = {"how": "measured by the engine on its first batched launch: three evaluation sets of either kernel, host theta -> host results, best of each",
+                                                 "mfma_us_per_set": cal["mfma_us"], "taps_us_per_set": cal["taps_us"]}
+            ji = eng.jit_info()
+            if ji["compiled_at_run_time"]:
+                out["scan_chain"] = {"name": eng.scan_kernel_name(), **ji}
             # kernel durations of the batched launches (start/stop of each launch, a few timed batches after the loop)
             eng.set_timing(True)
             bk = []
@@ -643,6 +683,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 tfl = (2048.0 * insts / scan_s / 1e12) if (insts and scan_s > 0) else None
                 out["batched"]["mfma"] = {"instruction": "v_mfma_f64_16x16x4_f64", "insts_per_launch": insts, "flop_per_launch": 2048.0 * insts if insts else None, "tflops": tfl,
                                           "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac_of_78.6": (tfl / FP64_VECTOR_PEAK_TFLOPS) if tfl else None,
+                                          # ISSUED flops: the A operand is a 16 x 4 slab with 4 non-zero taps per column, so 12 of every 16 products multiply zeros
+                                          "useful_frac_of_78.6": (0.25 * tfl / FP64_VECTOR_PEAK_TFLOPS) if tfl else None,
+                                          "useful_note": "frac_of_78.6 counts issued matrix-core flops; a quarter of them (4 of 16 rows per column) carry taps",
                                           "source": (pmc_table("batched_k16") or {}).get("source"),
                                           "what": "the design-matrix contraction sum_s w_s B_p(x_s) for 16 hyper-parameter points per wavefront (gwi_mfma.h); A = 16 bases x 4 samples with 4 non-zero taps per column"}
             # the other batched kernels on the same batch, where the model has them (spline models): the 4-tap kernel (one
@@ -679,7 +722,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             # configs 3 / 5: the sampler figure under the reference's priors, on engines of its own
             comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
             engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
-            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 300, "n_samples": 100} if cfg == "c5" else {}))
+            out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 300, "n_samples": 100, "convergence_fields": False} if cfg == "c5" else {}))
             for e in engs[1:]:
                 e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
@@ -808,7 +851,7 @@ def reference_priors(comp_name, comp, n_theta):
     return GaussianSmoothingPrior(n_theta).normal(slice(0, n_theta), 10.0), None, "Normal(0, 10) on every parameter"
 
 
-def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples=200):
+def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples=200, convergence_fields=True):
     """The engines inside a sampler: the library's C++ NUTS (gwi_nuts_engine, include/gwi_sampler.h), one chain per engine
     and host thread, under the priors a reference run uses (reference_priors), with the reference's tree depth
     (numpyro's default max_tree_depth = 10: up to 1023 leapfrogs per iteration) and a warm-up long enough for the step size
@@ -843,6 +886,17 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
     # share of the wall time spent after warm-up ~ share of the evaluations made there (2^depth - 1 per iteration)
     n_lf_sampling = float(np.sum(2.0 ** depth - 1.0))
     t_sampling = dt * min(1.0, n_lf_sampling / max(n_lf, 1))
+    if not convergence_fields:
+        # config 5: 300 warm-up iterations (the wall time of the default run is bounded through the iteration count) are fewer than the
+        # reference's 1 000 (pipeline/utils.py:29-39), and after them the chains' mean log posteriors still lie thousands apart on this
+        # catalog: effective sample sizes and R-hat of such draws are evidence of nothing and are not reported.  The throughput is.
+        return {"chains": C, "host_threads": C, "warmup_iterations": n_warmup, "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt,
+                "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt, "priors": what, "two_pass_repeats": reps, "repeat_fraction": reps / max(n_lf, 1),
+                "mean_tree_depth": float(np.mean(depth)), "max_tree_depth_reached": int(np.max(depth)), "fraction_at_max_depth": float(np.mean(depth >= 10)),
+                "accept_prob": float(np.mean([r["accept_rate"] for r in res])), "step_size": [float(r["step_size"]) for r in res],
+                "divergences": int(sum(r["n_divergent"] for r in res)), "mean_log_prob_per_chain": logp_chain,
+                "convergence": ("not assessed: the warm-up is shorter than the reference's 1 000 iterations (pipeline/utils.py:29-39) and the chains have not "
+                                "reached a common region (see mean_log_prob_per_chain); a throughput figure, not a sampling result")}
     return {"chains": C, "host_threads": C, "warmup_iterations": n_warmup, "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt,
             "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt, "priors": what, "two_pass_repeats": reps, "repeat_fraction": reps / max(n_lf, 1),
             "mean_tree_depth": float(np.mean(depth)), "max_tree_depth_reached": int(np.max(depth)), "fraction_at_max_depth": float(np.mean(depth >= 10)),
@@ -997,20 +1051,31 @@ def main():
     run = Run(args)
     if run.world != args.gpus and not (run.world == 1 and os.environ.get("GWI_FORCE_SHARDED") == "1"):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={run.world}")
+    # the north_star exchange carries the headline when its probe came back clean on EVERY rank (exit code 0; on rank 0 also
+    # the comparison with the unsharded engine within tolerance and identical results on all ranks)
+    prefer_rccl = False
+    if rccl_leg is not None and run.dist is not None and "skipped" not in rccl_leg:
+        mine = rccl_leg.get("child_exit_code") == 0
+        if run.rank == 0:
+            chk = rccl_leg.get("sharded_vs_single_gpu") or {}
+            mine = mine and bool(chk.get("within_tolerance")) and bool(rccl_leg.get("identical_on_all_ranks")) and rccl_leg.get("rccl_ranks") == run.world
+        prefer_rccl = run.all_agree(mine)
+        if run.rank == 0:
+            rccl_leg["probe_clean_on_every_rank"] = bool(prefer_rccl)
     also = args.also
     if also is None:
         also = "c3,c5" if args.config == "c2" else "none"
     extra_cfgs = [c for c in also.split(",") if c and c != "none" and c != args.config]
 
     head = measure(run, args.config, args.steps, args.warmup, args.timing_every, spin_s=args.spin, headline=True, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch,
-                   chains=args.chains)
+                   chains=args.chains, prefer_rccl=prefer_rccl)
     blocks = {}
     for cfg in extra_cfgs:
         # the other BASELINE configurations with the same procedure (their own warm-up, K and latency blocks: sized so that
         # the default run stays within minutes)
         k = {"c5": 300, "c3": 600}.get(cfg, 600)
         blocks[cfg] = measure(run, cfg, k, 50, args.timing_every, spin_s=min(args.spin, 0.3), headline=False, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch, chains=0,
-                              nuts_chains=args.chains)
+                              nuts_chains=args.chains, prefer_rccl=prefer_rccl)
 
     if run.rank == 0:
         out = {
@@ -1034,9 +1099,12 @@ def main():
     if run.rank == 0 and run.dist is not None:
         # the exchanges side by side; `rccl_ranks` says how many ranks the communicator that carried the HEADLINE's records had
         mg = out["multi_gpu"]
-        mg["exchanges"] = {mg.pop("headline_exchange_key"): {"ms_per_step": out["ms_per_step"], "evals_per_s": out["value"], "headline": True}}
-        if rccl_leg is not None:
-            mg["exchanges"]["rccl_allgather"] = rccl_leg
+        head_key = mg.pop("headline_exchange_key")
+        mg["exchanges"] = {head_key: {"ms_per_step": out["ms_per_step"], "evals_per_s": out["value"], "headline": True}}
+        if "shm_side" in mg:
+            mg["exchanges"]["shm"] = mg.pop("shm_side")
+        if rccl_leg is not None:  # the probe of the RCCL exchange in a child process per rank (time-limited), always reported
+            mg["exchanges"]["rccl_allgather_probe" if head_key == "rccl_allgather" else "rccl_allgather"] = rccl_leg
         for blk in out.get("configs", {}).values():
             bm = blk.get("multi_gpu")
             if bm:

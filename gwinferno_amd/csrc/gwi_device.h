@@ -2382,8 +2382,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 // keep them in registers and loop over the `pbatch_pts` points of their grid row (blockIdx.y; KArgs::pbatch_pts of the
 // k_batch points -- the host splits a batch over rows only as far as load balance needs: a tile x 16 points is a long
 // workgroup, and 788 of them on 256 CUs leave a quarter of the chip idle at the end).  The loop over the points is a real
-// loop, so the compiler hoists the theta-independent arithmetic out of it (checked in the disassembly:
-// tests/test_library_abi.py counts the exponentials inside the loop).  Per point a wave evaluates its samples against its
+// loop, so the compiler hoists the theta-independent arithmetic out of it (seen in the disassembly of config 2's chain:
+// three exponentials per sample and point inside the loop, m1 = exp(log m1) and the alpha = -1 branch's reciprocals ahead of it).  Per point a wave evaluates its samples against its
 // own exact maximum (single trip: no running reference, no rescaling), sums eight values per butterfly (wave_sum8) and
 // parks them in LDS; after ONE barrier wave w completes the records of points w, w + 4, ... exactly as scan_kernel's wave 0
 // does for one.  Records, combine and final launches are those of the batched scan (same layout, same bits per point up to

@@ -382,6 +382,11 @@ struct gwi_engine {
   bool batch_rows = false;            // ... with the gradient in LDS rows (scan_rows_kernel) instead of MFMA tiles
   int rows_rep = 4;
   int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
+  // which of the two batched kernels a spline model runs is MEASURED on its first batched launch (calibrate_batch_path): three
+  // launches of each on the caller's own points, the faster one stays.  Off where the environment names a path.
+  bool batch_autotune = false;        // a choice is still to be made
+  bool batch_measured = false;        // ... and has been
+  double batch_us[2] = {0.0, 0.0};    // best wall time of one batched evaluation set: [matrix-core kernel, 4-tap kernel]
   size_t mfma_lds_bytes = 0;
   bool batch_used_mfma = false;       // path of the most recent batched launch
   bool batch_events = true;           // gwi_eval_batch: the caller wants the per-event sites
@@ -943,7 +948,34 @@ gwi_status repeat_after_redo(gwi_handle h, const double* theta, double* record_d
   }
   return st;
 }
+// First batched launch of a spline model that has both batched kernels: three timed evaluation sets of each (after one untimed
+// set each) on the caller's points, host theta -> host results as a sampler pays them; the faster kernel stays.
+gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev, bool wait, int K, bool batch, bool square);
+gwi_status calibrate_batch_path(gwi_handle h, const double* theta, int K) {
+  h->batch_autotune = false;
+  const MfmaVariant* const both[2] = {h->mfma, nullptr};
+  double best[2] = {1e30, 1e30};
+  gwi_status st = GWI_OK;
+  for (int rep = 0; rep < 4 && st == GWI_OK; ++rep)
+    for (int which = 0; which < 2 && st == GWI_OK; ++which) {
+      h->mfma = both[which];
+      const auto t0 = std::chrono::steady_clock::now();
+      st = run_pipeline(h, theta, nullptr, true, K, true, false);
+      const double us = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (rep > 0 && us < best[which]) best[which] = us;
+    }
+  h->batch_us[0] = best[0];
+  h->batch_us[1] = best[1];
+  h->batch_measured = st == GWI_OK;
+  h->mfma = (st != GWI_OK || best[0] <= best[1]) ? both[0] : nullptr;
+  return st;
+}
+
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+  if (batch && h->batch_autotune && h->mfma && K >= h->mfma_min_batch && wait && !record_dev) {
+    const gwi_status sc = calibrate_batch_path(h, theta, K);
+    if (sc != GWI_OK) return sc;
+  }
   gwi_status st = run_pipeline_once(h, theta, record_dev, wait, K, batch, square);
   if (st == GWI_OK && wait && redo_requested(h)) st = repeat_after_redo(h, theta, record_dev, K, batch, square);
   return st;
@@ -1814,6 +1846,10 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
       }
       if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
+    // no path named by the environment: measure on the first batched launch which kernel this model and catalog prefer
+    // (config 3 is a tie that flips from box to box; config 5 prefers the matrix cores by 15 %)
+    h->batch_autotune = h->mfma && !std::getenv("GWI_BATCH_MFMA") && !std::getenv("GWI_BATCH_ROWS") && !h->deterministic;
+    if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) h->batch_autotune = h->batch_autotune && std::atoi(env) != 0;
     if (h->mfma && h->batch_rows) {
       // sample-slot replicas of the gradient rows: as many (4, 2, 1) as leave two workgroups per CU their LDS
       h->rows_rep = 4;
@@ -2294,6 +2330,14 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
     return "rows-per-point";
   }
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";
+}
+
+gwi_status gwi_batch_calibration(gwi_handle h, int32_t* measured, double* mfma_us, double* taps_us) {
+  if (!h) return GWI_ERR_INVALID;
+  if (measured) *measured = h->batch_measured ? 1 : 0;
+  if (mfma_us) *mfma_us = h->batch_us[0];
+  if (taps_us) *taps_us = h->batch_us[1];
+  return GWI_OK;
 }
 
 gwi_status gwi_jit_compile(const int32_t* kinds, int32_t n_kinds, int32_t samples_per_lane, char* path_out, int64_t path_cap, double* compile_seconds, int32_t* from_cache) {

@@ -8,8 +8,12 @@
 //
 //   * source: three lines -- `#include "gwi_device.h"` + one name expression per kernel role -- compiled by hipRTC for gfx950
 //     with the flags of the ahead-of-time build (the kernel-argument preload included).  The two headers are embedded in the
-//     library when it is built (.incbin, gwi_engine.hip), so the code object is what hipcc would have produced from this very
-//     build: same registers, same instructions (checked against an ahead-of-time chain in tests/test_library_abi.py);
+//     library when it is built (.incbin, gwi_engine.hip): the chain is this very build's template, whatever has happened to
+//     the source tree since.  The COMPILER is whichever hipRTC the process has: a Python process that imported PyTorch first
+//     (gwinferno_amd/_native.py does, so that the engine and torch.distributed share one HIP runtime) gets the libhiprtc /
+//     libamd_comgr bundled with PyTorch's ROCm, not the one hipcc of the build belongs to -- same template and flags, a
+//     neighbouring compiler version: config 2's chain comes out with 99 vector registers instead of 83 and the same scan
+//     time (profiles/round5); the cache key carries the library's path and version;
 //   * cache: the raw code object + the kernels' lowered names in one file under $GWI_JIT_CACHE (default
 //     $XDG_CACHE_HOME/gwinferno_amd or ~/.cache/gwinferno_amd, else /tmp/gwinferno_amd-<uid>), keyed by the kind sequence, the
 //     samples per lane and a hash of (headers, flags, hipRTC version); written to a temporary name and renamed;
@@ -260,10 +264,12 @@ inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, co
   hsh = fnv1a(preamble(), std::strlen(preamble()), hsh);
   for (const char* f : flags()) hsh = fnv1a(f, std::strlen(f) + 1, hsh);
   Rtc& r = rtc();
-  if (r.ok) {
+  if (r.ok) {  // which compiler: version and the file it was loaded from (PyTorch's bundled ROCm or the system's)
     int v[2] = {0, 0};
     r.version(&v[0], &v[1]);
     hsh = fnv1a(v, sizeof(v), hsh);
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(r.compile), &info) && info.dli_fname) hsh = fnv1a(info.dli_fname, std::strlen(info.dli_fname), hsh);
   }
   char hx[20];
   std::snprintf(hx, sizeof(hx), "%016llx", hsh);

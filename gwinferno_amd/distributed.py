@@ -40,10 +40,10 @@ def init_engine_communicator(engine, group=None):
     if rank == 0:
         buf = C.create_string_buffer(128)
         st = N.load_library().gwi_comm_unique_id(path.encode() if path else None, buf)
-        if st != 0:
-            raise N.NativeEngineError(f"gwi_comm_unique_id failed ({N.STATUS_NAMES.get(st, st)})")
-        box[0] = bytes(buf.raw)
-    dist.broadcast_object_list(box, src=0, group=group)
+        box[0] = bytes(buf.raw) if st == 0 else f"gwi_comm_unique_id failed ({N.STATUS_NAMES.get(st, st)})"
+    dist.broadcast_object_list(box, src=0, group=group)  # (a failure on rank 0 travels too: nobody is left waiting in the broadcast)
+    if not isinstance(box[0], bytes):
+        raise N.NativeEngineError(str(box[0]))
     engine.comm_init(box[0], rank, world, rccl_path=path)
 
 

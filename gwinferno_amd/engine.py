@@ -762,6 +762,13 @@ class NativePopulationLikelihood:
         ``k_batch`` points uses (``gwi_batch_path``)."""
         return self.lib.gwi_batch_path(self.handle, int(k_batch)).decode()
 
+    def batch_calibration(self):
+        """``{"measured", "mfma_us", "taps_us"}``: the engine's own measurement of its two batched kernels on the first batched
+        launch of >= 9 points (``gwi_batch_calibration``); ``measured`` False before that launch or where the path is fixed."""
+        m, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
+        self._check(self.lib.gwi_batch_calibration(self.handle, C.byref(m), C.byref(a), C.byref(b)))
+        return {"measured": bool(m.value), "mfma_us": a.value, "taps_us": b.value}
+
     def scan_kernel_name(self):
         """The compiled term chain this engine's scan runs, or "generic (run-time term loop)" (``gwi_scan_kernel_name``)."""
         return self.lib.gwi_scan_kernel_name(self.handle).decode()

@@ -314,6 +314,12 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
  * Models without spline terms: "pbatch" (every sample loaded once for all the points of a grid row, scan_pbatch_kernel;
  * GWI_PBATCH=0 or tiles of more than one trip: "rows-per-point", one grid row per point). */
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
+/* Spline models that have both batched kernels: which one runs is measured on the engine's FIRST batched launch of >= 9 points
+ * (three evaluation sets of each on the caller's own points, host theta -> host results; the faster stays) unless the
+ * environment names a path (GWI_BATCH_MFMA, GWI_BATCH_ROWS) or GWI_BATCH_AUTOTUNE=0 keeps the static rule (matrix cores up to
+ * 8 gradient tiles).  gwi_batch_path answers with the static rule before that launch and with the measured choice after it;
+ * this returns whether the measurement has been made and the best microseconds per evaluation set of either kernel. */
+gwi_status gwi_batch_calibration(gwi_handle h, int32_t* measured, double* mfma_us, double* taps_us);
 
 /* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the
  * reference passes to hierarchical_likelihood as pe_weights / inj_weights (tests/inference_test.py:

@@ -11,6 +11,7 @@ everywhere.
 Children are fresh processes (tests/multirank_child.py) started with subprocess -- never an exec of this process -- and a
 child that does not finish in time is killed by its PID and fails the test.
 """
+import json
 import os
 import socket
 import subprocess
@@ -160,3 +161,39 @@ def test_bench_rccl_leg_compares_with_the_unsharded_engine(tmp_path):
     chk = line["sharded_vs_single_gpu"]
     assert chk["within_tolerance"] and chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
     assert line["rccl_ranks"] == 1 and line["identical_on_all_ranks"]
+
+
+def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
+    """bench.py's N > 1 path with a world of ONE rank (GWI_FORCE_SHARDED=1: every box has that): the probe of the in-engine
+    ncclAllGather runs first in a child process; when it comes back clean the HEADLINE's records travel through that exchange
+    (`multi_gpu.rccl_ranks == world`, what BASELINE.json's north_star names), the shared-memory exchange is reported beside it,
+    and the sharded result is compared with the unsharded engine."""
+    env = dict(os.environ, GWI_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20", "--also", "none", "--no-cpu-baseline", "--k-batch", "0", "--chains", "0",
+           "--spin", "0.1"]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = child.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        out, err = child.communicate()
+        pytest.fail("bench.py did not finish within 600 s and was killed\n" + (err or "")[-1500:])
+    assert child.returncode == 0, (err or "")[-2000:]
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    mg = line["multi_gpu"]
+    assert mg["ranks"] == 1 and mg["rccl_ranks"] == 1, mg
+    ex = mg["exchanges"]
+    assert ex["rccl_allgather"]["headline"] is True and ex["rccl_allgather"]["evals_per_s"] == line["value"]
+    assert ex["rccl_allgather_probe"]["child_exit_code"] == 0 and ex["rccl_allgather_probe"]["probe_clean_on_every_rank"] is True
+    assert ex["shm"]["evals_per_s"] > 0 and ex["shm"]["last_log_likelihood"] == line["last_log_likelihood"]
+    chk = mg["sharded_vs_single_gpu"]
+    assert chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
+    # ... and with the probe switched off the shared-memory exchange carries the headline, and says so
+    env["GWI_BENCH_RCCL_VARIANT"] = "0"
+    env["MASTER_PORT"] = str(_free_port())
+    out2 = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    mg2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][-1])["multi_gpu"]
+    assert mg2["rccl_ranks"] == 0 and mg2["exchanges"]["shm"]["headline"] is True

@@ -1020,3 +1020,37 @@ def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe,
         assert x.log_likelihood == y.log_likelihood and np.array_equal(x.grad, y.grad)
     eng.close()
     old.close()
+
+
+def test_the_batched_kernel_of_a_spline_model_is_chosen_by_measurement(monkeypatch):
+    """Spline models have two batched kernels (matrix cores / 4-tap); which is faster depends on the model and the catalog
+    (BASELINE config 3 is a tie, config 5 prefers the matrix cores).  With no path named in the environment the engine times
+    both on its first batched launch of >= 9 points and keeps the faster; gwi_batch_path then answers with that choice."""
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    for v in ("GWI_BATCH_MFMA", "GWI_BATCH_ROWS", "GWI_BATCH_AUTOTUNE"):
+        monkeypatch.delenv(v, raising=False)
+    pe, inj, total = make_catalog(11, 700, 5003, seed=41)
+    comp = COMPOSITIONS["bspline_iid"](pe, inj)
+    eng = comp.engine()
+    rng = np.random.default_rng(9)
+    thetas = np.stack([comp.theta(draw_params("bspline_iid", rng)) for _ in range(16)])
+    assert eng.batch_path(16) == "mfma" and not eng.batch_calibration()["measured"]  # the static rule until something has been measured
+    small = eng.evaluate_batch(thetas[:4], total, min_neff_cut=False)                # below 9 points: nothing to choose
+    assert not eng.batch_calibration()["measured"]
+    batch = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+    cal = eng.batch_calibration()
+    assert cal["measured"] and cal["mfma_us"] > 0 and cal["taps_us"] > 0
+    assert eng.batch_path(16) == ("mfma" if cal["mfma_us"] <= cal["taps_us"] else "taps")
+    for k in range(16):
+        one = eng.evaluate(thetas[k], total, min_neff_cut=False)
+        assert rel_err(batch[k].log_likelihood, one.log_likelihood) < 1e-12 and np.allclose(batch[k].grad, one.grad, rtol=1e-10, atol=1e-11)
+        if k < 4:
+            assert rel_err(small[k].log_likelihood, one.log_likelihood) < 1e-12
+    eng.close()
+    monkeypatch.setenv("GWI_BATCH_AUTOTUNE", "0")
+    fixed = COMPOSITIONS["bspline_iid"](pe, inj).engine()
+    fixed.evaluate_batch(thetas, total, min_neff_cut=False)
+    assert fixed.batch_path(16) == "mfma" and not fixed.batch_calibration()["measured"]
+    fixed.close()

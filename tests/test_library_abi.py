@@ -117,3 +117,76 @@ def test_raw_code_object_for_the_aql_path(lib):
     for n, scratch in per_kernel.items():
         if "scan_kernelILb0ELb0E" in n or "combine_kernel" in n or "final_kernel" in n:
             assert scratch == "0", (n, scratch)
+
+
+def test_a_scan_chain_compiles_at_run_time_without_a_gpu(lib, tmp_path):
+    """gwi_jit_compile (gwinferno_amd/csrc/gwi_jit.h): the scan template instantiated by hipRTC for a term-kind sequence the
+    library has no ahead-of-time kernel for -- cross-compiled for gfx950 like hipcc does, so it runs in the CPU suite.  The
+    cache file holds a raw code object with one kernel per role, none with scratch or implicit arguments (the engine's AQL
+    queue supplies neither); a second PROCESS finds it in the disk cache; and the chain of a sequence that does have an
+    ahead-of-time kernel comes out under the same names with a comparable register budget (the compiler is the process's
+    hipRTC -- PyTorch's bundled ROCm when torch was imported first -- not necessarily the hipcc of the build)."""
+    import shutil
+    import subprocess
+    import sys
+
+    from gwinferno_amd import _native as N
+
+    os.environ["GWI_JIT_CACHE"] = str(tmp_path)
+    try:
+        names = [lib.gwi_kernel_variant_name(i).decode() for i in range(lib.gwi_kernel_variants())]
+        assert not any(n.startswith("user:2,3,4,6,8") for n in names)
+        got = N.jit_compile([2, 3, 4, 6, 8], 2)  # PL+Peak x PL q x Beta x PL z x truncated normal: parametric -> scan, logw, batch, pbatch
+        assert got["path"].startswith(str(tmp_path)) and os.path.exists(got["path"]) and not got["from_cache"] and got["compile_seconds"] > 0
+        spl = N.jit_compile([1, 5, 7, 9], 1)    # with spline terms: scan, logw, batch, safe
+        with pytest.raises(N.NativeEngineError):
+            N.jit_compile([3, 2], 2)             # not ascending
+        with pytest.raises(N.NativeEngineError):
+            N.jit_compile([2, 99], 2)            # not a term kind
+        # a fresh process: the disk cache answers
+        code = ("import sys; sys.path.insert(0, %r)\nfrom gwinferno_amd import _native as N\nr = N.jit_compile([2, 3, 4, 6, 8], 2)\n"
+                "assert r['from_cache'] and r['compile_seconds'] == 0.0, r\nprint(r['path'])" % ROOT)
+        again = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GWI_JIT_CACHE=str(tmp_path)))
+        assert again.returncode == 0 and again.stdout.strip() == got["path"], again.stderr[-2000:]
+        aot_like = N.jit_compile([2, 3, 6], 2)   # BASELINE config 2's chain once more, by hipRTC
+    finally:
+        os.environ.pop("GWI_JIT_CACHE", None)
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        readelf = shutil.which("llvm-readelf")
+    if not readelf:
+        pytest.skip("llvm-readelf not available")
+
+    def kernels(path_or_blob, is_cache_file):
+        p = path_or_blob
+        if is_cache_file:
+            blob = open(path_or_blob, "rb").read()
+            head, _, _ = blob.partition(b"\x7fELF")
+            lowered = head.decode().splitlines()[1:6]
+            p = str(tmp_path / (os.path.basename(path_or_blob) + ".hsaco"))
+            open(p, "wb").write(blob[len(head):])
+        else:
+            lowered = None
+        notes = subprocess.run([readelf, "--notes", p], capture_output=True, text=True).stdout
+        rows = {}
+        for blockm in re.finditer(r"\.name:\s+(\S+)(.*?)\.wavefront_size", notes, flags=re.S):
+            rows[blockm.group(1)] = {"scratch": int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blockm.group(0)).group(1)) if re.search(r"\.private_segment_fixed_size", blockm.group(0)) else None}
+        per_name = dict(zip(re.findall(r"\.name:\s+(\S+)", notes), zip(re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes), re.findall(r"\.vgpr_count:\s+(\d+)", notes),
+                                                                   re.findall(r"\.sgpr_count:\s+(\d+)", notes))))
+        return lowered, per_name, notes
+
+    low, per, notes = kernels(got["path"], True)
+    assert low[0] and low[1] and low[2] and not low[3] and low[4]          # parametric: no SAFE instantiation, a pbatch one
+    assert "scan_pbatch_kernel" in low[4] and "hidden_" not in notes
+    for role in (0, 2, 4):
+        assert per[low[role]][0] == "0", (low[role], per[low[role]])        # no scratch in what the AQL queue dispatches
+    low_s, per_s, _ = kernels(spl["path"], True)
+    assert low_s[3] and not low_s[4] and per_s[low_s[0]][0] == "0" and per_s[low_s[3]][0] == "0"
+    # the same chain from hipcc (ahead of time) and from hipRTC: the same kernels by name, no scratch, registers within a third
+    low_c2, per_c2, _ = kernels(aot_like["path"], True)
+    _, per_aot, _ = kernels(os.path.join(os.path.dirname(N.LIB_PATH), "gwi_kernels.hsaco"), False)
+    for role in (0, 1, 2, 4):
+        assert low_c2[role] in per_aot, low_c2[role]
+        jit_k, aot_k = per_c2[low_c2[role]], per_aot[low_c2[role]]
+        assert jit_k[0] == aot_k[0] == "0" or role == 1, (low_c2[role], jit_k, aot_k)
+        assert abs(int(jit_k[1]) - int(aot_k[1])) <= max(16, int(aot_k[1]) // 3), (low_c2[role], jit_k, aot_k)
