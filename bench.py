@@ -631,6 +631,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             "last_log_likelihood": last_ll,
             "setup": setup,
             "two_pass_repeats": eng.two_pass_repeats(),
+            # which scan kernel ran: an ahead-of-time chain by name, a chain compiled at gwi_create by hipRTC ("jit:..."; the time
+            # that cost this process, 0 when the disk cache supplied the code object) or the generic kernel
+            "scan_chain": {"name": eng.scan_kernel_name(), **eng.jit_info()},
         }
         if dist is not None:
             key = "shm" if exchange.startswith("host shared-memory") else ("rccl_allgather" if exchange.startswith("ncclAllGather") else "torch_all_gather")
@@ -660,9 +663,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             if cal["measured"]:  # spline models: the engine timed both of its batched kernels on its first batched launch and kept the faster
                 out["batched"]["path_choice"] = {"how": "measured by the engine on its first batched launch: three evaluation sets of either kernel, host theta -> host results, best of each",
                                                  "mfma_us_per_set": cal["mfma_us"], "taps_us_per_set": cal["taps_us"]}
-            ji = eng.jit_info()
-            if ji["compiled_at_run_time"]:
-                out["scan_chain"] = {"name": eng.scan_kernel_name(), **ji}
+
             # kernel durations of the batched launches (start/stop of each launch, a few timed batches after the loop)
             eng.set_timing(True)
             bk = []

@@ -1575,6 +1575,11 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     std::string why;
     jit::Chain* jc = jit::get_chain(kinds, spec->n_terms, U, gwi_embedded_device_h, gwi_embedded_engine_h, why);
     hipModule_t mod = jc ? jit::module_on(jc, h->device, why) : nullptr;
+    if (jc && !mod && jc->from_cache) {  // a cache file the runtime does not accept: drop it and compile once more
+      jit::discard_chain(jc);
+      jc = jit::get_chain(kinds, spec->n_terms, U, gwi_embedded_device_h, gwi_embedded_engine_h, why);
+      mod = jc ? jit::module_on(jc, h->device, why) : nullptr;
+    }
     bool ok = mod != nullptr;
     for (int role = 0; role < jit::kRoles && ok; ++role) {
       if (jc->lowered[role].empty()) continue;

@@ -230,9 +230,30 @@ inline const char* preamble() {
 
 // Compile (or fetch from the disk cache) the chain of `kinds` with U samples per lane.  `device_h` / `engine_h`: the texts of
 // gwi_device.h and include/gwi_engine.h this library was built from.  Process-wide cache; returns nullptr and says why.
-inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, const char* engine_h, std::string& why) {
+inline std::mutex& chains_mutex() {
   static std::mutex mu;
+  return mu;
+}
+inline std::vector<Chain*>& chains_list() {
   static std::vector<Chain*> chains;
+  return chains;
+}
+// A cached code object the runtime refuses to load (a file damaged on disk): forget the chain and its file, so that the next
+// get_chain() compiles afresh.  The Chain object itself is leaked (another engine may still hold it).
+inline void discard_chain(Chain* c) {
+  std::lock_guard<std::mutex> lock(chains_mutex());
+  auto& v = chains_list();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == c) {
+      v.erase(v.begin() + (long)i);
+      break;
+    }
+  if (!c->path.empty()) std::remove(c->path.c_str());
+}
+
+inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, const char* engine_h, std::string& why) {
+  std::mutex& mu = chains_mutex();
+  std::vector<Chain*>& chains = chains_list();
   if (n < 1 || n > GWI_MAX_TERMS || (U != 1 && U != 2)) {
     why = "jit: 1 to 12 term kinds, one or two samples per lane";
     return nullptr;

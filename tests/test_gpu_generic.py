@@ -261,3 +261,37 @@ def test_run_time_compiled_chain_is_the_ahead_of_time_chain(comp_name, monkeypat
     assert again.evaluate(thetas[0], total, min_neff_cut=False).log_likelihood == jit.evaluate(thetas[0], total, min_neff_cut=False).log_likelihood
     for e in (aot, jit, again):
         e.close()
+
+
+def test_a_damaged_cache_file_is_recompiled(tmp_path):
+    """The disk cache is a convenience: a code object the runtime refuses to load (damaged on disk) is deleted and the chain
+    compiled again -- the engine still runs its own chain, not the generic kernel."""
+    import subprocess
+    import sys
+
+    from gwinferno_amd import _native as N
+
+    env = dict(os.environ, GWI_JIT_CACHE=str(tmp_path), GWI_FORCE_JIT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nimport numpy as np\nfrom gwinferno_amd.compositions import COMPOSITIONS, draw_params\n"
+            "from gwinferno_amd.synthetic import make_catalog\npe, inj, total = make_catalog(5, 300, 2000, seed=3)\ncomp = COMPOSITIONS['plpeak'](pe, inj)\n"
+            "eng = comp.engine()\nr = eng.evaluate(comp.theta(draw_params('plpeak', np.random.default_rng(1))), total, min_neff_cut=False)\n"
+            "print(eng.scan_kernel_name(), eng.jit_info()['from_cache'], repr(r.log_likelihood))" % root)
+    first = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert first.returncode == 0, first.stderr[-1500:]
+    name, hit, ll = first.stdout.split()[-3:]
+    assert name.startswith("jit:") and hit == "False"
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".gwijit")]
+    assert len(files) == 1
+    path = os.path.join(tmp_path, files[0])
+    blob = bytearray(open(path, "rb").read())
+    start = blob.index(b"\x7fELF")
+    blob[start + 64 : start + 4096] = bytes(4096 - 64)  # keep the magic (the cache reader checks that much), wreck the headers behind it
+    open(path, "wb").write(bytes(blob))
+    second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert second.returncode == 0, second.stderr[-1500:]
+    name2, hit2, ll2 = second.stdout.split()[-3:]
+    assert name2 == name and hit2 == "False" and ll2 == ll  # compiled afresh, same answer
+    third = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert third.stdout.split()[-3:] == [name, "True", ll]  # ... and the repaired file serves the next process
+    assert N is not None

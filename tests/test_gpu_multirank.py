@@ -187,7 +187,8 @@ def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
     ex = mg["exchanges"]
     assert ex["rccl_allgather"]["headline"] is True and ex["rccl_allgather"]["evals_per_s"] == line["value"]
     assert ex["rccl_allgather_probe"]["child_exit_code"] == 0 and ex["rccl_allgather_probe"]["probe_clean_on_every_rank"] is True
-    assert ex["shm"]["evals_per_s"] > 0 and ex["shm"]["last_log_likelihood"] == line["last_log_likelihood"]
+    # (the two exchanges sum the records on different paths -- device-side final reduce vs the host's -- : last bits may differ)
+    assert ex["shm"]["evals_per_s"] > 0 and abs(ex["shm"]["last_log_likelihood"] - line["last_log_likelihood"]) <= 1e-12 * abs(line["last_log_likelihood"])
     chk = mg["sharded_vs_single_gpu"]
     assert chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
     # ... and with the probe switched off the shared-memory exchange carries the headline, and says so

@@ -31,11 +31,37 @@ for c in c3 c5; do
     python3 $R/tools/batch_run.py --config $c --k 16 --n 100 $flag > $out/run.json 2> /dev/null
   done
 done
+# ---- round 5: (a) the same single evaluations through a chain compiled at gwi_create (GWI_FORCE_JIT=1: hipRTC) and through the
+# generic kernel (GWI_FORCE_GENERIC=1: run-time term loop) -- what a product of densities without an ahead-of-time chain runs;
+# (b) batched launches of the parametric config 2: one load per sample (scan_pbatch_kernel) against one grid row per point
+# (GWI_PBATCH=0), with the FETCH_SIZE / WRITE_SIZE passes that show what each streams from beyond L2
+for mode in jit generic; do
+  [ $mode = jit ] && export GWI_FORCE_JIT=1 || export GWI_FORCE_GENERIC=1
+  export GWI_QUIET=1
+  for c in $CONFIGS; do
+    out=$R/gpurun_out/prof/chain_${c}_$mode
+    mkdir -p $out
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --config $c --steps 200 --warmup 20 $B > $out/bench_under_trace.json 2> /dev/null
+    python3 $R/bench.py --config $c --steps 1000 --warmup 100 --also none $B > $out/bench.json 2> /dev/null
+  done
+  unset GWI_FORCE_JIT GWI_FORCE_GENERIC GWI_QUIET
+done
+for path in pbatch rowsperpoint; do
+  out=$R/gpurun_out/prof/batch_c2_$path
+  mkdir -p $out
+  [ $path = rowsperpoint ] && export GWI_PBATCH=0 || unset GWI_PBATCH
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 40 > $out/run_under_trace.json 2> /dev/null
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $out/mfma -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
+  python3 $R/tools/batch_run.py --config c2 --k 16 --n 100 > $out/run.json 2> /dev/null
+done
+unset GWI_PBATCH
 # the driver's own command, for the record
 cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_form.json 2> /dev/null
 # summarise on the box (the raw traces exceed what gpurun carries back) and keep only the summary
 unset GWI_BATCH_MFMA
-python3 tools/summarize_profiles.py ${ROUND:-round4} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
+python3 tools/summarize_profiles.py ${ROUND:-round5} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
 cp gpurun_out/prof/bench_driver_form.json gpurun_out/profile_summary/ 2>/dev/null
 rm -rf $R/gpurun_out/prof
 ls -la $R/gpurun_out/profile_summary
