@@ -711,10 +711,10 @@ bool pbatch_applies(const gwi_engine* h) {
 // Points per grid row of a pbatch launch of K points.  One row (every sample loaded once for all K points) is the least work,
 // but a tile x K points is a long workgroup: the rows are split until the launch has about eight workgroups per CU to balance
 // (config 2, K = 16: 788 tiles on 256 CUs -- one row leaves a quarter of the chip idle behind the CUs that drew four tiles).
-int pbatch_points(const gwi_engine* h, int K) {
+int pbatch_points(const gwi_engine* h, int K, int on_bgeo = -1) {
   int pts = h->pbatch_pts;
   if (pts <= 0) {
-    const long long blocks = h->use_bgeo ? h->bgeo.n_scan_blocks : h->n_scan_blocks;
+    const long long blocks = (on_bgeo < 0 ? h->use_bgeo : on_bgeo != 0) ? h->bgeo.n_scan_blocks : h->n_scan_blocks;
     int rows = 1;
     while (rows < K && blocks * rows < 8LL * h->n_cus) rows *= 2;
     pts = (K + rows - 1) / rows;
@@ -729,7 +729,9 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   // ... and so does any replica count other than the 16 the regular kernels are built for (GWI_GACC_REP)
   const bool safe = !logw && h->variant->has(jit::kSafe) && (h->generic || h->kargs.two_pass || h->kargs.deterministic || h->gacc_rep != (1 << kRegularRepShift));
   // parametric models: a batched launch on single-trip tiles loads every sample once for all its points (scan_pbatch_kernel)
-  const bool pb = batch && !safe && !logw && pbatch_applies(h);
+  // ... where a grid row holds more than one point: with one point per row (small catalogs: the rows are split until the launch
+  // fills the chip) it has nothing to share and the one-row-per-point kernel is the same thing without the staging
+  const bool pb = batch && !safe && !logw && pbatch_applies(h) && pbatch_points(h, K) > 1;
   h->scan_role = logw ? jit::kLogw : (safe ? jit::kSafe : (pb ? jit::kPbatch : (batch ? jit::kBatch : jit::kScan)));
   ScanFn fn = h->variant->fn[h->scan_role];
   h->scan_is_safe = safe;
@@ -2331,7 +2333,7 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   if (h->variant && h->variant->has(jit::kPbatch) && !h->generic) {  // parametric model: one load per sample where the tiles of a launch of k_batch points are single trips
     const long long gran = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;
     const bool bg = k_batch >= 4 && h->bgeo.distinct;
-    if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran) return "pbatch";
+    if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran && pbatch_points(h, k_batch, bg ? 1 : 0) > 1) return "pbatch";
     return "rows-per-point";
   }
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";

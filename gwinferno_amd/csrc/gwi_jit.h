@@ -369,6 +369,7 @@ inline hipModule_t module_on(Chain* c, int device, std::string& why) {
   const hipError_t e = hipModuleLoadData(&m, c->code.data());
   if (e != hipSuccess) {
     why = std::string("jit: hipModuleLoadData: ") + hipGetErrorString(e);
+    (void)hipGetLastError();  // the runtime keeps the failure as its "last error": the next launch's check must not find it
     return nullptr;
   }
   c->modules.emplace_back(device, m);

@@ -960,11 +960,11 @@ def test_device_gradient_against_finite_differences_of_the_device_value(comp_nam
 
 
 @pytest.mark.parametrize("comp_name,n_ev,n_pe,n_inj,env", [
-    ("plpeak", 11, 700, 5003, {}),                                   # ragged tiles; the BASELINE config-2 chain
-    ("plpeak_full", 7, 1000, 4000, {}),                              # config 1: 16 scalar sums per sample -> two butterflies per point
+    ("plpeak", 11, 700, 5003, {"GWI_PBATCH_PTS": "4"}),              # ragged tiles; the BASELINE config-2 chain (a catalog this small would get one point per row: forced)
+    ("plpeak_full", 7, 1000, 4000, {"GWI_PBATCH_PTS": "8"}),         # config 1: 16 scalar sums per sample -> two butterflies per point
     ("plpeak", 5, 300, 70, {"GWI_PBATCH_PTS": "3"}),                 # rows of 3, 3, ... points: a last row with fewer; waves without samples
     ("plpeak_smooth", 9, 512, 2048, {"GWI_PBATCH_PTS": "16"}),       # exactly one full trip per tile; one grid row for the whole batch
-    ("chm_powerlaw", 6, 900, 3000, {}),                              # theta-dependent truncation (POWERLAW_BOUNDS)
+    ("chm_powerlaw", 6, 900, 3000, {"GWI_PBATCH_PTS": "5"}),         # theta-dependent truncation (POWERLAW_BOUNDS)
     ("plpeak", 20, 30000, 300000, {}),                               # tiles of several trips for single evaluations: batches on single-trip tiles of their own
 ])
 def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe, n_inj, env, monkeypatch):
