@@ -9,11 +9,11 @@ import os
 
 import numpy as np
 
-GWI_ABI_VERSION = 2
+GWI_ABI_VERSION = 3
 GWI_MAX_TERMS = 12
 GWI_MAX_THETA = 256
-GWI_MAX_NORMS = 8
-GWI_MAX_COLS = 16
+GWI_MAX_NORMS = 12
+GWI_MAX_COLS = 32
 
 # term kinds (include/gwi_engine.h)
 TERM_POWERLAW = 1

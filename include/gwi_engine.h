@@ -38,11 +38,11 @@
 extern "C" {
 #endif
 
-#define GWI_ABI_VERSION 2 /* 2: GWI_TERM_PLPEAK takes ONE column (log x) */
+#define GWI_ABI_VERSION 3 /* 2: GWI_TERM_PLPEAK takes ONE column (log x); 3: GWI_MAX_NORMS 8 -> 12, GWI_MAX_COLS 16 -> 32 (gwi_spec grows) */
 #define GWI_MAX_TERMS 12
 #define GWI_MAX_THETA 256
-#define GWI_MAX_NORMS 8
-#define GWI_MAX_COLS 16
+#define GWI_MAX_NORMS 12 /* one grid normaliser per term at most */
+#define GWI_MAX_COLS 32  /* twelve terms x two columns + kappa fit */
 
 typedef int32_t gwi_status;
 enum {

@@ -46,6 +46,12 @@ def test_creating_and_destroying_engines_leaves_device_memory_where_it_was():
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
 
+    import gc
+
+    from gwinferno_amd import likelihood
+
+    likelihood.clear_engine_cache()
+    gc.collect()  # engines of earlier tests that are still awaiting collection would free their memory in the middle of the loop
     pe, inj, total = make_catalog(12, 2000, 20000, seed=9)
     free = []
     for it in range(41):

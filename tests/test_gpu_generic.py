@@ -231,8 +231,11 @@ def test_run_time_compiled_chain_is_the_ahead_of_time_chain(comp_name, monkeypat
     assert not aot.scan_kernel_name().startswith(("jit:", "generic"))
     monkeypatch.setenv("GWI_FORCE_JIT", "1")
     monkeypatch.setenv("GWI_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("GWI_PBATCH_PTS", "3")  # parametric chains: the batch below runs the chain's pbatch kernel (a catalog this small would get one point per row)
     comp = COMPOSITIONS[comp_name](pe, inj)
     jit = comp.engine()
+    if "bspline" not in comp_name:
+        assert jit.batch_path(5) == "pbatch"
     info = jit.jit_info()
     assert jit.scan_kernel_name().startswith("jit:") and info["compiled_at_run_time"], (jit.scan_kernel_name(), info)
     assert jit.dispatch_info() == "aql: active"
@@ -295,3 +298,53 @@ def test_a_damaged_cache_file_is_recompiled(tmp_path):
     third = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert third.stdout.split()[-3:] == [name, "True", ll]  # ... and the repaired file serves the next process
     assert N is not None
+
+
+def test_a_model_beyond_the_former_limits(monkeypatch, tmp_path):
+    """BASELINE config 5's model (seven B-spline terms x PL z: all EIGHT normalisers the ABI allowed until round 5) times the
+    effective-spin model BSplineEffectiveSpinDims (separable.py:706-778: two more normalised linear-spline terms): ten terms,
+    nine normalisers, twelve columns, 123 hyper-parameters -- a chain no ahead-of-time kernel exists for (compiled at gwi_create)
+    -- against the C oracle."""
+    from gwinferno_amd import models as M
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    base = COMPOSITIONS["bspline_full"]
+
+    class FullPlusEffectiveSpins(base):
+        NE, NP = 10, 8
+
+        def __init__(self, pe, inj, **kw):
+            super().__init__(pe, inj, **kw)
+            self.PARAMS = dict(self.PARAMS, e_coefs=(self.NE,), p_coefs=(self.NP,))
+            self.chi_model = M.BSplineEffectiveSpinDims(self.NE, self.NP, self.pe["chi_eff"], self.pe["chi_p"], self.inj["chi_eff"], self.inj["chi_p"], normalize=True)
+
+        def placeholder(self):
+            q = super().placeholder()
+            q["e_coefs"], q["p_coefs"] = np.ones(self.NE), np.ones(self.NP)
+            return q
+
+        def spins(self, p, pe_samples):
+            return super().spins(p, pe_samples) * self.chi_model(p["e_coefs"], p["p_coefs"], pe_samples=pe_samples)
+
+    monkeypatch.setenv("GWI_JIT_CACHE", str(tmp_path))
+    pe, inj, total = make_catalog(9, 900, 6000, seed=61)
+    comp = FullPlusEffectiveSpins(pe, inj)
+    eng = comp.engine()
+    assert len(eng.bound.terms) == 10 and len(eng.bound.norms) == 9 and eng.n_theta == 105 + 18
+    assert eng.scan_kernel_name().startswith("jit:6,7,7,7,7,7,7,7,9,9"), eng.scan_kernel_name()
+    orc = COracle(eng.bound)
+    rng = np.random.default_rng(12)
+    for _ in range(3):
+        p = draw_params("bspline_full", rng)
+        p["e_coefs"], p["p_coefs"] = rng.uniform(0.2, 2.0, size=10), rng.uniform(0.2, 2.0, size=8)
+        th = comp.theta(p)
+        got, ref = eng.evaluate(th, total, min_neff_cut=False), orc.evaluate(th, total, min_neff_cut=False)
+        assert rel_err(got.log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        assert rel_err(got.log_bfs, ref["logBFs"]) < VALUE_RTOL and rel_err(got.norms, ref["norms"]) < VALUE_RTOL
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    batch = eng.evaluate_batch(np.stack([th, th]), total, min_neff_cut=False)
+    assert rel_err(batch[1].log_likelihood, got.log_likelihood) < 1e-12
+    eng.close()

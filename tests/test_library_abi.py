@@ -48,7 +48,7 @@ def test_struct_sizes_match_header(lib):
 
 
 def test_version_and_variants(lib):
-    assert lib.gwi_abi_version() == 2  # 2: GWI_TERM_PLPEAK takes one column (log x)
+    assert lib.gwi_abi_version() == 3  # 2: GWI_TERM_PLPEAK takes one column (log x); 3: twelve normalisers, 32 columns
     names = [lib.gwi_kernel_variant_name(i).decode() for i in range(lib.gwi_kernel_variants())]
     for needed in ("plpeak+plq+plz", "plpeak+plq+beta2+tilt2+plz", "plq+plz+spline5", "plz+spline7", "plz+spline3", "pl+plq+plz"):
         assert needed in names
