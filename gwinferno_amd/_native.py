@@ -235,6 +235,7 @@ EXPORTED_SYMBOLS = [
     "gwi_two_pass_repeats",
     "gwi_batch_path",
     "gwi_batch_calibration",
+    "gwi_batch_kernel_note",
     "gwi_selftime",
     "gwi_last_kernel_ms",
     "gwi_set_timing",
@@ -364,6 +365,9 @@ def load_library():
     if hasattr(lib, "gwi_batch_calibration"):
         lib.gwi_batch_calibration.restype = C.c_int32
         lib.gwi_batch_calibration.argtypes = [vp, _IP, _DP, _DP]
+    if hasattr(lib, "gwi_batch_kernel_note"):
+        lib.gwi_batch_kernel_note.restype = C.c_char_p
+        lib.gwi_batch_kernel_note.argtypes = [vp]
     if hasattr(lib, "gwi_jit_compile"):  # absent from older builds loaded through GWI_ENGINE_LIB for A/B timing
         lib.gwi_jit_compile.restype = C.c_int32
         lib.gwi_jit_compile.argtypes = [_IP, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, _DP, _IP]

@@ -43,10 +43,15 @@ __asm__(
     "gwi_embedded_engine_h:\n"
     ".incbin \"gwi_engine.h\"\n"
     ".byte 0\n"
+    ".global gwi_embedded_mfma_h\n"
+    "gwi_embedded_mfma_h:\n"
+    ".incbin \"gwi_mfma.h\"\n"
+    ".byte 0\n"
     ".popsection\n");
 #endif
 extern "C" const char gwi_embedded_device_h[];
 extern "C" const char gwi_embedded_engine_h[];
+extern "C" const char gwi_embedded_mfma_h[];
 
 namespace {
 
@@ -384,6 +389,12 @@ struct gwi_engine {
   int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
   // which of the two batched kernels a spline model runs is MEASURED on its first batched launch (calibrate_batch_path): three
   // launches of each on the caller's own points, the faster one stays.  Off where the environment names a path.
+  // a spline model without an ahead-of-time matrix-core instantiation gets one compiled (gwi_jit.h) on its first batched launch
+  // of >= 9 points -- where both kernels are then measured -- or at gwi_create when GWI_BATCH_MFMA=1 asks for that path
+  MfmaVariant* jit_mfma = nullptr;    // owned record of that instantiation (mfma points at it once it is loaded)
+  hipFunction_t jit_mfma_fn = nullptr;
+  bool mfma_jit_pending = false;      // worth trying, not tried yet
+  std::string mfma_jit_note;
   bool batch_autotune = false;        // a choice is still to be made
   bool batch_measured = false;        // ... and has been
   double batch_us[2] = {0.0, 0.0};    // best wall time of one batched evaluation set: [matrix-core kernel, 4-tap kernel]
@@ -746,6 +757,18 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   }
   if (batch && !safe && !logw) {
     h->batch_used_mfma = h->mfma && K >= h->mfma_min_batch;
+    if (h->batch_used_mfma && h->mfma == h->jit_mfma && h->jit_mfma_fn) {  // ... the instantiation compiled at run time: a module launch, the argument block as the buffer
+      size_t bytes = sizeof(KArgs);
+      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &h->kargs, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+      const unsigned gy_m = (unsigned)((K + kPts - 1) / kPts);
+      h->aql_now = false;
+      if (h->timing)
+        (void)hipExtModuleLaunchKernel(h->jit_mfma_fn, (unsigned)grid * kBlock, gy_m, 1, kBlock, 1, 1, h->mfma_lds_bytes, h->stream, nullptr, extra, h->ev[0], h->ev[1], 0);
+      else
+        (void)hipModuleLaunchKernel(h->jit_mfma_fn, (unsigned)grid, gy_m, 1, kBlock, 1, 1, (unsigned)h->mfma_lds_bytes, h->stream, nullptr, extra);
+      GWI_HIP(hipGetLastError());
+      return GWI_OK;
+    }
     if (h->batch_used_mfma) {  // 16 points per wavefront: the grid's second dimension counts groups of 16
       launch_timed(h, 0, h->batch_rows ? h->mfma->rows_fn : h->mfma->fn, dim3(grid, (K + kPts - 1) / kPts), dim3(kBlock), h->mfma_lds_bytes, h->kargs, offsetof(KArgs, theta));
       GWI_HIP(hipGetLastError());
@@ -950,6 +973,71 @@ gwi_status repeat_after_redo(gwi_handle h, const double* theta, double* record_d
   }
   return st;
 }
+// The matrix-core batched kernel for a spline model that has no ahead-of-time instantiation of it: scan_mfma_kernel
+// instantiated for this model's kinds and tile counts by hipRTC (gwi_jit.h), loaded as a module.  Returns whether h->mfma is set.
+bool try_jit_mfma(gwi_handle h) {
+  h->mfma_jit_pending = false;
+  const gwi_spec& s = h->spec;
+  int kts[GWI_MAX_TERMS], tiles_total = 0, row_doubles = 0;
+  bool any_spline = false;
+  for (int t = 0; t < s.n_terms; ++t) {
+    const int kind = s.terms[t].kind;
+    if (kind == GWI_TERM_EXP_SPLINE_LERP) {
+      h->mfma_jit_note = "the interpolated-grid spline term has no matrix-core form";
+      return false;
+    }
+    const bool spline = kind == GWI_TERM_EXP_SPLINE || kind == GWI_TERM_LINEAR_SPLINE;
+    const int tiles = spline ? (s.terms[t].n_basis + 15) / 16 : 0;
+    any_spline = any_spline || spline;
+    kts[t] = kind + 100 * tiles;
+    tiles_total += tiles;
+    row_doubles += spline ? kSplineStage : term_cols(kind);
+  }
+  if (!any_spline || tiles_total > 8) {  // more than eight gradient tiles: the 4-tap kernel wins by arithmetic (DESIGN section 0 of round 4, row 4)
+    h->mfma_jit_note = any_spline ? "more than eight 16-basis gradient tiles" : "no spline term";
+    return false;
+  }
+  std::string why;
+  jit::Chain* c = jit::get_chain(kts, s.n_terms, 0, gwi_embedded_device_h, gwi_embedded_engine_h, why, gwi_embedded_mfma_h);
+  hipModule_t mod = c ? jit::module_on(c, h->device, why) : nullptr;
+  if (c && !mod && c->from_cache) {
+    jit::discard_chain(c);
+    c = jit::get_chain(kts, s.n_terms, 0, gwi_embedded_device_h, gwi_embedded_engine_h, why, gwi_embedded_mfma_h);
+    mod = c ? jit::module_on(c, h->device, why) : nullptr;
+  }
+  hipFunction_t fn = nullptr;
+  if (mod && hipModuleGetFunction(&fn, mod, c->lowered[jit::kScan].c_str()) != hipSuccess) {
+    why = "jit: hipModuleGetFunction(" + c->lowered[jit::kScan] + ") failed";
+    (void)hipGetLastError();
+    fn = nullptr;
+  }
+  int scratch = 0;
+  if (fn && hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess && scratch > 0) {
+    why = "the instantiation spills registers to scratch (" + std::to_string(scratch) + " B per lane)";
+    fn = nullptr;
+  }
+  if (!fn) {
+    h->mfma_jit_note = why;
+    return false;
+  }
+  MfmaVariant* v = new MfmaVariant();
+  std::memset(v, 0, sizeof(*v));
+  v->name = c->name.c_str();
+  v->n = s.n_terms;
+  for (int t = 0; t < s.n_terms; ++t) {
+    v->kinds[t] = kts[t] % 100;
+    v->tiles[t] = kts[t] / 100;
+  }
+  v->row_doubles = row_doubles;
+  h->jit_mfma = v;
+  h->jit_mfma_fn = fn;
+  h->mfma = v;
+  h->batch_rows = false;
+  h->mfma_lds_bytes = sizeof(double) * mfma_lds_doubles(s.n_theta, s.n_terms, row_doubles, 0);
+  h->mfma_jit_note = "compiled " + c->name + (c->from_cache ? " (disk cache)" : "");
+  return true;
+}
+
 // First batched launch of a spline model that has both batched kernels: three timed evaluation sets of each (after one untimed
 // set each) on the caller's points, host theta -> host results as a sampler pays them; the faster kernel stays.
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev, bool wait, int K, bool batch, bool square);
@@ -974,6 +1062,7 @@ gwi_status calibrate_batch_path(gwi_handle h, const double* theta, int K) {
 }
 
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
+  if (batch && h->mfma_jit_pending && K >= h->mfma_min_batch && wait && !record_dev) h->batch_autotune = try_jit_mfma(h);
   if (batch && h->batch_autotune && h->mfma && K >= h->mfma_min_batch && wait && !record_dev) {
     const gwi_status sc = calibrate_batch_path(h, theta, K);
     if (sc != GWI_OK) return sc;
@@ -1331,6 +1420,11 @@ void destroy_impl(gwi_engine* h) {
     ~VariantGuard() { delete v; }
   } guard{h->jit_variant};
   h->jit_variant = nullptr;
+  struct MfmaGuard {
+    MfmaVariant* v;
+    ~MfmaGuard() { delete v; }
+  } mguard{h->jit_mfma};
+  h->jit_mfma = nullptr;
   if (h->host_only) {
     if (h->shm_base) munmap(h->shm_base, h->shm_bytes);
     delete h;
@@ -1857,6 +1951,19 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
     // (config 3 is a tie that flips from box to box; config 5 prefers the matrix cores by 15 %)
     h->batch_autotune = h->mfma && !std::getenv("GWI_BATCH_MFMA") && !std::getenv("GWI_BATCH_ROWS") && !h->deterministic;
     if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) h->batch_autotune = h->batch_autotune && std::atoi(env) != 0;
+    // a spline model without an ahead-of-time matrix-core instantiation: compiled on its first batched launch of >= 9 points and
+    // measured against the 4-tap kernel there (GWI_BATCH_MFMA=1: compiled now and used; GWI_JIT=0 / GWI_BATCH_AUTOTUNE=0: not at all)
+    {
+      bool jit_ok = !h->generic && !h->deterministic && !find_mfma_variant(*spec) && !std::getenv("GWI_BATCH_ROWS");
+      if (const char* env = std::getenv("GWI_JIT")) jit_ok = jit_ok && std::atoi(env) != 0;
+      if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) jit_ok = jit_ok && std::atoi(env) != 0;
+      const char* want = std::getenv("GWI_BATCH_MFMA");
+      if (jit_ok && want && std::atoi(want) >= 1) {
+        if (try_jit_mfma(h) && std::atoi(want) >= 2) h->mfma_min_batch = 1;
+      } else if (jit_ok && !want) {
+        h->mfma_jit_pending = true;
+      }
+    }
     if (h->mfma && h->batch_rows) {
       // sample-slot replicas of the gradient rows: as many (4, 2, 1) as leave two workgroups per CU their LDS
       h->rows_rep = 4;
@@ -2339,6 +2446,8 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";
 }
 
+const char* gwi_batch_kernel_note(gwi_handle h) { return h ? h->mfma_jit_note.c_str() : ""; }
+
 gwi_status gwi_batch_calibration(gwi_handle h, int32_t* measured, double* mfma_us, double* taps_us) {
   if (!h) return GWI_ERR_INVALID;
   if (measured) *measured = h->batch_measured ? 1 : 0;
@@ -2352,7 +2461,7 @@ gwi_status gwi_jit_compile(const int32_t* kinds, int32_t n_kinds, int32_t sample
   int ks[GWI_MAX_TERMS];
   for (int t = 0; t < n_kinds; ++t) ks[t] = kinds[t];
   std::string why;
-  jit::Chain* c = jit::get_chain(ks, n_kinds, samples_per_lane, gwi_embedded_device_h, gwi_embedded_engine_h, why);
+  jit::Chain* c = jit::get_chain(ks, n_kinds, samples_per_lane, gwi_embedded_device_h, gwi_embedded_engine_h, why, samples_per_lane == 0 ? gwi_embedded_mfma_h : nullptr);
   if (!c) {
     std::fprintf(stderr, "gwi_jit_compile: %s\n", why.c_str());
     if (path_out && path_cap > 0) std::snprintf(path_out, (size_t)path_cap, "%s", why.c_str());

@@ -21,6 +21,9 @@
 //   * hipRTC is bound with dlopen (no link-time dependency).  Where it is missing or the compilation fails the engine says
 //     why once and runs the generic kernel; GWI_JIT=0 switches the whole mechanism off.
 //
+// The batched matrix-core kernel of a spline model (gwi_mfma.h: scan_mfma_kernel, keyed by kinds AND 16-basis tile counts) is
+// compiled the same way where no ahead-of-time instantiation fits (get_chain with U = 0; gwi_engine.hip: try_jit_mfma).
+//
 // Compilation needs no GPU (hipRTC cross-compiles like hipcc): gwi_jit_compile() is part of the CPU test-suite.
 #ifndef GWI_JIT_H
 #define GWI_JIT_H
@@ -227,6 +230,12 @@ inline const char* preamble() {
          "typedef unsigned short uint16_t;\ntypedef unsigned char uint8_t;\n#define offsetof(t, m) __builtin_offsetof(t, m)\n"
          "#include \"gwi_device.h\"\n";
 }
+// ... and for the batched matrix-core kernel of a spline model (gwi_mfma.h includes gwi_device.h itself)
+inline const char* preamble_mfma() {
+  return "typedef signed int int32_t;\ntypedef long int64_t;\ntypedef unsigned int uint32_t;\ntypedef unsigned long uint64_t;\n"
+         "typedef unsigned short uint16_t;\ntypedef unsigned char uint8_t;\n#define offsetof(t, m) __builtin_offsetof(t, m)\n"
+         "#include \"gwi_mfma.h\"\n";
+}
 
 // Compile (or fetch from the disk cache) the chain of `kinds` with U samples per lane.  `device_h` / `engine_h`: the texts of
 // gwi_device.h and include/gwi_engine.h this library was built from.  Process-wide cache; returns nullptr and says why.
@@ -251,18 +260,24 @@ inline void discard_chain(Chain* c) {
   if (!c->path.empty()) std::remove(c->path.c_str());
 }
 
-inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, const char* engine_h, std::string& why) {
+// U = 0 (with `mfma_h`, the text of gwi_mfma.h): the batched matrix-core kernel scan_mfma_kernel of a spline model instead of the
+// scan roles -- `kinds` then hold kind + 100 x (16-basis gradient tiles of the term), as gwi_mfma.h's chain takes them; one
+// kernel (role kScan of the returned object).
+inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, const char* engine_h, std::string& why, const char* mfma_h = nullptr) {
   std::mutex& mu = chains_mutex();
   std::vector<Chain*>& chains = chains_list();
-  if (n < 1 || n > GWI_MAX_TERMS || (U != 1 && U != 2)) {
+  const bool mfma = U == 0 && mfma_h != nullptr;
+  if (n < 1 || n > GWI_MAX_TERMS || (U != 1 && U != 2 && !mfma)) {
     why = "jit: 1 to 12 term kinds, one or two samples per lane";
     return nullptr;
   }
-  for (int t = 0; t < n; ++t)
-    if (kinds[t] < 1 || kinds[t] > GWI_TERM_EXP_SPLINE_LERP || (t > 0 && kinds[t] < kinds[t - 1])) {
+  for (int t = 0; t < n; ++t) {
+    const int k = mfma ? kinds[t] % 100 : kinds[t], k_prev = t > 0 ? (mfma ? kinds[t - 1] % 100 : kinds[t - 1]) : 0;
+    if (k < 1 || k > GWI_TERM_EXP_SPLINE_LERP || k < k_prev || (mfma && (kinds[t] / 100 < 0 || kinds[t] / 100 > 8))) {
       why = "jit: term kinds are the GWI_TERM_* numbers in ascending order";
       return nullptr;
     }
+  }
   std::lock_guard<std::mutex> lock(mu);
   for (Chain* c : chains) {
     bool same = c->n == n && c->samples_per_lane == U;
@@ -278,11 +293,13 @@ inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, co
     c->spline = c->spline || is_spline_kind(kinds[t]);
     ks += (t ? "," : "") + std::to_string(kinds[t]);
   }
-  c->name = "jit:" + ks + "/u" + std::to_string(U);
+  c->name = mfma ? "jit-mfma:" + ks : "jit:" + ks + "/u" + std::to_string(U);
+  const char* const pre = mfma ? preamble_mfma() : preamble();
   // key of the build: headers + flags (+ the hipRTC version, read below when the library is there)
   unsigned long long hsh = fnv1a(device_h, std::strlen(device_h));
   hsh = fnv1a(engine_h, std::strlen(engine_h), hsh);
-  hsh = fnv1a(preamble(), std::strlen(preamble()), hsh);
+  if (mfma) hsh = fnv1a(mfma_h, std::strlen(mfma_h), hsh);
+  hsh = fnv1a(pre, std::strlen(pre), hsh);
   for (const char* f : flags()) hsh = fnv1a(f, std::strlen(f) + 1, hsh);
   Rtc& r = rtc();
   if (r.ok) {  // which compiler: version and the file it was loaded from (PyTorch's bundled ROCm or the system's)
@@ -298,7 +315,7 @@ inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, co
   std::string file_ks = ks;
   for (char& ch : file_ks)
     if (ch == ',') ch = '-';
-  if (!dir.empty()) c->path = dir + "/chain_" + file_ks + "_u" + std::to_string(U) + "_" + hx + ".gwijit";
+  if (!dir.empty()) c->path = dir + (mfma ? "/mfma_" : "/chain_") + file_ks + "_u" + std::to_string(U) + "_" + hx + ".gwijit";
   if (!c->path.empty() && read_cache(c->path, *c)) {
     c->from_cache = true;
     chains.push_back(c);
@@ -310,17 +327,17 @@ inline Chain* get_chain(const int* kinds, int n, int U, const char* device_h, co
     return nullptr;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  const char* header_texts[2] = {device_h, engine_h};
-  const char* header_names[2] = {"gwi_device.h", "gwi_engine.h"};
+  const char* header_texts[3] = {device_h, engine_h, mfma_h};
+  const char* header_names[3] = {"gwi_device.h", "gwi_engine.h", "gwi_mfma.h"};
   hiprtcProgram prog = nullptr;
-  if (r.create(&prog, preamble(), "gwi_jit_chain.hip", 2, header_texts, header_names) != HIPRTC_SUCCESS) {
+  if (r.create(&prog, pre, "gwi_jit_chain.hip", mfma ? 3 : 2, header_texts, header_names) != HIPRTC_SUCCESS) {
     why = "jit: hiprtcCreateProgram failed";
     delete c;
     return nullptr;
   }
   std::string exprs[kRoles];
   for (int role = 0; role < kRoles; ++role) {
-    exprs[role] = name_expression(*c, role);
+    exprs[role] = mfma ? (role == kScan ? "&gwi::scan_mfma_kernel<1, " + ks + ">" : std::string()) : name_expression(*c, role);
     if (!exprs[role].empty()) r.add_name(prog, exprs[role].c_str());
   }
   const hiprtcResult rc = r.compile(prog, (int)flags().size(), const_cast<const char**>(flags().data()));

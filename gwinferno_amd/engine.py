@@ -767,7 +767,8 @@ class NativePopulationLikelihood:
         launch of >= 9 points (``gwi_batch_calibration``); ``measured`` False before that launch or where the path is fixed."""
         m, a, b = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
         self._check(self.lib.gwi_batch_calibration(self.handle, C.byref(m), C.byref(a), C.byref(b)))
-        return {"measured": bool(m.value), "mfma_us": a.value, "taps_us": b.value}
+        note = self.lib.gwi_batch_kernel_note(self.handle) if hasattr(self.lib, "gwi_batch_kernel_note") else b""
+        return {"measured": bool(m.value), "mfma_us": a.value, "taps_us": b.value, "matrix_core_kernel": (note or b"").decode()}
 
     def scan_kernel_name(self):
         """The compiled term chain this engine's scan runs, or "generic (run-time term loop)" (``gwi_scan_kernel_name``)."""

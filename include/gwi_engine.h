@@ -320,6 +320,11 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
  * 8 gradient tiles).  gwi_batch_path answers with the static rule before that launch and with the measured choice after it;
  * this returns whether the measurement has been made and the best microseconds per evaluation set of either kernel. */
 gwi_status gwi_batch_calibration(gwi_handle h, int32_t* measured, double* mfma_us, double* taps_us);
+/* A spline model whose kinds and basis counts have no ahead-of-time matrix-core instantiation gets one compiled at run time
+ * (gwinferno_amd/csrc/gwi_jit.h) on its first batched launch of >= 9 points (at gwi_create with GWI_BATCH_MFMA=1): this says what
+ * happened -- "compiled jit-mfma:6,207,107 ..." or why not (more than eight 16-basis gradient tiles, a term without a matrix-core
+ * form, register spills, hipRTC missing); "" before the attempt and for models that have an ahead-of-time instantiation. */
+const char* gwi_batch_kernel_note(gwi_handle h);
 
 /* Per-sample log-weights log(p(theta|Lambda)/prior) (-inf for excluded samples), the arrays the
  * reference passes to hierarchical_likelihood as pe_weights / inj_weights (tests/inference_test.py:
@@ -435,7 +440,8 @@ const char* gwi_scan_kernel_name(gwi_handle h);
  * ~/.cache/gwinferno_amd).  Without hipRTC (or with GWI_JIT=0) such models run the generic kernel.
  *
  * gwi_jit_compile(): compile (or find in the cache) the chain of `kinds` (GWI_TERM_* numbers, ascending) with
- * `samples_per_lane` (1 | 2) samples per lane -- needs no GPU.  path_out (nullable, path_cap bytes) receives the cache file
+ * `samples_per_lane` (1 | 2) samples per lane -- needs no GPU (samples_per_lane = 0: the batched matrix-core kernel of a spline
+ * model instead, `kinds` then being kind + 100 x 16-basis gradient tiles of each term, as gwi_batch_kernel_note names it).  path_out (nullable, path_cap bytes) receives the cache file
  * ("" when no cache directory is writable), or the reason on failure; compile_seconds = hipRTC time spent by THIS call chain
  * (0 when the code object came from the cache), from_cache = 1 then.  GWI_ERR_UNSUPPORTED: hipRTC missing / compilation failed.
  * gwi_jit_info(): whether this engine's scan kernel was compiled at run time, what that cost this process and whether the

@@ -348,3 +348,49 @@ def test_a_model_beyond_the_former_limits(monkeypatch, tmp_path):
     batch = eng.evaluate_batch(np.stack([th, th]), total, min_neff_cut=False)
     assert rel_err(batch[1].log_likelihood, got.log_likelihood) < 1e-12
     eng.close()
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_matrix_core_batched_kernel_compiled_at_run_time(which, monkeypatch, tmp_path):
+    """A spline model whose kinds and basis counts have no ahead-of-time instantiation of the batched matrix-core kernel
+    (gwi_mfma.h) gets one from hipRTC: forced with GWI_BATCH_MFMA=1 (compiled at gwi_create) it is held against single
+    evaluations, the C oracle and itself (bit-reproducible); left alone, the engine compiles it on its first batched launch of
+    >= 9 points and measures it against the 4-tap kernel like an ahead-of-time one."""
+    from gwinferno_amd.synthetic import make_catalog
+    from oracle.c_oracle import COracle
+
+    monkeypatch.setenv("GWI_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("GWI_MAX_BATCH", "24")
+    pe, inj, total = make_catalog(11, 1300, 9000, seed=31 + which)
+    cls = _compositions()[which]
+    rng = np.random.default_rng(50 + which)
+    comp = cls(pe, inj)
+    thetas = np.stack([comp.theta(cls.draw(rng)) for _ in range(19)])
+    monkeypatch.setenv("GWI_BATCH_MFMA", "1")
+    forced = cls(pe, inj).engine()
+    cal = forced.batch_calibration()
+    assert forced.batch_path(16) == "mfma" and cal["matrix_core_kernel"].startswith("compiled jit-mfma:"), cal
+    orc = COracle(forced.bound)
+    singles = [forced.evaluate(t, total, min_neff_cut=False) for t in thetas]
+    for K in (9, 16, 19):
+        a, b = forced.evaluate_batch(thetas[:K], total, min_neff_cut=False), forced.evaluate_batch(thetas[:K], total, min_neff_cut=False)
+        for k in range(K):
+            assert rel_err(a[k].log_likelihood, singles[k].log_likelihood) < 1e-12
+            assert np.allclose(a[k].log_bfs, singles[k].log_bfs, rtol=1e-12, atol=1e-12)
+            assert np.allclose(a[k].grad, singles[k].grad, rtol=1e-10, atol=1e-11)
+            assert a[k].log_likelihood == b[k].log_likelihood and np.array_equal(a[k].grad, b[k].grad)
+        ref = orc.evaluate(thetas[0], total, min_neff_cut=False)
+        assert rel_err(a[0].log_likelihood, ref["log_likelihood"]) < VALUE_RTOL
+        scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
+        assert float(np.max(np.abs(a[0].grad - ref["grad"]))) / scale < 1e-8
+    forced.close()
+    monkeypatch.delenv("GWI_BATCH_MFMA")
+    auto = cls(pe, inj).engine()
+    assert auto.batch_path(16) == "taps" and auto.batch_calibration()["matrix_core_kernel"] == ""  # nothing compiled, nothing measured yet
+    batch = auto.evaluate_batch(thetas[:16], total, min_neff_cut=False)
+    cal = auto.batch_calibration()
+    assert cal["measured"] and cal["matrix_core_kernel"].startswith("compiled jit-mfma:") and cal["mfma_us"] > 0 and cal["taps_us"] > 0
+    assert auto.batch_path(16) == ("mfma" if cal["mfma_us"] <= cal["taps_us"] else "taps")
+    for k in range(16):
+        assert rel_err(batch[k].log_likelihood, singles[k].log_likelihood) < 1e-12 and np.allclose(batch[k].grad, singles[k].grad, rtol=1e-10, atol=1e-11)
+    auto.close()

@@ -149,6 +149,8 @@ def test_a_scan_chain_compiles_at_run_time_without_a_gpu(lib, tmp_path):
         again = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GWI_JIT_CACHE=str(tmp_path)))
         assert again.returncode == 0 and again.stdout.strip() == got["path"], again.stderr[-2000:]
         aot_like = N.jit_compile([2, 3, 6], 2)   # BASELINE config 2's chain once more, by hipRTC
+        mm = N.jit_compile([5, 5, 6, 107, 107], 0)  # the batched matrix-core kernel of a spline model: kind + 100 x gradient tiles
+        assert os.path.basename(mm["path"]).startswith("mfma_5-5-6-107-107")
     finally:
         os.environ.pop("GWI_JIT_CACHE", None)
     readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
@@ -180,6 +182,8 @@ def test_a_scan_chain_compiles_at_run_time_without_a_gpu(lib, tmp_path):
     assert "scan_pbatch_kernel" in low[4] and "hidden_" not in notes
     for role in (0, 2, 4):
         assert per[low[role]][0] == "0", (low[role], per[low[role]])        # no scratch in what the AQL queue dispatches
+    low_m, per_m, _ = kernels(mm["path"], True)
+    assert "scan_mfma_kernel" in low_m[0] and not any(low_m[1:]) and per_m[low_m[0]][0] == "0"  # one kernel, no scratch
     low_s, per_s, _ = kernels(spl["path"], True)
     assert low_s[3] and not low_s[4] and per_s[low_s[0]][0] == "0" and per_s[low_s[3]][0] == "0"
     # the same chain from hipcc (ahead of time) and from hipRTC: the same kernels by name, no scratch, registers within a third
