@@ -635,6 +635,36 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             # that cost this process, 0 when the disk cache supplied the code object) or the generic kernel
             "scan_chain": {"name": eng.scan_kernel_name(), **eng.jit_info()},
         }
+        if dist is None and headline:
+            # What the NumPyro seam adds on the host (likelihood._host_callback: the function jax.pure_callback calls once per leapfrog):
+            # theta array in -> engine -> packed (summary, per-event sites, gradient) arrays out, without JAX's own dispatch and
+            # device synchronisation around the callback, which no image here can measure.
+            try:
+                from gwinferno_amd import likelihood as L
+
+                flags_cb = dict(marginalize_selection=False, min_neff_cut=False, max_variance_cut=False)
+                host_cb = L._host_callback(eng, float(total), float(n_ev), flags_cb)
+                for i in range(50):
+                    host_cb(thetas[i % len(thetas)])
+                n_cb = 1000
+                t0c = time.perf_counter()
+                for i in range(n_cb):
+                    host_cb(thetas[i % len(thetas)])
+                dtc = time.perf_counter() - t0c
+                tbk = np.stack(thetas[:16])
+                for _ in range(5):
+                    host_cb(tbk)
+                t0c = time.perf_counter()
+                for _ in range(60):
+                    host_cb(tbk)
+                dtb = time.perf_counter() - t0c
+                out["numpyro_seam"] = {"host_callback_us_per_eval": 1e6 * dtc / n_cb, "host_callback_evals_per_s": n_cb / dtc,
+                                       "host_callback_vectorized_16_chains_us_per_eval": 1e6 * dtb / (60 * 16), "host_callback_vectorized_16_chains_evals_per_s": 60 * 16 / dtb,
+                                       "what": ("the host function behind jax.pure_callback (one call per leapfrog; 16 points per call under vmap / chain_method='vectorized'), "
+                                                "timed without JAX: an upper bound on what NumPyro NUTS can reach through the seam -- JAX's dispatch and synchronisation "
+                                                "around the callback come on top and are unmeasured here (python -m gwinferno_amd.jax_check --nuts N on a box with JAX)")}
+            except Exception as exc:
+                out["numpyro_seam"] = {"error": repr(exc)}
         if dist is not None:
             key = "shm" if exchange.startswith("host shared-memory") else ("rccl_allgather" if exchange.startswith("ncclAllGather") else "torch_all_gather")
             rccl_ranks = world if (key == "rccl_allgather" or (key == "torch_all_gather" and run.backend == "nccl")) else 0

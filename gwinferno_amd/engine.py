@@ -651,6 +651,55 @@ class NativePopulationLikelihood:
         self._batch_keepalive = (opt, summ)
         return values_and_grads
 
+    def configure_callback(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, summary_fields=None):
+        """What the NumPyro seam calls once per leapfrog (``likelihood._host_callback``): returns
+        ``call(theta) -> (summary[len(summary_fields)], per_event[3, n_ev], grad[n_theta])`` for one point and
+        ``call_batch(thetas[K, n_theta]) -> (summary[K, ...], per_event[K, 3, n_ev], grad[K, n_theta])`` for K <= max_batch points
+        (one ``gwi_eval_batch``), with the option struct and the argument marshalling done here once.  Every call returns FRESH
+        arrays (the caller -- JAX -- may keep them).  ``summary_fields``: names of ``gwi_summary`` members, in the order wanted."""
+        fields = [f[0] for f in N.GwiSummary._fields_ if f[0] != "reserved"]
+        idx = np.array([fields.index(k) for k in (summary_fields or fields)], dtype=np.intp)
+        n_words = C.sizeof(N.GwiSummary) // 8
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        r_opt = C.byref(opt)
+        lib, handle, n_ev, n_theta = self.lib, self.handle, self.n_ev, self.n_theta
+        theta_buf = np.zeros(n_theta)
+        p_theta = N.as_dp(theta_buf)
+        summ1 = N.GwiSummary()
+        view1 = np.frombuffer(summ1, dtype=np.float64)
+        r_summ1 = C.byref(summ1)
+        dp = N.as_dp
+
+        pe_buf, grad_buf = np.zeros((3, n_ev)), np.zeros(n_theta)
+        args1 = (handle, p_theta, r_opt, r_summ1, dp(grad_buf), dp(pe_buf[0]), dp(pe_buf[1]), dp(pe_buf[2]), None)  # (a ctypes pointer costs ~1 us to make: made once)
+        eval1 = lib.gwi_eval
+
+        def call(theta):
+            theta_buf[:] = theta
+            st = eval1(*args1)
+            if st != 0:
+                self._check(st)
+            return view1[idx], pe_buf.copy(), grad_buf.copy()
+
+        batch_state = {}
+
+        def call_batch(thetas):
+            K = thetas.shape[0]
+            stt = batch_state.get(K)
+            if stt is None:
+                summ = (N.GwiSummary * K)()
+                stt = batch_state[K] = (summ, np.frombuffer(summ, dtype=np.float64).reshape(K, n_words), np.zeros((K, n_theta)))
+            summ, view, tbuf = stt
+            tbuf[:] = thetas
+            lb, ln, lv, grads = np.empty((K, n_ev)), np.empty((K, n_ev)), np.empty((K, n_ev)), np.empty((K, n_theta))
+            st = lib.gwi_eval_batch(handle, dp(tbuf), K, r_opt, summ, dp(grads), dp(lb), dp(ln), dp(lv), None)
+            if st != 0:
+                self._check(st)
+            return view[:, idx], np.stack([lb, ln, lv], axis=1), grads
+
+        self._callback_keepalive = (opt, summ1, batch_state, pe_buf, grad_buf, theta_buf)
+        return call, call_batch
+
     def value_and_grad(self, theta):  # replaced by configure()
         raise RuntimeError("call configure(total_inj, ...) first")
 
