@@ -966,6 +966,7 @@ def test_device_gradient_against_finite_differences_of_the_device_value(comp_nam
     ("plpeak_smooth", 9, 512, 2048, {"GWI_PBATCH_PTS": "16"}),       # exactly one full trip per tile; one grid row for the whole batch
     ("chm_powerlaw", 6, 900, 3000, {"GWI_PBATCH_PTS": "5"}),         # theta-dependent truncation (POWERLAW_BOUNDS)
     ("plpeak", 20, 30000, 300000, {}),                               # tiles of several trips for single evaluations: batches on single-trip tiles of their own
+    ("plpeak", 8, 800, 6000, {"GWI_MAX_BATCH": "40", "GWI_PBATCH_PTS": "16"}),  # 40 points: grid rows of 16, 16 and 8 (the LDS staging holds 16)
 ])
 def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe, n_inj, env, monkeypatch):
     """scan_pbatch_kernel (batched launches of models without spline terms: every sample loaded once for all the points of a
@@ -994,10 +995,10 @@ def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe,
             p["mmin"], p["mmax"] = rng.uniform(3.0, 8.0), rng.uniform(70.0, 120.0)
         return comp.theta(p)
 
-    for K in (1, 2, 5, 16):
+    for K in (1, 2, 5, 16) + ((40,) if env.get("GWI_MAX_BATCH") == "40" else ()):
         thetas = np.stack([draw() for _ in range(K)])
         for flags in (dict(min_neff_cut=False), dict(min_neff_cut=False, marginalize_selection=True)):
-            if flags.get("marginalize_selection") and K not in (2, 16):
+            if flags.get("marginalize_selection") and K not in (2, 16, 40):
                 continue
             new_b, old_b = eng.evaluate_batch(thetas, total, **flags), old.evaluate_batch(thetas, total, **flags)
             for k in range(K):
