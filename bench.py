@@ -751,7 +751,23 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                     for w in ws:
                         w.join()
                     over[str(T)] = {"evals_per_s": T * n_o * K / dto, "us_per_eval": 1e6 * dto / (T * n_o * K)}
-                out["batched"]["sets_in_flight"] = dict(over, what=f"T blocking sets of {K} points side by side, one host thread and one engine per set (same catalog, same GPU)")
+                # the same from ONE host thread: gwi_eval_batch_begin on set i + 1 before gwi_eval_batch_end on set i
+                for T in (2, 3):
+                    hv = [e.configure_batch_async(K, total, min_neff_cut=False) for e in set_engs[:T]]
+                    for rep in range(2):  # first lap untimed
+                        n_1 = 30 if rep == 0 else n_o
+                        t0 = time.perf_counter()
+                        for j in range(T - 1):
+                            hv[j][0](tb)
+                        for it in range(n_1 * T):
+                            hv[(it + T - 1) % T][0](tb)
+                            hv[it % T][1]()
+                        for j in range(T - 1):
+                            hv[(n_1 * T + j) % T][1]()
+                        dto = time.perf_counter() - t0
+                    n_sets = n_o * T + T - 1
+                    over[f"{T}_one_thread"] = {"evals_per_s": n_sets * K / dto, "us_per_eval": 1e6 * dto / (n_sets * K)}
+                out["batched"]["sets_in_flight"] = dict(over, what=f"T blocking sets of {K} points side by side, one host thread and one engine per set (same catalog, same GPU); 'T_one_thread': T sets in flight from ONE thread through gwi_eval_batch_begin / gwi_eval_batch_end")
                 for e in set_engs[1:]:
                     e.close()
             except Exception as exc:  # a secondary figure: never the reason a line is missing

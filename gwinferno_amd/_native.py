@@ -219,6 +219,8 @@ EXPORTED_SYMBOLS = [
     "gwi_eval_begin",
     "gwi_eval_end",
     "gwi_eval_batch",
+    "gwi_eval_batch_begin",
+    "gwi_eval_batch_end",
     "gwi_eval_sequence",
     "gwi_log_weights",
     "gwi_partial_len",
@@ -303,6 +305,11 @@ def load_library():
     lib.gwi_eval_end.argtypes = [vp, C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_eval_batch.restype = C.c_int32
     lib.gwi_eval_batch.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
+    if hasattr(lib, "gwi_eval_batch_begin"):
+        lib.gwi_eval_batch_begin.restype = C.c_int32
+        lib.gwi_eval_batch_begin.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), C.c_int32, C.c_int32]
+        lib.gwi_eval_batch_end.restype = C.c_int32
+        lib.gwi_eval_batch_end.argtypes = [vp, C.POINTER(GwiSummary), _DP, _DP, _DP, _DP, _DP]
     lib.gwi_eval_sequence.restype = C.c_int32
     lib.gwi_eval_sequence.argtypes = [vp, _DP, C.c_int32, C.POINTER(GwiOptions), _DP, _DP, C.c_int32, C.POINTER(C.c_float)]
     lib.gwi_log_weights.restype = C.c_int32

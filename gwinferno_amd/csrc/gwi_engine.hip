@@ -464,6 +464,9 @@ struct gwi_engine {
   bool last_host_rows = false;   // how the most recent run_pipeline publishes (what its waiter must poll)
   bool pending = false;          // gwi_eval_begin issued, gwi_eval_end not yet called
   bool pending_sq = false;
+  bool pending_batch = false;          // ... the pending evaluation is a batch (gwi_eval_batch_begin)
+  int pending_k = 0;
+  std::vector<double> pending_thetas;
   gwi_options pending_opt{};
   std::string err;
   // the engine's own AQL queue (gwi_aql.h): plain single-point evaluations are dispatched through it
@@ -2540,7 +2543,7 @@ gwi_status gwi_eval_begin(gwi_handle h, const double* theta, const gwi_options* 
 
 gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double* log_bfs, double* log_neffs, double* variances, double* norms) {
   if (!h) return GWI_ERR_INVALID;
-  if (!h->pending) return fail(h, GWI_ERR_INVALID, "gwi_eval_end without gwi_eval_begin");
+  if (!h->pending || h->pending_batch) return fail(h, GWI_ERR_INVALID, "gwi_eval_end without gwi_eval_begin");
   h->pending = false;
   GWI_HIP(hipSetDevice(h->device));
   gwi_status st;
@@ -2576,28 +2579,64 @@ gwi_status gwi_eval(gwi_handle h, const double* theta, const gwi_options* opt, g
   return gwi_eval_end(h, summary, grad, log_bfs, log_neffs, variances, norms);
 }
 
-gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries, double* grads,
-                          double* log_bfs, double* log_neffs, double* variances, double* norms) {
+gwi_status gwi_eval_batch_begin(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, int32_t want_grad, int32_t want_events) {
   if (!h || !thetas || !opt || !h->variant || k_batch < 1) return GWI_ERR_INVALID;
   if (k_batch > h->max_batch) return fail(h, GWI_ERR_INVALID, "k_batch exceeds the engine's max_batch (GWI_MAX_BATCH, default 16)");
   if (opt->max_variance_cut && (opt->marginalize_selection || opt->min_neff_cut))
     return fail(h, GWI_ERR_INVALID, "max_variance_cut requires marginalize_selection and min_neff_cut to be off (analysis.py:237-243)");
   if (h->host_only) return fail(h, GWI_ERR_NO_DEVICE, "host-only handle: no device to evaluate on");
-  gwi_status st = busy_guard(h, "gwi_eval_batch");
+  gwi_status st = busy_guard(h, "gwi_eval_batch_begin");
   if (st != GWI_OK) return st;
   GWI_HIP(hipSetDevice(h->device));
-  const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
-  const bool need_sq = opt->marginalize_selection && grads;
-  h->batch_events = log_bfs || log_neffs || variances;
-  if (need_sq) {
+  const size_t len = (size_t)record_len(h);
+  h->pending_opt = *opt;
+  h->pending_sq = opt->marginalize_selection && want_grad;
+  h->pending_k = k_batch;
+  h->pending_thetas.assign(thetas, thetas + (size_t)k_batch * h->spec.n_theta);  // a repeat (reference exponent outrun) needs the points again
+  h->batch_events = want_events != 0;
+  // which of its two batched kernels a spline model runs is measured on its first batched launch: blocking, here
+  if (h->mfma_jit_pending && k_batch >= h->mfma_min_batch) h->batch_autotune = try_jit_mfma(h);
+  if (h->batch_autotune && h->mfma && k_batch >= h->mfma_min_batch) {
+    st = calibrate_batch_path(h, thetas, k_batch);
+    if (st != GWI_OK) return st;
+  }
+  if (h->pending_sq) {  // squared-weight pass first, blocking: the regular pass then leaves its per-event arrays in place
     st = run_pipeline(h, thetas, nullptr, true, k_batch, true, /*square=*/true);
     if (st != GWI_OK) return st;
     h->sq_records.assign(h->h_record, h->h_record + len * k_batch);
   }
-  st = run_pipeline(h, thetas, nullptr, true, k_batch, true);
+  st = run_pipeline(h, thetas, nullptr, /*wait=*/false, k_batch, true);
   if (st != GWI_OK) return st;
+  h->pending = true;
+  h->pending_batch = true;
+  return GWI_OK;
+}
+
+gwi_status gwi_eval_batch_end(gwi_handle h, gwi_summary* summaries, double* grads, double* log_bfs, double* log_neffs, double* variances, double* norms) {
+  if (!h) return GWI_ERR_INVALID;
+  if (!h->pending || !h->pending_batch) return fail(h, GWI_ERR_INVALID, "gwi_eval_batch_end without gwi_eval_batch_begin");
+  h->pending = false;
+  h->pending_batch = false;
+  GWI_HIP(hipSetDevice(h->device));
+  const int K = h->pending_k;
+  gwi_status st;
+  if (h->last_host_rows) {
+    st = wait_for_rows(h, K);
+  } else {
+    st = wait_for_stamp(h, h->h_fin, K * h->final_groups);
+    if (st == GWI_OK) merge_final_records(h, K);
+    if (st == GWI_OK) st = wait_for_norms(h, h->h_record, K);
+  }
+  if (st != GWI_OK) return st;
+  if (redo_requested(h)) {  // repeat, blocking (the squared-weight pass, if any, went through run_pipeline already)
+    st = repeat_after_redo(h, h->pending_thetas.data(), nullptr, K, true, false);
+    if (st != GWI_OK) return st;
+  }
+  const size_t n = (size_t)h->n_ev, len = (size_t)record_len(h);
+  const gwi_options* opt = &h->pending_opt;
+  const bool need_sq = h->pending_sq && grads;
   const int n_theta = h->spec.n_theta, n_norms = h->spec.n_norms;
-  for (int k = 0; k < k_batch; ++k) {
+  for (int k = 0; k < K; ++k) {
     gwi_summary s;
     assemble(h, h->h_record + k * len, 1, opt, &s, grads ? grads + (size_t)k * n_theta : nullptr, norms ? norms + (size_t)k * n_norms : nullptr, h->host_consts[k],
              need_sq ? h->sq_records.data() + k * len : nullptr);
@@ -2610,6 +2649,13 @@ gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, c
     if (variances) std::memcpy(variances + k * n, ev + 2 * n, sizeof(double) * n);
   }
   return GWI_OK;
+}
+
+gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries, double* grads,
+                          double* log_bfs, double* log_neffs, double* variances, double* norms) {
+  const gwi_status st = gwi_eval_batch_begin(h, thetas, k_batch, opt, grads != nullptr, (log_bfs || log_neffs || variances) ? 1 : 0);
+  if (st != GWI_OK) return st;
+  return gwi_eval_batch_end(h, summaries, grads, log_bfs, log_neffs, variances, norms);
 }
 
 gwi_status gwi_comm_unique_id(const char* rccl_path, void* id128) {

@@ -651,6 +651,36 @@ class NativePopulationLikelihood:
         self._batch_keepalive = (opt, summ)
         return values_and_grads
 
+    def configure_batch_async(self, k_batch, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False):
+        """:meth:`configure_batch` in two halves (``gwi_eval_batch_begin`` / ``gwi_eval_batch_end``): ``begin(thetas[K, n_theta])``
+        issues the launches of the K points and returns, ``end() -> (log_likelihood[K], grad[K, n_theta])`` waits for them (buffers
+        allocated once, valid until the next ``end``).  Two or three engines driven alternately from ONE thread keep as many sets in
+        flight: the scans of the others run while a set is in its combine / final launches and on the host."""
+        K = int(k_batch)
+        opt = self._options(total_inj, nobs, marginalize_selection, min_neff_cut, max_variance_cut)
+        summ = (N.GwiSummary * K)()
+        thetas_buf, grads, values = np.zeros((K, self.n_theta)), np.zeros((K, self.n_theta)), np.zeros(K)
+        begin_args = (self.handle, N.as_dp(thetas_buf), K, C.byref(opt), 1, 0)
+        end_args = (self.handle, summ, N.as_dp(grads), None, None, None, None)
+        lib = self.lib
+        summ_view = np.frombuffer(summ, dtype=np.float64).reshape(K, -1)[:, 0]
+
+        def begin(thetas):
+            thetas_buf[:] = thetas
+            st = lib.gwi_eval_batch_begin(*begin_args)
+            if st != 0:
+                self._check(st)
+
+        def end():
+            st = lib.gwi_eval_batch_end(*end_args)
+            if st != 0:
+                self._check(st)
+            values[:] = summ_view
+            return values, grads
+
+        self._batch_async_keepalive = (opt, summ, thetas_buf)
+        return begin, end
+
     def configure_callback(self, total_inj, nobs=None, marginalize_selection=False, min_neff_cut=True, max_variance_cut=False, summary_fields=None):
         """What the NumPyro seam calls once per leapfrog (``likelihood._host_callback``): returns
         ``call(theta) -> (summary[len(summary_fields)], per_event[3, n_ev], grad[n_theta])`` for one point and

@@ -307,6 +307,15 @@ gwi_status gwi_eval_end(gwi_handle h, gwi_summary* summary, double* grad, double
 gwi_status gwi_eval_batch(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, gwi_summary* summaries,
                           double* grads, double* log_bfs, double* log_neffs, double* variances, double* norms);
 
+/* The same in two halves, like gwi_eval_begin / gwi_eval_end: begin does the host prelude and issues the launches of the K points
+ * (after, on a spline model's first batch, the blocking measurement of its two batched kernels; and after the blocking
+ * squared-weight pass when opt->marginalize_selection and want_grad), end waits for and assembles them.  A blocking batch leaves
+ * the GPU to its combine / final launches and the host for a third of its time: two or three sets in flight -- one handle each,
+ * ONE host thread -- fill it (config 2, K = 16: 243 k -> 315-360 k evaluations per second).  want_events: the per-event sites
+ * will be asked for at gwi_eval_batch_end.  One evaluation or batch per handle may be pending. */
+gwi_status gwi_eval_batch_begin(gwi_handle h, const double* thetas, int32_t k_batch, const gwi_options* opt, int32_t want_grad, int32_t want_events);
+gwi_status gwi_eval_batch_end(gwi_handle h, gwi_summary* summaries, double* grads, double* log_bfs, double* log_neffs, double* variances, double* norms);
+
 /* Which kernel a batched launch of k_batch points would use: "taps" (one grid row per point, 4-tap gradient into LDS rows;
  * the default) or "mfma" (GWI_BATCH_MFMA=1 at gwi_create, models with spline terms whose term sequence and basis counts
  * have a matrix-core instantiation, k_batch >= 9: the spline-coefficient gradient as a v_mfma_f64_16x16x4 GEMM over 16

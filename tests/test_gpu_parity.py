@@ -485,6 +485,55 @@ def test_batched_evaluation_matches_single(comp_name):
     eng.close()
 
 
+@pytest.mark.parametrize("comp_name", ["plpeak", "bspline_test", "chm_bspline"])
+def test_batches_in_two_halves_from_one_thread(comp_name, monkeypatch):
+    """gwi_eval_batch_begin / gwi_eval_batch_end: two engines on the same catalog, driven alternately from ONE thread (a set of
+    points in flight on each), return bit for bit what the blocking gwi_eval_batch returns for the same points -- and the state
+    machine refuses a second begin, an end without a begin, and gwi_eval_end on a pending batch."""
+    from gwinferno_amd._native import NativeEngineError
+    from gwinferno_amd.compositions import COMPOSITIONS, draw_params
+    from gwinferno_amd.synthetic import make_catalog
+
+    monkeypatch.setenv("GWI_PBATCH_PTS", "4")  # (parametric chains: the several-points-per-workgroup kernel also at this size)
+    pe, inj, total = make_catalog(11, 700, 5003, seed=41)
+    comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(2)]
+    engs = [c.engine() for c in comps]
+    assert engs[0].handle != engs[1].handle
+    rng = np.random.default_rng(8)
+    K = 12
+    sets = [np.stack([comps[0].theta(draw_params(comp_name, rng)) for _ in range(K)]) for _ in range(4)]
+    blocking = [tuple(np.copy(a) for a in engs[0].configure_batch(K, total, min_neff_cut=False)(t)) for t in sets]
+    halves = [e.configure_batch_async(K, total, min_neff_cut=False) for e in engs]
+    got = [None] * len(sets)
+    halves[0][0](sets[0])
+    for i in range(1, len(sets)):  # set i goes out before set i - 1 is collected
+        halves[i % 2][0](sets[i])
+        v, g = halves[(i - 1) % 2][1]()
+        got[i - 1] = (v.copy(), g.copy())
+    v, g = halves[(len(sets) - 1) % 2][1]()
+    got[-1] = (v.copy(), g.copy())
+    for (bv, bg), (av, ag) in zip(blocking, got):
+        assert np.array_equal(bv, av)
+        assert np.array_equal(bg, ag) or np.allclose(bg, ag, rtol=1e-13, atol=1e-13)  # (LDS atomics: the 4-tap kernel's gradient may differ in its last bits from run to run)
+    # the state machine
+    begin, end = halves[0]
+    with pytest.raises(NativeEngineError, match="without gwi_eval_batch_begin"):
+        end()
+    begin(sets[0])
+    with pytest.raises(NativeEngineError):
+        begin(sets[1])
+    with pytest.raises(NativeEngineError):
+        engs[0].evaluate(sets[0][0], total, min_neff_cut=False)
+    st = engs[0].lib.gwi_eval_end(engs[0].handle, None, None, None, None, None, None)
+    assert st == -1  # GWI_ERR_INVALID
+    v, g = end()
+    assert np.array_equal(v, blocking[0][0])
+    one = engs[0].evaluate(sets[0][3], total, min_neff_cut=False)  # and the handle is free again
+    assert rel_err(one.log_likelihood, v[3]) < 1e-12
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("path", ["mfma", "rows"])
 @pytest.mark.parametrize("comp_name", ["bspline_test", "bspline_iid", "bspline_full", "bspline_defaults", "bspline_chieff"])
 def test_batched_launch_on_the_matrix_cores(comp_name, path, monkeypatch):
