@@ -807,6 +807,11 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
             engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
             out["native_nuts"] = native_nuts(engs, comp_name, comp, total, thetas, **({"n_warmup": 300, "n_samples": 100, "convergence_fields": False} if cfg == "c5" else {}))
+            try:  # the same sampler with its chains in lock step on the batched kernels (a secondary figure)
+                out["native_nuts_lockstep"] = (native_nuts_lockstep(engs[:1], 16, comp_name, comp, total, thetas, 30, 10) if cfg == "c5" else
+                                               native_nuts_lockstep(engs[:2], 16, comp_name, comp, total, thetas, 60, 30))
+            except Exception as exc:
+                out["native_nuts_lockstep"] = {"error": repr(exc)}
             for e in engs[1:]:
                 e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
@@ -887,6 +892,10 @@ def multi_chain(eng, eng_comp, comp_name, pe, inj, total, thetas, C, steps, dev)
     for c in more:
         c.engine().close()
     out["native_nuts"] = native_nuts(all_engines, comp_name, eng_comp, total, thetas)
+    try:  # the same sampler with its chains in lock step on the batched kernel: two groups of 16 chains, one host thread
+        out["native_nuts_lockstep"] = native_nuts_lockstep(all_engines[:2], 16, comp_name, eng_comp, total, thetas, 100, 50)
+    except Exception as exc:
+        out["native_nuts_lockstep"] = {"error": repr(exc)}
     for c in extra:
         c.engine().close()
     return out
@@ -994,6 +1003,40 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
             "ess_note": ("bulk ESS (multi-chain, Geyer) of the post-warm-up draws of all chains, per second of the sampling phase; within_chain_*: the same "
                          "estimator on each chain alone.  A multi-chain ESS near the chain count with healthy within-chain ESS and a large split R-hat means the "
                          "chains sit in different modes of this synthetic catalog's posterior (compare mean_log_prob_per_chain), not that they mix slowly")}
+
+
+def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, thetas, n_warmup, n_samples):
+    """Vectorised chains inside the library (gwi_nuts_engine_lockstep): len(engines) groups of chains_per_engine chains, every
+    leapfrog step of a group ONE batched launch, the groups alternating on one host thread -- numpyro's
+    chain_method="vectorized" (examples/utils.py:63-85).  Same priors and tree depth as native_nuts; a THROUGHPUT figure
+    (likelihood evaluations per second as the sampler sees them), bounded through the iteration count."""
+    from gwinferno_amd.sampling import lockstep_stats, nuts_engine_lockstep
+
+    G, K = len(engines), int(chains_per_engine)
+    prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
+    starts = np.stack([thetas[c % len(thetas)] for c in range(G * K)])
+    if bij is not None:
+        for k in np.flatnonzero(bij.kind == 3):
+            starts[:, k] = bij.lo[k]
+    kw = dict(max_tree_depth=10, seed=1, min_neff_cut=False)
+    nuts_engine_lockstep(engines, K, total, prior, bij, starts, n_warmup=2, n_samples=2, **dict(kw, max_tree_depth=4))  # code paths, batch-path measurement
+    repeats0 = sum(e.two_pass_repeats() for e in engines)
+    t0 = time.perf_counter()
+    res = nuts_engine_lockstep(engines, K, total, prior, bij, starts, n_warmup=n_warmup, n_samples=n_samples, **kw)
+    dt = time.perf_counter() - t0
+    st = lockstep_stats()
+    n_lf = sum(r["n_evals"] for r in res)
+    depth = np.concatenate([r["tree_depth"] for r in res])
+    per_chain = [int(r["n_evals"]) for r in res]
+    return {"mean_points_per_batch": st["mean_points_per_batch"], "evals_per_chain_min_max": [min(per_chain), max(per_chain)],
+            "per_batch_us": {"collect": st["collect_us_per_batch"], "chains": st["chains_us_per_batch"], "issue": st["issue_us_per_batch"]},
+            "note": ("chains that need fewer evaluations finish earlier and the batches shrink: mean_points_per_batch of chains_per_group is what the batched "
+                     "kernels get to work with; chains started from prior draws on this synthetic catalog differ by up to 10x in evaluations"),
+            "chains": G * K, "groups": G, "chains_per_group": K, "host_threads": 1, "batch_path": engines[0].batch_path(K), "warmup_iterations": n_warmup,
+            "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt,
+            "two_pass_repeats": sum(e.two_pass_repeats() for e in engines) - repeats0, "mean_tree_depth": float(np.mean(depth)),
+            "accept_prob": float(np.mean([r["accept_rate"] for r in res])), "divergences": int(sum(r["n_divergent"] for r in res)),
+            "what": "gwi_nuts_engine_lockstep: every leapfrog step of a group of chains is one gwi_eval_batch_begin / _end; groups alternate on one host thread"}
 
 
 RCCL_LEG_FLAG = "--rccl-leg"

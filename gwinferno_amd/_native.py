@@ -206,6 +206,7 @@ class GwiSmoothingPenalty(C.Structure):
 
 # include/gwi_sampler.h: int32 (*)(void* user, const double* x, double* log_prob, double* grad)
 GWI_TARGET_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+GWI_BATCH_TARGET_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 LIB_PATH = os.environ.get("GWI_ENGINE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgwi_engine.so")
 
@@ -256,7 +257,7 @@ EXPORTED_SYMBOLS = [
     "gwi_jit_info",
 ]
 # ... and include/gwi_sampler.h
-EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine"]
+EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine", "gwi_nuts_run_lockstep", "gwi_nuts_engine_lockstep", "gwi_nuts_lockstep_stats"]
 
 _lib = None
 
@@ -385,6 +386,14 @@ def load_library():
     lib.gwi_nuts_engine.restype = C.c_int32
     lib.gwi_nuts_engine.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiParamPrior), C.POINTER(GwiSmoothingPenalty), C.c_int32, _DP,
                                     C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
+    if hasattr(lib, "gwi_nuts_run_lockstep"):
+        lib.gwi_nuts_run_lockstep.restype = C.c_int32
+        lib.gwi_nuts_run_lockstep.argtypes = [GWI_BATCH_TARGET_FN, vp, C.c_int32, C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
+        lib.gwi_nuts_lockstep_stats.restype = None
+        lib.gwi_nuts_lockstep_stats.argtypes = [_DP]
+        lib.gwi_nuts_engine_lockstep.restype = C.c_int32
+        lib.gwi_nuts_engine_lockstep.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiParamPrior), C.POINTER(GwiSmoothingPenalty),
+                                                 C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
     if lib.gwi_abi_version() != GWI_ABI_VERSION:
         raise NativeEngineError(f"ABI mismatch: library {lib.gwi_abi_version()} vs binding {GWI_ABI_VERSION}")
     _lib = lib

@@ -13,11 +13,24 @@
 //   gwi_nuts_engine   target = engine log-likelihood + Normal priors + P-spline difference penalties
 //                     (pipeline/utils.py:163-216) on constrained parameters mapped by interval / positive
 //                     bijectors; chains run in one host thread each, every chain on its own engine handle
+//   gwi_nuts_run_lockstep / gwi_nuts_engine_lockstep
+//                     K chains advanced together, ONE batched evaluation (gwi_eval_batch: the several-points-per-launch
+//                     kernels) per leapfrog step of all of them -- numpyro's chain_method="vectorized".  Every chain runs
+//                     the unchanged run_nuts on a stack of its own (ucontext); its target hands the point to the scheduler
+//                     and is resumed with the batch's result.  One host thread, G groups of chains (an engine each) in
+//                     flight: group g's launches run while the others' chains do their host arithmetic.
 #include "gwi_sampler.h"
 
+#include <ucontext.h>
+
+#include <chrono>
 #include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <random>
 #include <string>
 #include <thread>
@@ -321,6 +334,9 @@ struct EngineTarget {
   const gwi_smoothing_penalty* pens;
   int n_pens, n_theta;
   Vec theta, dth, dlogj, grad_ll, d1, d2;
+  // lock-step chains: the likelihood at e.theta comes from the group's batched launch instead of a blocking gwi_eval
+  int (*eval_hook)(void* hook_user, const double* theta, double* ll, double* grad_ll) = nullptr;
+  void* hook_user = nullptr;
 };
 
 int engine_target(void* user, const double* u, double* logp, double* grad) {
@@ -354,7 +370,11 @@ int engine_target(void* user, const double* u, double* logp, double* grad) {
   // one blocking evaluation; the sequence entry picks gwi_eval_sharded when the handle carries a communicator
   // (every rank then runs the same chain from the same seed: the exchanged records make the bits identical)
   double ll = 0.0;
-  if (gwi_eval_sequence(e.h, e.theta.data(), 1, &e.lopt, &ll, e.grad_ll.data(), 0, nullptr) != GWI_OK) return 1;
+  if (e.eval_hook) {
+    if (e.eval_hook(e.hook_user, e.theta.data(), &ll, e.grad_ll.data()) != 0) return 1;
+  } else if (gwi_eval_sequence(e.h, e.theta.data(), 1, &e.lopt, &ll, e.grad_ll.data(), 0, nullptr) != GWI_OK) {
+    return 1;
+  }
   double lp = ll + logj;
   for (int i = 0; i < n; ++i) {
     double g = e.grad_ll[i];
@@ -390,6 +410,201 @@ int engine_target(void* user, const double* u, double* logp, double* grad) {
   return 0;
 }
 
+// ---- lock-step chains ------------------------------------------------------------------------------------------------
+// A chain = the unchanged run_nuts on a stack of its own.  Its target (fiber_eval) stores the point, switches to the
+// scheduler, and finds the value and gradient in place when it is switched back to.
+struct Lockstep;
+struct Fiber {
+  Lockstep* owner = nullptr;
+  int chain = 0, group = 0;
+  ucontext_t ctx{};
+  std::unique_ptr<char[]> stack;
+  bool done = false, waiting = false;
+  int rc = 0;
+  const double* req_x = nullptr;  // the point this chain wants evaluated (dim doubles, owned by the chain)
+  double* out_lp = nullptr;
+  double* out_grad = nullptr;
+  void (*body)(Fiber&) = nullptr;
+  void* body_user = nullptr;
+};
+
+struct LockstepBackend {  // K points of one group: issue, then collect (value + gradient per point)
+  virtual ~LockstepBackend() = default;
+  virtual int begin(int group, int k, const int32_t* chains, const double* xs) = 0;
+  virtual int end(int group, int k, double* lps, double* grads) = 0;
+};
+
+thread_local double last_stats[6] = {0, 0, 0, 0, 0, 0};  // gwi_nuts_lockstep_stats
+
+struct Lockstep {
+  int dim = 0;
+  ucontext_t sched{};
+  bool failed = false;
+  std::vector<Fiber> fibers;
+  static constexpr size_t kStack = 512 * 1024;  // run_nuts recurses to max_tree_depth with a few hundred bytes per frame (vectors live on the heap)
+
+  static void entry(unsigned lo, unsigned hi) {
+    Fiber& f = *reinterpret_cast<Fiber*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    f.body(f);
+    f.done = true;  // returning switches to uc_link = the scheduler
+  }
+  // the chain's target: hand the point over, sleep until the group's batch is back
+  static int fiber_eval(Fiber& f, const double* x, double* lp, double* grad) {
+    if (f.owner->failed) return 1;
+    f.req_x = x;
+    f.out_lp = lp;
+    f.out_grad = grad;
+    f.waiting = true;
+    swapcontext(&f.ctx, &f.owner->sched);
+    return f.owner->failed ? 1 : 0;
+  }
+  void resume(Fiber& f) {
+    f.waiting = false;
+    swapcontext(&sched, &f.ctx);
+  }
+  void start(Fiber& f) {
+    f.stack.reset(new char[kStack]);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.get();
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &sched;
+    const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+    makecontext(&f.ctx, (void (*)())entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+    resume(f);  // runs to its first evaluation (or to its end)
+  }
+
+  // chains of group g = fibers with .group == g.  Returns 0, or 1 when the backend failed (every chain then unwinds).
+  int run(LockstepBackend& be, int n_groups) {
+    struct Group {
+      std::vector<int> members, live;
+      std::vector<int32_t> ids;
+      Vec xs, lps, grads;
+      bool pending = false;
+    };
+    std::vector<Group> groups(n_groups);
+    for (size_t i = 0; i < fibers.size(); ++i) groups[fibers[i].group].members.push_back((int)i);
+    for (Fiber& f : fibers) start(f);
+    auto issue = [&](int g) {  // gather the points of the group's waiting chains and launch them
+      Group& G = groups[g];
+      G.live.clear();
+      G.ids.clear();
+      for (int i : G.members)
+        if (!fibers[i].done && fibers[i].waiting) {
+          G.live.push_back(i);
+          G.ids.push_back(fibers[i].chain);
+        }
+      G.pending = false;
+      if (G.live.empty() || failed) return;
+      const size_t k = G.live.size();
+      G.xs.resize(k * dim);
+      G.lps.resize(k);
+      G.grads.resize(k * dim);
+      for (size_t j = 0; j < k; ++j) std::memcpy(G.xs.data() + j * dim, fibers[G.live[j]].req_x, sizeof(double) * dim);
+      if (be.begin(g, (int)k, G.ids.data(), G.xs.data()) != 0) {
+        failed = true;
+        return;
+      }
+      G.pending = true;
+    };
+    // GWI_LOCKSTEP_STATS=1: where the wall time went (stderr): collecting (mostly waiting for the GPU), the chains' own
+    // arithmetic between two evaluations, gathering + issuing
+    const bool print_stats = std::getenv("GWI_LOCKSTEP_STATS") != nullptr;
+    const bool stats = true;  // (five clock reads per batch of evaluations)
+    using clk = std::chrono::steady_clock;
+    double t_end = 0, t_host = 0, t_issue = 0;
+    long long n_batches = 0, n_points = 0;
+    auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
+    const clk::time_point t_all = clk::now();
+    for (int g = 0; g < n_groups; ++g) issue(g);
+    for (bool any = true; any;) {
+      any = false;
+      for (int g = 0; g < n_groups; ++g) {
+        Group& G = groups[g];
+        if (!G.pending) continue;
+        any = true;
+        const size_t k = G.live.size();
+        clk::time_point t0 = clk::now();
+        if (be.end(g, (int)k, G.lps.data(), G.grads.data()) != 0) failed = true;
+        if (stats) {
+          t_end += since(t0);
+          t0 = clk::now();
+          ++n_batches;
+          n_points += (long long)k;
+        }
+        G.pending = false;
+        const std::vector<int> live = G.live;
+        for (size_t j = 0; j < k; ++j) {  // hand the results over; each chain runs on to its next evaluation
+          Fiber& f = fibers[live[j]];
+          if (!failed) {
+            *f.out_lp = G.lps[j];
+            std::memcpy(f.out_grad, G.grads.data() + j * dim, sizeof(double) * dim);
+          }
+          resume(f);
+        }
+        if (stats) {
+          t_host += since(t0);
+          t0 = clk::now();
+        }
+        issue(g);
+        if (stats) t_issue += since(t0);
+      }
+    }
+    last_stats[0] = (double)n_batches;
+    last_stats[1] = (double)n_points;
+    last_stats[2] = t_end;
+    last_stats[3] = t_host;
+    last_stats[4] = t_issue;
+    last_stats[5] = since(t_all);
+    if (print_stats && n_batches > 0)
+      std::fprintf(stderr, "[gwi lockstep] %lld batches, %.2f points each; per batch: collect %.1f us, chains %.1f us, issue %.1f us; wall %.3f s\n", n_batches,
+                   (double)n_points / n_batches, 1e6 * t_end / n_batches, 1e6 * t_host / n_batches, 1e6 * t_issue / n_batches, since(t_all));
+    if (failed)  // let every chain that is still asleep unwind (its target now returns 1 without switching)
+      for (Fiber& f : fibers)
+        while (!f.done) resume(f);
+    return failed ? 1 : 0;
+  }
+};
+
+struct CallbackBackend : LockstepBackend {  // an arbitrary batched target: evaluated at collect time
+  gwi_batch_target_fn fn;
+  void* user;
+  int dim;
+  std::vector<int32_t> ids;
+  Vec xs;
+  int begin(int, int k, const int32_t* chains, const double* x) override {
+    ids.assign(chains, chains + k);
+    xs.assign(x, x + (size_t)k * dim);
+    return 0;
+  }
+  int end(int, int k, double* lps, double* grads) override { return fn(user, k, ids.data(), xs.data(), lps, grads) != 0; }
+};
+
+struct EngineBackend : LockstepBackend {  // group g = engine handles[g]; the points are constrained hyper-parameters
+  const gwi_handle* handles;
+  gwi_options lopt;
+  std::vector<gwi_summary> summaries;
+  int begin(int g, int k, const int32_t*, const double* thetas) override { return gwi_eval_batch_begin(handles[g], thetas, k, &lopt, 1, 0) != GWI_OK; }
+  int end(int g, int k, double* lls, double* grads) override {
+    summaries.resize(k);
+    if (gwi_eval_batch_end(handles[g], summaries.data(), grads, nullptr, nullptr, nullptr, nullptr) != GWI_OK) return 1;
+    for (int j = 0; j < k; ++j) lls[j] = summaries[j].log_likelihood;
+    return 0;
+  }
+};
+
+void constrain_draws(double* out, size_t ns, int n_theta, const gwi_param_prior* priors) {  // unconstrained draws -> hyper-parameters
+  for (size_t k = 0; k < ns; ++k)
+    for (int i = 0; i < n_theta; ++i) {
+      double& v = out[k * n_theta + i];
+      if (priors[i].kind == GWI_BIJECT_INTERVAL)
+        v = priors[i].lo + (priors[i].hi - priors[i].lo) / (1.0 + std::exp(-v));
+      else if (priors[i].kind == GWI_BIJECT_POSITIVE)
+        v = std::exp(v);
+      else if (priors[i].kind == GWI_BIJECT_FIXED)
+        v = priors[i].lo;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -417,16 +632,7 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
     const size_t ns = (size_t)opt->n_samples;
     double* out = samples + (size_t)c * ns * n_theta;
     rc[c] = run_nuts(t, u0 + (size_t)c * n_theta, o, out, logp ? logp + (size_t)c * ns : nullptr, tree_depth ? tree_depth + (size_t)c * ns : nullptr, results ? results + c : nullptr);
-    for (size_t k = 0; k < ns && rc[c] == 0; ++k)  // unconstrained draws -> constrained hyper-parameters
-      for (int i = 0; i < n_theta; ++i) {
-        double& v = out[k * n_theta + i];
-        if (priors[i].kind == GWI_BIJECT_INTERVAL)
-          v = priors[i].lo + (priors[i].hi - priors[i].lo) / (1.0 + std::exp(-v));
-        else if (priors[i].kind == GWI_BIJECT_POSITIVE)
-          v = std::exp(v);
-        else if (priors[i].kind == GWI_BIJECT_FIXED)
-          v = priors[i].lo;
-      }
+    if (rc[c] == 0) constrain_draws(out, ns, n_theta, priors);
   };
   if (n_chains == 1) {
     chain(0);
@@ -437,6 +643,110 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
   }
   for (int c = 0; c < n_chains; ++c)
     if (rc[c] != 0) return rc[c] == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;
+  return GWI_OK;
+}
+
+void gwi_nuts_lockstep_stats(double* out6) {
+  if (out6) std::memcpy(out6, last_stats, sizeof(last_stats));
+}
+
+gwi_status gwi_nuts_run_lockstep(gwi_batch_target_fn fn, void* user, int32_t dim, int32_t n_chains, const double* x0, const gwi_nuts_options* opt, double* samples,
+                                 double* logp, int32_t* tree_depth, gwi_nuts_result* results) {
+  if (!fn || dim < 1 || n_chains < 1 || !x0 || !opt || !samples || opt->n_warmup < 0 || opt->n_samples < 0) return GWI_ERR_INVALID;
+  struct Job {
+    const double* x0;
+    gwi_nuts_options o;
+    double *samples, *logp;
+    int32_t* depth;
+    gwi_nuts_result* res;
+    int dim;
+  };
+  std::vector<Job> jobs(n_chains);
+  Lockstep ls;
+  ls.dim = dim;
+  ls.fibers.resize(n_chains);
+  const size_t ns = (size_t)opt->n_samples;
+  for (int c = 0; c < n_chains; ++c) {
+    gwi_nuts_options o = *opt;
+    o.seed = opt->seed + 1000ULL * (unsigned long long)c;
+    jobs[c] = Job{x0 + (size_t)c * dim, o, samples + (size_t)c * ns * dim, logp ? logp + (size_t)c * ns : nullptr, tree_depth ? tree_depth + (size_t)c * ns : nullptr,
+                  results ? results + c : nullptr, dim};
+    Fiber& f = ls.fibers[c];
+    f.owner = &ls;
+    f.chain = c;
+    f.group = 0;
+    f.body_user = &jobs[c];
+    f.body = [](Fiber& fb) {
+      Job& j = *static_cast<Job*>(fb.body_user);
+      Target t{[](void* u, const double* x, double* lp, double* g) -> int32_t { return Lockstep::fiber_eval(*static_cast<Fiber*>(u), x, lp, g); }, &fb, j.dim};
+      fb.rc = run_nuts(t, j.x0, j.o, j.samples, j.logp, j.depth, j.res);
+    };
+  }
+  CallbackBackend be;
+  be.fn = fn;
+  be.user = user;
+  be.dim = dim;
+  const int failed = ls.run(be, 1);
+  if (failed) return GWI_ERR_HIP;
+  for (int c = 0; c < n_chains; ++c)
+    if (ls.fibers[c].rc != 0) return ls.fibers[c].rc == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;
+  return GWI_OK;
+}
+
+gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups, int32_t chains_per_group, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors,
+                                    const gwi_smoothing_penalty* pens, int32_t n_pens, const double* u0, const gwi_nuts_options* opt, double* samples, double* logp,
+                                    int32_t* tree_depth, gwi_nuts_result* results) {
+  if (!handles || n_groups < 1 || chains_per_group < 1 || n_theta < 1 || !lopt || !priors || !u0 || !opt || !samples) return GWI_ERR_INVALID;
+  for (int k = 0; k < n_pens; ++k)
+    if (!pens || pens[k].offset < 0 || pens[k].count < 2 || pens[k].offset + pens[k].count > n_theta || pens[k].degree < 1 || pens[k].degree >= pens[k].count) return GWI_ERR_INVALID;
+  const int n_chains = n_groups * chains_per_group;
+  struct Job {
+    EngineTarget e;
+    const double* u0;
+    gwi_nuts_options o;
+    double *samples, *logp;
+    int32_t* depth;
+    gwi_nuts_result* res;
+  };
+  std::vector<Job> jobs(n_chains);
+  Lockstep ls;
+  ls.dim = n_theta;
+  ls.fibers.resize(n_chains);
+  const size_t ns = (size_t)opt->n_samples;
+  for (int c = 0; c < n_chains; ++c) {
+    gwi_nuts_options o = *opt;
+    o.seed = opt->seed + 1000ULL * (unsigned long long)c;
+    Fiber& f = ls.fibers[c];
+    f.owner = &ls;
+    f.chain = c;
+    f.group = c / chains_per_group;
+    Job& j = jobs[c];
+    j.e = EngineTarget{handles[f.group], *lopt, priors, pens, n_pens, n_theta, Vec(n_theta), Vec(n_theta), Vec(n_theta), Vec(n_theta), {}, {}};
+    // the chain's likelihood evaluation = a slot in its group's batched launch
+    j.e.eval_hook = [](void* u, const double* theta, double* ll, double* g) -> int { return Lockstep::fiber_eval(*static_cast<Fiber*>(u), theta, ll, g); };
+    j.e.hook_user = &f;
+    j.u0 = u0 + (size_t)c * n_theta;
+    j.o = o;
+    j.samples = samples + (size_t)c * ns * n_theta;
+    j.logp = logp ? logp + (size_t)c * ns : nullptr;
+    j.depth = tree_depth ? tree_depth + (size_t)c * ns : nullptr;
+    j.res = results ? results + c : nullptr;
+    f.body_user = &j;
+    f.body = [](Fiber& fb) {
+      Job& jb = *static_cast<Job*>(fb.body_user);
+      Target t{engine_target, &jb.e, jb.e.n_theta};
+      fb.rc = run_nuts(t, jb.u0, jb.o, jb.samples, jb.logp, jb.depth, jb.res);
+    };
+  }
+  EngineBackend be;
+  be.handles = handles;
+  be.lopt = *lopt;
+  const int failed = ls.run(be, n_groups);
+  if (failed) return GWI_ERR_HIP;
+  for (int c = 0; c < n_chains; ++c) {
+    if (ls.fibers[c].rc != 0) return ls.fibers[c].rc == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;
+    constrain_draws(samples + (size_t)c * ns * n_theta, ns, n_theta, priors);
+  }
   return GWI_OK;
 }
 

@@ -550,6 +550,120 @@ def nuts_native(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, 
     return out
 
 
+def nuts_native_lockstep(batch_target, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0):
+    """Lock-step chains on a Python BATCHED target (``gwi_nuts_run_lockstep``): ``batch_target(xs[k, d], chain_ids[k]) ->
+    (log_probs[k], grads[k, d])`` is called once per leapfrog step of all running chains (numpyro's
+    ``chain_method="vectorized"``).  Chain ``c`` uses seed ``seed + 1000 c`` and draws exactly what :func:`nuts_native`
+    draws with that seed.  Returns one dict per chain."""
+    import ctypes as C
+
+    from . import _native as N
+
+    lib = N.load_library()
+    theta0s = np.atleast_2d(N.f64(theta0s))
+    n_chains, d = theta0s.shape
+    err = []
+
+    def cb(_user, k, ids, xs, lps, grads):
+        try:
+            v, g = batch_target(np.ctypeslib.as_array(xs, (k, d)).copy(), np.ctypeslib.as_array(ids, (k,)).copy())
+            np.ctypeslib.as_array(lps, (k,))[:] = v
+            np.ctypeslib.as_array(grads, (k, d))[:] = g
+            return 0
+        except Exception as exc:  # propagate through the C frames
+            err.append(exc)
+            return 1
+
+    samples, logp, depth = np.empty((n_chains, n_samples, d)), np.empty((n_chains, n_samples)), np.empty((n_chains, n_samples), dtype=np.int32)
+    res = (N.GwiNutsResult * n_chains)()
+    opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
+    st = lib.gwi_nuts_run_lockstep(N.GWI_BATCH_TARGET_FN(cb), None, d, n_chains, N.as_dp(theta0s), C.byref(opt), N.as_dp(samples), N.as_dp(logp),
+                                   depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    if err:
+        raise err[0]
+    if st == -1:
+        raise ValueError("gwi_nuts_run_lockstep: a starting point has zero probability or a non-finite gradient")
+    if st != 0:
+        raise N.NativeEngineError(f"gwi_nuts_run_lockstep: {N.STATUS_NAMES.get(st, st)}")
+    out = []
+    for c in range(n_chains):
+        r = _result_dict(res[c])
+        r.update(samples=samples[c], log_prob=logp[c], tree_depth=depth[c])
+        out.append(r)
+    return out
+
+
+def lockstep_stats():
+    """Of this thread's last lock-step run (``gwi_nuts_lockstep_stats``): batches, mean points per batch, and where the wall
+    time went per batch (collecting = mostly waiting for the GPU, the chains' own arithmetic, gathering + issuing)."""
+    from . import _native as N
+
+    out = np.zeros(6)
+    N.load_library().gwi_nuts_lockstep_stats(N.as_dp(out))
+    nb = max(out[0], 1.0)
+    return {"batches": int(out[0]), "mean_points_per_batch": out[1] / nb, "collect_us_per_batch": 1e6 * out[2] / nb, "chains_us_per_batch": 1e6 * out[3] / nb,
+            "issue_us_per_batch": 1e6 * out[4] / nb, "wall_s": out[5]}
+
+
+def _engine_sampler_args(engines, n_theta, prior, bijector, theta0s, total_inj, likelihood_flags):
+    from . import _native as N
+
+    bij = bijector if bijector is not None else Bijector(n_theta)
+    pri = (N.GwiParamPrior * n_theta)()
+    for i in range(n_theta):
+        pri[i] = N.GwiParamPrior(int(bij.kind[i]), 0, float(bij.lo[i]), float(bij.hi[i]), float(prior.sigmas[i]))
+    pens = (N.GwiSmoothingPenalty * max(1, len(prior.penalties)))()
+    for k, (sl, tau, deg) in enumerate(prior.penalties):
+        start, stop, step = sl.indices(n_theta)
+        if step != 1:
+            raise ValueError("smoothing penalties act on contiguous slices")
+        pens[k] = N.GwiSmoothingPenalty(start, stop - start, deg, 0, tau)
+    u0 = N.f64(np.stack([bij.inverse(t) for t in theta0s]))
+    if not np.all(np.isfinite(u0)):
+        raise ValueError("starting points must lie strictly inside the parameter supports")
+    return pri, pens, u0, engines[0]._options(total_inj, **likelihood_flags)
+
+
+def nuts_engine_lockstep(engines, chains_per_engine, total_inj, prior, bijector, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0,
+                         **likelihood_flags):
+    """Lock-step NUTS inside the library (``gwi_nuts_engine_lockstep``): ``len(engines) * chains_per_engine`` chains, the chains of
+    group ``g`` on ``engines[g]``, every leapfrog step of a group ONE batched launch (``gwi_eval_batch``'s kernels) -- numpyro's
+    ``chain_method="vectorized"`` (examples/utils.py:63-85).  One host thread; with two or three engines the groups' launches
+    overlap each other's host arithmetic.  Same target and return value as :func:`nuts_engine` (``theta0s[c]``: constrained
+    starting point of chain ``c``, chain ``c`` in group ``c // chains_per_engine``)."""
+    import ctypes as C
+
+    from . import _native as N
+
+    engines = list(engines)
+    theta0s = np.atleast_2d(N.f64(theta0s))
+    n_chains, n_theta = theta0s.shape
+    K = int(chains_per_engine)
+    if len(engines) * K != n_chains:
+        raise ValueError("theta0s must hold len(engines) * chains_per_engine starting points")
+    lib = engines[0].lib
+    pri, pens, u0, lopt = _engine_sampler_args(engines, n_theta, prior, bijector, theta0s, total_inj, likelihood_flags)
+    handles = (C.c_void_p * len(engines))(*[e.handle for e in engines])
+    samples = np.empty((n_chains, n_samples, n_theta))
+    logp = np.empty((n_chains, n_samples))
+    depth = np.empty((n_chains, n_samples), dtype=np.int32)
+    res = (N.GwiNutsResult * n_chains)()
+    opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
+    st = lib.gwi_nuts_engine_lockstep(handles, len(engines), K, n_theta, C.byref(lopt), pri, pens, len(prior.penalties), N.as_dp(u0), C.byref(opt), N.as_dp(samples),
+                                      N.as_dp(logp), depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    if st == -1:
+        raise ValueError("gwi_nuts_engine_lockstep: a chain's starting point has zero likelihood (a cut, or outside the model's support) or a non-finite gradient")
+    if st != 0:
+        msgs = "; ".join(lib.gwi_last_error(e.handle).decode() for e in engines)
+        raise N.NativeEngineError(f"gwi_nuts_engine_lockstep: {N.STATUS_NAMES.get(st, st)}: {msgs}")
+    out = []
+    for c in range(n_chains):
+        r = _result_dict(res[c])
+        r.update(samples=samples[c], log_prob=logp[c], tree_depth=depth[c])
+        out.append(r)
+    return out
+
+
 def nuts_engine(engines, total_inj, prior, bijector, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, **likelihood_flags):
     """NUTS on ``engine log-likelihood + prior`` entirely inside the library (``gwi_nuts_engine``): one host
     thread and one engine per chain, no Python between two likelihood evaluations.
@@ -568,20 +682,7 @@ def nuts_engine(engines, total_inj, prior, bijector, theta0s, n_warmup=200, n_sa
     if len(engines) != n_chains:
         raise ValueError("one engine per chain")
     lib = engines[0].lib
-    bij = bijector if bijector is not None else Bijector(n_theta)
-    pri = (N.GwiParamPrior * n_theta)()
-    for i in range(n_theta):
-        pri[i] = N.GwiParamPrior(int(bij.kind[i]), 0, float(bij.lo[i]), float(bij.hi[i]), float(prior.sigmas[i]))
-    pens = (N.GwiSmoothingPenalty * max(1, len(prior.penalties)))()
-    for k, (sl, tau, deg) in enumerate(prior.penalties):
-        start, stop, step = sl.indices(n_theta)
-        if step != 1:
-            raise ValueError("smoothing penalties act on contiguous slices")
-        pens[k] = N.GwiSmoothingPenalty(start, stop - start, deg, 0, tau)
-    u0 = N.f64(np.stack([bij.inverse(t) for t in theta0s]))
-    if not np.all(np.isfinite(u0)):
-        raise ValueError("starting points must lie strictly inside the parameter supports")
-    lopt = engines[0]._options(total_inj, **likelihood_flags)
+    pri, pens, u0, lopt = _engine_sampler_args(engines, n_theta, prior, bijector, theta0s, total_inj, likelihood_flags)
     handles = (C.c_void_p * n_chains)(*[e.handle for e in engines])
     samples = np.empty((n_chains, n_samples, n_theta))
     logp = np.empty((n_chains, n_samples))

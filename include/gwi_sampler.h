@@ -70,6 +70,33 @@ gwi_status gwi_nuts_engine(const gwi_handle* handles, int32_t n_chains, int32_t 
                            const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt, double* samples, double* log_prob,
                            int32_t* tree_depth, gwi_nuts_result* results);
 
+/* Lock-step chains -- numpyro's chain_method="vectorized" (examples/utils.py:63-85 with num_chains > 1 on one device): all
+ * chains are advanced together and every leapfrog step of all of them is ONE batched evaluation.
+ *
+ * On an arbitrary batched target: fn evaluates the k points xs[k][dim] of the chains chain_ids[k] (k shrinks as chains
+ * finish; chains whose trees need fewer steps in an iteration start their next iteration -- nothing idles) and writes
+ * log_probs[k], grads[k][dim].  x0[n_chains][dim]; outputs as gwi_nuts_run's with a leading chain axis; chain c uses seed
+ * opt->seed + 1000 c and draws, bit for bit, what gwi_nuts_run draws with that seed on the same target. */
+typedef int32_t (*gwi_batch_target_fn)(void* user, int32_t k, const int32_t* chain_ids, const double* xs, double* log_probs, double* grads);
+gwi_status gwi_nuts_run_lockstep(gwi_batch_target_fn fn, void* user, int32_t dim, int32_t n_chains, const double* x0, const gwi_nuts_options* opt, double* samples,
+                                 double* log_prob, int32_t* tree_depth, gwi_nuts_result* results);
+
+/* ... and on engines: n_groups * chains_per_group chains, the chains of group g on handles[g] through gwi_eval_batch_begin /
+ * gwi_eval_batch_end (chains_per_group <= that engine's max_batch: 16 unless GWI_MAX_BATCH says otherwise) -- the batched
+ * kernels (several points per workgroup for parametric chains, the matrix-core kernel for spline models).  One host thread:
+ * while group g's launches run, the chains of the other groups do their host arithmetic and issue theirs, so two or three
+ * groups keep the GPU busy.  Target, arguments and outputs as gwi_nuts_engine (u0[n_chains][n_theta], chain c in group
+ * c / chains_per_group).  Handles without a communicator. */
+gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups, int32_t chains_per_group, int32_t n_theta, const gwi_options* lopt,
+                                    const gwi_param_prior* priors, const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt,
+                                    double* samples, double* log_prob, int32_t* tree_depth, gwi_nuts_result* results);
+
+/* Of the calling thread's last lock-step run: out6 = { batched evaluations made, points in them (their quotient is the mean
+ * batch size: chains whose trees need fewer steps finish earlier and the batches shrink -- a run whose chains need very
+ * different numbers of evaluations gains little from lock step), seconds collecting (mostly waiting for the GPU), seconds in the
+ * chains' own arithmetic, seconds gathering + issuing, wall seconds }.  GWI_LOCKSTEP_STATS=1 prints the same to stderr. */
+void gwi_nuts_lockstep_stats(double* out6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,6 +266,65 @@ def test_native_nuts_chains_in_threads_equal_chains_run_alone():
         e.close()
 
 
+def test_lockstep_chains_on_the_engine_match_the_batched_callback_path():
+    """gwi_nuts_engine_lockstep (two groups of five chains, each group's leapfrog steps one gwi_eval_batch_begin / _end on
+    its engine, target assembled in C++) against gwi_nuts_run_lockstep on the Python statement of the same target fed by
+    the same engine's blocking gwi_eval_batch: same seeds, same batches, same chains."""
+    from gwinferno_amd.sampling import nuts_engine, nuts_engine_lockstep, nuts_native_lockstep
+
+    engs, total, prior, bij, theta0, _ = _native_nuts_setup(2)
+    K = 5
+    starts = np.stack([theta0 + 0.03 * c for c in range(2 * K)])
+    # (a short warm-up: the two statements of the prior differ in their last bits and the Hamiltonian dynamics amplify that -- to
+    # 1e-11 ... 1e-6 within sixty iterations depending on the chain, further with the large steps that follow a mass-matrix update:
+    # tools/lockstep_diverge.py.  What must be EQUAL is the structure: every chain's trees, evaluation for evaluation.)
+    kw = dict(n_warmup=8, n_samples=50, seed=11, max_tree_depth=5)
+    res = nuts_engine_lockstep(engs, K, total, prior, bij, starts, min_neff_cut=False, **kw)
+    assert len(res) == 2 * K
+    again = nuts_engine_lockstep(engs, K, total, prior, bij, starts, min_neff_cut=False, **kw)
+    assert all(np.array_equal(a["samples"], b["samples"]) for a, b in zip(res, again))  # deterministic
+    sizes = []
+
+    def batch_target(us, ids):
+        sizes.append(len(ids))
+        fw = [bij.forward(u) for u in us]
+        thetas = np.stack([f[0] for f in fw])
+        out = engs[0].evaluate_batch(thetas, total, min_neff_cut=False)
+        lps, grads = [], []
+        for (theta, dth, dlogj, logj), r in zip(fw, out):
+            lp, gp = prior(theta)
+            lps.append(r.log_likelihood + lp + logj)
+            grads.append((r.grad + gp) * dth + dlogj)
+        return np.array(lps), np.stack(grads)
+
+    for g in range(2):
+        u0 = np.stack([bij.inverse(t) for t in starts[g * K : (g + 1) * K]])
+        ref = nuts_native_lockstep(batch_target, u0, **dict(kw, seed=11 + 1000 * g * K))
+        for j in range(K):
+            a, b = res[g * K + j], ref[j]
+            th_b = np.array([bij.forward(u)[0] for u in b["samples"]])
+            assert a["n_evals"] == b["n_evals"] and np.array_equal(a["tree_depth"], b["tree_depth"])
+            assert np.allclose(a["samples"], th_b, rtol=1e-4, atol=1e-5)
+            assert np.allclose(a["log_prob"], b["log_prob"], rtol=1e-5)
+    assert max(sizes) == K and min(sizes) < K
+    # lock-step chains are chains: same posterior as the threaded sampler's (pooled means within a fraction of the posterior width)
+    kw = dict(n_warmup=60, n_samples=60, seed=11, max_tree_depth=5)
+    res = nuts_engine_lockstep(engs, K, total, prior, bij, starts, min_neff_cut=False, **kw)
+    draws = np.concatenate([r["samples"] for r in res])
+    thr = nuts_engine(engs, total, prior, bij, starts[:2], min_neff_cut=False, **dict(kw, n_samples=300))
+    pooled = np.concatenate([r["samples"] for r in thr])
+    sd = pooled.std(axis=0)
+    assert np.all(np.abs(draws.mean(axis=0) - pooled.mean(axis=0)) < 0.6 * sd)
+    assert np.all(np.isfinite(draws)) and all(0.4 < r["accept_rate"] <= 1.0 for r in res)
+    # more chains per group than the engine's largest batch: refused with the engine's message
+    with pytest.raises(Exception, match="max_batch"):
+        nuts_engine_lockstep(engs[:1], 40, total, prior, bij, np.stack([theta0] * 40), min_neff_cut=False, n_warmup=2, n_samples=2)
+    one = engs[0].evaluate(theta0, total, min_neff_cut=False)  # the handle is left usable (nothing pending)
+    assert np.isfinite(one.log_likelihood)
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["chm_powerlaw", "chm_bspline"])
 def test_construct_hierarchical_model_matches_the_reference(name):
     """construct_hierarchical_model (analysis.py:359-424) with the distribution classes of this package, fed the way

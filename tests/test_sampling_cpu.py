@@ -129,6 +129,57 @@ def test_native_nuts_is_reproducible_counts_and_propagates_errors():
         nuts_native(broken, np.zeros(5), n_warmup=5, n_samples=5)
 
 
+def test_lockstep_chains_draw_what_separate_chains_draw():
+    """gwi_nuts_run_lockstep: K chains (each the unchanged NUTS on a stack of its own), ONE batched target call per leapfrog
+    step of all of them.  The batching only changes WHEN a chain's evaluations happen: chain c must draw, bit for bit,
+    what gwi_nuts_run draws with seed + 1000 c -- also when chains finish at different times (the batch shrinks), when one
+    chain starts on a dead point, and when the target fails mid-run."""
+    from gwinferno_amd.sampling import nuts_native, nuts_native_lockstep
+
+    target, _, _ = _gaussian()
+    sizes = []
+
+    def batch(xs, ids):
+        sizes.append(len(ids))
+        assert len(set(ids.tolist())) == len(ids)
+        vg = [target(x) for x in xs]
+        return np.array([v for v, _ in vg]), np.stack([g for _, g in vg])
+
+    starts = np.stack([np.zeros(5), np.ones(5), -np.ones(5), 0.5 * np.ones(5), np.linspace(-1, 1, 5), 2 * np.ones(5), -0.3 * np.ones(5)])
+    res = nuts_native_lockstep(batch, starts, n_warmup=60, n_samples=40, seed=5)
+    total = 0
+    for c, r in enumerate(res):
+        alone = nuts_native(target, starts[c], n_warmup=60, n_samples=40, seed=5 + 1000 * c)
+        assert np.array_equal(r["samples"], alone["samples"]) and np.array_equal(r["tree_depth"], alone["tree_depth"])
+        assert r["n_evals"] == alone["n_evals"] and r["step_size"] == alone["step_size"] and r["accept_rate"] == alone["accept_rate"]
+        total += r["n_evals"]
+    assert sum(sizes) == total and max(sizes) == len(starts) and min(sizes) < len(starts)  # full batches, then a shrinking tail
+    assert sizes[0] == len(starts) and np.mean(sizes) > 0.8 * len(starts)
+
+    # a chain whose starting point is dead: the others are not disturbed, the call reports it
+    def walled(xs, ids):
+        v, g = batch(xs, ids)
+        return np.where(xs[:, 0] > 5.0, -np.inf, v), g
+
+    with pytest.raises(ValueError, match="starting point"):
+        nuts_native_lockstep(walled, np.stack([np.zeros(5), 9.0 * np.ones(5)]), n_warmup=5, n_samples=5)
+
+    # a failing target unwinds every chain and the exception comes back through the C frames
+    calls = [0]
+
+    def broken(xs, ids):
+        calls[0] += 1
+        if calls[0] > 7:
+            raise ZeroDivisionError("target failed")
+        return batch(xs, ids)
+
+    with pytest.raises(ZeroDivisionError):
+        nuts_native_lockstep(broken, starts[:3], n_warmup=20, n_samples=5)
+    assert calls[0] == 8  # no evaluation after the failure
+    again = nuts_native_lockstep(batch, starts[:2], n_warmup=10, n_samples=5, seed=1)  # and the library is usable afterwards
+    assert again[0]["samples"].shape == (5, 5)
+
+
 def test_native_nuts_survives_a_wall_and_matches_the_numpy_sampler_statistically():
     from gwinferno_amd.sampling import nuts_native
 
