@@ -1005,7 +1005,7 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
                          "chains sit in different modes of this synthetic catalog's posterior (compare mean_log_prob_per_chain), not that they mix slowly")}
 
 
-def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, thetas, n_warmup, n_samples):
+def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, thetas, n_warmup, n_samples, common_start=None):
     """Vectorised chains inside the library (gwi_nuts_engine_lockstep): len(engines) groups of chains_per_engine chains, every
     leapfrog step of a group ONE batched launch, the groups alternating on one host thread -- numpyro's
     chain_method="vectorized" (examples/utils.py:63-85).  Same priors and tree depth as native_nuts; a THROUGHPUT figure
@@ -1014,7 +1014,7 @@ def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, the
 
     G, K = len(engines), int(chains_per_engine)
     prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
-    starts = np.stack([thetas[c % len(thetas)] for c in range(G * K)])
+    starts = np.stack([thetas[c % len(thetas)] if common_start is None else thetas[common_start] for c in range(G * K)])
     if bij is not None:
         for k in np.flatnonzero(bij.kind == 3):
             starts[:, k] = bij.lo[k]
@@ -1030,8 +1030,9 @@ def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, the
     per_chain = [int(r["n_evals"]) for r in res]
     return {"mean_points_per_batch": st["mean_points_per_batch"], "evals_per_chain_min_max": [min(per_chain), max(per_chain)],
             "per_batch_us": {"collect": st["collect_us_per_batch"], "chains": st["chains_us_per_batch"], "issue": st["issue_us_per_batch"]},
+            "starts": "one prior draw per chain (as native_nuts)" if common_start is None else f"every chain from prior draw {common_start}, seeds differ",
             "note": ("chains that need fewer evaluations finish earlier and the batches shrink: mean_points_per_batch of chains_per_group is what the batched "
-                     "kernels get to work with; chains started from prior draws on this synthetic catalog differ by up to 10x in evaluations"),
+                     "kernels get to work with; chains started from different prior draws on this synthetic catalog differ by up to 15x in evaluations"),
             "chains": G * K, "groups": G, "chains_per_group": K, "host_threads": 1, "batch_path": engines[0].batch_path(K), "warmup_iterations": n_warmup,
             "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt,
             "two_pass_repeats": sum(e.two_pass_repeats() for e in engines) - repeats0, "mean_tree_depth": float(np.mean(depth)),

@@ -23,6 +23,8 @@ engs = [c.engine() for c in comps]
 thetas = [comps[0].theta(draw_params(comp_name, rng)) for _ in range(G * K)]
 prior, bij, _ = reference_priors(comp_name, comps[0], engs[0].n_theta)
 starts = np.stack(thetas)
+if os.environ.get("LOCKSTEP_SAME_START"):  # every chain from the same point (seeds differ)
+    starts = np.stack([thetas[int(os.environ["LOCKSTEP_SAME_START"]) - 1]] * (G * K))
 if bij is not None:
     for k in np.flatnonzero(bij.kind == 3):
         starts[:, k] = bij.lo[k]
