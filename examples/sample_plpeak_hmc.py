@@ -10,7 +10,10 @@ With `--chains C` (C > 1) C independent NUTS chains run on the one GPU, one engi
 flight together (gwi_eval_begin / gwi_eval_end): chains of different tree depths overlap instead of queueing.
 `--native` runs the library's C++ sampler instead (gwi_nuts_engine, include/gwi_sampler.h): the same algorithm,
 target and priors with no Python between two evaluations -- one host thread per chain, each on its own engine.
-    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut] [--chains C] [--native]"""
+`--native --lockstep` advances the chains together instead (gwi_nuts_engine_lockstep: numpyro's chain_method="vectorized"):
+every leapfrog step of up to 16 chains is ONE batched launch, two groups of chains alternate on one host thread
+(`--chains 32 --native --lockstep`).
+    python examples/sample_plpeak_hmc.py [n_events n_pe n_inj] [--hmc] [--neff-cut] [--chains C] [--native [--lockstep]]"""
 import os
 import sys
 import time
@@ -19,7 +22,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gwinferno_amd.compositions import COMPOSITIONS  # noqa: E402
-from gwinferno_amd.sampling import Bijector, GaussianSmoothingPrior, hmc, make_async_target, make_target, nuts, nuts_chains, nuts_engine  # noqa: E402
+from gwinferno_amd.sampling import (Bijector, GaussianSmoothingPrior, hmc, lockstep_stats, make_async_target, make_target, nuts, nuts_chains, nuts_engine,  # noqa: E402
+                                    nuts_engine_lockstep)
 from gwinferno_amd.synthetic import make_catalog  # noqa: E402
 
 use_hmc = "--hmc" in sys.argv
@@ -45,14 +49,26 @@ bij = Bijector(eng.n_theta).interval(idx["mpp"], 5.0, 100.0).interval(idx["lam"]
 # end on it -- reported as divergences -- exactly as under numpyro)
 target = make_target(eng, total, prior, bijector=bij, min_neff_cut="--neff-cut" in sys.argv)
 if "--native" in sys.argv:
-    engines = [eng] + [COMPOSITIONS["plpeak"](pe, inj).engine() for _ in range(n_chains - 1)]
+    lockstep = "--lockstep" in sys.argv
+    per_group = min(16, n_chains)
+    n_groups = (n_chains + per_group - 1) // per_group if lockstep else n_chains
+    if lockstep:
+        n_chains = n_groups * per_group
+    engines = [eng] + [COMPOSITIONS["plpeak"](pe, inj).engine() for _ in range(n_groups - 1)]
     rng = np.random.default_rng(0)
     starts = np.stack([bij.forward(bij.inverse(theta0) + (0.05 * rng.normal(size=eng.n_theta) if c else 0.0))[0] for c in range(n_chains)])
     t0 = time.perf_counter()
-    res = nuts_engine(engines, total, prior, bij, starts, n_warmup=200, n_samples=200, seed=1, min_neff_cut="--neff-cut" in sys.argv)
+    if lockstep:
+        res = nuts_engine_lockstep(engines, per_group, total, prior, bij, starts, n_warmup=200, n_samples=200, seed=1, min_neff_cut="--neff-cut" in sys.argv)
+    else:
+        res = nuts_engine(engines, total, prior, bij, starts, n_warmup=200, n_samples=200, seed=1, min_neff_cut="--neff-cut" in sys.argv)
     dt = time.perf_counter() - t0
     n_ev_total = sum(r["n_evals"] for r in res)
-    print(f"native sampler, {n_chains} chain(s): {n_ev_total} engine evaluations in {dt:.2f}s ({n_ev_total / dt:.0f} evals/s aggregate)")
+    print(f"native sampler, {n_chains} chain(s){' in lock step' if lockstep else ''}: {n_ev_total} engine evaluations in {dt:.2f}s ({n_ev_total / dt:.0f} evals/s aggregate)")
+    if lockstep:
+        st = lockstep_stats()
+        print(f"  {n_groups} group(s) of {per_group} chains ('{eng.batch_path(per_group)}' kernel): {st['batches']} batched evaluations of {st['mean_points_per_batch']:.1f} points on average")
+        res = res[:8]  # (the per-chain lines below: the first eight)
     allth = np.concatenate([r["samples"] for r in res])
     for c, r in enumerate(res):
         print(f"  chain {c}: accept {r['accept_rate']:.2f}, step {r['step_size']:.3g}, mean tree depth {r['tree_depth'].mean():.1f}, {r['n_divergent']} divergent")
