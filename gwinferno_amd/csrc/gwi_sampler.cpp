@@ -532,9 +532,8 @@ struct Lockstep {
           n_points += (long long)k;
         }
         G.pending = false;
-        const std::vector<int> live = G.live;
-        for (size_t j = 0; j < k; ++j) {  // hand the results over; each chain runs on to its next evaluation
-          Fiber& f = fibers[live[j]];
+        for (size_t j = 0; j < k; ++j) {  // hand the results over; each chain runs on to its next evaluation (G.live is rebuilt by issue() below, not before)
+          Fiber& f = fibers[G.live[j]];
           if (!failed) {
             *f.out_lp = G.lps[j];
             std::memcpy(f.out_grad, G.grads.data() + j * dim, sizeof(double) * dim);
