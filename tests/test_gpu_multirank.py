@@ -198,3 +198,39 @@ def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
     assert out2.returncode == 0, out2.stderr[-2000:]
     mg2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][-1])["multi_gpu"]
     assert mg2["rccl_ranks"] == 0 and mg2["exchanges"]["shm"]["headline"] is True
+
+
+def test_bench_in_the_drivers_launch_form_with_two_ranks_on_this_box(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- the form the driver launches for N > 1 --
+    on whatever this box has.  With two GPUs the in-engine RCCL all-gather carries the headline; on a one-GPU box both ranks
+    share the device, RCCL is skipped WITH ITS REASON (it cannot place two ranks of a communicator on one device) and the
+    shared-memory exchange carries it: either way two processes evaluate their shards of events and injections on the GPU,
+    exchange the partial records once per evaluation, and the result equals the unsharded engine's."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GWI_QUIET="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20"]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = child.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, 9)  # the launcher and its two ranks: this exact process group
+        out, err = child.communicate()
+        pytest.fail("the two-rank bench did not finish within 900 s and was killed\n" + (err or "")[-1500:])
+    assert child.returncode == 0, (err or "")[-2500:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-1500:]  # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 200 and line["warmup"] == 20 and line["scaling"] == "strong" and line["value"] > 0
+    mg = line["multi_gpu"]
+    assert mg["ranks"] == 2 and len(mg["per_rank"]) == 2
+    assert sorted(r["n_ev"] for r in mg["per_rank"]) == [34, 35] and all(r["n_inj"] == 25000 for r in mg["per_rank"])  # SURVEY 8e's partition of 69 events / 50 k injections
+    chk = mg["sharded_vs_single_gpu"]
+    assert chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
+    ex = mg["exchanges"]
+    if _device_count() >= 2:
+        assert mg["rccl_ranks"] == 2 and ex["rccl_allgather"]["headline"] is True
+    else:
+        assert mg["rccl_ranks"] == 0 and ex["shm"]["headline"] is True and ex["shm"]["evals_per_s"] == line["value"]
+        assert "one device" in ex["rccl_allgather"]["skipped"] and mg["devices_shared_between_ranks"] == 1
