@@ -65,3 +65,20 @@ for w in workers:
     w.join()
 dt = time.perf_counter() - t0
 print(f"{cfg}: {C_THREADS} threads x {calls * 1024} evaluations in {dt:.1f} s ({C_THREADS * calls * 1024 / dt:.0f} evals/s aggregate), value mismatches per thread: {bad_t}")
+
+# batches in two halves, three engines driven alternately from this thread: every set against the blocking result
+halves = [e.configure_batch_async(16, total, min_neff_cut=False) for e in engines[:3]]
+n_sets = max(30, n // 32)
+bad_h = 0
+t0 = time.perf_counter()
+halves[0][0](ths)
+halves[1][0](ths)
+for i in range(n_sets):
+    halves[(i + 2) % 3][0](ths)
+    v, _ = halves[i % 3][1]()
+    bad_h += int(np.sum(v != refb))
+for j in range(2):
+    v, _ = halves[(n_sets + j) % 3][1]()
+    bad_h += int(np.sum(v != refb))
+dt = time.perf_counter() - t0
+print(f"{cfg}: {n_sets + 2} sets of 16 in two halves, three in flight from one thread, in {dt:.1f} s ({(n_sets + 2) * 16 / dt:.0f} evals/s), value mismatches: {bad_h}")
