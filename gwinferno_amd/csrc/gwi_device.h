@@ -2500,7 +2500,11 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     }
     // the wave's exact maximum for this point: every weight is <= 1 x its linear part.  (Reusing the previous point's reference
     // where it lies within 150 e-folds -- two compares and ballots instead of the DPP maximum -- measured nothing: EXPERIMENTS.md)
+#ifdef GWI_AB_PBATCH_NOMAX  // timing-only ablation: no cross-lane maximum (wrong reference)
+    const double m = uniform(mx_lane);
+#else
     const double m = wave_max(mx_lane);
+#endif
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -2529,8 +2533,14 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     for (int v = kNV; v < kSumGroups * 8; ++v) vals[v] = 0.0;
 #pragma unroll
     for (int g = 0; g < kSumGroups; ++g) {
+#ifdef GWI_AB_PBATCH_NOSUM  // timing-only ablation: no butterfly (every value still reaches LDS once: eight stores of 64 lanes)
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+        if ((lane & 7) == v) s_part[wave][kk][8 * g + (lane >> 3)] = vals[8 * g + v];
+#else
       const double z = wave_sum8(vals + 8 * g);
       if ((lane & 7) == 0) s_part[wave][kk][8 * g + (lane >> 3)] = z;
+#endif
     }
     if (lane == 0) s_m[wave][kk] = m;
   }
