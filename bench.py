@@ -5,7 +5,13 @@ One *step* = one value-and-gradient evaluation of ``hierarchical_likelihood`` (l
 and every diagnostic site) for one hyper-parameter point, end to end from a host ``theta`` to host
 results, with the catalog already resident in HBM -- what one NUTS leapfrog costs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5|b50k|def50k] [--full] [--detail PATH]
+
+The LAST line of stdout is ONE compact, strict JSON object (<= 4 KB, `compact_line`): the contract's keys, `roofline`,
+`cpu_baseline`, a short entry per further configuration under `configs` and, for N > 1, a short `multi_gpu` block.  Everything
+else this script measures goes to the side file (`--detail`, default ./bench_detail.json), never to stdout.  The default run
+holds the core legs only (timed K steps, latency distribution, kernel durations, blocking K = 16 batches, bounded CPU
+baseline); `--full` adds the secondary legs (sets in flight, the other batched kernels, chains, the library's NUTS, ...).
 
 N = 1: a single engine.  N > 1: one rank per GPU (events and injections sharded across ranks, each rank scans
 its shard, ONE exchange of the ~1 KiB partial records -- an ncclAllGather (RCCL over xGMI) inside the engine, with the
@@ -37,6 +43,10 @@ CONFIGS = {
     "c2": ("plpeak", "c2", 4, "C2: PL+Peak m1 x PL q x PL z, 69 ev x 5000 PE x 50k inj"),
     "c3": ("bspline_iid", "c3", 8, "C3: B-spline m1(30) x PL q x IID spin mag(16) x IID tilt(16) x PL z, 69 ev x 5000 PE x 100k inj"),
     "c5": ("bspline_full", "c5", 9, "C5: B-spline m1(30) q(14) a1,a2(12) ct1,ct2(12) x PL z x spline z(12), 200 ev x 10000 PE x 500k inj"),
+    # the size north_star's last sentence names (69 x 5000 x 50k: the catalog of config 2) under B-spline models: config 3's composition, and the
+    # reference's DEFAULT spline counts (pipeline/utils.py:29-39, 104-155: m1 50, q 30, a 16+16, tilt 16+16, z 20 = 164 coefficients + lamb)
+    "b50k": ("bspline_iid", "c2", 8, "C3's model (B-spline m1(30) x PL q x IID spin mag(16), tilt(16) x PL z) at 69 ev x 5000 PE x 50k inj"),
+    "def50k": ("bspline_defaults", "c2", 9, "reference default spline counts: m1(50) q(30) a1,a2(16) ct1,ct2(16) x PL z x spline z(20), 69 ev x 5000 PE x 50k inj"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -127,6 +137,12 @@ def read_clocks(device=None):
     return out or None
 
 
+def device_identity(torch, index):
+    """PCI address of HIP device `index` ("domain:bus:device"): what tells two ranks apart that believe they hold different GPUs."""
+    p = torch.cuda.get_device_properties(index)
+    return f"{getattr(p, 'pci_domain_id', 0):04x}:{getattr(p, 'pci_bus_id', index):02x}:{getattr(p, 'pci_device_id', 0):02x}"
+
+
 def host_cores():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota of the container, if any
@@ -138,7 +154,7 @@ def host_cores():
     return avail
 
 
-def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, numpy_reference=True):
+def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=6.0, numpy_reference=False):
     """The C/OpenMP restatement (oracle/gwpop_oracle.c: value + gradient + sites, same flat model description as the GPU
     engine receives) timed on the host cores, plus the NumPy restatement of the REFERENCE formulation (dense Cox-de Boor
     design matrices contracted per evaluation, value only, one core).  Checker code, never the product path."""
@@ -147,7 +163,7 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
     orc = COracle(comp.engine().bound)
     avail = host_cores()
 
-    def rate(nt, repeats=3):
+    def rate(nt, repeats=2):
         """evaluations per second at nt threads: best of `repeats` single evaluations after one untimed"""
         orc.evaluate(thetas[0], total, min_neff_cut=False, n_threads=nt)
         best = None
@@ -166,7 +182,7 @@ def cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0, nu
         affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         affinity = avail
-    probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 16), min(affinity, 256)})}
+    probe = {nt: rate(nt) for nt in sorted({avail, max(1, avail // 2), min(avail, 16), min(affinity, 256)})}
     # ... and the probe's two best counts are then run SUSTAINED (half the budget each, the smaller count first): a burst of a few
     # evaluations on every visible CPU can beat the cgroup's CPU quota that a run of seconds is throttled to (a 16-CPU quota
     # on a 128-CPU box: 356 evals/s in the probe, 8 sustained)
@@ -266,6 +282,135 @@ def percentiles(seconds):
     return {"median_ms_per_step": float(np.median(ms)), "p5_ms": float(np.percentile(ms, 5)), "p95_ms": float(np.percentile(ms, 95)), "n_evals": int(ms.size)}
 
 
+LINE_LIMIT = 4096  # bytes: the driver reads the last line out of a bounded tail of stdout (round 5's 23 KB line was cut and not parsed)
+
+
+def strict(x, digits=None):
+    """A copy of x that `json.dumps(..., allow_nan=False)` accepts: NaN / +-Infinity -> None, NumPy scalars and arrays -> Python;
+    floats rounded to `digits` significant digits when given."""
+    if isinstance(x, dict):
+        return {str(k): strict(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [strict(v, digits) for v in x]
+    if isinstance(x, np.ndarray):
+        return strict(x.tolist(), digits)
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if not np.isfinite(x):
+            return None
+        return float(f"{x:.{digits}g}") if digits else x
+    return x
+
+
+def _pick(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def _roofline_entry(blk):
+    r = blk.get("roofline") or {}
+    return {"bound": r.get("bound", "hbm"), "kernel": _pick(blk, "scan_chain", "name") or r.get("kernel"), "achieved": r.get("achieved"), "peak": r.get("peak"),
+            "unit": r.get("unit", "GB/s"), "frac": r.get("frac"), "traffic": r.get("traffic"), "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+            "avg_kernel_us": r.get("avg_kernel_us"), "timed_launches": r.get("timed_launches"), "dispatch": r.get("dispatch"),
+            "measured_read_peak_gbs": _pick(r, "measured_peak", "read_gbs")}
+
+
+def _cpu_entry(blk):
+    c = blk.get("cpu_baseline")
+    if not c:
+        return None
+    return {"value": c.get("value"), "unit": c.get("unit", "evals/s"), "cores": c.get("cores"), "kind": c.get("kind"), "sample": c.get("sample"),
+            "single_thread_evals_per_s": c.get("single_thread_evals_per_s"), "cpu_model": _pick(c, "host", "cpu_model"), "cgroup_cpu_quota": _pick(c, "host", "cgroup_cpu_quota")}
+
+
+def _batched_entry(blk):
+    b = blk.get("batched")
+    if not b:
+        return None
+    out = {"k": b.get("k_batch"), "evals_per_s": b.get("evals_per_s"), "path": b.get("path"), "scan_us": _pick(b, "avg_kernel_us", "scan")}
+    if _pick(b, "mfma", "frac_of_78.6") is not None:
+        out["mfma_issued_frac"] = _pick(b, "mfma", "frac_of_78.6")
+        out["mfma_useful_frac"] = _pick(b, "mfma", "useful_frac_of_78.6")
+    return out
+
+
+def _multi_gpu_entry(blk):
+    m = blk.get("multi_gpu")
+    if not m:
+        return None
+    ex = m.get("exchanges") or {}
+    out = {"ranks": m.get("ranks"), "rccl_ranks": m.get("rccl_ranks"), "exchange": (m.get("exchange") or "")[:80], "rendezvous_backend": m.get("rendezvous_backend"),
+           "devices_shared_between_ranks": m.get("devices_shared_between_ranks"), "sharded_vs_single_gpu": m.get("sharded_vs_single_gpu"),
+           "evals_per_s": {k: v.get("evals_per_s") for k, v in ex.items() if isinstance(v, dict) and v.get("evals_per_s") is not None},
+           "per_rank_scan_us": [_pick(r, "avg_kernel_us", "scan") for r in (m.get("per_rank") or [])][:8],
+           "per_rank_events": [r.get("n_ev") for r in (m.get("per_rank") or [])][:8]}
+    probe = ex.get("rccl_allgather_probe") or (ex.get("rccl_allgather") if "child_exit_code" in (ex.get("rccl_allgather") or {}) or "skipped" in (ex.get("rccl_allgather") or {}) else None)
+    if probe:
+        out["rccl_probe"] = {k: (v[:300] if isinstance(v, str) else v) for k, v in probe.items()
+                             if k in ("child_exit_code", "error", "skipped", "probe_clean_on_every_rank", "identical_on_all_ranks", "evals_per_s", "rccl_debug_tail", "unique_devices")}
+    return out
+
+
+def compact_line(detail, detail_path=None):
+    """The record the driver keeps: the contract's keys, `roofline` and `cpu_baseline` of the headline configuration, one short
+    entry per further configuration, a short `multi_gpu` block for N > 1 -- picked out of the DETAIL dict (what `measure`
+    returns per configuration, merged in main()).  Pure: tests/test_bench_line_cpu.py runs it on canned detail."""
+    line = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = detail.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "n_events", "n_pe", "n_inj", "n_theta", "parallelism")}
+    line["median_ms_per_step"] = detail.get("median_ms_per_step")
+    line["roofline"] = _roofline_entry(detail)
+    line["cpu_baseline"] = _cpu_entry(detail)
+    line["batched"] = _batched_entry(detail)
+    cfgs = {}
+    for name, blk in (detail.get("configs") or {}).items():
+        if not blk:
+            continue
+        r = blk.get("roofline") or {}
+        c = blk.get("cpu_baseline") or {}
+        b = _batched_entry(blk) or {}
+        cfgs[name] = {"workload": _pick(blk, "config", "workload"), "n_theta": _pick(blk, "config", "n_theta"), "value": blk.get("value"), "ms_per_step": blk.get("ms_per_step"),
+                      "steps": blk.get("steps"), "kernel": _pick(blk, "scan_chain", "name"), "scan_us": _pick(r, "avg_kernel_us", "scan"), "frac": r.get("frac"),
+                      "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"), "traffic": r.get("traffic"), "cpu": c.get("value"), "cpu_cores": c.get("cores"),
+                      "batched_k16_evals_per_s": b.get("evals_per_s"), "batched_path": b.get("path"), "batched_scan_us": b.get("scan_us")}
+        if b.get("mfma_issued_frac") is not None:
+            cfgs[name]["mfma_issued_frac"], cfgs[name]["mfma_useful_frac"] = b["mfma_issued_frac"], b["mfma_useful_frac"]
+        mg = _multi_gpu_entry(blk)
+        if mg:
+            cfgs[name]["multi_gpu"] = {k: mg[k] for k in ("rccl_ranks", "sharded_vs_single_gpu", "evals_per_s")}
+    if cfgs:
+        line["configs"] = cfgs
+    mg = _multi_gpu_entry(detail)
+    if mg:
+        line["multi_gpu"] = mg
+    line["detail"] = detail_path
+    line = strict(line, digits=6)
+    for name, blk in (line.get("configs") or {}).items():
+        line["configs"][name] = {k: v for k, v in blk.items() if v is not None}  # a leg that did not run is absent, not null
+    return line
+
+
+def dump_line(line):
+    """Strict JSON on one line; sheds the least important blocks (never the contract's keys, `roofline` or `cpu_baseline`) should it
+    ever exceed LINE_LIMIT, and says so."""
+    line = dict(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    for victim in ("batched", "configs", "multi_gpu"):
+        if len(text.encode()) <= LINE_LIMIT:
+            break
+        line[victim] = f"dropped: line over {LINE_LIMIT} bytes; see the detail file"
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert "\n" not in text and len(text.encode()) <= LINE_LIMIT
+    return text
+
+
 class Run:
     """Process-wide context: rank, world, device and the torch.distributed group (if any)."""
 
@@ -309,6 +454,13 @@ class Run:
                 dist.init_process_group(backend)
             self.dist = dist
             self.backend = backend
+            # one process per GPU means ONE GPU per process: with a GPU per rank every rank must sit on a device of its own (a launcher
+            # that hands two ranks the same LOCAL_RANK, or a HIP_VISIBLE_DEVICES that maps two ordinals onto one card, would otherwise
+            # time two shards on one GPU and call it scaling)
+            self.devices = [None] * self.world
+            dist.all_gather_object(self.devices, device_identity(torch, self.local_rank))
+            if self.shared_devices is None and len(set(self.devices)) != self.world:
+                raise SystemExit(f"[rank {self.rank}] ranks do not hold distinct GPUs: {self.devices}")
         # Bring torch's device context (and, for N > 1, the barrier's communicator) up NOW: their lazy start-up inside the
         # fence just ahead of the timed region would leave the GPU idle for tens to hundreds of milliseconds after the warm-up,
         # long enough for its clocks to drop, and the first timed steps would run at them.
@@ -345,10 +497,12 @@ class Run:
         return box
 
 
-def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4, nuts_chains=0, prefer_rccl=False):
+def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, with_cpu=True, k_batch=16, chains=4, nuts_chains=0, prefer_rccl=False, full=False,
+            cpu_budget_s=6.0):
     """One configuration: W warm-up + exactly K timed steps (barrier + synchronise on both sides, max over ranks), then
-    the latency distribution of >= 1000 further evaluations, kernel durations of >= 20 timed launches, and the secondary
-    throughput figures.  Returns the dict that goes into the JSON line (rank 0) or None."""
+    the latency distribution of >= 1000 further evaluations, kernel durations of >= 20 timed launches, blocking K-point batches
+    and the bounded CPU baseline; with `full` also the secondary throughput figures.  Returns the DETAIL dict of this
+    configuration (rank 0; `compact_line` picks the record's fields from it) or None."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.engine import pin_thread_to_device
     from gwinferno_amd.synthetic import make_config_catalog
@@ -367,7 +521,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
     eng = comp.engine(device=dev, rank=rank, world=world)
     setup = {"device_s": time.perf_counter() - t_setup,
              "what": "model objects + gwi_create_ingest: raw catalog columns up, masks / logs / dVc/dz / kappa by the ingest kernel (SURVEY 8f rank 1)"}
-    if rank == 0 and world == 1 and torch.cuda.is_available():  # the host path beside it: NumPy evaluates the same setup expressions, gwi_create uploads
+    if full and rank == 0 and world == 1 and torch.cuda.is_available():  # the host path beside it: NumPy evaluates the same setup expressions, gwi_create uploads
         t_host = time.perf_counter()
         host_comp = COMPOSITIONS[comp_name](pe, inj)
         host_comp.engine(device=dev, device_setup=False).close()
@@ -429,8 +583,8 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
         ll_sh, g_sh = step(0)
         g_sh = np.array(g_sh)
         if rank == 0:
-            full = COMPOSITIONS[comp_name](pe, inj)
-            eng_full = full.engine(device=dev)
+            whole = COMPOSITIONS[comp_name](pe, inj)
+            eng_full = whole.engine(device=dev)
             r_full = eng_full.evaluate(thetas[0], total, min_neff_cut=False)
             scale = max(1.0, float(np.max(np.abs(r_full.grad))))
             sharded_check = {"log_likelihood_rel_err": abs(ll_sh - r_full.log_likelihood) / max(1e-300, abs(r_full.log_likelihood)),
@@ -520,15 +674,17 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                                 "median_ms_per_step": float(np.median(lat) * 1e3)})
 
     # ---- the same loop driven from Python through the allocation-free closure (what a NumPy sampler pays per step)
-    n_py = min(max(steps, 200), 2000)
-    for i in range(min(50, n_py)):
-        step(i)
-    run.fence()
-    t0p = time.perf_counter()
-    for i in range(n_py):
-        step(i)
-    run.fence()
-    python_driven = n_py / run.max_over_ranks(time.perf_counter() - t0p)
+    python_driven = None
+    if full:
+        n_py = min(max(steps, 200), 2000)
+        for i in range(min(50, n_py)):
+            step(i)
+        run.fence()
+        t0p = time.perf_counter()
+        for i in range(n_py):
+            step(i)
+        run.fence()
+        python_driven = n_py / run.max_over_ranks(time.perf_counter() - t0p)
 
     # ---- N > 1, secondary figures: (a) one independent chain per GPU over the WHOLE catalog (numpyro
     # chain_method="parallel"): no exchange, per-GPU work fixed (weak scaling); (b) the same sharded evaluation with the
@@ -561,7 +717,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             eng_shm.close()
 
     replicas = None
-    if dist is not None:
+    if dist is not None and full:
         rep = COMPOSITIONS[comp_name](pe, inj)
         eng_rep = rep.engine(device=dev)
         n_rep = max(200, steps // 2)
@@ -635,7 +791,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             # that cost this process, 0 when the disk cache supplied the code object) or the generic kernel
             "scan_chain": {"name": eng.scan_kernel_name(), **eng.jit_info()},
         }
-        if dist is None and headline:
+        if dist is None and headline and full:
             # What the NumPyro seam adds on the host (likelihood._host_callback: the function jax.pure_callback calls once per leapfrog):
             # theta array in -> engine -> packed (summary, per-event sites, gradient) arrays out, without JAX's own dispatch and
             # device synchronisation around the callback, which no image here can measure.
@@ -725,6 +881,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             try:
                 import threading
 
+                if not full:
+                    raise StopIteration
+
                 extra_comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(2)]
                 set_engs = [eng] + [c.engine(device=dev) for c in extra_comps]
                 fns = [e.configure_batch(K, total, min_neff_cut=False) for e in set_engs]
@@ -770,12 +929,14 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 out["batched"]["sets_in_flight"] = dict(over, what=f"T blocking sets of {K} points side by side, one host thread and one engine per set (same catalog, same GPU); 'T_one_thread': T sets in flight from ONE thread through gwi_eval_batch_begin / gwi_eval_batch_end")
                 for e in set_engs[1:]:
                     e.close()
+            except StopIteration:
+                pass
             except Exception as exc:  # a secondary figure: never the reason a line is missing
                 out["batched"]["sets_in_flight"] = {"error": repr(exc)}
             # the other batched kernels on the same batch, where the model has them (spline models): the 4-tap kernel (one
             # grid row per point, LDS atomics) and the LDS-row variant of the 16-points-per-wavefront kernel
             alts = {}
-            for alt_name, env_kv in (("taps", {"GWI_BATCH_MFMA": "0"}), ("mfma", {"GWI_BATCH_MFMA": "1"}), ("rows", {"GWI_BATCH_ROWS": "1"})):
+            for alt_name, env_kv in ((("taps", {"GWI_BATCH_MFMA": "0"}), ("mfma", {"GWI_BATCH_MFMA": "1"}), ("rows", {"GWI_BATCH_ROWS": "1"})) if full else ()):
                 saved = {k_: os.environ.get(k_) for k_ in env_kv}
                 os.environ.update(env_kv)
                 try:
@@ -800,9 +961,9 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 out["batched"]["other_paths"] = alts
                 out["batched"]["paths"] = ("taps: one grid row per point, 4-tap gradient into LDS rows (scan_kernel BATCH); mfma: 16 points per wavefront, gradient as "
                                            "v_mfma_f64_16x16x4 tiles (gwi_mfma.h); rows: the same kernel with the gradient in conflict-free LDS rows")
-        if dist is None and headline and chains > 1:
+        if dist is None and headline and chains > 1 and full:
             out.update(multi_chain(eng, comp, comp_name, pe, inj, total, thetas, chains, steps, dev))
-        elif dist is None and nuts_chains > 1:
+        elif dist is None and nuts_chains > 1 and full:
             # configs 3 / 5: the sampler figure under the reference's priors, on engines of its own
             comps = [comp] + [COMPOSITIONS[comp_name](pe, inj) for _ in range(nuts_chains - 1)]
             engs = [eng] + [c.engine(device=dev) for c in comps[1:]]
@@ -815,7 +976,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             for e in engs[1:]:
                 e.close()
         if with_cpu and world == 1:  # reported at N = 1 only (rank 0), as the contract asks
-            out["cpu_baseline"] = cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=8.0 if headline else 5.0, numpy_reference=cfg != "c5")
+            out["cpu_baseline"] = cpu_baseline(comp, comp_name, pe, inj, pool, thetas, total, budget_s=cpu_budget_s, numpy_reference=full and cfg != "c5")
     if dist is not None:
         dist.barrier()
     eng.close()
@@ -1068,6 +1229,10 @@ def rccl_leg_main(argv):
     pe, inj, total = make_config_catalog(cat_name)
     comp = COMPOSITIONS[comp_name](pe, inj)
     eng = comp.engine(device=local, rank=rank, world=world)
+    devices = [None] * world
+    dist.all_gather_object(devices, device_identity(torch, local))
+    if len(set(devices)) != world:
+        raise SystemExit(f"[rccl leg, rank {rank}] ranks do not hold distinct GPUs: {devices}")
     init_engine_communicator(eng)  # ncclCommInitRank; the unique id travels through torch.distributed
     rng = np.random.default_rng(1234)
     thetas = [comp.theta(draw_params(comp_name, rng)) for _ in range(64)]
@@ -1102,7 +1267,7 @@ def rccl_leg_main(argv):
         print(json.dumps({"evals_per_s": n / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / n, "steps": n, "rccl_ranks": world, "workload": desc,
                           "exchange": "one ncclAllGather of the ~1 KiB partial records per evaluation, on the engine's own stream (gwi_eval_sharded)",
                           "last_log_likelihood": float(ll[-1]), "identical_on_all_ranks": bool(same), "sharded_vs_single_gpu": sharded_check,
-                          "two_pass_repeats": eng.two_pass_repeats()}), flush=True)
+                          "two_pass_repeats": eng.two_pass_repeats(), "unique_devices": len(set(devices)) == world, "devices": devices}), flush=True)
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -1120,7 +1285,11 @@ def run_rccl_leg(args):
         env.setdefault(k, v)
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)  # the child makes a plain env:// rendezvous of its own (rank 0 hosts the store)
-    limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", "150"))
+    world = int(env.get("WORLD_SIZE", "1"))
+    env.setdefault("NCCL_DEBUG", "WARN")  # a failed first contact should say why: the warnings' tail goes into multi_gpu.rccl_probe
+    # communicator start-up grows with the ranks (a ring over xGMI per channel, one bootstrap connection per peer), and so do N
+    # processes importing torch and loading the code objects side by side: 120 s + 15 s per rank unless told otherwise
+    limit = float(os.environ.get("GWI_BENCH_RCCL_TIMEOUT", str(120 + 15 * world)))
     cmd = [sys.executable, os.path.abspath(__file__), RCCL_LEG_FLAG, "--config", args.config, "--steps", str(max(200, min(args.steps, 2000)))]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
@@ -1130,7 +1299,10 @@ def run_rccl_leg(args):
         child.kill()  # this exact PID
         out, err = child.communicate()
         code = 124
-    res = {"child_exit_code": code}
+    res = {"child_exit_code": code, "time_limit_s": limit}
+    warn = [ln for ln in (err or "").splitlines() if "NCCL WARN" in ln or "RCCL" in ln and "error" in ln.lower()]
+    if code != 0:
+        res["rccl_debug_tail"] = (" | ".join(warn) or (err or "").strip())[-300:]
     lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
     if lines and code == 0:
         try:
@@ -1152,7 +1324,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="headline configuration (default: BASELINE config 2, the one the metric is quoted on)")
-    ap.add_argument("--also", default=None, help="comma-separated further configs reported under `configs` (default: c3,c5 when the headline is c2; 'none' disables)")
+    ap.add_argument("--also", default=None, help="comma-separated further configs reported under `configs` (default with headline c2: c3,c5,b50k,def50k at N = 1, c3,c5 at N > 1; 'none' disables)")
+    ap.add_argument("--full", action="store_true", help="also run the secondary legs (sets in flight, the other batched kernels, chains, the library's NUTS, host-side setup, NumPy reference formulation); they go to the detail file")
+    ap.add_argument("--detail", default="bench_detail.json", help="side file for everything that is not in the compact line ('' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-batch", type=int, default=16, help="also time batched evaluation (K hyper-points per launch); 0 disables")
     ap.add_argument("--chains", type=int, default=4, help="also time this many independent chains interleaved on one GPU (begin/end); <= 1 disables")
@@ -1188,22 +1362,28 @@ def main():
             chk = rccl_leg.get("sharded_vs_single_gpu") or {}
             mine = mine and bool(chk.get("within_tolerance")) and bool(rccl_leg.get("identical_on_all_ranks")) and rccl_leg.get("rccl_ranks") == run.world
         prefer_rccl = run.all_agree(mine)
+        # what the OTHER ranks' children said when they failed (rank 0's own child may merely have timed out waiting for them)
+        fails = [r for r in run.gather_rows({"rank": run.rank, "child_exit_code": rccl_leg.get("child_exit_code"), "tail": rccl_leg.get("rccl_debug_tail")}) if r["child_exit_code"] != 0]
         if run.rank == 0:
             rccl_leg["probe_clean_on_every_rank"] = bool(prefer_rccl)
+            if fails:
+                rccl_leg["failed_ranks"] = fails[:8]
+                if not rccl_leg.get("rccl_debug_tail"):
+                    rccl_leg["rccl_debug_tail"] = f"rank {fails[0]['rank']}: {fails[0]['tail']}"[-300:]
     also = args.also
     if also is None:
-        also = "c3,c5" if args.config == "c2" else "none"
+        also = ("c3,c5,b50k,def50k" if args.gpus == 1 else "c3,c5") if args.config == "c2" else "none"
     extra_cfgs = [c for c in also.split(",") if c and c != "none" and c != args.config]
 
     head = measure(run, args.config, args.steps, args.warmup, args.timing_every, spin_s=args.spin, headline=True, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch,
-                   chains=args.chains, prefer_rccl=prefer_rccl)
+                   chains=args.chains, prefer_rccl=prefer_rccl, full=args.full, cpu_budget_s=6.0)
     blocks = {}
     for cfg in extra_cfgs:
         # the other BASELINE configurations with the same procedure (their own warm-up, K and latency blocks: sized so that
         # the default run stays within minutes)
         k = {"c5": 300, "c3": 600}.get(cfg, 600)
         blocks[cfg] = measure(run, cfg, k, 50, args.timing_every, spin_s=min(args.spin, 0.3), headline=False, with_cpu=not args.no_cpu_baseline, k_batch=args.k_batch, chains=0,
-                              nuts_chains=args.chains, prefer_rccl=prefer_rccl)
+                              nuts_chains=args.chains, prefer_rccl=prefer_rccl, full=args.full, cpu_budget_s=2.0)
 
     if run.rank == 0:
         out = {
@@ -1246,7 +1426,15 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
+        detail_path = None
+        if args.detail:
+            try:
+                with open(args.detail, "w") as fh:
+                    json.dump(strict(out), fh, allow_nan=False, indent=1)
+                detail_path = args.detail
+            except OSError as exc:
+                print(f"[bench] could not write {args.detail}: {exc}", file=sys.stderr)
+        print(dump_line(compact_line(out, detail_path)), flush=True)  # the ONE JSON line, last thing on stdout
     if run.dist is not None:
         # the line is out: a rank that does not come back from the shutdown (a peer lost in the RCCL variant) must not
         # hold the run

@@ -141,6 +141,30 @@ def test_rccl_eight_ranks_on_eight_gpus(tmp_path):
     check(results, configs, 8)
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def check_compact_line(stdout, world):
+    """The LAST line of bench.py's stdout: strict JSON, at most 4 KB, the contract's keys, and for the N > 1 path a short `multi_gpu` block."""
+    last = stdout.strip().splitlines()[-1]
+    assert last.startswith("{") and len(last.encode()) <= 4096, (len(last), last[:200])
+
+    def refuse(name):
+        raise ValueError(name)
+
+    line = json.loads(last, parse_constant=refuse)
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    assert line["n_gpus"] == world and line["value"] > 0 and line["ms_per_step"] > 0 and line["dtype"] == "f64"
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and roof["avg_kernel_us"]["scan"] > 0
+    mg = line["multi_gpu"]
+    assert mg["ranks"] == world and mg["rccl_ranks"] in (0, world) and len(mg["per_rank_events"]) == world and sum(mg["per_rank_events"]) == 69
+    chk = mg["sharded_vs_single_gpu"]
+    assert chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
+    return line
+
+
 def test_bench_rccl_leg_compares_with_the_unsharded_engine(tmp_path):
     """bench.py's in-engine RCCL leg (a child per rank; here a world of one rank) reports `sharded_vs_single_gpu` like the
     shared-memory path: the gathered-record result against an unsharded engine, value and whole gradient."""
@@ -171,8 +195,9 @@ def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
     env = dict(os.environ, GWI_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    detail_file = str(tmp_path / "detail.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20", "--also", "none", "--no-cpu-baseline", "--k-batch", "0", "--chains", "0",
-           "--spin", "0.1"]
+           "--spin", "0.1", "--detail", detail_file]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         out, err = child.communicate(timeout=600)
@@ -181,7 +206,10 @@ def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
         out, err = child.communicate()
         pytest.fail("bench.py did not finish within 600 s and was killed\n" + (err or "")[-1500:])
     assert child.returncode == 0, (err or "")[-2000:]
-    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    compact = check_compact_line(out, world=1)
+    assert compact["multi_gpu"]["rccl_ranks"] == 1 and compact["multi_gpu"]["rccl_probe"]["child_exit_code"] == 0 and compact["detail"] == detail_file
+    line = json.load(open(detail_file))  # everything else: the side file
+    assert line["value"] == pytest.approx(compact["value"], rel=1e-5)
     mg = line["multi_gpu"]
     assert mg["ranks"] == 1 and mg["rccl_ranks"] == 1, mg
     ex = mg["exchanges"]
@@ -196,7 +224,8 @@ def test_bench_multi_gpu_headline_is_the_rccl_exchange(tmp_path):
     env["MASTER_PORT"] = str(_free_port())
     out2 = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
-    mg2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][-1])["multi_gpu"]
+    assert check_compact_line(out2.stdout, world=1)["multi_gpu"]["rccl_ranks"] == 0
+    mg2 = json.load(open(detail_file))["multi_gpu"]
     assert mg2["rccl_ranks"] == 0 and mg2["exchanges"]["shm"]["headline"] is True
 
 
@@ -211,7 +240,7 @@ def test_bench_in_the_drivers_launch_form_with_two_ranks_on_this_box(tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20"]
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, start_new_session=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path), start_new_session=True)
     try:
         out, err = child.communicate(timeout=900)
     except subprocess.TimeoutExpired:
@@ -221,8 +250,17 @@ def test_bench_in_the_drivers_launch_form_with_two_ranks_on_this_box(tmp_path):
     assert child.returncode == 0, (err or "")[-2500:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-1500:]  # rank 0 prints ONE line
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 200 and line["warmup"] == 20 and line["scaling"] == "strong" and line["value"] > 0
+    compact = check_compact_line(out, world=2)
+    assert compact["steps"] == 200 and compact["warmup"] == 20 and compact["scaling"] == "strong"
+    # rccl_ranks: the ranks of the communicator that carried the HEADLINE's records -- the world with a GPU per rank, 0 when the ranks share one
+    assert compact["multi_gpu"]["rccl_ranks"] == (2 if _device_count() >= 2 else 0)
+    assert compact["multi_gpu"]["per_rank_events"] == [35, 34] and set(compact["configs"]) == {"c3", "c5"}
+    for blk in compact["configs"].values():  # the B-spline configs sharded the same way, each against the unsharded engine
+        chk = blk["multi_gpu"]["sharded_vs_single_gpu"]
+        assert blk["value"] > 0 and chk["log_likelihood_rel_err"] <= 1e-9 and chk["grad_max_err_over_scale"] <= 1e-8
+    assert compact["detail"] == "bench_detail.json"  # written to the working directory (here: tmp_path)
+    line = json.load(open(tmp_path / "bench_detail.json"))
+    assert line["n_gpus"] == 2 and line["value"] == pytest.approx(compact["value"], rel=1e-5)
     mg = line["multi_gpu"]
     assert mg["ranks"] == 2 and len(mg["per_rank"]) == 2
     assert sorted(r["n_ev"] for r in mg["per_rank"]) == [34, 35] and all(r["n_inj"] == 25000 for r in mg["per_rank"])  # SURVEY 8e's partition of 69 events / 50 k injections

@@ -157,7 +157,7 @@ def main(round_name, dst=None):
             how = "compiled at gwi_create (hipRTC, GWI_FORCE_JIT=1)" if mode == "jit" else "generic kernel: run-time term loop (GWI_FORCE_GENERIC=1)"
             c_lines.append(f"| {cfg} | {r['Name'].split('(')[0].replace('void ', '')[:70]} | {how} | {r['Calls']} | {t_us:.2f} | {gbs:.0f} | {gbs / 8000.0:.3f} | {bench.get('value', float('nan')):.0f} |")
             traffic.setdefault("other_chains", {})[f"{cfg}_{mode}"] = {"scan_avg_us_rocprof": t_us, "algorithmic_gbs": gbs, "frac_of_8tbs": gbs / 8000.0, "evals_per_s": bench.get("value"),
-                                                                       "scan_chain": bench.get("scan_chain")}
+                                                                       "scan_chain": bench.get("scan_chain") or bench.get("roofline", {}).get("kernel")}
     if len(c_lines) > 2:
         lines += ["", "The same single evaluations when the model's term sequence has NO ahead-of-time chain: the chain hipRTC compiles at gwi_create, and the generic kernel that runs where hipRTC is missing:", ""] + c_lines
     with open(os.path.join(dst, "SUMMARY.md"), "w") as fh:
