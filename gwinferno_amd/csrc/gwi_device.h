@@ -1313,8 +1313,8 @@ struct ChainImpl<U, TAKEN, K, Rest...> {
 //      terms are evaluated once for the value (columns loaded on the spot, no prefetch) and once more for the gradient,
 //      whose every entry -- scalar parameters included -- goes through the workgroup's LDS rows like the spline
 //      coefficients of the compiled chains (kSpline = true selects that mode of scan_kernel).  No register state indexed by
-//      a run-time term number, hence no scratch; several times slower than a compiled chain, which
-//      `python -m gwinferno_amd.add_variant` builds when it matters.
+//      a run-time term number, hence no scratch; 2-2.7 x the scan time of a compiled chain, which gwi_create obtains from
+//      hipRTC where it can (gwi_jit.h); this kernel is what runs where it cannot.
 constexpr int kGenericChain = 0;
 #define GWI_FOR_EACH_KIND(X)                                                                                             \
   X(GWI_TERM_POWERLAW) X(GWI_TERM_PLPEAK) X(GWI_TERM_POWERLAW_RATIO) X(GWI_TERM_BETA) X(GWI_TERM_TILT_MIXTURE)           \
@@ -2106,6 +2106,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
               for (int u = 0; u < kU; ++u) {
                 if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
                 double w = weight(u), wfac = 1.0;
+                if constexpr (ChainT::kAbsorb) wfac = w > 0.0 ? 1.0 : 0.0;  // a rejected weight takes the absorbing term's pre-weighted states with it
                 if (a.square) {
                   wfac = w;
                   w *= w;
@@ -2150,6 +2151,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
         for (int u = 0; u < kU; ++u) {
           if (u > 0 && i + u * kBlock - lane >= n_tile) continue;
           double w = weight(u, m), wfac = 1.0;
+          if constexpr (ChainT::kAbsorb) wfac = w > 0.0 ? 1.0 : 0.0;  // (as above: value and gradient stay consistent)
           if (a.square) {
             wfac = w;
             w *= w;
@@ -2513,6 +2515,7 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
       if constexpr (ChainT::kAbsorb) {
         const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u] - m, 0);
         w = (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+        wfac = w > 0.0 ? 1.0 : 0.0;  // a rejected weight takes the absorbing term's pre-weighted states with it
       } else {
         w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
       }

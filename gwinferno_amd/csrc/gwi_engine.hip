@@ -209,7 +209,6 @@ const Variant kVariants[] = {
     GWI_VARIANT("smooth", K_SM),
     GWI_VARIANT("plpeaksmooth", K_PS),
 #endif
-#include "gwi_user_variants.inc"
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -387,15 +386,19 @@ struct gwi_engine {
   bool batch_rows = false;            // ... with the gradient in LDS rows (scan_rows_kernel) instead of MFMA tiles
   int rows_rep = 4;
   int mfma_min_batch = 9;             // ... from this many points per launch (a wave carries 16)
-  // which of the two batched kernels a spline model runs is MEASURED on its first batched launch (calibrate_batch_path): three
-  // launches of each on the caller's own points, the faster one stays.  Off where the environment names a path.
+  // which of the two batched kernels a spline model runs follows a STATIC rule (matrix cores from 9 points on when the model has
+  // <= 8 gradient tiles): the two kernels sum in different orders, so the choice must not depend on a race of wall times -- same
+  // model + same catalog shape = same kernel = same bits, on every handle and every box.  GWI_BATCH_AUTOTUNE=1 opts into the
+  // measurement (calibrate_batch_path: three launches of each on the caller's own points on the first batched launch, the faster
+  // one stays; per handle, costs 8 extra evaluation sets once, and results then depend on which kernel won).
   // a spline model without an ahead-of-time matrix-core instantiation gets one compiled (gwi_jit.h) on its first batched launch
-  // of >= 9 points -- where both kernels are then measured -- or at gwi_create when GWI_BATCH_MFMA=1 asks for that path
+  // of >= 9 points, or at gwi_create when GWI_BATCH_MFMA=1 asks for that path
   MfmaVariant* jit_mfma = nullptr;    // owned record of that instantiation (mfma points at it once it is loaded)
   hipFunction_t jit_mfma_fn = nullptr;
   bool mfma_jit_pending = false;      // worth trying, not tried yet
   std::string mfma_jit_note;
-  bool batch_autotune = false;        // a choice is still to be made
+  bool autotune_wanted = false;       // GWI_BATCH_AUTOTUNE=1
+  bool batch_autotune = false;        // a choice is still to be made (only ever true when autotune_wanted)
   bool batch_measured = false;        // ... and has been
   double batch_us[2] = {0.0, 0.0};    // best wall time of one batched evaluation set: [matrix-core kernel, 4-tap kernel]
   size_t mfma_lds_bytes = 0;
@@ -1065,7 +1068,7 @@ gwi_status calibrate_batch_path(gwi_handle h, const double* theta, int K) {
 }
 
 gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = nullptr, bool wait = true, int K = 1, bool batch = false, bool square = false) {
-  if (batch && h->mfma_jit_pending && K >= h->mfma_min_batch && wait && !record_dev) h->batch_autotune = try_jit_mfma(h);
+  if (batch && h->mfma_jit_pending && K >= h->mfma_min_batch && wait && !record_dev) h->batch_autotune = try_jit_mfma(h) && h->autotune_wanted;
   if (batch && h->batch_autotune && h->mfma && K >= h->mfma_min_batch && wait && !record_dev) {
     const gwi_status sc = calibrate_batch_path(h, theta, K);
     if (sc != GWI_OK) return sc;
@@ -1715,7 +1718,7 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
       for (int t = 0; t < spec->n_terms; ++t) cmd += (t ? " " : "") + std::to_string(spec->terms[t].kind);
       std::fprintf(stderr,
                    "gwi: term-kind sequence [%s] has no ahead-of-time scan kernel and none could be compiled now (%s): using the generic one (run-time term loop, "
-                   "several times slower).  `python -m gwinferno_amd.add_variant %s` adds an ahead-of-time chain (~1 min, then restart the process).\n",
+                   "2-2.7 x the scan time).  `python -m gwinferno_amd.precompile %s` on a machine with libhiprtc fills a cache directory this one can be pointed at (GWI_JIT_CACHE).\n",
                    cmd.c_str(), h->jit_note.c_str(), cmd.c_str());
     }
   }
@@ -1950,16 +1953,16 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
       }
       if (std::atoi(env) >= 2) h->mfma_min_batch = 1;
     }
-    // no path named by the environment: measure on the first batched launch which kernel this model and catalog prefer
-    // (config 3 is a tie that flips from box to box; config 5 prefers the matrix cores by 15 %)
-    h->batch_autotune = h->mfma && !std::getenv("GWI_BATCH_MFMA") && !std::getenv("GWI_BATCH_ROWS") && !h->deterministic;
-    if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) h->batch_autotune = h->batch_autotune && std::atoi(env) != 0;
-    // a spline model without an ahead-of-time matrix-core instantiation: compiled on its first batched launch of >= 9 points and
-    // measured against the 4-tap kernel there (GWI_BATCH_MFMA=1: compiled now and used; GWI_JIT=0 / GWI_BATCH_AUTOTUNE=0: not at all)
+    // no path named by the environment: the static rule above stands (config 3 is a tie between the kernels that flipped from box
+    // to box when it was measured by default, config 5 prefers the matrix cores by 15 %); GWI_BATCH_AUTOTUNE=1 measures instead
+    if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) h->autotune_wanted = std::atoi(env) != 0;
+    h->batch_autotune = h->autotune_wanted && h->mfma && !std::getenv("GWI_BATCH_MFMA") && !std::getenv("GWI_BATCH_ROWS") && !h->deterministic;
+    // a spline model without an ahead-of-time matrix-core instantiation: compiled on its first batched launch of >= 9 points and used
+    // from then on (GWI_BATCH_MFMA=1: compiled now; GWI_JIT=0 or GWI_BATCH_MFMA=0: not at all; GWI_BATCH_AUTOTUNE=1: measured against
+    // the 4-tap kernel there)
     {
       bool jit_ok = !h->generic && !h->deterministic && !find_mfma_variant(*spec) && !std::getenv("GWI_BATCH_ROWS");
       if (const char* env = std::getenv("GWI_JIT")) jit_ok = jit_ok && std::atoi(env) != 0;
-      if (const char* env = std::getenv("GWI_BATCH_AUTOTUNE")) jit_ok = jit_ok && std::atoi(env) != 0;
       const char* want = std::getenv("GWI_BATCH_MFMA");
       if (jit_ok && want && std::atoi(want) >= 1) {
         if (try_jit_mfma(h) && std::atoi(want) >= 2) h->mfma_min_batch = 1;
@@ -2594,8 +2597,9 @@ gwi_status gwi_eval_batch_begin(gwi_handle h, const double* thetas, int32_t k_ba
   h->pending_k = k_batch;
   h->pending_thetas.assign(thetas, thetas + (size_t)k_batch * h->spec.n_theta);  // a repeat (reference exponent outrun) needs the points again
   h->batch_events = want_events != 0;
-  // which of its two batched kernels a spline model runs is measured on its first batched launch: blocking, here
-  if (h->mfma_jit_pending && k_batch >= h->mfma_min_batch) h->batch_autotune = try_jit_mfma(h);
+  // a matrix-core kernel still to be compiled is compiled on the first batched launch, and (GWI_BATCH_AUTOTUNE=1 only) measured
+  // against the 4-tap kernel: blocking, here
+  if (h->mfma_jit_pending && k_batch >= h->mfma_min_batch) h->batch_autotune = try_jit_mfma(h) && h->autotune_wanted;
   if (h->batch_autotune && h->mfma && k_batch >= h->mfma_min_batch) {
     st = calibrate_batch_path(h, thetas, k_batch);
     if (st != GWI_OK) return st;

@@ -32,10 +32,13 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
 
+#include <cctype>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -140,16 +143,44 @@ inline unsigned long long fnv1a(const void* data, size_t n, unsigned long long h
   return h;
 }
 
-inline bool make_dirs(const std::string& path) {
-  for (size_t i = 1; i <= path.size(); ++i)
-    if (i == path.size() || path[i] == '/') {
-      const std::string sub = path.substr(0, i);
-      if (mkdir(sub.c_str(), 0700) != 0 && errno != EEXIST) return false;
-    }
+// A cache directory is trusted only if it is OURS: a real directory (not a link), owned by this user, writable by nobody else.
+// What it holds is loaded onto the GPU inside this process, so a directory someone else could have prepared -- the predictable
+// /tmp fallback above all -- is skipped, and the caller goes on to the next candidate or compiles without a cache.
+inline bool trusted_dir(const std::string& path, std::string* why = nullptr) {
+  struct stat st;
+  if (lstat(path.c_str(), &st) != 0) {
+    if (why) *why = path + ": " + std::strerror(errno);
+    return false;
+  }
+  if (!S_ISDIR(st.st_mode)) {
+    if (why) *why = path + " is not a directory (a symbolic link is not followed)";
+    return false;
+  }
+  if (st.st_uid != geteuid()) {
+    if (why) *why = path + " belongs to another user";
+    return false;
+  }
+  if (st.st_mode & (S_IWGRP | S_IWOTH)) {
+    if (why) *why = path + " is writable by group or others";
+    return false;
+  }
   return access(path.c_str(), W_OK | X_OK) == 0;
 }
 
-// where compiled chains are kept; "" when nowhere is writable (every process then compiles for itself)
+inline bool make_dirs(const std::string& path, std::string* why = nullptr) {
+  for (size_t i = 1; i <= path.size(); ++i)
+    if (i == path.size() || path[i] == '/') {
+      const std::string sub = path.substr(0, i);
+      if (mkdir(sub.c_str(), 0700) != 0 && errno != EEXIST) {
+        if (why) *why = sub + ": " + std::strerror(errno);
+        return false;
+      }
+    }
+  return trusted_dir(path, why);
+}
+
+// where compiled chains are kept; "" when no candidate is both writable and trusted (every process then compiles for itself,
+// and says so once)
 inline std::string cache_dir() {
   std::vector<std::string> cands;
   if (const char* e = std::getenv("GWI_JIT_CACHE")) {
@@ -162,15 +193,53 @@ inline std::string cache_dir() {
       if (*hm) cands.push_back(std::string(hm) + "/.cache/gwinferno_amd");
     cands.push_back("/tmp/gwinferno_amd-" + std::to_string((long)getuid()));
   }
-  for (const std::string& c : cands)
-    if (make_dirs(c)) return c;
+  std::string refused;
+  for (const std::string& c : cands) {
+    std::string why;
+    if (make_dirs(c, &why)) return c;
+    refused += (refused.empty() ? "" : "; ") + why;
+  }
+  static std::once_flag said;
+  std::call_once(said, [&] {
+    if (!std::getenv("GWI_QUIET"))
+      std::fprintf(stderr, "gwinferno_amd: no trusted cache directory for run-time compiled kernels (%s): compiling in this process only\n", refused.c_str());
+  });
   return "";
 }
 
-// cache file: "GWIJIT1\n", the five lowered names (one per line, empty lines for absent roles), then the code object
+// two independent 64-bit FNV-1a passes over everything a cache file holds besides the digest itself
+inline void digest_of(const Chain& c, unsigned long long out[2]) {
+  const unsigned long long seeds[2] = {1469598103934665603ull, 0x9e3779b97f4a7c15ull};
+  for (int k = 0; k < 2; ++k) {
+    unsigned long long h = fnv1a(&c.n, sizeof(c.n), seeds[k]);
+    h = fnv1a(c.kinds, sizeof(int) * (size_t)c.n, h);
+    h = fnv1a(&c.samples_per_lane, sizeof(c.samples_per_lane), h);
+    for (int r = 0; r < kRoles; ++r) h = fnv1a(c.lowered[r].c_str(), c.lowered[r].size() + 1, h);
+    out[k] = fnv1a(c.code.data(), c.code.size(), h);
+  }
+}
+inline bool plausible_symbol(const std::string& s) {
+  for (const char ch : s)
+    if (!(std::isalnum((unsigned char)ch) || ch == '_' || ch == '$' || ch == '.')) return false;
+  return s.size() < 4096;
+}
+
+// cache file: "GWIJIT2\n", the five lowered names (one per line, empty lines for absent roles), a line with the digest of
+// (kinds, samples per lane, names, code object) in hex, then the code object.  A file is used only if it is a regular file of
+// this user (opened without following links) whose digest matches -- a damaged or foreign file is recompiled over, never loaded.
 inline bool read_cache(const std::string& path, Chain& c) {
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+    close(fd);
+    return false;
+  }
+  FILE* f = fdopen(fd, "rb");
+  if (!f) {
+    close(fd);
+    return false;
+  }
   std::vector<char> all;
   char buf[65536];
   size_t got;
@@ -185,20 +254,38 @@ inline bool read_cache(const std::string& path, Chain& c) {
     ++pos;
     return true;
   };
-  std::string magic;
-  if (!line(magic) || magic != "GWIJIT1") return false;
+  auto reject = [&] {
+    for (int r = 0; r < kRoles; ++r) c.lowered[r].clear();
+    c.code.clear();
+    return false;
+  };
+  std::string magic, hex;
+  if (!line(magic) || magic != "GWIJIT2") return false;
   for (int r = 0; r < kRoles; ++r)
-    if (!line(c.lowered[r])) return false;
-  if (all.size() - pos < 64 || std::memcmp(all.data() + pos, "\177ELF", 4) != 0) return false;
+    if (!line(c.lowered[r]) || !plausible_symbol(c.lowered[r])) return reject();
+  if (!line(hex) || hex.size() != 32) return reject();
+  if (all.size() - pos < 64 || std::memcmp(all.data() + pos, "\177ELF", 4) != 0) return reject();
   c.code.assign(all.begin() + (long)pos, all.end());
+  unsigned long long want[2];
+  digest_of(c, want);
+  char have[40];
+  std::snprintf(have, sizeof(have), "%016llx%016llx", want[0], want[1]);
+  if (hex != have) return reject();
   return true;
 }
 inline bool write_cache(const std::string& path, const Chain& c) {
   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) return false;
-  bool ok = std::fputs("GWIJIT1\n", f) >= 0;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+  if (!f) {
+    if (fd >= 0) close(fd);
+    return false;
+  }
+  unsigned long long dg[2];
+  digest_of(c, dg);
+  bool ok = std::fputs("GWIJIT2\n", f) >= 0;
   for (int r = 0; r < kRoles; ++r) ok = ok && std::fprintf(f, "%s\n", c.lowered[r].c_str()) >= 0;
+  ok = ok && std::fprintf(f, "%016llx%016llx\n", dg[0], dg[1]) >= 0;
   ok = ok && std::fwrite(c.code.data(), 1, c.code.size(), f) == c.code.size();
   ok = (std::fclose(f) == 0) && ok;
   if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {

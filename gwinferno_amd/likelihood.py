@@ -54,6 +54,7 @@ def clear_engine_cache():
     memory is released when the last reference goes (``NativePopulationLikelihood.__del__``)."""
     _ENGINES.clear()
     _ONE_SIDED.clear()
+    _INTERNED.clear()
 
 
 def _is_traced(values):
@@ -490,6 +491,8 @@ def construct_hierarchical_model(
 
 
 _ONE_SIDED = {}
+_ZEROS = {}     # shape -> the one zeros column array-valued weights of that shape share (_array_density)
+_INTERNED = {}  # (shape, content hash) -> the first array seen with that content
 
 
 def _cut(arr, side):
@@ -527,7 +530,23 @@ def _array_density(weights, log):
 
     w = np.ascontiguousarray(weights, dtype=np.float64)
     side = side_of(w)
-    zeros = np.zeros(w.shape)
+    # The engine caches key columns and static factors by IDENTITY of their source arrays (lazy.Column.key, static_key); the
+    # reference calls these functions once per likelihood evaluation with a freshly computed array, so equal arrays must map to
+    # the same objects here or every call would build (and evict) an engine: one shared zeros column per shape, and the weights
+    # themselves interned by a content hash (one pass over the data, as LogValues(values=...) does for log-weights).
+    zeros = _ZEROS.get(w.shape)
+    if zeros is None:
+        zeros = _ZEROS[w.shape] = np.zeros(w.shape)
+        while len(_ZEROS) > 8:
+            _ZEROS.pop(next(iter(_ZEROS)))
+    if not log:
+        import hashlib
+
+        digest = (w.shape, hashlib.blake2b(memoryview(w).cast("B"), digest_size=16).hexdigest())
+        w = _INTERNED.setdefault(digest, w)
+        _INTERNED[digest] = _INTERNED.pop(digest)  # most recently used last
+        while len(_INTERNED) > max(1, int(os.environ.get("GWI_ENGINE_CACHE", "8"))):
+            _INTERNED.pop(next(iter(_INTERNED)))
     unit = Factor(N.TERM_POWERLAW, side, [Column("id", zeros)], [0.0], consts=(0.0, 1.0), flags=N.POWERLAW_UNNORMALISED, tag="array-weights")
     return Density([unit], side, [(1.0, LogValues(values=w) if log else w)], 0.0)
 

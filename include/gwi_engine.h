@@ -323,11 +323,13 @@ gwi_status gwi_eval_batch_end(gwi_handle h, gwi_summary* summaries, double* grad
  * Models without spline terms: "pbatch" (every sample loaded once for all the points of a grid row, scan_pbatch_kernel;
  * GWI_PBATCH=0 or tiles of more than one trip: "rows-per-point", one grid row per point). */
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
-/* Spline models that have both batched kernels: which one runs is measured on the engine's FIRST batched launch of >= 9 points
- * (three evaluation sets of each on the caller's own points, host theta -> host results; the faster stays) unless the
- * environment names a path (GWI_BATCH_MFMA, GWI_BATCH_ROWS) or GWI_BATCH_AUTOTUNE=0 keeps the static rule (matrix cores up to
- * 8 gradient tiles).  gwi_batch_path answers with the static rule before that launch and with the measured choice after it;
- * this returns whether the measurement has been made and the best microseconds per evaluation set of either kernel. */
+/* Spline models that have both batched kernels: which one runs follows a STATIC rule by default (matrix cores from 9 points per
+ * launch on, up to 8 gradient tiles; otherwise the 4-tap kernel) -- the two kernels sum in different orders, so the same model on
+ * the same catalog must not get one or the other from a race of wall times.  The environment can name a path (GWI_BATCH_MFMA,
+ * GWI_BATCH_ROWS) or, with GWI_BATCH_AUTOTUNE=1, ask for a measurement on the engine's FIRST batched launch of >= 9 points (three
+ * evaluation sets of each on the caller's own points, host theta -> host results; the faster stays; per handle; last-bit results
+ * then depend on which kernel won).  gwi_batch_path answers with the static rule, or with the measured choice after that launch;
+ * this returns whether a measurement has been made and the best microseconds per evaluation set of either kernel. */
 gwi_status gwi_batch_calibration(gwi_handle h, int32_t* measured, double* mfma_us, double* taps_us);
 /* A spline model whose kinds and basis counts have no ahead-of-time matrix-core instantiation gets one compiled at run time
  * (gwinferno_amd/csrc/gwi_jit.h) on its first batched launch of >= 9 points (at gwi_create with GWI_BATCH_MFMA=1): this says what
@@ -437,8 +439,8 @@ const char* gwi_dispatch_info(gwi_handle h);
 /* Name of the scan kernel this engine runs: the compiled term chain ("plq+plz+spline5", ...; gwi_kernel_variant_name) or
  * "generic (run-time term loop)" -- any product of <= GWI_MAX_TERMS terms has a kernel (the reference's model function
  * multiplies whatever densities the user picks: tests/inference_test.py:256-260, examples/simple_bspline_example.py:58-71);
- * products outside the compiled set run the generic kernel, several times slower, and `python -m gwinferno_amd.add_variant`
- * adds a compiled chain where that matters. */
+ * products outside the ahead-of-time set get a chain compiled at gwi_create ("jit:...", below); the generic kernel (2-2.7 x the
+ * scan time) runs only where that is impossible. */
 const char* gwi_scan_kernel_name(gwi_handle h);
 
 /* ---- scan chains compiled at run time (gwinferno_amd/csrc/gwi_jit.h) ---------------------------------------------------
@@ -446,12 +448,16 @@ const char* gwi_scan_kernel_name(gwi_handle h);
  * models/bsplines/separable.py:295-778).  A product of terms whose kind sequence has no ahead-of-time scan kernel gets one
  * at gwi_create: the scan template instantiated for exactly that sequence by hipRTC (gfx950, the flags of the library's
  * own build, from the headers embedded in the library), kept as a code object under $GWI_JIT_CACHE (default
- * ~/.cache/gwinferno_amd).  Without hipRTC (or with GWI_JIT=0) such models run the generic kernel.
+ * ~/.cache/gwinferno_amd).  Without hipRTC (or with GWI_JIT=0) such models run the generic kernel.  The cache is trusted only as
+ * far as it is the caller's: a directory that is a link, belongs to another user or is writable by group / others is skipped
+ * (next candidate, else compile in this process only, said once on stderr); a cache file is a regular 0600 file of this user
+ * carrying a digest of (kinds, samples per lane, kernel names, code object) and is compiled over, never loaded, when it does not
+ * match (tests/test_jit_cache_cpu.py).
  *
  * gwi_jit_compile(): compile (or find in the cache) the chain of `kinds` (GWI_TERM_* numbers, ascending) with
  * `samples_per_lane` (1 | 2) samples per lane -- needs no GPU (samples_per_lane = 0: the batched matrix-core kernel of a spline
  * model instead, `kinds` then being kind + 100 x 16-basis gradient tiles of each term, as gwi_batch_kernel_note names it).  path_out (nullable, path_cap bytes) receives the cache file
- * ("" when no cache directory is writable), or the reason on failure; compile_seconds = hipRTC time spent by THIS call chain
+ * ("" when no cache directory is both writable and trusted), or the reason on failure; compile_seconds = hipRTC time spent by THIS call chain
  * (0 when the code object came from the cache), from_cache = 1 then.  GWI_ERR_UNSUPPORTED: hipRTC missing / compilation failed.
  * gwi_jit_info(): whether this engine's scan kernel was compiled at run time, what that cost this process and whether the
  * disk cache supplied it; note = why the generic kernel runs where it does ("" otherwise).  All outputs nullable. */

@@ -355,7 +355,8 @@ def test_matrix_core_batched_kernel_compiled_at_run_time(which, monkeypatch, tmp
     """A spline model whose kinds and basis counts have no ahead-of-time instantiation of the batched matrix-core kernel
     (gwi_mfma.h) gets one from hipRTC: forced with GWI_BATCH_MFMA=1 (compiled at gwi_create) it is held against single
     evaluations, the C oracle and itself (bit-reproducible); left alone, the engine compiles it on its first batched launch of
-    >= 9 points and measures it against the 4-tap kernel like an ahead-of-time one."""
+    >= 9 points and uses it from then on (the static rule); with GWI_BATCH_AUTOTUNE=1 it measures it against the 4-tap kernel
+    like an ahead-of-time one."""
     from gwinferno_amd.synthetic import make_catalog
     from oracle.c_oracle import COracle
 
@@ -385,12 +386,18 @@ def test_matrix_core_batched_kernel_compiled_at_run_time(which, monkeypatch, tmp
         assert float(np.max(np.abs(a[0].grad - ref["grad"]))) / scale < 1e-8
     forced.close()
     monkeypatch.delenv("GWI_BATCH_MFMA")
-    auto = cls(pe, inj).engine()
-    assert auto.batch_path(16) == "taps" and auto.batch_calibration()["matrix_core_kernel"] == ""  # nothing compiled, nothing measured yet
-    batch = auto.evaluate_batch(thetas[:16], total, min_neff_cut=False)
-    cal = auto.batch_calibration()
-    assert cal["measured"] and cal["matrix_core_kernel"].startswith("compiled jit-mfma:") and cal["mfma_us"] > 0 and cal["taps_us"] > 0
-    assert auto.batch_path(16) == ("mfma" if cal["mfma_us"] <= cal["taps_us"] else "taps")
-    for k in range(16):
-        assert rel_err(batch[k].log_likelihood, singles[k].log_likelihood) < 1e-12 and np.allclose(batch[k].grad, singles[k].grad, rtol=1e-10, atol=1e-11)
-    auto.close()
+    for autotune in (False, True):
+        if autotune:
+            monkeypatch.setenv("GWI_BATCH_AUTOTUNE", "1")
+        auto = cls(pe, inj).engine()
+        assert auto.batch_path(16) == "taps" and auto.batch_calibration()["matrix_core_kernel"] == ""  # nothing compiled, nothing measured yet
+        batch = auto.evaluate_batch(thetas[:16], total, min_neff_cut=False)
+        cal = auto.batch_calibration()
+        assert cal["matrix_core_kernel"].startswith("compiled jit-mfma:") and cal["measured"] == autotune
+        if autotune:
+            assert cal["mfma_us"] > 0 and cal["taps_us"] > 0 and auto.batch_path(16) == ("mfma" if cal["mfma_us"] <= cal["taps_us"] else "taps")
+        else:
+            assert auto.batch_path(16) == "mfma"
+        for k in range(16):
+            assert rel_err(batch[k].log_likelihood, singles[k].log_likelihood) < 1e-12 and np.allclose(batch[k].grad, singles[k].grad, rtol=1e-10, atol=1e-11)
+        auto.close()

@@ -1072,10 +1072,11 @@ def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe,
     old.close()
 
 
-def test_the_batched_kernel_of_a_spline_model_is_chosen_by_measurement(monkeypatch):
-    """Spline models have two batched kernels (matrix cores / 4-tap); which is faster depends on the model and the catalog
-    (BASELINE config 3 is a tie, config 5 prefers the matrix cores).  With no path named in the environment the engine times
-    both on its first batched launch of >= 9 points and keeps the faster; gwi_batch_path then answers with that choice."""
+def test_the_batched_kernel_of_a_spline_model_static_by_default_measured_on_request(monkeypatch):
+    """Spline models have two batched kernels (matrix cores / 4-tap) that sum in different orders.  By DEFAULT the choice is a
+    static rule (matrix cores from 9 points on, up to 8 gradient tiles): two handles of one model give the same bits, nothing is
+    timed.  GWI_BATCH_AUTOTUNE=1 opts into the measurement: the engine times both on its first batched launch of >= 9 points and
+    keeps the faster; gwi_batch_path then answers with that choice."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
 
@@ -1083,9 +1084,18 @@ def test_the_batched_kernel_of_a_spline_model_is_chosen_by_measurement(monkeypat
         monkeypatch.delenv(v, raising=False)
     pe, inj, total = make_catalog(11, 700, 5003, seed=41)
     comp = COMPOSITIONS["bspline_iid"](pe, inj)
-    eng = comp.engine()
     rng = np.random.default_rng(9)
     thetas = np.stack([comp.theta(draw_params("bspline_iid", rng)) for _ in range(16)])
+    fixed, twin = comp.engine(), COMPOSITIONS["bspline_iid"](pe, inj).engine()
+    a, b = fixed.evaluate_batch(thetas, total, min_neff_cut=False), twin.evaluate_batch(thetas, total, min_neff_cut=False)
+    for e in (fixed, twin):
+        assert e.batch_path(16) == "mfma" and not e.batch_calibration()["measured"]
+    for k in range(16):  # same model, same catalog, another handle: the same kernel, the same bits (the matrix-core gradient is fixed-order)
+        assert a[k].log_likelihood == b[k].log_likelihood and np.array_equal(a[k].grad, b[k].grad)
+    fixed.close()
+    twin.close()
+    monkeypatch.setenv("GWI_BATCH_AUTOTUNE", "1")
+    eng = COMPOSITIONS["bspline_iid"](pe, inj).engine()
     assert eng.batch_path(16) == "mfma" and not eng.batch_calibration()["measured"]  # the static rule until something has been measured
     small = eng.evaluate_batch(thetas[:4], total, min_neff_cut=False)                # below 9 points: nothing to choose
     assert not eng.batch_calibration()["measured"]
@@ -1099,8 +1109,3 @@ def test_the_batched_kernel_of_a_spline_model_is_chosen_by_measurement(monkeypat
         if k < 4:
             assert rel_err(small[k].log_likelihood, one.log_likelihood) < 1e-12
     eng.close()
-    monkeypatch.setenv("GWI_BATCH_AUTOTUNE", "0")
-    fixed = COMPOSITIONS["bspline_iid"](pe, inj).engine()
-    fixed.evaluate_batch(thetas, total, min_neff_cut=False)
-    assert fixed.batch_path(16) == "mfma" and not fixed.batch_calibration()["measured"]
-    fixed.close()

@@ -157,20 +157,17 @@ def test_distribution_log_prob_faces_bind_to_the_reference_values():
         D.BSplineDistribution(0.0, 1.0, cs, grx, I.BSpline(20).bases(gr))
 
 
-def test_add_variant_line_for_an_unsupported_sequence():
-    """A model whose sorted term-kind sequence has no compiled kernel is refused by gwi_create with the command that adds
-    it; gwinferno_amd.add_variant validates the sequence and writes the GWI_VARIANT line (build not run here)."""
-    from gwinferno_amd import add_variant as A
+def test_precompile_command_validates_a_kind_sequence():
+    """`python -m gwinferno_amd.precompile KIND ...` (a command line over gwi_jit_compile): the sequence checks and the
+    samples-per-lane rule the engine itself applies; the compilation itself is covered by tests/test_jit_cache_cpu.py."""
+    from gwinferno_amd import precompile as P
 
-    assert A.variant_line([2, 3, 6, 7, 7, 7, 7]) == '    GWI_VARIANT_U("user:2,3,6,7,7,7,7", 2, 2, 3, 6, 7, 7, 7, 7),\n'
-    assert ", 1, 3, 6, 7, 7, 7, 7, 7, 7)" in A.variant_line([3, 6, 7, 7, 7, 7, 7, 7])  # six splines: one sample per lane
+    assert P.check_kinds([2, 3, 6, 7, 7, 7, 7]) == [2, 3, 6, 7, 7, 7, 7] and P.default_samples_per_lane([2, 3, 6, 7, 7, 7, 7]) == 2
+    assert P.default_samples_per_lane([3, 6, 7, 7, 7, 7, 7, 7]) == 1  # six splines: one sample per lane
+    assert P.check_kinds([5, 5, 6, 107, 107], mfma=True) == [5, 5, 6, 107, 107]
     for bad in ([7, 3], [0], [15], list(range(1, 14))):
         with pytest.raises(ValueError):
-            A.variant_line(bad)
-    inc = open(A.INC).read()
-    assert "GWI_VARIANT" in inc.split("\n")[0] or inc.startswith("//")  # the include file exists and is part of kVariants
-    src = open(os.path.join(os.path.dirname(A.INC), "gwi_engine.hip")).read()
-    assert '#include "gwi_user_variants.inc"' in src
+            P.check_kinds(bad)
 
 
 def test_ratio_term_takes_log_m1_from_the_mass_spline(monkeypatch):
@@ -241,3 +238,29 @@ def test_pspline_coefficient_prior_mirror():
         with pytest.raises(AssertionError):
             d.log_prob(np.zeros(int(n) + 1))
     assert PSplineCoeficientPrior(20, 1.0).diff_order == 2  # the reference's default
+
+
+@pytest.mark.parametrize("log", [False, True])
+def test_equal_weight_arrays_key_the_same_engine(log):
+    """The reference calls per_event_log_bayes_factors / detection_efficiency once per likelihood evaluation with a freshly
+    computed array.  The engine caches key on identities of source arrays, so `_array_density` interns equal arrays (content
+    hash) and shares one zeros column per shape: a second call with an equal array -- another object -- must produce the keys
+    of the first (no new engine, no eviction), and a different array must not."""
+    from gwinferno_amd import likelihood as L
+    from gwinferno_amd.engine import structure_key
+    from gwinferno_amd.lazy import static_key
+
+    L.clear_engine_cache()
+    g = _array_golden()
+    with np.errstate(all="ignore"):
+        a = g["lw_pe"] if log else np.exp(g["lw_pe"])
+
+    def one_sided_key(d):
+        return (d.side, tuple(f.structure() + tuple(c.key() for c in f.columns) for f in d.factors), tuple((sgn, static_key(x)) for sgn, x in d.log_static))
+
+    first, again, other = L._array_density(a, log), L._array_density(a.copy(), log), L._array_density(a + (0.5 if log else 1e-3), log)
+    assert one_sided_key(first) == one_sided_key(again) != one_sided_key(other)
+    with np.errstate(all="ignore"):
+        b = g["lw_inj"] if log else np.exp(g["lw_inj"])
+    assert structure_key(first, L._array_density(b, log)) == structure_key(again, L._array_density(b.copy(), log))
+    L.clear_engine_cache()
