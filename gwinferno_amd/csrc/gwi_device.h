@@ -119,7 +119,7 @@ struct KArgs {
   int square, k_batch;     // k_batch: hyper-parameter points of a batched launch (scan_mfma_kernel: 16 per grid row); square != 0: accumulate with w^2 instead of w (the sum_j w_j^2 dl_j/dtheta numerators
                            // the gradient of marginalize_selection needs); records then carry 2M as exponent
   int nref_row0;           // first row of tile_nref this launch reads and writes (0: single evaluation, 1: batched launch)
-  int pbatch_pts;          // scan_pbatch_kernel: hyper-parameter points per grid row (<= kPbatchMaxPts)
+  int pbatch_pts;          // scan_pbatch_kernel: > 0: rows mode, hyper-parameter points per grid row (<= kPbatchMaxPts); < 0: balanced mode, minus the number of scan workgroups
   const ThetaBlock* tblocks;  // batched launches only: [gridDim.y]
   double derived[GWI_MAX_TERMS][kMaxDerived];
   double theta[GWI_MAX_THETA];
@@ -170,6 +170,31 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_take<0x142, 0xa>(v));
   v = fmax(v, dpp_take<0x143, 0xc>(v));
   return lane63(v);
+}
+
+// The wave's maximum to single precision -- for a REFERENCE exponent, which only has to lie within a few units of the true
+// maximum (weights are exp(l - m); m off by 6e-8 |m| moves nothing but the split between the record's exponent and its sums).
+// A double goes through the DPP network as two 32-bit moves + a canonicalising v_max_f64 + the v_max_f64 itself per step (26
+// vector instructions for the six steps of wave_max); here the value becomes an ordered 32-bit key (the float's bits, the
+// lower 31 flipped for negative values: signed-integer order = float order, -inf the smallest) and every step is ONE
+// v_max_i32 with a DPP operand: 11 vector instructions, the key's way back on the scalar unit.  NaN never gets here.
+__device__ __forceinline__ double wave_max_coarse(double v) {
+  const int bits = __float_as_int((float)v);
+  int k = bits ^ ((bits >> 31) & 0x7fffffff);
+  // v_max_i32 with the DPP operand in place (the compiler makes a copy + a DPP move + the maximum of every step).  A lane without
+  // a source, or in a row outside the mask, is not written and keeps its own key.  The s_nop are the two wait states a DPP read
+  // needs after a vector write of the same register (the hazard recogniser does not look inside an asm block).
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(k));
+  const int top = __builtin_amdgcn_readlane(k, 63);
+  return (double)__int_as_float(top ^ ((top >> 31) & 0x7fffffff));
 }
 
 // Eight sums over the wavefront at once: a halving butterfly.  v_permlane32_swap / v_permlane16_swap (gfx950) exchange the
@@ -239,20 +264,47 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // v_max/v_min return the non-NaN operand, so a NaN argument gives 0: NaN can only enter through a
 // non-finite hyper-parameter, which the host rejects before launching (theta_finite in the engine);
 // data NaNs sit in samples already excluded by kappa = -inf.  expm1 shares the core: 2^n (1 + rq) - 1 = fma(2^n, rq, 2^n - 1), exact for n = 0.
+// minimax coefficients of (e^r - 1)/r on |r| <= 0.3466, degree 8 (tools/exp_poly.py: weighted for the relative error of e^r)
+#define GWI_EXP_C0 9.99999999999913181e-01
+#define GWI_EXP_C1 4.99999999996100564e-01
+#define GWI_EXP_C2 1.66666666677465963e-01
+#define GWI_EXP_C3 4.16666669853561281e-02
+#define GWI_EXP_C4 8.33333300756820827e-03
+#define GWI_EXP_C5 1.38888081598322684e-03
+#define GWI_EXP_C6 1.98416032733609286e-04
+#define GWI_EXP_C7 2.48820124271676425e-05
+#define GWI_EXP_C8 2.74767496787804738e-06
 __device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
   double r;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
   return r;
 }
+// Round 6 (GWI_EXP_TAYLOR=0, the default): three vector instructions fewer per exponential, where the parity budget has room --
+//   * q = an eighth-degree MINIMAX polynomial for (e^r - 1)/r on |r| <= 0.3466 instead of the tenth-degree Taylor series: the
+//     relative error of e^r = 1 + r q(r) is <= 1.6e-14 over the whole interval (tools/exp_poly.py; the Taylor series: 6e-15 at its
+//     ends), eight FMAs instead of ten;
+//   * r = x - n ln2 in ONE fused multiply-add with ln2 rounded to double (off by 2.3e-17): r is then off by 2.3e-17 |n|, i.e. the
+//     result by 2e-14 relative at |x| = 700 and 1e-13 at the |l| of a few thousand that spline models under the reference's priors
+//     reach -- against a bar of 1e-10 on per-sample log-weights and 1e-9 on log_l (tests: every golden and oracle comparison at
+//     its old tolerance).  The shift of fast_exp_shift stays exact: it is applied to the exponent field.
+#ifndef GWI_EXP_TAYLOR
+#define GWI_EXP_TAYLOR 0
+#endif
 struct ExpParts {
   double rq;  // e^r - 1
   int n;
 };
-__device__ __forceinline__ ExpParts exp_parts(double x) {
-  x = fmin(fmax(x, -1000.0), 710.0);
-  const double nf = __builtin_rint(x * 1.4426950408889634);
-  double r = fma(nf, -6.93147180369123816490e-01, x);
-  r = fma(nf, -1.90821492927058770002e-10, r);
+__device__ __forceinline__ double exp_reduce(double x, double nf) {
+#if GWI_EXP_TAYLOR
+  const double r = fma(nf, -6.93147180369123816490e-01, x);
+  return fma(nf, -1.90821492927058770002e-10, r);
+#else
+  return fma(nf, -6.93147180559945286227e-01, x);
+#endif
+}
+// (e^r - 1)/r, |r| <= 0.3466
+__device__ __forceinline__ double exp_q(double r) {
+#if GWI_EXP_TAYLOR
   double q = 1.0 / 39916800.0;            // 1/11!
   q = fma_sc(q, r, 1.0 / 3628800.0);
   q = fma_sc(q, r, 1.0 / 362880.0);
@@ -263,9 +315,25 @@ __device__ __forceinline__ ExpParts exp_parts(double x) {
   q = fma_sc(q, r, 1.0 / 24.0);
   q = fma_sc(q, r, 1.0 / 6.0);
   q = fma(q, r, 0.5);
-  q = fma(q, r, 1.0);
+  return fma(q, r, 1.0);
+#else
+  double q = GWI_EXP_C8;
+  q = fma_sc(q, r, GWI_EXP_C7);
+  q = fma_sc(q, r, GWI_EXP_C6);
+  q = fma_sc(q, r, GWI_EXP_C5);
+  q = fma_sc(q, r, GWI_EXP_C4);
+  q = fma_sc(q, r, GWI_EXP_C3);
+  q = fma_sc(q, r, GWI_EXP_C2);
+  q = fma_sc(q, r, GWI_EXP_C1);
+  return fma_sc(q, r, GWI_EXP_C0);
+#endif
+}
+__device__ __forceinline__ ExpParts exp_parts(double x) {
+  x = fmin(fmax(x, -1000.0), 710.0);
+  const double nf = __builtin_rint(x * 1.4426950408889634);
+  const double r = exp_reduce(x, nf);
   ExpParts p;
-  p.rq = q * r;
+  p.rq = exp_q(r) * r;
   p.n = (int)nf;
   return p;
 }
@@ -285,20 +353,8 @@ constexpr int kNoRef = -2147483647 - 1;  // tile_nref: no reference yet / tile w
 __device__ __forceinline__ double fast_exp_shift(double x, int shift) {
   x = fmin(fmax(x, -7.0e5), 7.0e5);
   const double nf = __builtin_rint(x * kLog2e);
-  double r = fma(nf, -6.93147180369123816490e-01, x);
-  r = fma(nf, -1.90821492927058770002e-10, r);
-  double q = 1.0 / 39916800.0;
-  q = fma_sc(q, r, 1.0 / 3628800.0);
-  q = fma_sc(q, r, 1.0 / 362880.0);
-  q = fma_sc(q, r, 1.0 / 40320.0);
-  q = fma_sc(q, r, 1.0 / 5040.0);
-  q = fma_sc(q, r, 1.0 / 720.0);
-  q = fma_sc(q, r, 1.0 / 120.0);
-  q = fma_sc(q, r, 1.0 / 24.0);
-  q = fma_sc(q, r, 1.0 / 6.0);
-  q = fma(q, r, 0.5);
-  q = fma(q, r, 1.0);
-  return ldexp(fma(q, r, 1.0), (int)nf - shift);
+  const double r = exp_reduce(x, nf);
+  return ldexp(fma(exp_q(r), r, 1.0), (int)nf - shift);
 }
 __device__ __forceinline__ double fast_expm1(double x) {
   const ExpParts p = exp_parts(x);
@@ -1911,12 +1967,16 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
   const int h_n_ev = (int)(h_geom & ((1u << kGeomEventBits) - 1u));
   const int h_chunk_pe = unpack_chunk(h_chunks & 0xffffu), h_chunk_inj = unpack_chunk(h_chunks >> 16);
   const long long h_n_pe = hu_n_pe, h_n_inj = hu_n_inj;
-  KernargWarm<(int)sizeof...(Ks), BATCH> warm;
-  warm.issue();
   // BATCH: blockIdx.y selects the hyper-parameter point; records of point k follow those of k-1 (a single launch of the SAFE
   // instantiation has one grid row)
   const int kb = (BATCH || SAFE) ? (int)blockIdx.y : 0;
   const int n_norm_blocks = WRITE_LOGW ? 0 : h_n_norms;
+  // The argument block's lines are requested by hand-written scalar loads the compiler does not track (KernargWarm): their
+  // destinations are safe only on a path that reaches warm.settle().  The normaliser workgroups below return without it, so the
+  // loads are issued AFTER that branch (one scalar compare later).  Round 6 found them issued ahead of it: on the normaliser
+  // path the compiler was free to reuse a destination register while its load was still in flight, and after a change of the
+  // register allocation the high half of the completion stamp sat in one -- a normaliser stamp then came out as
+  // (low dword of some pointer) << 32 | seq now and then, and the host waited ten seconds for a stamp that never matched.
   if ((int)blockIdx.x < n_norm_blocks) {  // wave-uniform, whole workgroup
     const bool batch_n = BATCH || (SAFE && a.tblocks != nullptr);
     const int j = blockIdx.x;
@@ -1924,6 +1984,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
     norm_block(a.norms, batch_n ? a.tblocks[kb].theta : a.theta, a.n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, s_theta, &s_wrec[0][0]);
     return;
   }
+  KernargWarm<(int)sizeof...(Ks), BATCH> warm;
+  warm.issue();
   const int b = (int)blockIdx.x - n_norm_blocks;
   const int n_pe_blocks = h_n_ev * h_tiles;
 
@@ -2423,22 +2485,28 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     norm_block(a.norms, a.tblocks[kb].theta, a.n_theta, j, a.norm_out_host + kb * h_n_norms + j, a.norm_stamps_host + kb * h_n_norms + j, a.norm_seq, &s_out[0][0], &s_m[0][0]);
     return;
   }
-  const int b = (int)blockIdx.x - n_norm_blocks;
+  const int g_wg = (int)blockIdx.x - n_norm_blocks;
   const int n_pe_blocks = h_n_ev * h_tiles;
-  long long start, end, base;
-  if (b < n_pe_blocks) {
-    const int e = b / h_tiles;
-    const int t = b - e * h_tiles;
-    start = (long long)t * h_chunk_pe;
-    end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
-    base = (long long)e * h_n_pe;
+  const long long n_blocks_total = (long long)n_pe_blocks + a.n_inj_tiles;
+  // ---- which (tile, point) UNITS this workgroup evaluates, in tile-major order u = tile x K + point.
+  // rows mode (pbatch_pts > 0): tile blockIdx.x, the pbatch_pts points of grid row blockIdx.y.  Balanced mode (pbatch_pts = -G < 0,
+  // one grid row of G scan workgroups): the launch has as many workgroups as the chip holds at once (or the next smaller count that gives them equal
+  // shares) and workgroup g takes the g-th of G equal runs of the unit sequence -- a run crosses a tile boundary once or twice,
+  // the tile is loaded when it changes.  No workgroup is left to run alone at the end of the launch, which at config 2's size
+  // (788 tiles x 16 points on 1280 resident workgroups) was a third of the scan's time.
+  unsigned u_next, u_end;
+  if (a.pbatch_pts > 0) {
+    const int pts = a.pbatch_pts < kPbatchMaxPts ? a.pbatch_pts : kPbatchMaxPts;
+    const int k_first = (int)blockIdx.y * pts;
+    u_next = (unsigned)g_wg * (unsigned)K + (unsigned)k_first;
+    u_end = u_next + (unsigned)(K - k_first < pts ? K - k_first : pts);
   } else {
-    const int t = b - n_pe_blocks;
-    start = (long long)t * h_chunk_inj;
-    end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
-    base = 0;
+    // (the workgroup count comes with the arguments: gridDim would be an implicit kernel argument, which the AQL queue does not supply)
+    const unsigned n_units = (unsigned)n_blocks_total * (unsigned)K, n_wg = (unsigned)(-a.pbatch_pts);
+    const unsigned q = n_units / n_wg, r = n_units - q * n_wg, g = (unsigned)g_wg;
+    u_next = g * q + (g < r ? g : r);
+    u_end = u_next + q + (g < r ? 1u : 0u);
   }
-  const long long col_base = b < n_pe_blocks ? base : inj_offset(h_n_ev, h_n_pe);
   const double* const head_cols[kHeadCols] = {hc0, hc1, hc2, hc3, hc4};
   const double* lcols[sizeof...(Ks)][2];
   ColFill<1, 0, Ks...>::run(lcols, head_cols, a);
@@ -2450,19 +2518,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
   ctx.gacc = nullptr;
   ctx.rep_shift = 0;
   const double* kappa_col = hc0;
-
-  // ---- the tile's samples: ONE trip (the host sizes the tiles of this launch to <= kU x 256 samples), resident in registers
   ChainT chain;
   double kap[kU];
-  const int n_tile = (int)(end - start);
-#pragma unroll
-  for (int u = 0; u < kU; ++u) {
-    const int iu = tid + u * kBlock;
-    if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
-    const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
-    kap[u] = gload(kappa_col, idx);
-    chain.load(0, u, 0, ctx, idx);
-  }
   if (n_norm_blocks == 0 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.seq_dev = a.norm_seq;
   for (int p = lane; p < a.n_theta; p += 64) s_out[wave][p] = 0.0;  // wave-private: no barrier needed before its own use
   // theta slot of every scalar sum (the same for every point)
@@ -2473,9 +2530,40 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     chain.init();
     chain.collect(0, ctx, unused + 2, th + 2);
   }
-  const int pts = a.pbatch_pts < kPbatchMaxPts ? a.pbatch_pts : kPbatchMaxPts;
-  const int k0 = (int)blockIdx.y * pts;
-  const int n_k = K - k0 < pts ? K - k0 : pts;  // points of this grid row (wave-uniform)
+  int b = -1, n_tile = 0;
+  while (u_next < u_end) {  // one pass per SEGMENT: up to kPbatchMaxPts consecutive points of one tile (wave-uniform throughout)
+  const int b_seg = (int)(u_next / (unsigned)K);
+  const int k0 = (int)(u_next - (unsigned)b_seg * (unsigned)K);
+  int n_k = K - k0;
+  if ((unsigned)n_k > u_end - u_next) n_k = (int)(u_end - u_next);
+  if (n_k > kPbatchMaxPts) n_k = kPbatchMaxPts;
+  u_next += (unsigned)n_k;
+  if (b_seg != b) {
+    // ---- the tile's samples: ONE trip (the host sizes the tiles of this launch to <= kU x 256 samples), resident in registers
+    b = b_seg;
+    long long start, end, col_base;
+    if (b < n_pe_blocks) {
+      const int e = b / h_tiles;
+      const int t = b - e * h_tiles;
+      start = (long long)t * h_chunk_pe;
+      end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
+      col_base = (long long)e * h_n_pe;
+    } else {
+      const int t = b - n_pe_blocks;
+      start = (long long)t * h_chunk_inj;
+      end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
+      col_base = inj_offset(h_n_ev, h_n_pe);
+    }
+    n_tile = (int)(end - start);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int iu = tid + u * kBlock;
+      if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
+      const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
+      kap[u] = gload(kappa_col, idx);
+      chain.load(0, u, 0, ctx, idx);
+    }
+  }
   for (int kk = 0; kk < n_k; ++kk) {
     const ThetaBlock* tb = a.tblocks + (k0 + kk);
     ctx.theta = tb->theta;
@@ -2500,12 +2588,13 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
       if (!live[u]) ell[u] = GWI_NEG_INF;
       mx_lane = fmax(mx_lane, ell[u]);
     }
-    // the wave's exact maximum for this point: every weight is <= 1 x its linear part.  (Reusing the previous point's reference
-    // where it lies within 150 e-folds -- two compares and ballots instead of the DPP maximum -- measured nothing: EXPERIMENTS.md)
+    // the wave's maximum for this point (to single precision, wave_max_coarse): every weight is <= (1 + 1e-7 |m|) x its linear part
 #ifdef GWI_AB_PBATCH_NOMAX  // timing-only ablation: no cross-lane maximum (wrong reference)
     const double m = uniform(mx_lane);
-#else
+#elif defined(GWI_AB_PBATCH_EXACT_MAX)  // A/B: round 5's double-precision maximum
     const double m = wave_max(mx_lane);
+#else
+    const double m = wave_max_coarse(mx_lane);  // within 6e-8 |m| of the wave's maximum: a reference, not a result
 #endif
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -2548,9 +2637,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     if (lane == 0) s_m[wave][kk] = m;
   }
   __syncthreads();
-  // ---- records: wave w completes points w, w + 4, ... of this row (scan_kernel's parametric epilogue, per point)
+  // ---- records: wave w completes points w, w + 4, ... of this segment (scan_kernel's parametric epilogue, per point)
   static_assert(kWaves == 4, "the quad broadcasts below assume four waves");
-  const long long n_blocks_total = (long long)n_pe_blocks + a.n_inj_tiles;
   int slot = 0;
 #pragma unroll
   for (int v = 2; v < kNV; ++v) slot = (lane == v) ? th[v] : slot;
@@ -2579,6 +2667,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
+  if (u_next < u_end) __syncthreads();  // the staging rows are reused by the next segment
+  }  // segments
 }
 
 // ---- the tail as separate launches (GWI_FUSED_TAIL=0, and the reference point for A/B timing) -------

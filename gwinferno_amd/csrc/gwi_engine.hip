@@ -379,8 +379,11 @@ struct gwi_engine {
   Variant* jit_variant = nullptr;     // owned: the variant record of a chain compiled at gwi_create (variant points at it)
   hipFunction_t jit_fn[jit::kRoles] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // ... its kernels in the chain's module on this device
   std::string jit_note;               // why the generic kernel runs although a chain could have been compiled (gwi_jit_info)
+  long long aql_rerings = 0;          // times a wait on the AQL queue rang the doorbell a second time (aql_wait_slow)
   bool pbatch = false;                // parametric model: batched launches load every sample once (scan_pbatch_kernel)
-  int pbatch_pts = 0;                 // ... points per grid row (0: chosen per launch from the batch size and the grid)
+  int pbatch_pts = 0;                 // ... GWI_PBATCH_PTS: points per grid row in rows mode (0: chosen per launch from the batch size and the grid)
+  bool pbatch_balanced = true;        // ... (tile, point) units dealt out evenly to one round of resident workgroups (GWI_PBATCH_BALANCED=0: rows mode)
+  int pbatch_wgs_per_cu = 4;          // ... resident workgroups of scan_pbatch_kernel per CU (occupancy query at gwi_create)
   int scan_role = jit::kScan;         // role of the scan launch being issued
   const MfmaVariant* mfma = nullptr;  // batched launches with 16 points per wavefront (gwi_mfma.h), when the model qualifies
   bool batch_rows = false;            // ... with the gradient in LDS rows (scan_rows_kernel) instead of MFMA tiles
@@ -739,6 +742,15 @@ int pbatch_points(const gwi_engine* h, int K, int on_bgeo = -1) {
   return std::max(1, std::min(pts, kPbatchMaxPts));
 }
 
+// Balanced mode: how many workgroups a pbatch launch of K points gets.  One round of resident workgroups, or the next smaller
+// count with which every workgroup draws the same number of (tile, point) units: ceil(N / ceil(N / capacity)).
+int pbatch_workgroups(const gwi_engine* h, int K, int on_bgeo = -1) {
+  const long long blocks = (on_bgeo < 0 ? h->use_bgeo : on_bgeo != 0) ? h->bgeo.n_scan_blocks : h->n_scan_blocks;
+  const long long n_units = blocks * K, capacity = (long long)h->n_cus * h->pbatch_wgs_per_cu;
+  const long long per_wg = (n_units + capacity - 1) / capacity;
+  return (int)((n_units + per_wg - 1) / per_wg);
+}
+
 gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   if (logw) h->aql_now = false;  // the log-weight variant is another kernel and always goes through the HIP stream
   const int grid = (h->use_bgeo && !logw ? h->bgeo.n_scan_blocks : h->n_scan_blocks) + (logw ? 0 : h->spec.n_norms);  // the first n_norms workgroups integrate the normaliser grids
@@ -748,15 +760,22 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   // parametric models: a batched launch on single-trip tiles loads every sample once for all its points (scan_pbatch_kernel)
   // ... where a grid row holds more than one point: with one point per row (small catalogs: the rows are split until the launch
   // fills the chip) it has nothing to share and the one-row-per-point kernel is the same thing without the staging
-  const bool pb = batch && !safe && !logw && pbatch_applies(h) && pbatch_points(h, K) > 1;
+  const bool pb = batch && !safe && !logw && pbatch_applies(h) && (h->pbatch_balanced ? K > 1 : pbatch_points(h, K) > 1);
   h->scan_role = logw ? jit::kLogw : (safe ? jit::kSafe : (pb ? jit::kPbatch : (batch ? jit::kBatch : jit::kScan)));
   ScanFn fn = h->variant->fn[h->scan_role];
   h->scan_is_safe = safe;
   h->kargs.k_batch = batch ? K : 1;
   if (pb) {
+    const size_t used = offsetof(KArgs, theta);  // the points' hyper-parameters travel in their ThetaBlocks
+    if (h->pbatch_balanced) {
+      const int n_wg = pbatch_workgroups(h, K);
+      h->kargs.pbatch_pts = -n_wg;
+      launch_timed(h, 0, fn, dim3(h->spec.n_norms * K + n_wg, 1), dim3(kBlock), 0, h->sblock, used);
+      GWI_HIP(hipGetLastError());
+      return GWI_OK;
+    }
     const int pts = pbatch_points(h, K);
     h->kargs.pbatch_pts = pts;
-    const size_t used = offsetof(KArgs, theta);  // the points' hyper-parameters travel in their ThetaBlocks
     launch_timed(h, 0, fn, dim3(grid - h->spec.n_norms + h->spec.n_norms * K, (K + pts - 1) / pts), dim3(kBlock), 0, h->sblock, used);
     GWI_HIP(hipGetLastError());
     return GWI_OK;
@@ -1083,8 +1102,12 @@ gwi_status run_pipeline(gwi_handle h, const double* theta, double* record_dev = 
 template <typename Ready>
 gwi_status aql_wait_slow(gwi_handle h, Ready ready, const char* what) {
   const auto t0 = std::chrono::steady_clock::now();
+  bool rung_again = false;
   for (unsigned long long spin = 1;; ++spin) {
-    if (ready()) return GWI_OK;
+    if (ready()) {
+      if (rung_again && !std::getenv("GWI_QUIET")) std::fprintf(stderr, "gwi: %s arrived only after the queue's doorbell was rung a second time\n", what);
+      return GWI_OK;
+    }
     // packets of this evaluation may still be in flight: the handle takes no further evaluations, and gwi_destroy
     // waits for the queue to drain (or leaks the buffers) instead of freeing memory a kernel may still write
     if (h->aq.failed()) {
@@ -1092,9 +1115,32 @@ gwi_status aql_wait_slow(gwi_handle h, Ready ready, const char* what) {
       return fail(h, GWI_ERR_HIP, h->aq.why());
     }
     __builtin_ia32_pause();
-    if ((spin & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
-      h->poisoned = true;
-      return fail(h, GWI_ERR_TIMEOUT, std::string(what) + " did not arrive from the AQL queue within 10 s");
+    if ((spin & 0xffff) == 0) {
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      hsa_queue_t* hq = h->aq.sq ? h->aq.sq->q : nullptr;
+      if (waited > 0.05 && !rung_again && hq) {
+        // 50 ms without a result is ~1000 evaluations' worth: if the command processor has not taken the packets (read index
+        // behind the write index), ring the doorbell once more with the last index written -- a doorbell that did not register
+        // would otherwise cost the whole evaluation; ringing twice with the same index is harmless
+        aql::Api& api = aql::api();
+        const uint64_t w = api.add_write_index(hq, 0), r = api.load_read_index(hq);
+        if (r < w) api.signal_store(hq->doorbell_signal, (hsa_signal_value_t)(w - 1));
+        rung_again = true;
+        h->aql_rerings++;
+      }
+      if (waited > 10.0) {
+        h->poisoned = true;
+        std::string state;
+        if (hq) {
+          aql::Api& api = aql::api();
+          state = " (queue write index " + std::to_string((unsigned long long)api.add_write_index(hq, 0)) + ", read index " + std::to_string((unsigned long long)api.load_read_index(hq)) +
+                  ", evaluation " + std::to_string((unsigned long long)h->seq) + ", doorbell rung again: " + (rung_again ? "yes" : "no") + "; normaliser stamps";
+          for (int j = 0; j < h->spec.n_norms && j < 16; ++j) state += " " + std::to_string((unsigned long long)h->h_norm_stamp[j]) + ":" + std::to_string(h->h_norm[j]);
+          state += "; redo word " + std::to_string((unsigned long long)*reinterpret_cast<volatile unsigned long long*>(h->h_redo)) + "; kernel " + (h->variant ? h->variant->name : "?") +
+                   ", role " + std::to_string(h->scan_role) + ", blocks " + std::to_string(h->n_scan_blocks) + ")";
+        }
+        return fail(h, GWI_ERR_TIMEOUT, std::string(what) + " did not arrive from the AQL queue within 10 s" + state);
+      }
     }
   }
 }
@@ -2093,6 +2139,16 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   h->pbatch = h->variant->has(jit::kPbatch) && !h->generic;
   if (const char* env = std::getenv("GWI_PBATCH")) h->pbatch = h->pbatch && std::atoi(env) != 0;
   if (const char* env = std::getenv("GWI_PBATCH_PTS")) h->pbatch_pts = std::max(0, std::atoi(env));
+  h->pbatch_balanced = h->pbatch_pts == 0;  // (naming a row size asks for the rows mode)
+  if (const char* env = std::getenv("GWI_PBATCH_BALANCED")) h->pbatch_balanced = std::atoi(env) != 0;
+  if (h->pbatch) {
+    int occ = 0;
+    const hipError_t oe = h->variant->jit ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->jit_fn[jit::kPbatch], kBlock, 0)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->variant->fn[jit::kPbatch], kBlock, 0);
+    if (oe != hipSuccess) (void)hipGetLastError();
+    h->pbatch_wgs_per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
+    if (const char* env = std::getenv("GWI_PBATCH_WGS_PER_CU")) h->pbatch_wgs_per_cu = std::max(1, std::min(16, std::atoi(env)));
+  }
   if (h->pbatch && !std::getenv("GWI_BATCH_GEOMETRY")) spb_batch = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;  // (not distinct below where that is the single geometry)
   if (spb_batch > 0 && !std::getenv("GWI_PE_CHUNK") && !std::getenv("GWI_INJ_CHUNK")) {
     auto& b = h->bgeo;
@@ -2446,7 +2502,9 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
   if (h->variant && h->variant->has(jit::kPbatch) && !h->generic) {  // parametric model: one load per sample where the tiles of a launch of k_batch points are single trips
     const long long gran = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;
     const bool bg = k_batch >= 4 && h->bgeo.distinct;
-    if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran && pbatch_points(h, k_batch, bg ? 1 : 0) > 1) return "pbatch";
+    if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran &&
+        (h->pbatch_balanced ? k_batch > 1 : pbatch_points(h, k_batch, bg ? 1 : 0) > 1))
+      return "pbatch";
     return "rows-per-point";
   }
   return (h->mfma && !safe && k_batch >= h->mfma_min_batch) ? (h->batch_rows ? "rows" : "mfma") : "taps";

@@ -132,10 +132,14 @@ def test_non_finite_hyper_parameter_takes_the_nan_branch(bad):
     assert np.array_equal(again.grad, good.grad)
 
 
-@pytest.mark.parametrize("cfg,comp_name", [("c5", "bspline_full"), ("c3", "bspline_iid"), ("c2", "plpeak")])
+@pytest.mark.parametrize("cfg,comp_name", [("c5", "bspline_full"), ("c3", "bspline_iid"), ("c2", "plpeak"), ("c2", "bspline_iid"), ("c2", "bspline_defaults")])
 def test_full_size_against_c_oracle(cfg, comp_name):
     """The BASELINE catalogs at FULL size (config 5: 2.5 M samples, 9 columns, 109 hyper-parameters) against the
-    C/OpenMP oracle on the host: value, every per-event site and the whole gradient."""
+    C/OpenMP oracle on the host: value, every per-event site and the whole gradient.  The last two are the size north_star's last
+    sentence names -- 69 events x 5000 PE x 50 k injections (config 2's catalog) -- under B-spline models: config 3's composition,
+    and the reference's DEFAULT spline counts (pipeline/utils.py:29-39, 104-155: 50 / 30 / 16 / 16 / 16 / 16 / 20 bases = 164
+    coefficients + lamb; what `setup_bspline_*` builds with no arguments); for these also a batch of 16 points (the kernel the
+    static rule picks: 12 gradient tiles keep the defaults on the 4-tap kernel) against the single evaluations."""
     from golden_util import rel_err
 
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
@@ -157,6 +161,15 @@ def test_full_size_against_c_oracle(cfg, comp_name):
         assert abs(got.summary.log_det_eff - ref["summary"].log_det_eff) < 1e-9 * abs(ref["summary"].log_det_eff)
         scale = max(1.0, float(np.max(np.abs(ref["grad"]))))
         assert float(np.max(np.abs(got.grad - ref["grad"]))) / scale < 1e-8
+    if cfg == "c2" and comp_name != "plpeak":
+        assert eng.n_theta == (165 if comp_name == "bspline_defaults" else 64)
+        thetas = np.stack([comp.theta(draw_params(comp_name, rng)) for _ in range(16)])
+        batch = eng.evaluate_batch(thetas, total, min_neff_cut=False)
+        assert eng.batch_path(16) == ("taps" if comp_name == "bspline_defaults" else "mfma")
+        for k in (0, 7, 15):
+            one = eng.evaluate(thetas[k], total, min_neff_cut=False)
+            assert rel_err(batch[k].log_likelihood, one.log_likelihood) < 1e-12
+            assert np.allclose(batch[k].grad, one.grad, rtol=1e-10, atol=1e-11)
     eng.close()
 
 

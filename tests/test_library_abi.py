@@ -119,6 +119,31 @@ def test_raw_code_object_for_the_aql_path(lib):
             assert scratch == "0", (n, scratch)
 
 
+def _check_kernarg_warm(path):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_kernarg_warm", os.path.join(ROOT, "tools", "check_kernarg_warm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.check(path)
+
+
+def test_hand_issued_argument_loads_are_settled_on_every_path():
+    """The scan kernels request the lines of their argument block with s_load_dwords written as asm, which the compiler does not
+    track (gwi_device.h: KernargWarm): until the s_waitcnt that settles them nothing may touch a destination register, on ANY
+    path.  Round 6: the normaliser workgroups branched away before the wait, the compiler reused a destination for the high half
+    of a completion stamp, and now and then a load landed in it -- a ten-second time-out on some boxes.  The disassembly of every
+    ahead-of-time kernel is walked (tools/check_kernarg_warm.py)."""
+    n, problems = _check_kernarg_warm(os.path.join(os.path.dirname(N_LIB_PATH()), "gwi_kernels.hsaco"))
+    assert n > 100 and not problems, problems[:5]
+
+
+def N_LIB_PATH():
+    from gwinferno_amd import _native as N
+
+    return N.LIB_PATH
+
+
 def test_a_scan_chain_compiles_at_run_time_without_a_gpu(lib, tmp_path):
     """gwi_jit_compile (gwinferno_amd/csrc/gwi_jit.h): the scan template instantiated by hipRTC for a term-kind sequence the
     library has no ahead-of-time kernel for -- cross-compiled for gfx950 like hipcc does, so it runs in the CPU suite.  The
@@ -177,6 +202,12 @@ def test_a_scan_chain_compiles_at_run_time_without_a_gpu(lib, tmp_path):
                                                                    re.findall(r"\.sgpr_count:\s+(\d+)", notes))))
         return lowered, per_name, notes
 
+    for made in (got, spl, aot_like):  # chains compiled at run time come from the same header: the same check on their code objects
+        blob = open(made["path"], "rb").read()
+        co = str(tmp_path / (os.path.basename(made["path"]) + ".co"))
+        open(co, "wb").write(blob[blob.index(b"\x7fELF"):])
+        n_warm, problems = _check_kernarg_warm(co)
+        assert n_warm >= 2 and not problems, problems[:5]
     low, per, notes = kernels(got["path"], True)
     assert low[0] and low[1] and low[2] and not low[3] and low[4]          # parametric: no SAFE instantiation, a pbatch one
     assert "scan_pbatch_kernel" in low[4] and "hidden_" not in notes
