@@ -742,6 +742,7 @@ int pbatch_points(const gwi_engine* h, int K, int on_bgeo = -1) {
   return std::max(1, std::min(pts, kPbatchMaxPts));
 }
 
+constexpr int kPbatchBalancedFrom = 8;  // points per launch from which the balanced mode is used
 // Balanced mode: how many workgroups a pbatch launch of K points gets.  One round of resident workgroups, or the next smaller
 // count with which every workgroup draws the same number of (tile, point) units: ceil(N / ceil(N / capacity)).
 int pbatch_workgroups(const gwi_engine* h, int K, int on_bgeo = -1) {
@@ -760,14 +761,17 @@ gwi_status launch_scan(gwi_handle h, bool logw, int K = 1, bool batch = false) {
   // parametric models: a batched launch on single-trip tiles loads every sample once for all its points (scan_pbatch_kernel)
   // ... where a grid row holds more than one point: with one point per row (small catalogs: the rows are split until the launch
   // fills the chip) it has nothing to share and the one-row-per-point kernel is the same thing without the staging
-  const bool pb = batch && !safe && !logw && pbatch_applies(h) && (h->pbatch_balanced ? K > 1 : pbatch_points(h, K) > 1);
+  // (balanced mode from eight points on: below that the shared loads no longer pay for the staging -- config 2, K = 4: 18.5 us
+  // against 17.4 with one grid row per point, K = 2: 12.8 against 11.3; profiles/round6/balanced_ab.txt)
+  const bool balanced = h->pbatch_balanced && K >= kPbatchBalancedFrom;
+  const bool pb = batch && !safe && !logw && pbatch_applies(h) && (balanced || pbatch_points(h, K) > 1);
   h->scan_role = logw ? jit::kLogw : (safe ? jit::kSafe : (pb ? jit::kPbatch : (batch ? jit::kBatch : jit::kScan)));
   ScanFn fn = h->variant->fn[h->scan_role];
   h->scan_is_safe = safe;
   h->kargs.k_batch = batch ? K : 1;
   if (pb) {
     const size_t used = offsetof(KArgs, theta);  // the points' hyper-parameters travel in their ThetaBlocks
-    if (h->pbatch_balanced) {
+    if (balanced) {
       const int n_wg = pbatch_workgroups(h, K);
       h->kargs.pbatch_pts = -n_wg;
       launch_timed(h, 0, fn, dim3(h->spec.n_norms * K + n_wg, 1), dim3(kBlock), 0, h->sblock, used);
@@ -2503,7 +2507,7 @@ const char* gwi_batch_path(gwi_handle h, int32_t k_batch) {
     const long long gran = (long long)pbatch_u(h->variant->samples_per_lane) * kBlock;
     const bool bg = k_batch >= 4 && h->bgeo.distinct;
     if (h->pbatch && (bg ? h->bgeo.chunk_pe : h->chunk_pe) <= gran && (bg ? h->bgeo.chunk_inj : h->chunk_inj) <= gran &&
-        (h->pbatch_balanced ? k_batch > 1 : pbatch_points(h, k_batch, bg ? 1 : 0) > 1))
+        ((h->pbatch_balanced && k_batch >= kPbatchBalancedFrom) || pbatch_points(h, k_batch, bg ? 1 : 0) > 1))
       return "pbatch";
     return "rows-per-point";
   }

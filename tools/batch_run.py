@@ -26,8 +26,10 @@ if args.rows:
 from gwinferno_amd.compositions import COMPOSITIONS, draw_params  # noqa: E402
 from gwinferno_amd.synthetic import make_config_catalog  # noqa: E402
 
-name = {"c2": "plpeak", "c3": "bspline_iid", "c5": "bspline_full", "c1": "plpeak_full"}[args.config]
-pe, inj, total = make_config_catalog(args.config)
+from bench import CONFIGS  # noqa: E402
+
+name, cat = CONFIGS[args.config][:2]
+pe, inj, total = make_config_catalog(cat)
 comp = COMPOSITIONS[name](pe, inj)
 eng = comp.engine()
 rng = np.random.default_rng(1234)

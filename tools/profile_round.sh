@@ -7,9 +7,9 @@
 # the profiled program comes directly after `--`.  tools/summarize_profiles.py turns the CSVs into profiles/<round>/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-CONFIGS=${@:-c2 c3 c5}
+CONFIGS=${@:-c2 c3 c5 b50k def50k}
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --k-batch 0 --chains 0 --also none --spin 0.2"
+B="--no-cpu-baseline --k-batch 0 --chains 0 --also none --spin 0.2 --detail /dev/null"
 for c in $CONFIGS; do
   out=$R/gpurun_out/prof/$c
   mkdir -p $out
@@ -19,9 +19,9 @@ for c in $CONFIGS; do
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS --output-format csv -d $out/sq_a -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $out/sq_b -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $out/lds -- python3 $R/bench.py --config $c --steps 60 --warmup 10 $B --timing-every 0 > /dev/null 2>&1
-  python3 $R/bench.py --config $c --steps 2000 --warmup 200 --also none > $out/bench.json 2> /dev/null
+  python3 $R/bench.py --config $c --steps 2000 --warmup 200 --also none --detail $out/bench_detail.json > $out/bench.json 2> /dev/null
 done
-for c in c3 c5; do
+for c in c3 c5 b50k def50k; do
   for path in taps mfma rows; do
     out=$R/gpurun_out/prof/batch_${c}_$path
     mkdir -p $out
@@ -31,7 +31,7 @@ for c in c3 c5; do
     python3 $R/tools/batch_run.py --config $c --k 16 --n 100 $flag > $out/run.json 2> /dev/null
   done
 done
-# ---- round 5: (a) the same single evaluations through a chain compiled at gwi_create (GWI_FORCE_JIT=1: hipRTC) and through the
+# ---- (a) the same single evaluations through a chain compiled at gwi_create (GWI_FORCE_JIT=1: hipRTC) and through the
 # generic kernel (GWI_FORCE_GENERIC=1: run-time term loop) -- what a product of densities without an ahead-of-time chain runs;
 # (b) batched launches of the parametric config 2: one load per sample (scan_pbatch_kernel) against one grid row per point
 # (GWI_PBATCH=0), with the FETCH_SIZE / WRITE_SIZE passes that show what each streams from beyond L2
@@ -46,22 +46,24 @@ for mode in jit generic; do
   done
   unset GWI_FORCE_JIT GWI_FORCE_GENERIC GWI_QUIET
 done
-for path in pbatch rowsperpoint; do
+for path in pbatch rows4 rowsperpoint; do  # balanced units (default) / round 5's four grid rows of four points / one grid row per point
   out=$R/gpurun_out/prof/batch_c2_$path
   mkdir -p $out
-  [ $path = rowsperpoint ] && export GWI_PBATCH=0 || unset GWI_PBATCH
+  unset GWI_PBATCH GWI_PBATCH_BALANCED
+  [ $path = rowsperpoint ] && export GWI_PBATCH=0
+  [ $path = rows4 ] && export GWI_PBATCH_BALANCED=0
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 40 > $out/run_under_trace.json 2> /dev/null
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $out/mfma -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
   python3 $R/tools/batch_run.py --config c2 --k 16 --n 100 > $out/run.json 2> /dev/null
 done
-unset GWI_PBATCH
+unset GWI_PBATCH GWI_PBATCH_BALANCED
 # the driver's own command, for the record
-cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_form.json 2> /dev/null
+cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail gpurun_out/prof/bench_driver_form_detail.json > gpurun_out/prof/bench_driver_form.json 2> /dev/null
 # summarise on the box (the raw traces exceed what gpurun carries back) and keep only the summary
 unset GWI_BATCH_MFMA
-python3 tools/summarize_profiles.py ${ROUND:-round5} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
-cp gpurun_out/prof/bench_driver_form.json gpurun_out/profile_summary/ 2>/dev/null
+python3 tools/summarize_profiles.py ${ROUND:-round6} $R/gpurun_out/profile_summary > $R/gpurun_out/profile_summary.log 2>&1
+cp gpurun_out/prof/bench_driver_form.json gpurun_out/prof/bench_driver_form_detail.json gpurun_out/profile_summary/ 2>/dev/null
 rm -rf $R/gpurun_out/prof
 ls -la $R/gpurun_out/profile_summary
