@@ -1053,8 +1053,8 @@ def multi_chain(eng, eng_comp, comp_name, pe, inj, total, thetas, C, steps, dev)
     for c in more:
         c.engine().close()
     out["native_nuts"] = native_nuts(all_engines, comp_name, eng_comp, total, thetas)
-    try:  # the same sampler with its chains in lock step on the batched kernel: two groups of 16 chains, one host thread
-        out["native_nuts_lockstep"] = native_nuts_lockstep(all_engines[:2], 16, comp_name, eng_comp, total, thetas, 100, 50)
+    try:  # the same sampler with its chains in lock step on the batched kernel: a queue of 64 chains over two groups of 16 slots, one host thread
+        out["native_nuts_lockstep"] = native_nuts_lockstep(all_engines[:2], 16, comp_name, eng_comp, total, thetas, 100, 50, n_chains=64)
     except Exception as exc:
         out["native_nuts_lockstep"] = {"error": repr(exc)}
     for c in extra:
@@ -1166,7 +1166,7 @@ def native_nuts(engines, comp_name, comp, total, thetas, n_warmup=300, n_samples
                          "chains sit in different modes of this synthetic catalog's posterior (compare mean_log_prob_per_chain), not that they mix slowly")}
 
 
-def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, thetas, n_warmup, n_samples, common_start=None):
+def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, thetas, n_warmup, n_samples, common_start=None, n_chains=None):
     """Vectorised chains inside the library (gwi_nuts_engine_lockstep): len(engines) groups of chains_per_engine chains, every
     leapfrog step of a group ONE batched launch, the groups alternating on one host thread -- numpyro's
     chain_method="vectorized" (examples/utils.py:63-85).  Same priors and tree depth as native_nuts; a THROUGHPUT figure
@@ -1174,13 +1174,14 @@ def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, the
     from gwinferno_amd.sampling import lockstep_stats, nuts_engine_lockstep
 
     G, K = len(engines), int(chains_per_engine)
+    C = int(n_chains or G * K)  # more chains than slots: a queue (gwi_nuts_engine_queue) -- a chain that ends hands its slot to the next one waiting
     prior, bij, what = reference_priors(comp_name, comp, engines[0].n_theta)
-    starts = np.stack([thetas[c % len(thetas)] if common_start is None else thetas[common_start] for c in range(G * K)])
+    starts = np.stack([thetas[c % len(thetas)] if common_start is None else thetas[common_start] for c in range(C)])
     if bij is not None:
         for k in np.flatnonzero(bij.kind == 3):
             starts[:, k] = bij.lo[k]
     kw = dict(max_tree_depth=10, seed=1, min_neff_cut=False)
-    nuts_engine_lockstep(engines, K, total, prior, bij, starts, n_warmup=2, n_samples=2, **dict(kw, max_tree_depth=4))  # code paths, batch-path measurement
+    nuts_engine_lockstep(engines, K, total, prior, bij, starts[: G * K], n_warmup=2, n_samples=2, **dict(kw, max_tree_depth=4))  # code paths warm
     repeats0 = sum(e.two_pass_repeats() for e in engines)
     t0 = time.perf_counter()
     res = nuts_engine_lockstep(engines, K, total, prior, bij, starts, n_warmup=n_warmup, n_samples=n_samples, **kw)
@@ -1194,7 +1195,7 @@ def native_nuts_lockstep(engines, chains_per_engine, comp_name, comp, total, the
             "starts": "one prior draw per chain (as native_nuts)" if common_start is None else f"every chain from prior draw {common_start}, seeds differ",
             "note": ("chains that need fewer evaluations finish earlier and the batches shrink: mean_points_per_batch of chains_per_group is what the batched "
                      "kernels get to work with; chains started from different prior draws on this synthetic catalog differ by up to 15x in evaluations"),
-            "chains": G * K, "groups": G, "chains_per_group": K, "host_threads": 1, "batch_path": engines[0].batch_path(K), "warmup_iterations": n_warmup,
+            "chains": C, "groups": G, "chains_per_group": K, "queued": C > G * K, "host_threads": 1, "batch_path": engines[0].batch_path(K), "warmup_iterations": n_warmup,
             "sampling_iterations": n_samples, "max_tree_depth": 10, "evals": n_lf, "evals_per_s": n_lf / dt, "us_per_leapfrog": 1e6 * dt / n_lf, "wall_s": dt,
             "two_pass_repeats": sum(e.two_pass_repeats() for e in engines) - repeats0, "mean_tree_depth": float(np.mean(depth)),
             "accept_prob": float(np.mean([r["accept_rate"] for r in res])), "divergences": int(sum(r["n_divergent"] for r in res)),

@@ -257,7 +257,7 @@ EXPORTED_SYMBOLS = [
     "gwi_jit_info",
 ]
 # ... and include/gwi_sampler.h
-EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine", "gwi_nuts_run_lockstep", "gwi_nuts_engine_lockstep", "gwi_nuts_lockstep_stats"]
+EXPORTED_SYMBOLS += ["gwi_nuts_run", "gwi_nuts_engine", "gwi_nuts_run_lockstep", "gwi_nuts_engine_lockstep", "gwi_nuts_lockstep_stats", "gwi_nuts_run_queue", "gwi_nuts_engine_queue"]
 
 _lib = None
 
@@ -394,6 +394,12 @@ def load_library():
         lib.gwi_nuts_engine_lockstep.restype = C.c_int32
         lib.gwi_nuts_engine_lockstep.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiParamPrior), C.POINTER(GwiSmoothingPenalty),
                                                  C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
+    if hasattr(lib, "gwi_nuts_run_queue"):
+        lib.gwi_nuts_run_queue.restype = C.c_int32
+        lib.gwi_nuts_run_queue.argtypes = [GWI_BATCH_TARGET_FN, vp, C.c_int32, C.c_int32, C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
+        lib.gwi_nuts_engine_queue.restype = C.c_int32
+        lib.gwi_nuts_engine_queue.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GwiOptions), C.POINTER(GwiParamPrior), C.POINTER(GwiSmoothingPenalty),
+                                              C.c_int32, _DP, C.POINTER(GwiNutsOptions), _DP, _DP, _IP, C.POINTER(GwiNutsResult)]
     if lib.gwi_abi_version() != GWI_ABI_VERSION:
         raise NativeEngineError(f"ABI mismatch: library {lib.gwi_abi_version()} vs binding {GWI_ABI_VERSION}")
     _lib = lib

@@ -473,8 +473,11 @@ struct Lockstep {
     resume(f);  // runs to its first evaluation (or to its end)
   }
 
-  // chains of group g = fibers with .group == g.  Returns 0, or 1 when the backend failed (every chain then unwinds).
-  int run(LockstepBackend& be, int n_groups) {
+  // slots <= 0: chains of group g = fibers with .group == g, all started at once.  slots > 0: a QUEUE of chains -- every group
+  // runs at most `slots` chains at a time and a chain that ends hands its slot to the next chain that has not started yet
+  // (whichever group asks first), so the batches stay full until the queue is empty; a chain's draws do not depend on when or
+  // where it ran.  Returns 0, or 1 when the backend failed (every chain then unwinds).
+  int run(LockstepBackend& be, int n_groups, int slots = 0) {
     struct Group {
       std::vector<int> members, live;
       std::vector<int32_t> ids;
@@ -482,10 +485,31 @@ struct Lockstep {
       bool pending = false;
     };
     std::vector<Group> groups(n_groups);
-    for (size_t i = 0; i < fibers.size(); ++i) groups[fibers[i].group].members.push_back((int)i);
-    for (Fiber& f : fibers) start(f);
+    size_t next_queued = fibers.size();
+    auto top_up = [&](int g) {  // queue mode: finished chains leave the group, queued ones take their slots
+      Group& G = groups[g];
+      size_t kept = 0;
+      for (int i : G.members)
+        if (!fibers[i].done) G.members[kept++] = i;
+      G.members.resize(kept);
+      while ((int)G.members.size() < slots && next_queued < fibers.size()) {
+        Fiber& f = fibers[next_queued];
+        f.group = g;
+        start(f);  // runs to its first evaluation (or to its end: a starting point without likelihood)
+        if (!f.done) G.members.push_back((int)next_queued);
+        ++next_queued;
+      }
+    };
+    if (slots > 0) {
+      next_queued = 0;
+      for (int g = 0; g < n_groups; ++g) top_up(g);
+    } else {
+      for (size_t i = 0; i < fibers.size(); ++i) groups[fibers[i].group].members.push_back((int)i);
+      for (Fiber& f : fibers) start(f);
+    }
     auto issue = [&](int g) {  // gather the points of the group's waiting chains and launch them
       Group& G = groups[g];
+      if (slots > 0) top_up(g);
       G.live.clear();
       G.ids.clear();
       for (int i : G.members)
@@ -651,7 +675,12 @@ void gwi_nuts_lockstep_stats(double* out6) {
 
 gwi_status gwi_nuts_run_lockstep(gwi_batch_target_fn fn, void* user, int32_t dim, int32_t n_chains, const double* x0, const gwi_nuts_options* opt, double* samples,
                                  double* logp, int32_t* tree_depth, gwi_nuts_result* results) {
-  if (!fn || dim < 1 || n_chains < 1 || !x0 || !opt || !samples || opt->n_warmup < 0 || opt->n_samples < 0) return GWI_ERR_INVALID;
+  return gwi_nuts_run_queue(fn, user, dim, n_chains, 0, x0, opt, samples, logp, tree_depth, results);
+}
+
+gwi_status gwi_nuts_run_queue(gwi_batch_target_fn fn, void* user, int32_t dim, int32_t n_chains, int32_t slots, const double* x0, const gwi_nuts_options* opt, double* samples,
+                              double* logp, int32_t* tree_depth, gwi_nuts_result* results) {
+  if (!fn || dim < 1 || n_chains < 1 || slots < 0 || !x0 || !opt || !samples || opt->n_warmup < 0 || opt->n_samples < 0) return GWI_ERR_INVALID;
   struct Job {
     const double* x0;
     gwi_nuts_options o;
@@ -685,7 +714,7 @@ gwi_status gwi_nuts_run_lockstep(gwi_batch_target_fn fn, void* user, int32_t dim
   be.fn = fn;
   be.user = user;
   be.dim = dim;
-  const int failed = ls.run(be, 1);
+  const int failed = ls.run(be, 1, slots);
   if (failed) return GWI_ERR_HIP;
   for (int c = 0; c < n_chains; ++c)
     if (ls.fibers[c].rc != 0) return ls.fibers[c].rc == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;
@@ -695,10 +724,19 @@ gwi_status gwi_nuts_run_lockstep(gwi_batch_target_fn fn, void* user, int32_t dim
 gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups, int32_t chains_per_group, int32_t n_theta, const gwi_options* lopt, const gwi_param_prior* priors,
                                     const gwi_smoothing_penalty* pens, int32_t n_pens, const double* u0, const gwi_nuts_options* opt, double* samples, double* logp,
                                     int32_t* tree_depth, gwi_nuts_result* results) {
-  if (!handles || n_groups < 1 || chains_per_group < 1 || n_theta < 1 || !lopt || !priors || !u0 || !opt || !samples) return GWI_ERR_INVALID;
+  if (n_groups < 1 || chains_per_group < 1) return GWI_ERR_INVALID;
+  return gwi_nuts_engine_queue(handles, n_groups, chains_per_group, n_groups * chains_per_group, n_theta, lopt, priors, pens, n_pens, u0, opt, samples, logp, tree_depth, results);
+}
+
+gwi_status gwi_nuts_engine_queue(const gwi_handle* handles, int32_t n_groups, int32_t slots_per_group, int32_t n_chains, int32_t n_theta, const gwi_options* lopt,
+                                 const gwi_param_prior* priors, const gwi_smoothing_penalty* pens, int32_t n_pens, const double* u0, const gwi_nuts_options* opt, double* samples,
+                                 double* logp, int32_t* tree_depth, gwi_nuts_result* results) {
+  const int chains_per_group = slots_per_group;
+  if (!handles || n_groups < 1 || slots_per_group < 1 || n_chains < 1 || n_theta < 1 || !lopt || !priors || !u0 || !opt || !samples) return GWI_ERR_INVALID;
   for (int k = 0; k < n_pens; ++k)
     if (!pens || pens[k].offset < 0 || pens[k].count < 2 || pens[k].offset + pens[k].count > n_theta || pens[k].degree < 1 || pens[k].degree >= pens[k].count) return GWI_ERR_INVALID;
-  const int n_chains = n_groups * chains_per_group;
+  // exactly n_groups x slots chains: the static assignment (chain c in group c / slots, all started at once); otherwise a queue
+  const bool queued = n_chains != n_groups * slots_per_group;
   struct Job {
     EngineTarget e;
     const double* u0;
@@ -718,7 +756,7 @@ gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups,
     Fiber& f = ls.fibers[c];
     f.owner = &ls;
     f.chain = c;
-    f.group = c / chains_per_group;
+    f.group = queued ? 0 : c / chains_per_group;  // (queued chains learn their group when they start)
     Job& j = jobs[c];
     j.e = EngineTarget{handles[f.group], *lopt, priors, pens, n_pens, n_theta, Vec(n_theta), Vec(n_theta), Vec(n_theta), Vec(n_theta), {}, {}};
     // the chain's likelihood evaluation = a slot in its group's batched launch
@@ -740,7 +778,7 @@ gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups,
   EngineBackend be;
   be.handles = handles;
   be.lopt = *lopt;
-  const int failed = ls.run(be, n_groups);
+  const int failed = ls.run(be, n_groups, queued ? slots_per_group : 0);
   if (failed) return GWI_ERR_HIP;
   for (int c = 0; c < n_chains; ++c) {
     if (ls.fibers[c].rc != 0) return ls.fibers[c].rc == 2 ? GWI_ERR_INVALID : GWI_ERR_HIP;

@@ -550,11 +550,12 @@ def nuts_native(target, theta0, n_warmup=200, n_samples=200, max_tree_depth=10, 
     return out
 
 
-def nuts_native_lockstep(batch_target, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0):
-    """Lock-step chains on a Python BATCHED target (``gwi_nuts_run_lockstep``): ``batch_target(xs[k, d], chain_ids[k]) ->
+def nuts_native_lockstep(batch_target, theta0s, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0, slots=0):
+    """Lock-step chains on a Python BATCHED target (``gwi_nuts_run_queue``): ``batch_target(xs[k, d], chain_ids[k]) ->
     (log_probs[k], grads[k, d])`` is called once per leapfrog step of all running chains (numpyro's
     ``chain_method="vectorized"``).  Chain ``c`` uses seed ``seed + 1000 c`` and draws exactly what :func:`nuts_native`
-    draws with that seed.  Returns one dict per chain."""
+    draws with that seed.  ``slots > 0``: at most that many chains run at a time; a chain that ends hands its slot to the next
+    one waiting, so the batches stay full until the queue is empty.  Returns one dict per chain."""
     import ctypes as C
 
     from . import _native as N
@@ -577,8 +578,8 @@ def nuts_native_lockstep(batch_target, theta0s, n_warmup=200, n_samples=200, max
     samples, logp, depth = np.empty((n_chains, n_samples, d)), np.empty((n_chains, n_samples)), np.empty((n_chains, n_samples), dtype=np.int32)
     res = (N.GwiNutsResult * n_chains)()
     opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
-    st = lib.gwi_nuts_run_lockstep(N.GWI_BATCH_TARGET_FN(cb), None, d, n_chains, N.as_dp(theta0s), C.byref(opt), N.as_dp(samples), N.as_dp(logp),
-                                   depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    st = lib.gwi_nuts_run_queue(N.GWI_BATCH_TARGET_FN(cb), None, d, n_chains, int(slots), N.as_dp(theta0s), C.byref(opt), N.as_dp(samples), N.as_dp(logp),
+                                depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
     if err:
         raise err[0]
     if st == -1:
@@ -630,7 +631,10 @@ def nuts_engine_lockstep(engines, chains_per_engine, total_inj, prior, bijector,
     group ``g`` on ``engines[g]``, every leapfrog step of a group ONE batched launch (``gwi_eval_batch``'s kernels) -- numpyro's
     ``chain_method="vectorized"`` (examples/utils.py:63-85).  One host thread; with two or three engines the groups' launches
     overlap each other's host arithmetic.  Same target and return value as :func:`nuts_engine` (``theta0s[c]``: constrained
-    starting point of chain ``c``, chain ``c`` in group ``c // chains_per_engine``)."""
+    starting point of chain ``c``, chain ``c`` in group ``c // chains_per_engine``).  MORE starting points than
+    ``len(engines) * chains_per_engine`` make a queue (``gwi_nuts_engine_queue``): every engine runs ``chains_per_engine`` chains
+    at a time and a chain that ends hands its slot to the next one waiting, so the batches stay full; chain ``c`` draws what it
+    would draw alone with seed ``seed + 1000 c`` wherever it runs."""
     import ctypes as C
 
     from . import _native as N
@@ -639,8 +643,8 @@ def nuts_engine_lockstep(engines, chains_per_engine, total_inj, prior, bijector,
     theta0s = np.atleast_2d(N.f64(theta0s))
     n_chains, n_theta = theta0s.shape
     K = int(chains_per_engine)
-    if len(engines) * K != n_chains:
-        raise ValueError("theta0s must hold len(engines) * chains_per_engine starting points")
+    if n_chains < len(engines) * K:
+        raise ValueError("theta0s must hold at least len(engines) * chains_per_engine starting points")
     lib = engines[0].lib
     pri, pens, u0, lopt = _engine_sampler_args(engines, n_theta, prior, bijector, theta0s, total_inj, likelihood_flags)
     handles = (C.c_void_p * len(engines))(*[e.handle for e in engines])
@@ -649,8 +653,8 @@ def nuts_engine_lockstep(engines, chains_per_engine, total_inj, prior, bijector,
     depth = np.empty((n_chains, n_samples), dtype=np.int32)
     res = (N.GwiNutsResult * n_chains)()
     opt = _nuts_options(n_warmup, n_samples, max_tree_depth, target_accept, seed)
-    st = lib.gwi_nuts_engine_lockstep(handles, len(engines), K, n_theta, C.byref(lopt), pri, pens, len(prior.penalties), N.as_dp(u0), C.byref(opt), N.as_dp(samples),
-                                      N.as_dp(logp), depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
+    st = lib.gwi_nuts_engine_queue(handles, len(engines), K, n_chains, n_theta, C.byref(lopt), pri, pens, len(prior.penalties), N.as_dp(u0), C.byref(opt), N.as_dp(samples),
+                                   N.as_dp(logp), depth.ctypes.data_as(C.POINTER(C.c_int32)), res)
     if st == -1:
         raise ValueError("gwi_nuts_engine_lockstep: a chain's starting point has zero likelihood (a cut, or outside the model's support) or a non-finite gradient")
     if st != 0:

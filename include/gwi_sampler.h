@@ -91,6 +91,20 @@ gwi_status gwi_nuts_engine_lockstep(const gwi_handle* handles, int32_t n_groups,
                                     const gwi_param_prior* priors, const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt,
                                     double* samples, double* log_prob, int32_t* tree_depth, gwi_nuts_result* results);
 
+/* A QUEUE of chains on the batched kernels: n_chains chains (any number) over n_groups x slots_per_group slots.  Every group runs
+ * at most slots_per_group chains at a time; a chain that has drawn its last sample hands its slot to the next chain that has not
+ * started yet, so the batches stay full until the queue is empty instead of shrinking as the quick chains finish (chains started
+ * from different points need up to 15 x different numbers of evaluations: gwi_nuts_lockstep_stats).  Chain c still draws, bit for
+ * bit, what gwi_nuts_run draws with seed opt->seed + 1000 c -- when and in which group it ran does not enter.  With n_chains ==
+ * n_groups x slots_per_group this is gwi_nuts_engine_lockstep (static assignment).  numpyro's counterpart: num_chains >
+ * device count under chain_method="parallel" (examples/utils.py:62, 118), run in rounds there.
+ * gwi_nuts_run_queue: the same for an arbitrary batched target (one group; slots = 0: every chain at once). */
+gwi_status gwi_nuts_engine_queue(const gwi_handle* handles, int32_t n_groups, int32_t slots_per_group, int32_t n_chains, int32_t n_theta, const gwi_options* lopt,
+                                 const gwi_param_prior* priors, const gwi_smoothing_penalty* penalties, int32_t n_penalties, const double* u0, const gwi_nuts_options* opt,
+                                 double* samples, double* log_prob, int32_t* tree_depth, gwi_nuts_result* results);
+gwi_status gwi_nuts_run_queue(gwi_batch_target_fn fn, void* user, int32_t dim, int32_t n_chains, int32_t slots, const double* x0, const gwi_nuts_options* opt, double* samples,
+                              double* log_prob, int32_t* tree_depth, gwi_nuts_result* results);
+
 /* Of the calling thread's last lock-step run: out6 = { batched evaluations made, points in them (their quotient is the mean
  * batch size: chains whose trees need fewer steps finish earlier and the batches shrink -- a run whose chains need very
  * different numbers of evaluations gains little from lock step), seconds collecting (mostly waiting for the GPU), seconds in the

@@ -206,6 +206,25 @@ int main() {
       if (std::memcmp(one.data(), &samples[(size_t)c * ns * n], sizeof(double) * ns * n) != 0 || r.n_evals != res[c].n_evals) return 13;
     }
     std::printf("lock step on engines: %d x %d chains equal the chains run alone\n", groups, per);
+    // 4. a QUEUE of chains: 11 chains over 2 groups x 2 slots -- a chain that ends hands its slot on; every chain still draws
+    //    what it draws alone, in whichever group and next to whichever chains it ran
+    const int queued = 11, slots = 2;
+    std::vector<double> uq((size_t)queued * n, 0.0), sq((size_t)queued * ns * n);
+    for (int c = 0; c < queued; ++c)
+      for (int i = 2; i < n; ++i) uq[(size_t)c * n + i] = 0.15 * c - 0.05 * i;
+    std::vector<gwi_nuts_result> rq(queued);
+    if (gwi_nuts_engine_queue(handles.data(), groups, slots, queued, n, &lopt, pri, &pen, 1, uq.data(), &o, sq.data(), nullptr, nullptr, rq.data()) != GWI_OK) return 14;
+    double st[6];
+    gwi_nuts_lockstep_stats(st);
+    for (int c = 0; c < queued; ++c) {
+      gwi_nuts_options oc = o;
+      oc.seed = o.seed + 1000ULL * c;
+      gwi_nuts_result r;
+      if (gwi_nuts_engine(handles.data(), 1, n, &lopt, pri, &pen, 1, &uq[(size_t)c * n], &oc, one.data(), nullptr, nullptr, &r) != GWI_OK) return 15;
+      if (std::memcmp(one.data(), &sq[(size_t)c * ns * n], sizeof(double) * ns * n) != 0 || r.n_evals != rq[c].n_evals) return 16;
+    }
+    if (st[1] / st[0] > slots || st[1] / st[0] < 1.6) return 17;  // never more than `slots` per batch, and close to full
+    std::printf("queue of chains on engines: %d chains over %d x %d slots, %.0f batches of %.2f points\n", queued, groups, slots, st[0], st[1] / st[0]);
   }
   std::printf("OK\n");
   return 0;

@@ -180,6 +180,65 @@ def test_lockstep_chains_draw_what_separate_chains_draw():
     assert again[0]["samples"].shape == (5, 5)
 
 
+def test_a_queue_of_chains_keeps_the_batches_full_and_draws_the_same():
+    """gwi_nuts_run_queue: 11 chains over 3 slots.  A chain that has drawn its last sample hands its slot to the next chain
+    waiting, so the batches stay full until the queue is empty (without the queue they shrink as quick chains finish); chain c
+    draws, bit for bit, what gwi_nuts_run draws with seed + 1000 c, whenever and next to whichever chains it ran.  Chains of
+    very different lengths (different warm-up trajectories from different starts), a dead starting point in the middle of the
+    queue and a failing target are covered."""
+    from gwinferno_amd.sampling import lockstep_stats, nuts_native, nuts_native_lockstep
+
+    target, _, _ = _gaussian()
+    sizes = []
+
+    def batch(xs, ids):
+        sizes.append(len(ids))
+        assert len(set(ids.tolist())) == len(ids)
+        vg = [target(x) for x in xs]
+        return np.array([v for v, _ in vg]), np.stack([g for _, g in vg])
+
+    rng = np.random.default_rng(12)
+    starts = rng.normal(size=(11, 5)) * np.linspace(0.2, 3.0, 11)[:, None]
+    res = nuts_native_lockstep(batch, starts, n_warmup=40, n_samples=25, seed=9, slots=3)
+    evals = []
+    for c, r in enumerate(res):
+        alone = nuts_native(target, starts[c], n_warmup=40, n_samples=25, seed=9 + 1000 * c)
+        assert np.array_equal(r["samples"], alone["samples"]) and np.array_equal(r["tree_depth"], alone["tree_depth"])
+        assert r["n_evals"] == alone["n_evals"] and r["step_size"] == alone["step_size"]
+        evals.append(r["n_evals"])
+    assert sum(sizes) == sum(evals) and max(sizes) == 3
+    # never more than three at a time, and full almost to the end: only the last chains run in a shrinking batch
+    tail = sorted(evals)[-1]
+    assert np.mean(sizes) > 2.6 and sum(1 for s in sizes if s < 3) <= tail
+    assert lockstep_stats()["mean_points_per_batch"] == pytest.approx(np.mean(sizes))
+    # every chain at once (slots = 0): the same draws again
+    flat = nuts_native_lockstep(batch, starts, n_warmup=40, n_samples=25, seed=9)
+    for a, b in zip(res, flat):
+        assert np.array_equal(a["samples"], b["samples"])
+
+    # a dead starting point in the queue: reported, the library stays usable
+    def walled(xs, ids):
+        v, g = batch(xs, ids)
+        return np.where(xs[:, 0] > 5.0, -np.inf, v), g
+
+    bad = starts.copy()
+    bad[6] = 9.0
+    with pytest.raises(ValueError, match="starting point"):
+        nuts_native_lockstep(walled, bad, n_warmup=5, n_samples=5, slots=3)
+    calls = [0]
+
+    def broken(xs, ids):
+        calls[0] += 1
+        if calls[0] > 30:
+            raise ZeroDivisionError("target failed")
+        return batch(xs, ids)
+
+    with pytest.raises(ZeroDivisionError):
+        nuts_native_lockstep(broken, starts, n_warmup=20, n_samples=5, slots=3)
+    assert calls[0] == 31
+    assert nuts_native_lockstep(batch, starts[:4], n_warmup=5, n_samples=5, seed=2, slots=2)[3]["samples"].shape == (5, 5)
+
+
 def test_native_nuts_survives_a_wall_and_matches_the_numpy_sampler_statistically():
     from gwinferno_amd.sampling import nuts_native
 
