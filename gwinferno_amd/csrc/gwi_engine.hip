@@ -2212,7 +2212,9 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   {
     const size_t n_groups = (size_t)n_ev + h->n_inj_groups;
     const size_t row_bytes = 64 * n_groups * (size_t)((3 + spec->n_theta + 6) / 7);  // self-validating 64-byte lines: 7 values + the sequence number
-    size_t host_final_limit = 64 * 1024;  // measured: config 3 (41 KB of rows) gains 2 us from host-final, config 5 (195 KB) loses 5
+    // measured per evaluation: config 3 (48 KB of rows) gains 2 us from host-final, the reference's default spline counts on 69 events
+    // (165 hyper-parameters: 114 KB) 0.85 us (27.35 against 28.21 us; profiles/round6/hostfinal_def50k.txt), config 5 (195 KB) loses 5-8
+    size_t host_final_limit = 120 * 1024;
     if (const char* env = std::getenv("GWI_HOST_FINAL_BYTES")) host_final_limit = (size_t)std::atoll(env);
     h->host_final = row_bytes <= host_final_limit;
     if (const char* env = std::getenv("GWI_HOST_FINAL")) h->host_final = h->host_final && std::atoi(env) != 0;
