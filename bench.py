@@ -335,6 +335,9 @@ def _batched_entry(blk):
     if not b:
         return None
     out = {"k": b.get("k_batch"), "evals_per_s": b.get("evals_per_s"), "path": b.get("path"), "scan_us": _pick(b, "avg_kernel_us", "scan")}
+    flight = {t: _pick(b, "sets_in_flight", f"{t}_one_thread", "evals_per_s") for t in (2, 3)}
+    if any(v is not None for v in flight.values()):  # T sets of k points in flight from ONE host thread (gwi_eval_batch_begin / _end)
+        out["sets_in_flight_one_thread_evals_per_s"] = {str(t): v for t, v in flight.items() if v is not None}
     if _pick(b, "mfma", "frac_of_78.6") is not None:
         out["mfma_issued_frac"] = _pick(b, "mfma", "frac_of_78.6")
         out["mfma_useful_frac"] = _pick(b, "mfma", "useful_frac_of_78.6")
@@ -881,7 +884,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
             try:
                 import threading
 
-                if not full:
+                if not full and not headline:  # (the default run keeps the one-thread form for the headline configuration only)
                     raise StopIteration
 
                 extra_comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(2)]
@@ -889,7 +892,7 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                 fns = [e.configure_batch(K, total, min_neff_cut=False) for e in set_engs]
                 n_o = max(40, min(400, steps // (2 * K)))
                 over = {}
-                for T in (2, 3):
+                for T in ((2, 3) if full else ()):
                     gate = threading.Barrier(T + 1)
 
                     def drive(f):

@@ -2137,12 +2137,20 @@ static gwi_status create_impl(const gwi_spec* spec, const double* const* pe_cols
   if (const char* env = std::getenv("GWI_BATCH_GEOMETRY")) {  // 0: batched launches on the single evaluation's geometry
     if (std::atoi(env) == 0) spb_batch = 0;
   }
-  // Parametric models batch on scan_pbatch_kernel (every sample loaded once for all the points of a launch), which takes
-  // single-trip tiles: the single evaluation's where those are single trips already (the BASELINE catalogs), else a batch
-  // geometry of one trip per workgroup.  GWI_PBATCH=0 keeps the one-grid-row-per-point kernel (A/B).
-  h->pbatch = h->variant->has(jit::kPbatch) && !h->generic;
-  if (const char* env = std::getenv("GWI_PBATCH")) h->pbatch = h->pbatch && std::atoi(env) != 0;
+  // Parametric models have two batched kernels: one grid row per point (scan_kernel BATCH: the catalog streams K times through
+  // L2 / the Infinity Cache) and scan_pbatch_kernel (every sample loaded once for the points a workgroup draws; single-trip
+  // tiles: the single evaluation's where those are single trips already, else a batch geometry of one trip per workgroup).
+  // Which one is faster turned out to depend on the BOX: round 5's boxes ran pbatch 3-8 % ahead (42.3 against 43.7 us at config 2,
+  // K = 16), every box of round 6 ran it 5-14 % behind at every catalog size from 1 to 8 x config 2 (49.4 against 54.8 us; 287
+  // against 327 us at 8 x; blocking 242-251 k against 215-227 k evals/s: profiles/round6/EXPERIMENTS.md section 5) although it issues
+  // 30 % fewer instructions and moves a seventh of the bytes -- the denser fp64 kernel is the one whose time varies from box to
+  // box.  The choice must be static (the two sum in different orders): the row-per-point kernel is the default since round 6,
+  // GWI_PBATCH=1 (or a row size, GWI_PBATCH_PTS) selects the one-load-per-sample kernel.
+  h->pbatch = false;
   if (const char* env = std::getenv("GWI_PBATCH_PTS")) h->pbatch_pts = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("GWI_PBATCH")) h->pbatch = std::atoi(env) != 0;
+  else h->pbatch = h->pbatch_pts > 0;
+  h->pbatch = h->pbatch && h->variant->has(jit::kPbatch) && !h->generic;
   h->pbatch_balanced = h->pbatch_pts == 0;  // (naming a row size asks for the rows mode)
   if (const char* env = std::getenv("GWI_PBATCH_BALANCED")) h->pbatch_balanced = std::atoi(env) != 0;
   if (h->pbatch) {

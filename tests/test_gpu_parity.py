@@ -1014,13 +1014,16 @@ def test_device_gradient_against_finite_differences_of_the_device_value(comp_nam
     ("plpeak", 5, 300, 70, {"GWI_PBATCH_PTS": "3"}),                 # rows of 3, 3, ... points: a last row with fewer; waves without samples
     ("plpeak_smooth", 9, 512, 2048, {"GWI_PBATCH_PTS": "16"}),       # exactly one full trip per tile; one grid row for the whole batch
     ("chm_powerlaw", 6, 900, 3000, {"GWI_PBATCH_PTS": "5"}),         # theta-dependent truncation (POWERLAW_BOUNDS)
-    ("plpeak", 20, 30000, 300000, {}),                               # tiles of several trips for single evaluations: batches on single-trip tiles of their own
+    ("plpeak", 20, 30000, 300000, {"GWI_PBATCH": "1"}),              # tiles of several trips for single evaluations: batches on single-trip tiles of their own; from 8 points on the BALANCED mode ((tile, point) units dealt out evenly)
     ("plpeak", 8, 800, 6000, {"GWI_MAX_BATCH": "40", "GWI_PBATCH_PTS": "16"}),  # 40 points: grid rows of 16, 16 and 8 (the LDS staging holds 16)
+    ("plpeak", 69, 5000, 50000, {"GWI_PBATCH": "1", "GWI_MAX_BATCH": "40"}),    # BASELINE config 2's shape: balanced mode, 788 tiles x 16 / 40 points over one round of workgroups (segments of up to 16 points)
+    ("plpeak_full", 3, 130, 200, {"GWI_PBATCH": "1"}),               # balanced mode with fewer units than workgroup slots: one unit per workgroup
 ])
 def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe, n_inj, env, monkeypatch):
-    """scan_pbatch_kernel (batched launches of models without spline terms: every sample loaded once for all the points of a
-    grid row) against the C oracle, against single evaluations and against the one-grid-row-per-point kernel (GWI_PBATCH=0),
-    for batch sizes on both sides of the host-final / device-final switch, with and without the squared-weight pass."""
+    """scan_pbatch_kernel (batched launches of models without spline terms: every sample loaded once for the points a workgroup
+    draws; GWI_PBATCH=1 or a row size -- the default since round 6 is the one-grid-row-per-point kernel) against the C oracle,
+    against single evaluations and against that default, in rows mode and in balanced mode, for batch sizes on both sides of the
+    host-final / device-final switch, with and without the squared-weight pass."""
     from gwinferno_amd.compositions import COMPOSITIONS, draw_params
     from gwinferno_amd.synthetic import make_catalog
     from oracle.c_oracle import COracle
@@ -1031,9 +1034,11 @@ def test_one_load_per_sample_batches_of_parametric_models(comp_name, n_ev, n_pe,
     comp = COMPOSITIONS[comp_name](pe, inj)
     eng = comp.engine()
     assert eng.batch_path(16) == "pbatch", eng.batch_path(16)
-    monkeypatch.setenv("GWI_PBATCH", "0")
-    old = COMPOSITIONS[comp_name](pe, inj).engine()
-    monkeypatch.delenv("GWI_PBATCH")
+    for k in env:
+        monkeypatch.delenv(k)
+    if "GWI_MAX_BATCH" in env:
+        monkeypatch.setenv("GWI_MAX_BATCH", env["GWI_MAX_BATCH"])
+    old = COMPOSITIONS[comp_name](pe, inj).engine()  # the default: one grid row per point
     assert old.batch_path(16) == "rows-per-point"
     orc = COracle(eng.bound)
     rng = np.random.default_rng(15)

@@ -46,12 +46,12 @@ for mode in jit generic; do
   done
   unset GWI_FORCE_JIT GWI_FORCE_GENERIC GWI_QUIET
 done
-for path in pbatch rows4 rowsperpoint; do  # balanced units (default) / round 5's four grid rows of four points / one grid row per point
+for path in pbatch rows4 rowsperpoint; do  # one load per sample, balanced units (GWI_PBATCH=1) / round 5's four grid rows of four points / one grid row per point (the default)
   out=$R/gpurun_out/prof/batch_c2_$path
   mkdir -p $out
   unset GWI_PBATCH GWI_PBATCH_BALANCED
-  [ $path = rowsperpoint ] && export GWI_PBATCH=0
-  [ $path = rows4 ] && export GWI_PBATCH_BALANCED=0
+  [ $path = pbatch ] && export GWI_PBATCH=1
+  [ $path = rows4 ] && export GWI_PBATCH=1 GWI_PBATCH_BALANCED=0
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 40 > $out/run_under_trace.json 2> /dev/null
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/tools/batch_run.py --config c2 --k 16 --n 10 > /dev/null 2>&1

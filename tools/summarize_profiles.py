@@ -131,8 +131,8 @@ def main(round_name, dst=None):
     lines += ["", "Batched launches, K = 16 hyper-parameter points (tools/batch_run.py; paths: `mfma` = the default for spline models, gwi_mfma.h; `taps` = GWI_BATCH_MFMA=0; `rows` = GWI_BATCH_ROWS=1). MFMA FLOP = 2048 x SQ_INSTS_MFMA; utilisation = that rate over the 78.6 TFLOP/s fp64 matrix peak (SQ_INSTS_VALU includes the matrix instructions):", ""] + b_lines
     lines += ["", "Scan-kernel SQ counters (separate `--pmc` passes; fp64 FLOP = 64 x (ADD + MUL + 2 FMA + TRANS) wave-instructions):", ""] + sq_lines
     if len(p_lines) > 2:
-        lines += ["", "Batched launches of the parametric config 2, K = 16 points: `pbatch` = scan_pbatch_kernel, a tile's samples loaded once for the run of points a workgroup draws (balanced mode: (tile, point) units dealt out evenly to one round of workgroups), "
-                  "`rowsperpoint` = GWI_PBATCH=0, one grid row per point (scan_kernel BATCH).  Bytes from beyond L2 per LAUNCH against the algorithmic bytes of one pass over the catalog:", ""] + p_lines
+        lines += ["", "Batched launches of the parametric config 2, K = 16 points: `pbatch` = scan_pbatch_kernel (GWI_PBATCH=1), a tile's samples loaded once for the run of points a workgroup draws (balanced mode: (tile, point) units dealt out evenly to one round of workgroups), "
+                  "`rows4` = the same kernel with round 5's four grid rows of four points, `rowsperpoint` = one grid row per point (scan_kernel BATCH: the default since round 6).  Bytes from beyond L2 per LAUNCH against the algorithmic bytes of one pass over the catalog:", ""] + p_lines
     # ---- chains compiled at gwi_create (hipRTC) and the generic kernel on the same configurations
     c_lines = ["| config | scan kernel | how | calls | scan avg us (rocprofv3) | algorithmic GB/s | frac of 8 TB/s | evals/s (untraced) |", "|---|---|---|---|---|---|---|---|"]
     alg_scalars = {"c1": 10, "c2": 4, "c3": 8, "c5": 9, "b50k": 8, "def50k": 9}
