@@ -320,8 +320,9 @@ gwi_status gwi_eval_batch_end(gwi_handle h, gwi_summary* summaries, double* grad
  * the default) or "mfma" (GWI_BATCH_MFMA=1 at gwi_create, models with spline terms whose term sequence and basis counts
  * have a matrix-core instantiation, k_batch >= 9: the spline-coefficient gradient as a v_mfma_f64_16x16x4 GEMM over 16
  * points per wavefront, gwinferno_amd/csrc/gwi_mfma.h).  Both are kept because both are measured: see DESIGN.md.
- * Models without spline terms: "pbatch" (every sample loaded once for all the points of a grid row, scan_pbatch_kernel;
- * GWI_PBATCH=0 or tiles of more than one trip: "rows-per-point", one grid row per point). */
+ * Models without spline terms: "rows-per-point" (one grid row per point, scan_kernel BATCH: the default since round 6) or
+ * "pbatch" (GWI_PBATCH=1 or a row size GWI_PBATCH_PTS: scan_pbatch_kernel, every sample loaded once for the points a workgroup
+ * draws; which of the two is faster depends on the box, within 10 %: profiles/round6/EXPERIMENTS.md section 5). */
 const char* gwi_batch_path(gwi_handle h, int32_t k_batch);
 /* Spline models that have both batched kernels: which one runs follows a STATIC rule by default (matrix cores from 9 points per
  * launch on, up to 8 gradient tiles; otherwise the 4-tap kernel) -- the two kernels sum in different orders, so the same model on
