@@ -878,64 +878,12 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
                                           "useful_note": "frac_of_78.6 counts issued matrix-core flops; a quarter of them (4 of 16 rows per column) carry taps",
                                           "source": (pmc_table("batched_k16") or {}).get("source"),
                                           "what": "the design-matrix contraction sum_s w_s B_p(x_s) for 16 hyper-parameter points per wavefront (gwi_mfma.h); A = 16 bases x 4 samples with 4 non-zero taps per column"}
-            # several sets in flight: a blocking batch leaves the GPU to its combine / final launches and the host for a third of its
-            # time; T host threads, each driving an engine of its own with blocking K-point sets (two or three groups of vectorised
-            # chains side by side), let the other sets' scans fill it.  The figure above stays the blocking one.
-            try:
-                import threading
-
-                if not full and not headline:  # (the default run keeps the one-thread form for the headline configuration only)
-                    raise StopIteration
-
-                extra_comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(2)]
-                set_engs = [eng] + [c.engine(device=dev) for c in extra_comps]
-                fns = [e.configure_batch(K, total, min_neff_cut=False) for e in set_engs]
-                n_o = max(40, min(400, steps // (2 * K)))
-                over = {}
-                for T in ((2, 3) if full else ()):
-                    gate = threading.Barrier(T + 1)
-
-                    def drive(f):
-                        for _ in range(10):
-                            f(tb)
-                        gate.wait()
-                        for _ in range(n_o):
-                            f(tb)
-                        gate.wait()
-
-                    ws = [threading.Thread(target=drive, args=(fns[i],)) for i in range(T)]
-                    for w in ws:
-                        w.start()
-                    gate.wait()
-                    t0o = time.perf_counter()
-                    gate.wait()
-                    dto = time.perf_counter() - t0o
-                    for w in ws:
-                        w.join()
-                    over[str(T)] = {"evals_per_s": T * n_o * K / dto, "us_per_eval": 1e6 * dto / (T * n_o * K)}
-                # the same from ONE host thread: gwi_eval_batch_begin on set i + 1 before gwi_eval_batch_end on set i
-                for T in (2, 3):
-                    hv = [e.configure_batch_async(K, total, min_neff_cut=False) for e in set_engs[:T]]
-                    for rep in range(2):  # first lap untimed
-                        n_1 = 30 if rep == 0 else n_o
-                        t0 = time.perf_counter()
-                        for j in range(T - 1):
-                            hv[j][0](tb)
-                        for it in range(n_1 * T):
-                            hv[(it + T - 1) % T][0](tb)
-                            hv[it % T][1]()
-                        for j in range(T - 1):
-                            hv[(n_1 * T + j) % T][1]()
-                        dto = time.perf_counter() - t0
-                    n_sets = n_o * T + T - 1
-                    over[f"{T}_one_thread"] = {"evals_per_s": n_sets * K / dto, "us_per_eval": 1e6 * dto / (n_sets * K)}
-                out["batched"]["sets_in_flight"] = dict(over, what=f"T blocking sets of {K} points side by side, one host thread and one engine per set (same catalog, same GPU); 'T_one_thread': T sets in flight from ONE thread through gwi_eval_batch_begin / gwi_eval_batch_end")
-                for e in set_engs[1:]:
-                    e.close()
-            except StopIteration:
-                pass
-            except Exception as exc:  # a secondary figure: never the reason a line is missing
-                out["batched"]["sets_in_flight"] = {"error": repr(exc)}
+            # several sets in flight (full: from T host threads and from one; default run: the one-thread form for the headline only)
+            if full or headline:
+                try:
+                    out["batched"]["sets_in_flight"] = sets_in_flight(eng, comp_name, pe, inj, total, tb, K, steps, dev, threaded=full)
+                except Exception as exc:  # a secondary figure: never the reason a line is missing
+                    out["batched"]["sets_in_flight"] = {"error": repr(exc)}
             # the other batched kernels on the same batch, where the model has them (spline models): the 4-tap kernel (one
             # grid row per point, LDS atomics) and the LDS-row variant of the 16-points-per-wavefront kernel
             alts = {}
@@ -984,6 +932,65 @@ def measure(run, cfg, steps, warmup, timing_every, spin_s=0.6, headline=False, w
         dist.barrier()
     eng.close()
     return out
+
+
+def sets_in_flight(eng, comp_name, pe, inj, total, tb, K, steps, dev, threaded):
+    """A blocking batch leaves the GPU to its combine / final launches and the host for a third of its time; with several sets of
+    K points in flight the other sets' scans fill it.  `threaded`: T host threads, each driving an engine of its own with blocking
+    sets; always: T sets in flight from ONE host thread (gwi_eval_batch_begin on set i + 1 before gwi_eval_batch_end on set i, an
+    engine per set).  The blocking figure stays the one quoted as `batched.evals_per_s`."""
+    import threading
+
+    from gwinferno_amd.compositions import COMPOSITIONS
+
+    extra_comps = [COMPOSITIONS[comp_name](pe, inj) for _ in range(2)]
+    set_engs = [eng] + [c.engine(device=dev) for c in extra_comps]
+    n_o = max(40, min(400, steps // (2 * K)))
+    over = {}
+    try:
+        if threaded:
+            fns = [e.configure_batch(K, total, min_neff_cut=False) for e in set_engs]
+            for T in (2, 3):
+                gate = threading.Barrier(T + 1)
+
+                def drive(f):
+                    for _ in range(10):
+                        f(tb)
+                    gate.wait()
+                    for _ in range(n_o):
+                        f(tb)
+                    gate.wait()
+
+                ws = [threading.Thread(target=drive, args=(fns[i],)) for i in range(T)]
+                for w in ws:
+                    w.start()
+                gate.wait()
+                t0o = time.perf_counter()
+                gate.wait()
+                dto = time.perf_counter() - t0o
+                for w in ws:
+                    w.join()
+                over[str(T)] = {"evals_per_s": T * n_o * K / dto, "us_per_eval": 1e6 * dto / (T * n_o * K)}
+        for T in (2, 3):
+            hv = [e.configure_batch_async(K, total, min_neff_cut=False) for e in set_engs[:T]]
+            for rep in range(2):  # first lap untimed
+                n_1 = 30 if rep == 0 else n_o
+                t0 = time.perf_counter()
+                for j in range(T - 1):
+                    hv[j][0](tb)
+                for it in range(n_1 * T):
+                    hv[(it + T - 1) % T][0](tb)
+                    hv[it % T][1]()
+                for j in range(T - 1):
+                    hv[(n_1 * T + j) % T][1]()
+                dto = time.perf_counter() - t0
+            n_sets = n_o * T + T - 1
+            over[f"{T}_one_thread"] = {"evals_per_s": n_sets * K / dto, "us_per_eval": 1e6 * dto / (n_sets * K)}
+    finally:
+        for e in set_engs[1:]:
+            e.close()
+    return dict(over, what=f"T blocking sets of {K} points side by side, one host thread and one engine per set (same catalog, same GPU); 'T_one_thread': T sets in flight "
+                           "from ONE thread through gwi_eval_batch_begin / gwi_eval_batch_end")
 
 
 def multi_chain(eng, eng_comp, comp_name, pe, inj, total, thetas, C, steps, dev):

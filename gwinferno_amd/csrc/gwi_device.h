@@ -2439,6 +2439,8 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_kernel(con
 }
 
 // ---- batched launches of PARAMETRIC chains: every sample is loaded once for all the points of the batch ---------------
+// (Opt-in since round 6 -- GWI_PBATCH=1 or a row size: which of this kernel and the one-grid-row-per-point scan is faster
+// depends on the box, within 10 %, and the default is the latter; gwi_engine.hip where h->pbatch is set.)
 // scan_kernel<.., BATCH = true, ..> runs one grid row per hyper-parameter point: K points stream the catalog K times
 // (through L2 / the Infinity Cache) and redo K times whatever a sample needs that does not depend on theta (PL+Peak:
 // m1 = exp(log m1), a quarter of its exponentials; log(mmin / m1); the address arithmetic, the prologue, the argument
@@ -2532,142 +2534,142 @@ __global__ __launch_bounds__(kBlock, GWI_SCAN_WAVES_PER_EU) void scan_pbatch_ker
   }
   int b = -1, n_tile = 0;
   while (u_next < u_end) {  // one pass per SEGMENT: up to kPbatchMaxPts consecutive points of one tile (wave-uniform throughout)
-  const int b_seg = (int)(u_next / (unsigned)K);
-  const int k0 = (int)(u_next - (unsigned)b_seg * (unsigned)K);
-  int n_k = K - k0;
-  if ((unsigned)n_k > u_end - u_next) n_k = (int)(u_end - u_next);
-  if (n_k > kPbatchMaxPts) n_k = kPbatchMaxPts;
-  u_next += (unsigned)n_k;
-  if (b_seg != b) {
-    // ---- the tile's samples: ONE trip (the host sizes the tiles of this launch to <= kU x 256 samples), resident in registers
-    b = b_seg;
-    long long start, end, col_base;
-    if (b < n_pe_blocks) {
-      const int e = b / h_tiles;
-      const int t = b - e * h_tiles;
-      start = (long long)t * h_chunk_pe;
-      end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
-      col_base = (long long)e * h_n_pe;
-    } else {
-      const int t = b - n_pe_blocks;
-      start = (long long)t * h_chunk_inj;
-      end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
-      col_base = inj_offset(h_n_ev, h_n_pe);
-    }
-    n_tile = (int)(end - start);
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int iu = tid + u * kBlock;
-      if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
-      const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
-      kap[u] = gload(kappa_col, idx);
-      chain.load(0, u, 0, ctx, idx);
-    }
-  }
-  for (int kk = 0; kk < n_k; ++kk) {
-    const ThetaBlock* tb = a.tblocks + (k0 + kk);
-    ctx.theta = tb->theta;
-    ctx.derived = tb->derived;
-    chain.init();
-    double ell[kU], lin[kU];
-    bool live[kU];
-    double mx_lane = GWI_NEG_INF;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int iu = tid + u * kBlock;
-      if (iu - lane >= n_tile) {  // wave-uniform: this wave has no u-th sample
-        live[u] = false;
-        ell[u] = GWI_NEG_INF;
-        lin[u] = 0.0;
-        continue;
-      }
-      lin[u] = 1.0;
-      ell[u] = kap[u] + chain.eval(u, 0, ctx, lin[u]);
-      // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
-      live[u] = (iu < n_tile) && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
-      if (!live[u]) ell[u] = GWI_NEG_INF;
-      mx_lane = fmax(mx_lane, ell[u]);
-    }
-    // the wave's maximum for this point (to single precision, wave_max_coarse): every weight is <= (1 + 1e-7 |m|) x its linear part
-#ifdef GWI_AB_PBATCH_NOMAX  // timing-only ablation: no cross-lane maximum (wrong reference)
-    const double m = uniform(mx_lane);
-#elif defined(GWI_AB_PBATCH_EXACT_MAX)  // A/B: round 5's double-precision maximum
-    const double m = wave_max(mx_lane);
-#else
-    const double m = wave_max_coarse(mx_lane);  // within 6e-8 |m| of the wave's maximum: a reference, not a result
-#endif
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (tid + u * kBlock - lane >= n_tile) continue;
-      double w, wfac = 1.0;
-      if constexpr (ChainT::kAbsorb) {
-        const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u] - m, 0);
-        w = (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
-        wfac = w > 0.0 ? 1.0 : 0.0;  // a rejected weight takes the absorbing term's pre-weighted states with it
+    const int b_seg = (int)(u_next / (unsigned)K);
+    const int k0 = (int)(u_next - (unsigned)b_seg * (unsigned)K);
+    int n_k = K - k0;
+    if ((unsigned)n_k > u_end - u_next) n_k = (int)(u_end - u_next);
+    if (n_k > kPbatchMaxPts) n_k = kPbatchMaxPts;
+    u_next += (unsigned)n_k;
+    if (b_seg != b) {
+      // ---- the tile's samples: ONE trip (the host sizes the tiles of this launch to <= kU x 256 samples), resident in registers
+      b = b_seg;
+      long long start, end, col_base;
+      if (b < n_pe_blocks) {
+        const int e = b / h_tiles;
+        const int t = b - e * h_tiles;
+        start = (long long)t * h_chunk_pe;
+        end = start + h_chunk_pe < h_n_pe ? start + h_chunk_pe : h_n_pe;
+        col_base = (long long)e * h_n_pe;
       } else {
-        w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+        const int t = b - n_pe_blocks;
+        start = (long long)t * h_chunk_inj;
+        end = start + h_chunk_inj < h_n_inj ? start + h_chunk_inj : h_n_inj;
+        col_base = inj_offset(h_n_ev, h_n_pe);
       }
-      if (a.square) {
-        wfac = w;
-        w *= w;
+      n_tile = (int)(end - start);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int iu = tid + u * kBlock;
+        if (iu - lane >= n_tile) continue;  // wave-uniform: no u-th sample for this wave
+        const SIdx idx{col_base + start, (unsigned)(iu < n_tile ? iu : n_tile - 1) << 3};
+        kap[u] = gload(kappa_col, idx);
+        chain.load(0, u, 0, ctx, idx);
       }
-      s1 += w;
-      s2 += w * w;
-      chain.accumulate(u, 0, ctx, w, wfac);
     }
-    double vals[kSumGroups * 8];
-    int th_unused[kNV];
-    vals[0] = s1;
-    vals[1] = s2;
-    chain.collect(0, ctx, vals + 2, th_unused + 2);
+    for (int kk = 0; kk < n_k; ++kk) {
+      const ThetaBlock* tb = a.tblocks + (k0 + kk);
+      ctx.theta = tb->theta;
+      ctx.derived = tb->derived;
+      chain.init();
+      double ell[kU], lin[kU];
+      bool live[kU];
+      double mx_lane = GWI_NEG_INF;
 #pragma unroll
-    for (int v = kNV; v < kSumGroups * 8; ++v) vals[v] = 0.0;
+      for (int u = 0; u < kU; ++u) {
+        const int iu = tid + u * kBlock;
+        if (iu - lane >= n_tile) {  // wave-uniform: this wave has no u-th sample
+          live[u] = false;
+          ell[u] = GWI_NEG_INF;
+          lin[u] = 0.0;
+          continue;
+        }
+        lin[u] = 1.0;
+        ell[u] = kap[u] + chain.eval(u, 0, ctx, lin[u]);
+        // NaN or +inf weights count as zero (tests/inference_test.py:172, 260); so do zero densities
+        live[u] = (iu < n_tile) && (ell[u] < GWI_POS_INF) && (ell[u] > GWI_NEG_INF) && (lin[u] > 0.0) && (lin[u] < GWI_POS_INF);
+        if (!live[u]) ell[u] = GWI_NEG_INF;
+        mx_lane = fmax(mx_lane, ell[u]);
+      }
+      // the wave's maximum for this point (to single precision, wave_max_coarse): every weight is <= (1 + 1e-7 |m|) x its linear part
+#ifdef GWI_AB_PBATCH_NOMAX  // timing-only ablation: no cross-lane maximum (wrong reference)
+      const double m = uniform(mx_lane);
+#elif defined(GWI_AB_PBATCH_EXACT_MAX)  // A/B: round 5's double-precision maximum
+      const double m = wave_max(mx_lane);
+#else
+      const double m = wave_max_coarse(mx_lane);  // within 6e-8 |m| of the wave's maximum: a reference, not a result
+#endif
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int g = 0; g < kSumGroups; ++g) {
+      for (int u = 0; u < kU; ++u) {
+        if (tid + u * kBlock - lane >= n_tile) continue;
+        double w, wfac = 1.0;
+        if constexpr (ChainT::kAbsorb) {
+          const double f = chain.finish(u, 0, ctx, live[u] ? lin[u] : 0.0, ell[u] - m, 0);
+          w = (f > 0.0 && f < GWI_POS_INF) ? f : 0.0;
+          wfac = w > 0.0 ? 1.0 : 0.0;  // a rejected weight takes the absorbing term's pre-weighted states with it
+        } else {
+          w = live[u] ? lin[u] * fast_exp(ell[u] - m) : 0.0;
+        }
+        if (a.square) {
+          wfac = w;
+          w *= w;
+        }
+        s1 += w;
+        s2 += w * w;
+        chain.accumulate(u, 0, ctx, w, wfac);
+      }
+      double vals[kSumGroups * 8];
+      int th_unused[kNV];
+      vals[0] = s1;
+      vals[1] = s2;
+      chain.collect(0, ctx, vals + 2, th_unused + 2);
+#pragma unroll
+      for (int v = kNV; v < kSumGroups * 8; ++v) vals[v] = 0.0;
+#pragma unroll
+      for (int g = 0; g < kSumGroups; ++g) {
 #ifdef GWI_AB_PBATCH_NOSUM  // timing-only ablation: no butterfly (every value still reaches LDS once: eight stores of 64 lanes)
 #pragma unroll
-      for (int v = 0; v < 8; ++v)
-        if ((lane & 7) == v) s_part[wave][kk][8 * g + (lane >> 3)] = vals[8 * g + v];
+        for (int v = 0; v < 8; ++v)
+          if ((lane & 7) == v) s_part[wave][kk][8 * g + (lane >> 3)] = vals[8 * g + v];
 #else
-      const double z = wave_sum8(vals + 8 * g);
-      if ((lane & 7) == 0) s_part[wave][kk][8 * g + (lane >> 3)] = z;
+        const double z = wave_sum8(vals + 8 * g);
+        if ((lane & 7) == 0) s_part[wave][kk][8 * g + (lane >> 3)] = z;
 #endif
+      }
+      if (lane == 0) s_m[wave][kk] = m;
     }
-    if (lane == 0) s_m[wave][kk] = m;
-  }
-  __syncthreads();
-  // ---- records: wave w completes points w, w + 4, ... of this segment (scan_kernel's parametric epilogue, per point)
-  static_assert(kWaves == 4, "the quad broadcasts below assume four waves");
-  int slot = 0;
+    __syncthreads();
+    // ---- records: wave w completes points w, w + 4, ... of this segment (scan_kernel's parametric epilogue, per point)
+    static_assert(kWaves == 4, "the quad broadcasts below assume four waves");
+    int slot = 0;
 #pragma unroll
-  for (int v = 2; v < kNV; ++v) slot = (lane == v) ? th[v] : slot;
-  const int vi = lane < kSumGroups * 8 ? lane : 0;
-  for (int kk = wave; kk < n_k; kk += kWaves) {
-    const double my_m = s_m[lane & 3][kk];
-    double part[kWaves];
+    for (int v = 2; v < kNV; ++v) slot = (lane == v) ? th[v] : slot;
+    const int vi = lane < kSumGroups * 8 ? lane : 0;
+    for (int kk = wave; kk < n_k; kk += kWaves) {
+      const double my_m = s_m[lane & 3][kk];
+      double part[kWaves];
 #pragma unroll
-    for (int w_ = 0; w_ < kWaves; ++w_) part[w_] = s_part[w_][kk][vi];
-    double M = fmax(my_m, dpp_take<0xB1, 0xf>(my_m));  // quad_perm [1,0,3,2]
-    M = fmax(M, dpp_take<0x4E, 0xf>(M));               // quad_perm [2,3,0,1]: the maximum of the four references, in every lane
-    double f_mine = (my_m == GWI_NEG_INF) ? 0.0 : fast_exp(my_m - M);
-    if (a.square) f_mine *= f_mine;
-    const double f0 = dpp_take<0x00, 0xf>(f_mine), f1 = dpp_take<0x55, 0xf>(f_mine), f2 = dpp_take<0xAA, 0xf>(f_mine), f3 = dpp_take<0xFF, 0xf>(f_mine);
-    const double t1 = fma(part[3], f3, fma(part[2], f2, fma(part[1], f1, part[0] * f0)));                      // sums of w: in wave order
-    const double t2 = fma(part[3], f3 * f3, fma(part[2], f2 * f2, fma(part[1], f1 * f1, part[0] * (f0 * f0))));  // S2 holds w^2
-    const double tot = lane == 1 ? t2 : t1;
-    double* out = a.partials + ((long long)(k0 + kk) * n_blocks_total + b) * a.rec_stride;
-    if (lane == 0) out[0] = a.square ? 2.0 * M : M;
-    if (lane < 2) out[1 + lane] = tot;
-    if (lane >= 2 && lane < kNV) unsafeAtomicAdd(&s_out[wave][slot], tot);  // several accumulators may feed one theta slot
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (int p = lane; p < a.n_theta; p += 64) {
-      out[kRecHeader + p] = s_out[wave][p];
-      s_out[wave][p] = 0.0;
+      for (int w_ = 0; w_ < kWaves; ++w_) part[w_] = s_part[w_][kk][vi];
+      double M = fmax(my_m, dpp_take<0xB1, 0xf>(my_m));  // quad_perm [1,0,3,2]
+      M = fmax(M, dpp_take<0x4E, 0xf>(M));               // quad_perm [2,3,0,1]: the maximum of the four references, in every lane
+      double f_mine = (my_m == GWI_NEG_INF) ? 0.0 : fast_exp(my_m - M);
+      if (a.square) f_mine *= f_mine;
+      const double f0 = dpp_take<0x00, 0xf>(f_mine), f1 = dpp_take<0x55, 0xf>(f_mine), f2 = dpp_take<0xAA, 0xf>(f_mine), f3 = dpp_take<0xFF, 0xf>(f_mine);
+      const double t1 = fma(part[3], f3, fma(part[2], f2, fma(part[1], f1, part[0] * f0)));                      // sums of w: in wave order
+      const double t2 = fma(part[3], f3 * f3, fma(part[2], f2 * f2, fma(part[1], f1 * f1, part[0] * (f0 * f0))));  // S2 holds w^2
+      const double tot = lane == 1 ? t2 : t1;
+      double* out = a.partials + ((long long)(k0 + kk) * n_blocks_total + b) * a.rec_stride;
+      if (lane == 0) out[0] = a.square ? 2.0 * M : M;
+      if (lane < 2) out[1 + lane] = tot;
+      if (lane >= 2 && lane < kNV) unsafeAtomicAdd(&s_out[wave][slot], tot);  // several accumulators may feed one theta slot
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      for (int p = lane; p < a.n_theta; p += 64) {
+        out[kRecHeader + p] = s_out[wave][p];
+        s_out[wave][p] = 0.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  }
-  if (u_next < u_end) __syncthreads();  // the staging rows are reused by the next segment
+    if (u_next < u_end) __syncthreads();  // the staging rows are reused by the next segment
   }  // segments
 }
 
