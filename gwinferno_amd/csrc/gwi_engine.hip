@@ -1109,7 +1109,10 @@ gwi_status aql_wait_slow(gwi_handle h, Ready ready, const char* what) {
   bool rung_again = false;
   for (unsigned long long spin = 1;; ++spin) {
     if (ready()) {
-      if (rung_again && !std::getenv("GWI_QUIET")) std::fprintf(stderr, "gwi: %s arrived only after the queue's doorbell was rung a second time\n", what);
+      // (said once per process: with several processes time-slicing one GPU an evaluation can simply take longer than 50 ms)
+      static std::atomic<bool> said{false};
+      if (rung_again && !std::getenv("GWI_QUIET") && !said.exchange(true))
+        std::fprintf(stderr, "gwi: waited more than 50 ms for %s and rang the queue's doorbell again as a precaution; they arrived (a busy or shared GPU does this too)\n", what);
       return GWI_OK;
     }
     // packets of this evaluation may still be in flight: the handle takes no further evaluations, and gwi_destroy
