@@ -325,6 +325,43 @@ def test_lockstep_chains_on_the_engine_match_the_batched_callback_path():
         e.close()
 
 
+def test_a_queue_of_chains_on_the_engines():
+    """gwi_nuts_engine_queue: eleven chains over two engines x three lock-step slots.  A chain that has drawn its last sample
+    hands its slot to the next one waiting (in either group), so the batches stay full until the queue is empty; a chain's draws
+    do not depend on where it ran -- checked against the callback form of the same queue (gwi_nuts_run_queue on the Python
+    statement of the target, fed by the same engine's blocking batches): same trees, evaluation for evaluation."""
+    from gwinferno_amd.sampling import lockstep_stats, nuts_engine_lockstep, nuts_native_lockstep
+
+    engs, total, prior, bij, theta0, _ = _native_nuts_setup(2)
+    slots, C = 3, 11
+    starts = np.stack([theta0 + 0.02 * c for c in range(C)])
+    kw = dict(n_warmup=8, n_samples=30, seed=5, max_tree_depth=5)
+    res = nuts_engine_lockstep(engs, slots, total, prior, bij, starts, min_neff_cut=False, **kw)
+    st = lockstep_stats()
+    assert len(res) == C and 2.0 < st["mean_points_per_batch"] <= slots
+    again = nuts_engine_lockstep(engs, slots, total, prior, bij, starts, min_neff_cut=False, **kw)
+    assert all(np.array_equal(a["samples"], b["samples"]) and a["n_evals"] == b["n_evals"] for a, b in zip(res, again))  # deterministic, wherever a chain ran
+
+    def batch_target(us, ids):
+        fw = [bij.forward(u) for u in us]
+        out = engs[0].evaluate_batch(np.stack([f[0] for f in fw]), total, min_neff_cut=False)
+        lps, grads = [], []
+        for (theta, dth, dlogj, logj), r in zip(fw, out):
+            lp, gp = prior(theta)
+            lps.append(r.log_likelihood + lp + logj)
+            grads.append((r.grad + gp) * dth + dlogj)
+        return np.array(lps), np.stack(grads)
+
+    ref = nuts_native_lockstep(batch_target, np.stack([bij.inverse(t) for t in starts]), slots=slots, **kw)
+    for a, b in zip(res, ref):  # (batches of at most three points take the same kernels and the same host-side sums in both forms)
+        assert a["n_evals"] == b["n_evals"] and np.array_equal(a["tree_depth"], b["tree_depth"])
+        th_b = np.array([bij.forward(u)[0] for u in b["samples"]])
+        assert np.allclose(a["samples"], th_b, rtol=1e-4, atol=1e-5)
+    assert np.isfinite(engs[0].evaluate(theta0, total, min_neff_cut=False).log_likelihood)  # nothing left pending
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["chm_powerlaw", "chm_bspline"])
 def test_construct_hierarchical_model_matches_the_reference(name):
     """construct_hierarchical_model (analysis.py:359-424) with the distribution classes of this package, fed the way
